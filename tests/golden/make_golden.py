@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by running the REAL reference classes (oracle/_ref/ref_harness).
+
+Runs only in the build container (needs /root/reference and `make -C oracle ref`).  The committed
+outputs (tests/golden/*.json.gz) are pure data: seeded synthetic inputs + what the reference computed.
+
+usage: python tests/golden/make_golden.py
+"""
+import gzip, json, os, random, subprocess, sys, tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("SP_REFERENCE", "/root/reference")
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+M80 = os.path.join(REF, "lib/mmseqs/data/VTML80.out")
+M40 = os.path.join(REF, "lib/mmseqs/data/VTML40.out")
+
+AA = "ACDEFGHIKLMNPQRSTVWY"
+# VTML40 background (first 20 entries of the header line of the matrix file)
+BG = [0.0819, 0.0169, 0.0453, 0.0616, 0.0465, 0.0745, 0.0217, 0.0549, 0.0582, 0.0905, 0.0274, 0.0435,
+      0.0506, 0.0375, 0.0447, 0.0533, 0.0569, 0.081, 0.0132, 0.0329]
+
+
+def rand_seq(rng, n):
+    return "".join(rng.choices(AA, weights=BG, k=n))
+
+
+def mutate(rng, s, nsub):
+    s = list(s)
+    for _ in range(nsub):
+        p = rng.randrange(len(s))
+        s[p] = rng.choice(AA)
+    return "".join(s)
+
+
+def make_case(seed, n_targets, n_queries, tmin, tmax, qmin, qmax, families=0):
+    rng = random.Random(seed)
+    T = []
+    for i in range(n_targets):
+        L = rng.randint(tmin, tmax)
+        s = rand_seq(rng, L)
+        r = rng.random()
+        if r < 0.08 and L > 40:      # low-complexity / tandem repeat stretch -> tantan masks it
+            unit = rand_seq(rng, rng.randint(1, 6))
+            p = rng.randrange(0, L - 30)
+            rep = (unit * 40)[: rng.randint(15, 30)]
+            s = s[:p] + rep + s[p + len(rep):]
+        elif r < 0.12:               # a few X / odd letters
+            s = list(s)
+            for _ in range(rng.randint(1, 4)):
+                s[rng.randrange(L)] = rng.choice("XBZJUO*x")
+            s = "".join(s)
+        T.append(s)
+    # families: near-identical targets so that one query collects many hits (exercises the top-N cut)
+    for f in range(families):
+        base = rand_seq(rng, rng.randint(60, 120))
+        for _ in range(rng.randint(20, 60)):
+            T[rng.randrange(n_targets)] = mutate(rng, base, rng.randint(0, 3)) + rand_seq(rng, rng.randint(0, 20))
+    Q = []
+    for i in range(n_queries):
+        L = rng.randint(qmin, qmax)
+        r = rng.random()
+        if r < 0.6:                  # planted: window of a target with 0-2 substitutions
+            for _ in range(100):
+                t = T[rng.randrange(n_targets)]
+                if len(t) >= L:
+                    break
+            p = rng.randrange(0, max(1, len(t) - L + 1))
+            q = mutate(rng, t[p:p + L], rng.choice([0, 0, 1, 1, 2]))
+            if rng.random() < 0.15 and L > 12:   # planted with a gap (exercises gapped SW / cigar)
+                c = rng.randrange(3, L - 3)
+                q = q[:c] + (rand_seq(rng, rng.randint(1, 2)) if rng.random() < 0.5 else "") + q[c + rng.randint(0, 2):]
+        elif r < 0.9:
+            q = rand_seq(rng, L)
+        elif r < 0.95:
+            q = list(rand_seq(rng, L)); q[rng.randrange(L)] = "X"; q = "".join(q)
+        else:
+            q = (rand_seq(rng, 2) * 20)[:L]      # biased composition
+        Q.append(q)
+    return T, Q
+
+
+CASES = {
+    # name: (seed, n_targets, n_queries, tmin, tmax, qmin, qmax, families, extra harness flags)
+    "small":   (11, 300, 96, 20, 400, 6, 30, 0, ["--dump-kmers", "8", "--dump-index"]),
+    "spacer":  (12345, 2000, 400, 50, 300, 9, 12, 0, ["--dump-kmers", "4"]),
+    "family":  (77, 1500, 120, 40, 250, 10, 40, 6, ["--dump-kmers", "0", "--max-seqs", "20"]),
+    "longq":   (5, 600, 40, 100, 1200, 40, 300, 2, ["--dump-kmers", "0"]),
+}
+
+
+def main():
+    if not os.path.exists(HARNESS):
+        sys.exit("build the harness first: make -C oracle ref")
+    only = sys.argv[1:]
+    for name, (seed, nt, nq, tmin, tmax, qmin, qmax, fam, flags) in CASES.items():
+        if only and name not in only:
+            continue
+        T, Q = make_case(seed, nt, nq, tmin, tmax, qmin, qmax, fam)
+        with tempfile.TemporaryDirectory() as d:
+            tf, qf, of = (os.path.join(d, x) for x in ("t.txt", "q.txt", "o.json"))
+            open(tf, "w").write("\n".join(T) + "\n")
+            open(qf, "w").write("\n".join(Q) + "\n")
+            subprocess.check_call([HARNESS, M80, M40, tf, qf, of] + flags)
+            ref = json.load(open(of))
+        doc = {"case": name, "seed": seed, "targets": T, "queries": Q, "flags": flags, "ref": ref}
+        out = os.path.join(HERE, name + ".json.gz")
+        with gzip.GzipFile(out, "wb", mtime=0) as f:
+            f.write(json.dumps(doc, separators=(",", ":")).encode())
+        print(name, "->", out, os.path.getsize(out), "bytes")
+
+
+if __name__ == "__main__":
+    main()
