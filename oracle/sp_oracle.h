@@ -1,0 +1,140 @@
+/*
+ * sp_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C, scalar CPU restatement of SpacePHARER's spacer->phage-ORF search hot path (the vendored
+ * MMseqs2 `prefilter` + `align` + `rescorediagonal` arithmetic).  It exists to CHECK the HIP
+ * implementation; nothing under spacepharer_amd/ may include, link or call it.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ *
+ * Parity status: PINNED.  Every stage is checked against golden vectors produced by the reference's
+ * own classes (oracle/ref_harness.cpp -> tests/golden/*.json.gz, see tests/test_oracle_golden.py).
+ *
+ * All citations are relative to /root/reference/lib/mmseqs/src/ unless they start with lib/.
+ */
+#ifndef SP_ORACLE_H
+#define SP_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPO_ALPH 21          /* ACDEFGHIKLMNPQRSTVWYX */
+#define SPO_KMER 6
+#define SPO_SPAN 8           /* spaced pattern 11011101 */
+
+typedef struct {
+    int alphabetSize;
+    short sub[SPO_ALPH][SPO_ALPH];      /* rounded bit-scaled scores (BaseMatrix.cpp:138-156)          */
+    double pBack[SPO_ALPH];             /* header background, rescaled (SubstitutionMatrix.cpp:395-399) */
+    double prob[SPO_ALPH][SPO_ALPH];    /* joint probabilities (SubstitutionMatrix.cpp:401-406)         */
+    double lambda;
+    unsigned char aa2num[256];
+    char num2aa[SPO_ALPH + 1];
+} spo_matrix;
+
+typedef struct {
+    uint32_t seqId;
+    int32_t score;
+    uint16_t diagonal;
+} spo_hit;
+
+typedef struct {
+    uint32_t dbKey;
+    int32_t score;          /* bit score, int(x+0.5) */
+    int32_t rawScore;       /* SW score1 */
+    float qcov, dbcov, seqId;
+    double eval;
+    uint32_t alnLength;
+    int32_t qStartPos, qEndPos;
+    uint32_t qLen;
+    int32_t dbStartPos, dbEndPos;
+    uint32_t dbLen;
+    int32_t passed;         /* Alignment::checkCriteria */
+    char backtrace[4096];   /* uncompressed M/I/D string */
+} spo_aln;
+
+typedef struct {
+    double lambda, K, a_I, b_I, alpha_I, beta_I, a_J, b_J, alpha_J, beta_J, sigma, tau;
+} spo_alp;
+
+typedef struct spo_ctx spo_ctx;
+
+/* ---- matrices ---- */
+int spo_matrix_init(spo_matrix *m, const char *matrixText, double bitFactor, double scoreBias);
+/* extended 3-mer table over the 20-letter alphabet: score[8000*8000], index[8000*8000], row stride 8000 */
+void spo_ext3(const spo_matrix *m, short *score, uint16_t *index);
+void spo_ext2(const spo_matrix *m, short *score, uint16_t *index);
+
+/* ---- per-sequence primitives ---- */
+int spo_map_sequence(const spo_matrix *m, const char *seq, int maxLen, unsigned char *out);
+void spo_local_bias(const spo_matrix *m, const unsigned char *seq, int L, float *bias);
+int spo_tantan_mask(const spo_matrix *m, unsigned char *seq, int L);
+
+/* ---- context: matrices + target set + index ---- */
+spo_ctx *spo_create(const char *seedMatrixText, const char *scoreMatrixText, float sensitivity,
+                    int maxSeqs, unsigned binSize /* 0 = derive from l2CacheSize like the reference */,
+                    uint64_t l2CacheSize);
+void spo_destroy(spo_ctx *c);
+int spo_kmer_thr(const spo_ctx *c);
+unsigned spo_bin_size(const spo_ctx *c);
+const spo_matrix *spo_seed_matrix(const spo_ctx *c);
+const spo_matrix *spo_ungapped_matrix(const spo_ctx *c);
+const spo_matrix *spo_aln_matrix(const spo_ctx *c);
+const short *spo_ext3_score(const spo_ctx *c);
+const uint16_t *spo_ext3_index(const spo_ctx *c);
+
+/* targets: ASCII residues concatenated, offsets[n+1] */
+int spo_set_targets(spo_ctx *c, const char *residues, const uint64_t *offsets, size_t n, int mask);
+size_t spo_num_targets(const spo_ctx *c);
+uint64_t spo_aa_db_size(const spo_ctx *c);
+const unsigned char *spo_masked_residues(const spo_ctx *c);   /* numeric, masked, concatenated */
+const uint64_t *spo_target_offsets(const spo_ctx *c);
+uint64_t spo_index_entries(const spo_ctx *c);
+const uint32_t *spo_index_offsets(const spo_ctx *c);           /* 20^6 + 1 */
+const uint32_t *spo_index_seqids(const spo_ctx *c);
+const uint16_t *spo_index_positions(const spo_ctx *c);
+uint64_t spo_index_digest(const spo_ctx *c);                   /* FNV-1a over (kmer,seqId,pos) u32 triples */
+uint64_t spo_masked_count(const spo_ctx *c);
+
+/* ---- prefilter: one query ---- */
+/* similar k-mer list of one window (KmerGenerator.cpp:107-216); returns count, writes up to cap */
+size_t spo_kmer_list(const spo_ctx *c, const unsigned char *kmer6, int thr, uint32_t *out, size_t cap);
+/* per-window thresholds: thr[i] = -1 for windows containing X (QueryMatcher.cpp:205-219) */
+int spo_window_thresholds(const spo_ctx *c, const unsigned char *q, int L, const float *bias, int *thr);
+/* QueryMatcher::match: double-hit diagonals in reference order (id, diag16); returns count */
+size_t spo_match(const spo_ctx *c, const char *query, int qLen, uint32_t *ids, uint16_t *diags, size_t cap,
+                 uint64_t *dbMatches, uint64_t *kmerListLen);
+/* QueryMatcher::matchQuery: final hit list (sorted by score desc, seqId asc); returns count */
+size_t spo_prefilter_query(const spo_ctx *c, const char *query, int qLen, spo_hit *out, size_t cap);
+/* ungapped diagonal score of one (target, diag16) incl. min(255-bias, .) clamp; also returns bias */
+int spo_ungapped_score(const spo_ctx *c, const char *query, int qLen, uint32_t seqId, uint16_t diag, int *biasOut);
+/* text exactly as QueryMatcher::prefilterHitToBuffer (QueryMatcher.h:114-126); returns bytes written */
+size_t spo_prefilter_text(const spo_hit *hits, size_t n, const uint32_t *keys, char *buf, size_t cap);
+
+/* ---- align ---- */
+void spo_set_alp(spo_ctx *c, const spo_alp *gapped, const spo_alp *gapless);
+double spo_evalue(const spo_ctx *c, int gapped, double score, double qLen);
+double spo_bitscore(const spo_ctx *c, int gapped, double score);
+/* Matcher::getSWResult for one pair (unmasked ASCII target); gapOpen/gapExtend as in the reference */
+int spo_align_pair(const spo_ctx *c, const char *query, int qLen, const char *target, int tLen, uint32_t dbKey,
+                   int gapOpen, int gapExtend, double evalThr, spo_aln *out);
+/* forward pass only: score / ref end / read end (StripedSmithWaterman.cpp:301-516, :519-687) */
+int spo_sw_forward(const spo_ctx *c, const char *query, int qLen, const char *target, int tLen,
+                   int gapOpen, int gapExtend, int *score, int *refEnd, int *readEnd, int *usedWord);
+/* sort by Matcher::compareHits and print as Matcher::resultToBuffer does (compressed cigar, -a 1) */
+size_t spo_alignment_text(spo_aln *res, size_t n, char *buf, size_t cap);
+
+/* ---- rescorediagonal (DistanceCalculator.h:93-201), ASCII sequences ---- */
+typedef struct { int score, startPos, endPos, diagonalLen, diagonal; unsigned distToDiagonal; } spo_local;
+void spo_rescore_diagonal(const spo_ctx *c, const char *q, int qLen, const char *t, int tLen, uint16_t diag,
+                          int mode /*1 substitution, 2 alignment*/, spo_local *out);
+
+uint64_t spo_fnv1a(const void *p, size_t n, uint64_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

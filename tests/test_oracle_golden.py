@@ -1,0 +1,198 @@
+"""Pins the CPU restatement (oracle/sp_oracle.c) against vectors produced by the REAL reference classes
+(tests/golden/*.json.gz, made by tests/golden/make_golden.py through oracle/_ref/ref_harness)."""
+import ctypes as C
+import struct
+
+import pytest
+
+from conftest import load_golden
+from oracle_lib import Alp, Oracle, lib
+
+CASES = ["small", "spacer", "family", "longq"]
+_or = {}
+
+
+def oracle_for(name):
+    if name not in _or:
+        g = load_golden(name)
+        r = g["ref"]
+        o = Oracle(sens=r["sens"], max_seqs=r["maxSeqs"], l2=r["l2cache"])
+        o.set_targets(g["targets"])
+        if "alpGapped" in r:
+            o.set_alp(Alp.from_ref(r["alpGapped"]), Alp.from_ref(r["alpGapless"]))
+        _or[name] = o
+    return _or[name]
+
+
+def test_matrices():
+    g = load_golden("small")["ref"]
+    o = oracle_for("small")
+    for which, key in (("seed", "seedMat"), ("ungapped", "ungappedMat"), ("aln", "alnMat")):
+        m = o.matrix(which)
+        sub = [m.sub[i][j] for i in range(21) for j in range(21)]
+        assert sub == g[key]["sub"], which
+        assert [m.pBack[i] for i in range(21)] == [float.fromhex(x) for x in g[key]["pBack"]]
+        assert m.num2aa.decode() == g[key]["num2aa"]
+        assert [m.aa2num[i] for i in range(128)] == g[key]["aa2num"]
+    assert lib().spo_kmer_thr(o.ctx) == g["kmerThr"] == 112
+    assert lib().spo_bin_size(o.ctx) == g["binSize"]
+
+
+def test_ext3_table():
+    g = load_golden("small")["ref"]["ext3"]
+    o = oracle_for("small")
+    L = lib()
+    sc = C.cast(L.spo_ext3_score(o.ctx), C.POINTER(C.c_short))
+    ix = C.cast(L.spo_ext3_index(o.ctx), C.POINTER(C.c_uint16))
+    assert g["size"] == 8000
+    for r, row in g["rows"].items():
+        r = int(r)
+        assert [sc[r * 8000 + z] for z in range(64)] == row["score"]
+        assert [ix[r * 8000 + z] for z in range(64)] == row["index"]
+    # whole-table digest: the reference hashes score (i16) then index (u32) of every row
+    import numpy as np
+    s = np.ctypeslib.as_array(sc, shape=(8000, 8000))
+    i = np.ctypeslib.as_array(ix, shape=(8000, 8000)).astype(np.uint32)
+    h = 0
+    for r in range(0, 8000):
+        h = L.spo_fnv1a(s[r].ctypes.data, 16000, h)
+        row = np.ascontiguousarray(i[r])
+        h = L.spo_fnv1a(row.ctypes.data, 32000, h)
+    assert "%016x" % h == g["digest"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_masking_and_index(name):
+    g = load_golden(name)
+    r = g["ref"]
+    o = oracle_for(name)
+    L = lib()
+    assert o.masked() == r["masked"]
+    assert L.spo_masked_count(o.ctx) == r["maskedResidues"]
+    assert L.spo_index_entries(o.ctx) == r["index"]["entries"] == r["totalKmerCount"]
+    assert "%016x" % L.spo_index_digest(o.ctx) == r["index"]["digest"]
+
+
+def test_index_triples_small():
+    g = load_golden("small")["ref"]["index"]
+    o = oracle_for("small")
+    L = lib()
+    off = C.cast(L.spo_index_offsets(o.ctx), C.POINTER(C.c_uint32))
+    sid = C.cast(L.spo_index_seqids(o.ctx), C.POINTER(C.c_uint32))
+    pos = C.cast(L.spo_index_positions(o.ctx), C.POINTER(C.c_uint16))
+    for k, s, p in g["triples"][:: max(1, len(g["triples"]) // 3000)]:
+        lst = [(sid[e], pos[e]) for e in range(off[k], off[k + 1])]
+        assert (s, p) in lst
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_bias_windows_kmers(name):
+    g = load_golden(name)
+    o = oracle_for(name)
+    L = lib()
+    seed = L.spo_seed_matrix(o.ctx)
+    for q in g["ref"]["queries"]:
+        s = g["queries"][q["id"]].encode()
+        num = C.create_string_buffer(len(s) + 1)
+        n = L.spo_map_sequence(seed, s, len(s), num)
+        assert n == q["L"]
+        bias = (C.c_float * (n + 1))()
+        L.spo_local_bias(seed, num, n, bias)
+        got = [struct.unpack("<I", struct.pack("<f", bias[i]))[0] for i in range(n)]
+        assert got == q["bias"]
+        if "windows" not in q:
+            continue
+        thr = (C.c_int * (n + 1))()
+        nw = L.spo_window_thresholds(o.ctx, num, n, bias, thr)
+        assert nw == len(q["windows"])
+        pat = (0, 1, 3, 4, 5, 7)
+        for w in q["windows"]:
+            i = w["i"]
+            if w.get("x"):
+                assert thr[i] == -1
+                continue
+            assert thr[i] == w["thr"]
+            kmer = bytes(num.raw[i + p] for p in pat)
+            out, cnt = o.kmer_list(kmer, w["thr"])
+            assert cnt == w["n"]
+            assert [out[z] for z in range(min(cnt, 16))] == w["head"]
+            arr = (C.c_uint64 * cnt)(*[out[z] for z in range(cnt)])   # the reference hashes size_t entries
+            assert "%016x" % L.spo_fnv1a(arr, 8 * cnt, 0) == w["digest"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_double_hit_diagonals(name):
+    g = load_golden(name)
+    o = oracle_for(name)
+    for q in g["ref"]["queries"]:
+        diag, dbm, klen = o.match(g["queries"][q["id"]])
+        assert dbm == q["dbMatches"]
+        assert diag == q["diag"], q["id"]
+        assert float(klen) / q["L"] == float.fromhex(q["kmersPerPos"]) if q["L"] else True
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_prefilter_hits(name):
+    g = load_golden(name)
+    o = oracle_for(name)
+    total = 0
+    for q in g["ref"]["queries"]:
+        s = g["queries"][q["id"]]
+        assert o.prefilter_list(s) == q["hits"], q["id"]
+        assert o.prefilter_text(s) == q["pref"]
+        total += len(q["hits"])
+    assert total > 0
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_evalues(name):
+    r = load_golden(name)["ref"]
+    o = oracle_for(name)
+    L = lib()
+    for key, v in r["evalueProbe"].items():
+        ql, s = (int(x) for x in key.split("_"))
+        ev, bits, evg, bitsg = (float.fromhex(x) for x in v)
+        assert L.spo_evalue(o.ctx, 1, float(s), float(ql)) == ev
+        assert L.spo_bitscore(o.ctx, 1, float(s)) == bits
+        assert L.spo_evalue(o.ctx, 0, float(s), float(ql)) == evg
+        assert L.spo_bitscore(o.ctx, 0, float(s)) == bitsg
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_alignments(name):
+    g = load_golden(name)
+    o = oracle_for(name)
+    n = 0
+    for a in g["ref"]["aln"]:
+        q = g["queries"][a["id"]]
+        passed = []
+        for raw in a["raw"]:
+            dbKey, bits, qs, qe, ts, te, alnLen, ev, ok, bt = raw
+            r = o.align(q, dbKey)
+            assert r.passed == ok, (a["id"], raw)
+            assert r.score == bits
+            assert r.qEndPos == qe and r.dbEndPos == te
+            if ok:
+                assert (r.qStartPos, r.dbStartPos, r.alnLength) == (qs, ts, alnLen), (a["id"], raw)
+                assert r.eval == float.fromhex(ev)
+                assert r.backtrace.decode() == bt
+                passed.append(r)
+            n += 1
+        assert o.alignment_text(passed) == a["text"], a["id"]
+    assert n > 0
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_rescorediagonal(name):
+    g = load_golden(name)
+    o = oracle_for(name)
+    for a, qh in zip(g["ref"]["aln"], g["ref"]["queries"]):
+        q = g["queries"][a["id"]]
+        for raw, hit in zip(a["rescore"], qh["hits"]):
+            dbKey, s1, s2, st, en, dlen, dist, diag, ev, bits = raw
+            r1 = o.rescore(q, dbKey, hit[2], 1)
+            r2 = o.rescore(q, dbKey, hit[2], 2)
+            assert r1.score == s1
+            assert (r2.score, r2.startPos, r2.endPos, r2.diagonalLen, r2.distToDiagonal, r2.diagonal) == (s2, st, en, dlen, dist, diag)
+            assert lib().spo_evalue(o.ctx, 0, float(s2), float(len(q))) == float.fromhex(ev)
+            assert int(lib().spo_bitscore(o.ctx, 0, float(s2)) + 0.5) == bits
