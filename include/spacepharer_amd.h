@@ -1,0 +1,133 @@
+/*
+ * spacepharer_amd.h -- C ABI of the MI355X-native implementation of SpacePHARER's spacer -> phage-ORF search
+ * hot path (the vendored MMseqs2 `prefilter`, `align` and `rescorediagonal` modules).
+ *
+ * Two levels:
+ *
+ *  (1) Module drop-ins.  Same argv as the reference modules receive (program and module name already
+ *      stripped, lib/mmseqs/src/commons/Application.cpp:196), same on-disk DB triples in and out, return value
+ *      = process exit status.  They replace
+ *          int prefilter      (int argc, const char **argv, const Command&)   lib/mmseqs/src/CommandDeclarations.h:79
+ *          int align          (int argc, const char **argv, const Command&)   lib/mmseqs/src/CommandDeclarations.h:5
+ *          int rescorediagonal(int argc, const char **argv, const Command&)   lib/mmseqs/src/CommandDeclarations.h:86
+ *      whose bodies are lib/mmseqs/src/prefiltering/Main.cpp:13-68, alignment/Main.cpp:12-32 and
+ *      alignment/rescorediagonal.cpp:381-431.  INTEGRATION.md shows the three-line Command wrappers.
+ *
+ *  (2) In-memory search context.  What the module drivers, bench.py and the parity tests call: matrices ->
+ *      target set (masking + k-mer index, built once, staged to HBM) -> query batch -> prefilter -> align.
+ *      It corresponds to the objects the reference builds per process:
+ *          Prefiltering::Prefiltering + getIndexTable   prefiltering/Prefiltering.cpp:22-221,499-537
+ *          Prefiltering::runSplit / QueryMatcher        prefiltering/Prefiltering.cpp:709-867
+ *          Alignment::run / Matcher::getSWResult        alignment/Alignment.cpp:255-549, Matcher.cpp:61-187
+ *          doRescorediagonal                            alignment/rescorediagonal.cpp:45-379
+ *
+ * Plain pointers and sizes only; no memory ownership crosses the boundary (callers own every buffer they pass,
+ * the context owns everything it allocates).  All functions return 0 on success and a negative code on error;
+ * sp_last_error() describes the last failure of the calling thread.  There is no CPU fallback: every compute entry
+ * point fails if no HIP device is available.
+ */
+#ifndef SPACEPHARER_AMD_H
+#define SPACEPHARER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_OK 0
+#define SP_ERR_ARG (-1)
+#define SP_ERR_DEVICE (-2)
+#define SP_ERR_STATE (-3)
+#define SP_ERR_IO (-4)
+#define SP_ERR_OVERFLOW (-5)
+#define SP_ERR_UNSUPPORTED (-6)
+
+/* ---- process level ---- */
+int sp_init(int device_mask);              /* bit i = use HIP device i; 0 = device of LOCAL_RANK (or 0) */
+void sp_shutdown(void);
+const char *sp_last_error(void);
+int sp_device_count(void);
+const char *sp_version(void);
+
+/* ---- (1) module drop-ins ---- */
+int sp_prefilter_run(int argc, const char **argv);        /* <i:queryDB> <i:targetDB> <o:prefilterDB> [flags]              */
+int sp_align_run(int argc, const char **argv);            /* <i:queryDB> <i:targetDB> <i:resultDB> <o:alignmentDB> [flags] */
+int sp_rescorediagonal_run(int argc, const char **argv);  /* <i:queryDB> <i:targetDB> <i:resultDB> <o:resultDB> [flags]    */
+
+/* ---- (2) in-memory search context ---- */
+typedef struct sp_ctx sp_ctx;
+
+typedef struct {
+    const char *seed_sub_mat;      /* --seed-sub-mat (aa part), e.g. "VTML80.out"; name of an embedded table, a path, or NAME.out:DATA */
+    const char *sub_mat;           /* --sub-mat (aa part), e.g. "VTML40.out" */
+    float sensitivity;             /* -s            (5.7 in SpacePHARER, src/workflow/PredictMatch.cpp:9-31) */
+    int kmer_score;                /* --k-score     (INT_MAX = derive from sensitivity) */
+    int max_seqs;                  /* --max-seqs    (300) */
+    int min_ungapped_score;        /* --min-ungapped-score (15) */
+    int mask;                      /* --mask        (1 = tantan) */
+    int gap_open;                  /* --gap-open aa part (16) */
+    int gap_extend;                /* --gap-extend  (2)  */
+    double evalue;                 /* -e            (200) */
+    int threads;                   /* host threads for index construction / output formatting (0 = all) */
+    unsigned bin_size;             /* 0 = derive from the host L2 size as the reference does (tie order at the --max-seqs cut) */
+} sp_search_params;
+
+void sp_default_params(sp_search_params *p);   /* SpacePHARER's predictmatch defaults */
+
+typedef struct { uint32_t seq_id; int32_t score; int16_t diagonal; int16_t pad; } sp_hit;   /* hit_t, QueryMatcher.h:35-50 */
+
+typedef struct {             /* Matcher::result_t, alignment/Matcher.h:32-90 (fields that reach the output DB) */
+    uint32_t db_key;
+    int32_t bit_score;
+    int32_t raw_score;
+    float seq_id;
+    double evalue;
+    int32_t q_start, q_end; uint32_t q_len;
+    int32_t db_start, db_end; uint32_t db_len;
+    uint32_t aln_len;
+    uint32_t cigar_offset;   /* into the cigar pool returned next to the results (uncompressed M/I/D string, NUL-terminated) */
+    int32_t passed;          /* Alignment::checkCriteria */
+} sp_alignment;
+
+typedef struct {             /* DistanceCalculator::LocalAlignment + statistics, rescorediagonal.cpp:227-252 */
+    int32_t score, start_pos, end_pos, diagonal_len, diagonal; uint32_t dist_to_diagonal;
+    double evalue; int32_t bit_score;
+} sp_rescore;
+
+sp_ctx *sp_ctx_create(const sp_search_params *p);
+void sp_ctx_destroy(sp_ctx *c);
+
+/* target set: ASCII residues concatenated, offsets[n+1]; keys may be NULL (key = index).  Builds the masked
+   sequence store and the k-mer index on the host and stages both into HBM. */
+int sp_ctx_set_targets(sp_ctx *c, const char *residues, const uint64_t *offsets, const uint32_t *keys, uint64_t n);
+/* query batch: ASCII residues concatenated, offsets[n+1]; uploaded once, stays resident until replaced */
+int sp_ctx_set_queries(sp_ctx *c, const char *residues, const uint64_t *offsets, uint64_t n);
+
+/* prefilter all resident queries; results stay on the device until fetched */
+int sp_ctx_prefilter(sp_ctx *c);
+/* hits: n_queries * max_seqs entries, counts: n_queries entries; seq_id = 0-based target index */
+int sp_ctx_get_hits(sp_ctx *c, sp_hit *hits, uint32_t *counts);
+int sp_ctx_max_seqs(const sp_ctx *c);
+
+/* align (query index, target index) pairs of the resident batch.  results[n]; cigars: caller buffer of cigar_cap
+   bytes, *cigar_used returns the bytes needed/used (SP_ERR_OVERFLOW if cigar_cap is too small). */
+int sp_ctx_align(sp_ctx *c, const uint32_t *query_idx, const uint32_t *target_idx, uint64_t n, sp_alignment *results,
+                 char *cigars, uint64_t cigar_cap, uint64_t *cigar_used);
+/* rescorediagonal core: mode 1 = substitution score, 2 = score + start/end */
+int sp_ctx_rescore(sp_ctx *c, const uint32_t *query_idx, const uint32_t *target_idx, const int16_t *diagonal, uint64_t n,
+                   int mode, sp_rescore *results);
+
+/* counters / timings of the last call, by name: "kmers", "db_matches", "diagonals", "diag_residues",
+   "hits", "index_entries", "masked_residues", "target_residues", "kmer_thr", "bin_size",
+   "ms_prep", "ms_match", "ms_score", "ms_select", "ms_sw_forward", "ms_sw_reverse", "ms_traceback",
+   "ms_index_build", "ms_upload" */
+double sp_ctx_stat(const sp_ctx *c, const char *name);
+/* raw HIP stream the context launches on (hipStream_t), for callers that time with their own events */
+void *sp_ctx_stream(const sp_ctx *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

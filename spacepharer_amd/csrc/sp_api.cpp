@@ -1,0 +1,274 @@
+// C ABI (include/spacepharer_amd.h): process-level state + the in-memory search context.
+#include "../../include/spacepharer_amd.h"
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "sp_gpu.h"
+#include "sp_host.h"
+#include "sp_modules.h"
+
+namespace {
+thread_local std::string g_err;
+int g_device = -1;
+std::mutex g_mu;
+
+double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+namespace sp {
+void setLastError(const std::string &e) { g_err = e; }
+int currentDevice() {
+    if (g_device >= 0) return g_device;
+    const char *lr = getenv("LOCAL_RANK");
+    return lr ? atoi(lr) : 0;
+}
+}  // namespace sp
+
+struct sp_ctx {
+    sp_search_params par;
+    std::string seedName, subName;
+    sp::SubMat seed, ungapped, aln;
+    sp::Gpu gpu;
+    sp::TargetSet targets;
+    sp::KmerIndex index;         // host copy is dropped after upload
+    uint64_t indexEntries = 0;
+    int kmerThr = 0;
+    unsigned binSize = 2;
+    int threads = 1;
+    std::vector<uint8_t> qres; std::vector<uint32_t> qoff; std::vector<char> qascii; std::vector<uint64_t> qasciiOff;
+    sp::Evaluer evGapped, evGapless;
+    bool haveGapped = false, haveGapless = false;
+    std::map<std::string, double> stats;
+    bool tablesUp = false;
+};
+
+extern "C" {
+
+const char *sp_last_error(void) { return g_err.c_str(); }
+const char *sp_version(void) { return "spacepharer_amd 0.1 (gfx950)"; }
+
+int sp_init(int device_mask) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    sp::Gpu probe;
+    int n = probe.deviceCount();
+    if (n <= 0) { g_err = "sp_init: no HIP device available (this library has no CPU path)"; return SP_ERR_DEVICE; }
+    int dev = -1;
+    if (device_mask) { for (int i = 0; i < 32; i++) if (device_mask & (1 << i)) { dev = i; break; } }
+    if (dev < 0) { const char *lr = getenv("LOCAL_RANK"); dev = lr ? atoi(lr) : 0; }
+    g_device = dev % n;
+    return SP_OK;
+}
+
+void sp_shutdown(void) { std::lock_guard<std::mutex> lk(g_mu); g_device = -1; }
+
+int sp_device_count(void) { sp::Gpu probe; return probe.deviceCount(); }
+
+void sp_default_params(sp_search_params *p) {
+    memset(p, 0, sizeof(*p));
+    p->seed_sub_mat = "VTML80.out";
+    p->sub_mat = "VTML40.out";
+    p->sensitivity = 5.7f;
+    p->kmer_score = INT_MAX;
+    p->max_seqs = 300;
+    p->min_ungapped_score = 15;
+    p->mask = 1;
+    p->gap_open = 16;
+    p->gap_extend = 2;
+    p->evalue = 200.0;
+    p->threads = 0;
+    p->bin_size = 0;
+}
+
+sp_ctx *sp_ctx_create(const sp_search_params *p) {
+    std::unique_ptr<sp_ctx> c(new sp_ctx);
+    c->par = *p;
+    c->seedName = p->seed_sub_mat ? p->seed_sub_mat : "VTML80.out";
+    c->subName = p->sub_mat ? p->sub_mat : "VTML40.out";
+    c->par.seed_sub_mat = c->seedName.c_str();
+    c->par.sub_mat = c->subName.c_str();
+    c->threads = p->threads > 0 ? p->threads : (int) std::max(1u, std::thread::hardware_concurrency());
+    std::string err;
+    // bit factors / score biases: prefiltering/Prefiltering.cpp:63-67, alignment/Alignment.cpp:157-162
+    if (!c->seed.load(c->seedName, (double) 8.0f, (double) -0.2f, err) || !c->ungapped.load(c->subName, (double) 2.0f, (double) -0.2f, err) ||
+        !c->aln.load(c->subName, (double) 2.0f, (double) 0.0f, err)) { g_err = err; return nullptr; }
+    c->kmerThr = sp::kmerThreshold(p->sensitivity, p->kmer_score, sp::kKmer);
+    if (!c->gpu.init(sp::currentDevice(), err)) { g_err = "sp_ctx_create: " + err + " (this library has no CPU path)"; return nullptr; }
+    c->stats["kmer_thr"] = c->kmerThr;
+    return c.release();
+}
+
+void sp_ctx_destroy(sp_ctx *c) { delete c; }
+
+int sp_ctx_max_seqs(const sp_ctx *c) { return (int) std::min<uint64_t>(c->targets.n, (uint64_t) c->par.max_seqs); }
+
+int sp_ctx_set_targets(sp_ctx *c, const char *residues, const uint64_t *offsets, const uint32_t *keys, uint64_t n) {
+    if (!c || !residues || !offsets) { g_err = "sp_ctx_set_targets: null argument"; return SP_ERR_ARG; }
+    std::string err;
+    double t0 = nowMs();
+    if (!c->tablesUp) {
+        std::vector<uint32_t> ext3;
+        sp::buildExt3(c->seed, ext3, c->threads);
+        if (!c->gpu.uploadTables(ext3, c->seed, c->ungapped, c->aln, err)) { g_err = err; return SP_ERR_DEVICE; }
+        c->tablesUp = true;
+    }
+    double t1 = nowMs();
+    sp::prepareTargets(c->seed, residues, offsets, keys, (size_t) n, c->par.mask != 0, c->threads, c->targets);
+    sp::buildIndex(c->seed, c->targets, c->kmerThr, c->threads, c->index);
+    c->indexEntries = c->index.entries.size();
+    double t2 = nowMs();
+    if (!c->gpu.uploadTargets(c->targets, c->index, err)) { g_err = err; return SP_ERR_DEVICE; }
+    c->index = sp::KmerIndex();     // HBM holds the index now
+    double t3 = nowMs();
+    c->binSize = c->par.bin_size ? c->par.bin_size : sp::binSizeFor((size_t) n, sp::hostL2CacheSize());
+    c->stats["ms_ext_table"] = t1 - t0;
+    c->stats["ms_index_build"] = t2 - t1;
+    c->stats["ms_upload"] = t3 - t2;
+    c->stats["index_entries"] = (double) c->indexEntries;
+    c->stats["masked_residues"] = (double) c->targets.maskedCount;
+    c->stats["target_residues"] = (double) c->targets.residues();
+    c->stats["bin_size"] = c->binSize;
+    c->haveGapped = c->haveGapless = false;
+    return SP_OK;
+}
+
+int sp_ctx_set_queries(sp_ctx *c, const char *residues, const uint64_t *offsets, uint64_t n) {
+    if (!c || !residues || !offsets) { g_err = "sp_ctx_set_queries: null argument"; return SP_ERR_ARG; }
+    if (offsets[n] >= (1ull << 32)) { g_err = "query batch larger than 4 GiB of residues"; return SP_ERR_ARG; }
+    c->qres.resize(offsets[n]);
+    c->qoff.resize(n + 1);
+    c->qascii.assign(residues, residues + offsets[n]);
+    c->qasciiOff.assign(offsets, offsets + n + 1);
+    for (uint64_t i = 0; i <= n; i++) c->qoff[i] = (uint32_t) offsets[i];
+    for (uint64_t i = 0; i < offsets[n]; i++) c->qres[i] = c->seed.aa2num[(uint8_t) residues[i]];
+    std::string err;
+    if (!c->gpu.uploadQueries(c->qres.data(), c->qoff.data(), (size_t) n, err)) { g_err = err; return SP_ERR_DEVICE; }
+    return SP_OK;
+}
+
+int sp_ctx_prefilter(sp_ctx *c) {
+    if (!c || c->targets.n == 0) { g_err = "sp_ctx_prefilter: no target set"; return SP_ERR_STATE; }
+    std::string err;
+    // maxResListLen = min(#targets, --max-seqs): prefiltering/Prefiltering.cpp:170
+    const int maxHits = sp_ctx_max_seqs(c);
+    if (!c->gpu.prefilter(c->kmerThr, c->binSize, maxHits, c->par.min_ungapped_score, err)) { g_err = err; return SP_ERR_OVERFLOW; }
+    sp::PrefilterCounters pc = c->gpu.counters();
+    sp::KernelTimes kt = c->gpu.times();
+    c->stats["kmers"] = (double) pc.kmers; c->stats["db_matches"] = (double) pc.dbMatches; c->stats["diagonals"] = (double) pc.diagonals;
+    c->stats["diag_residues"] = (double) pc.diagResidues; c->stats["hits"] = (double) pc.hits;
+    c->stats["ms_prep"] = kt.prep; c->stats["ms_match"] = kt.match; c->stats["ms_score"] = kt.score; c->stats["ms_select"] = kt.select;
+    return SP_OK;
+}
+
+int sp_ctx_get_hits(sp_ctx *c, sp_hit *hits, uint32_t *counts) {
+    std::vector<sp::GpuHit> h; std::vector<uint32_t> cnt; std::string err;
+    if (!c->gpu.downloadHits(h, cnt, err)) { g_err = err; return SP_ERR_DEVICE; }
+    const size_t nq = cnt.size(); const int mh = c->gpu.maxHits();
+    for (size_t q = 0; q < nq; q++) {
+        counts[q] = cnt[q];
+        for (uint32_t i = 0; i < cnt[q]; i++) {
+            const sp::GpuHit &g = h[q * mh + i];
+            sp_hit &o = hits[q * mh + i];
+            o.seq_id = g.seqId; o.score = g.score; o.diagonal = (int16_t) g.diag; o.pad = 0;
+        }
+    }
+    return SP_OK;
+}
+
+static bool ensureEvaluers(sp_ctx *c, bool gapped, std::string &err) {
+    if (gapped && !c->haveGapped) { if (!c->evGapped.init(c->aln.name, c->par.gap_open, c->par.gap_extend, c->targets.residues(), err)) return false; c->haveGapped = true; }
+    if (!gapped && !c->haveGapless) { if (!c->evGapless.init(c->aln.name, -1, -1, c->targets.residues(), err)) return false; c->haveGapless = true; }
+    return true;
+}
+
+int sp_ctx_align(sp_ctx *c, const uint32_t *qidx, const uint32_t *tidx, uint64_t n, sp_alignment *res, char *cigars, uint64_t cigarCap, uint64_t *cigarUsed) {
+    if (!c || c->targets.n == 0) { g_err = "sp_ctx_align: no target set"; return SP_ERR_STATE; }
+    std::string err;
+    if (!ensureEvaluers(c, true, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
+    std::vector<sp::SwPair> pairs(n);
+    for (uint64_t i = 0; i < n; i++) { pairs[i].query = qidx[i]; pairs[i].target = tidx[i]; }
+    std::vector<sp::SwForward> fwd;
+    if (!c->gpu.swForward(pairs.data(), (size_t) n, c->par.gap_open, c->par.gap_extend, fwd, err)) { g_err = err; return SP_ERR_DEVICE; }
+    // E-value gate between the passes (StripedSmithWaterman.cpp:188-200); scores repeat a lot, so memoise per (qLen, score)
+    std::vector<uint8_t> pass(n, 0);
+    std::map<uint64_t, double> memo;
+    for (uint64_t i = 0; i < n; i++) {
+        sp_alignment &r = res[i];
+        memset(&r, 0, sizeof(r));
+        const uint32_t qL = c->qoff[qidx[i] + 1] - c->qoff[qidx[i]];
+        const uint32_t tL = (uint32_t) (c->targets.offsets[tidx[i] + 1] - c->targets.offsets[tidx[i]]);
+        r.db_key = c->targets.keys[tidx[i]];
+        r.raw_score = fwd[i].score; r.q_len = qL; r.db_len = tL;
+        r.q_start = -1; r.db_start = -1; r.q_end = fwd[i].readEnd; r.db_end = fwd[i].refEnd;
+        r.bit_score = (int) (c->evGapped.bitScore(fwd[i].score) + 0.5);
+        if (fwd[i].refEnd == -1) continue;
+        const uint64_t mk = ((uint64_t) qL << 32) | (uint32_t) fwd[i].score;
+        auto it = memo.find(mk);
+        if (it == memo.end()) it = memo.emplace(mk, c->evGapped.evalue(fwd[i].score, qL)).first;
+        r.evalue = it->second;
+        pass[i] = !(r.evalue > c->par.evalue);
+    }
+    std::vector<sp::SwFull> full; std::vector<char> bt;
+    if (!c->gpu.swFinish(pass.data(), full, bt, err)) { g_err = err; return SP_ERR_DEVICE; }
+    uint64_t used = 0;
+    for (uint64_t i = 0; i < n; i++) if (pass[i]) used += (uint64_t) full[i].alnLen + 1;
+    if (cigarUsed) *cigarUsed = used;
+    if (used > cigarCap) { g_err = "sp_ctx_align: cigar buffer too small"; return SP_ERR_OVERFLOW; }
+    uint64_t at = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (!pass[i]) continue;
+        sp_alignment &r = res[i];
+        if (full[i].status != 0) { g_err = "sp_ctx_align: traceback failed for a pair (status " + std::to_string(full[i].status) + ")"; return SP_ERR_OVERFLOW; }
+        r.q_start = full[i].qStart; r.db_start = full[i].dbStart; r.aln_len = (uint32_t) full[i].alnLen;
+        r.seq_id = (float) full[i].identities / (float) full[i].alnLen;     // Util::computeSeqId, SEQ_ID_ALN_LEN
+        r.cigar_offset = (uint32_t) at;
+        memcpy(cigars + at, bt.data() + full[i].btOffset, (size_t) full[i].alnLen);
+        cigars[at + full[i].alnLen] = '\0';
+        at += (uint64_t) full[i].alnLen + 1;
+        r.passed = (r.evalue <= c->par.evalue) && (r.seq_id >= 0.0);     // Alignment::checkCriteria, -c 0 --min-seq-id 0 --min-aln-len 0
+    }
+    sp::KernelTimes kt = c->gpu.times();
+    c->stats["ms_sw_forward"] = kt.swForward; c->stats["ms_sw_reverse"] = kt.swReverse; c->stats["ms_traceback"] = kt.traceback;
+    return SP_OK;
+}
+
+int sp_ctx_rescore(sp_ctx *c, const uint32_t *qidx, const uint32_t *tidx, const int16_t *diag, uint64_t n, int mode, sp_rescore *res) {
+    if (!c || c->targets.n == 0) { g_err = "sp_ctx_rescore: no target set"; return SP_ERR_STATE; }
+    std::string err;
+    if (!ensureEvaluers(c, false, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
+    std::vector<sp::SwPair> pairs(n); std::vector<uint16_t> d(n);
+    for (uint64_t i = 0; i < n; i++) { pairs[i].query = qidx[i]; pairs[i].target = tidx[i]; d[i] = (uint16_t) diag[i]; }
+    std::vector<sp::DiagRescore> out;
+    if (!c->gpu.rescoreDiagonals(pairs.data(), d.data(), (size_t) n, mode, out, err)) { g_err = err; return SP_ERR_DEVICE; }
+    for (uint64_t i = 0; i < n; i++) {
+        const uint32_t qL = c->qoff[qidx[i] + 1] - c->qoff[qidx[i]];
+        res[i].score = out[i].score; res[i].start_pos = out[i].startPos; res[i].end_pos = out[i].endPos; res[i].diagonal_len = out[i].diagonalLen;
+        res[i].diagonal = out[i].diagonal; res[i].dist_to_diagonal = out[i].distToDiagonal;
+        res[i].evalue = c->evGapless.evalue(out[i].score, qL);
+        res[i].bit_score = (int) (c->evGapless.bitScore(out[i].score) + 0.5);
+    }
+    return SP_OK;
+}
+
+double sp_ctx_stat(const sp_ctx *c, const char *name) {
+    auto it = c->stats.find(name);
+    return it == c->stats.end() ? NAN : it->second;
+}
+
+void *sp_ctx_stream(const sp_ctx *c) { return c->gpu.stream(); }
+
+int sp_prefilter_run(int argc, const char **argv) { return sp::runPrefilterModule(argc, argv); }
+int sp_align_run(int argc, const char **argv) { return sp::runAlignModule(argc, argv); }
+int sp_rescorediagonal_run(int argc, const char **argv) { return sp::runRescoreDiagonalModule(argc, argv); }
+
+}  // extern "C"

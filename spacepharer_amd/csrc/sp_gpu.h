@@ -1,0 +1,80 @@
+// Device side of the search path: HBM-resident tables + the HIP kernels (sp_gpu.hip).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "sp_host.h"
+
+namespace sp {
+
+struct GpuHit { uint32_t seqId; uint16_t score; uint16_t diag; };
+
+struct SwPair { uint32_t query; uint32_t target; };          // indices into the resident query batch / target set
+struct SwForward { int32_t score; int32_t refEnd; int32_t readEnd; int32_t word; };
+struct SwFull {
+    int32_t qStart, dbStart;      // from the reverse pass
+    int32_t alnLen;               // length of the backtrace
+    int32_t identities;
+    uint32_t btOffset;            // into the backtrace byte pool
+    int32_t status;               // 0 ok
+};
+struct DiagRescore { int32_t score, startPos, endPos, diagonalLen, diagonal; uint32_t distToDiagonal; };
+
+struct PrefilterCounters {       // the K, M, D, H terms of the roofline formula
+    uint64_t kmers;              // similar k-mers generated (scanned windows only)
+    uint64_t dbMatches;          // index entries fetched
+    uint64_t diagonals;          // double-hit diagonals scored
+    uint64_t diagResidues;       // target residues read while scoring
+    uint64_t hits;               // hits written
+    uint64_t overflowQueries;    // queries whose hit stream exceeded the supported size
+};
+
+struct KernelTimes {             // HIP-event time of the last prefilter()/align() call, milliseconds
+    float prep = 0, match = 0, score = 0, select = 0, swForward = 0, swReverse = 0, traceback = 0;
+};
+
+class Gpu {
+public:
+    Gpu();
+    ~Gpu();
+    bool init(int device, std::string &err);
+    int deviceCount() const;
+    const std::string &deviceName() const { return name_; }
+
+    bool uploadTables(const std::vector<uint32_t> &ext3, const SubMat &seed, const SubMat &ungapped, const SubMat &aln, std::string &err);
+    bool uploadTargets(const TargetSet &ts, const KmerIndex &idx, std::string &err);
+    // queries: numeric residues (seed-matrix numbering) concatenated; off has nq+1 entries
+    bool uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std::string &err);
+    size_t numQueries() const { return nq_; }
+
+    // k-mer prefilter + ungapped diagonal scoring + selection for every resident query
+    bool prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore, std::string &err);
+    bool downloadHits(std::vector<GpuHit> &hits, std::vector<uint32_t> &counts, std::string &err);
+    PrefilterCounters counters() const { return counters_; }
+    KernelTimes times() const { return times_; }
+    int maxHits() const { return maxHits_; }
+
+    // Smith-Waterman (align module): forward pass for all pairs, then reverse pass + banded traceback for
+    // the pairs whose flag is set (the host applies the E-value gate in between)
+    bool swForward(const SwPair *pairs, size_t n, int gapOpen, int gapExtend, std::vector<SwForward> &out, std::string &err);
+    bool swFinish(const uint8_t *passMask, std::vector<SwFull> &out, std::vector<char> &backtraces, std::string &err);
+
+    // rescorediagonal: ungapped score on one diagonal of the UNMASKED residues, align matrix, no composition bias
+    bool rescoreDiagonals(const SwPair *pairs, const uint16_t *diags, size_t n, int mode, std::vector<DiagRescore> &out, std::string &err);
+
+    void sync();
+    void *stream() const { return stream_; }
+
+private:
+    struct Impl;
+    Impl *d_;
+    void *stream_ = nullptr;
+    std::string name_;
+    size_t nq_ = 0;
+    int maxHits_ = 0;
+    PrefilterCounters counters_{};
+    KernelTimes times_{};
+};
+
+}  // namespace sp

@@ -1,0 +1,778 @@
+// HIP kernels (gfx950 / MI355X) for SpacePHARER's spacer->phage-ORF search hot path, and the device context
+// that keeps the target index, the target residues and the similar-k-mer tables resident in HBM.
+//
+// Integer scan/lookup work bounded by random HBM gathers -- no MFMA.  Design notes are in DESIGN.md; the
+// reference semantics each kernel reproduces are cited next to it (paths under lib/mmseqs/src/).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+#include "sp_gpu.h"
+
+// the reference's AVX2 build has no FMA contraction; a few float/double expressions below must round identically
+#pragma clang fp contract(off)
+
+namespace sp {
+
+#define HIP_OK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            err = std::string(#call) + ": " + hipGetErrorString(e_);                                   \
+            return false;                                                                              \
+        }                                                                                              \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------
+// wave-level helpers (wave = 64 lanes)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int laneId() { return (int) (threadIdx.x & 63); }
+
+// LDS traffic between lanes of ONE wave: order it without a workgroup barrier (the four waves of a block work
+// on different queries and run different trip counts)
+__device__ __forceinline__ void waveSync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t waveSum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__device__ __forceinline__ uint64_t laneMaskLt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
+
+// bitonic sort of n (power of two) u64 keys by one wave; keys may live in LDS or in global scratch
+__device__ void waveBitonicSort(uint64_t *keys, uint32_t n, int lane) {
+    for (uint32_t k = 2; k <= n; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = lane; t < (n >> 1); t += 64) {
+                // t-th compare-exchange of this stage: insert a zero bit at position log2(j)
+                const uint32_t lo = t & (j - 1);
+                const uint32_t i = ((t - lo) << 1) | lo;
+                const uint32_t p = i | j;
+                const uint64_t a = keys[i], b = keys[p];
+                const bool up = ((i & k) == 0);
+                if ((a > b) == up) { keys[i] = b; keys[p] = a; }
+            }
+            waveSync();
+        }
+    }
+}
+
+__device__ __forceinline__ int extScore(uint32_t packed) { return (int) (packed >> 16) - 32768; }
+__device__ __forceinline__ uint32_t extIndex(uint32_t packed) { return packed & 0xFFFFu; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// K_prep: per query -- local composition bias, per-window k-mer thresholds, ungapped-profile correction
+//   SubstitutionMatrix::calcLocalAaBiasCorrection   commons/SubstitutionMatrix.cpp:85-114
+//   QueryMatcher::match threshold                    prefiltering/QueryMatcher.cpp:205-219
+//   UngappedAlignment::createProfile                 prefiltering/UngappedAlignment.cpp:295-355
+// one thread per query (spacer peptides are 9..30 residues)
+// ---------------------------------------------------------------------------------------------------------------
+struct PrepArgs {
+    const uint8_t *qres; const uint32_t *qoff; uint32_t nq;
+    const short *seedSub;      // 21x21
+    const double *seedBack;    // 21
+    const signed char *ungSub; // 21x21
+    int kmerThr; int ungMinAbs;   // |min S_ungapped|
+    float *biasf; short *qthr; signed char *qcorr; int *qbias; int *qself;
+};
+
+__global__ void k_prep(PrepArgs a) {
+    const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= a.nq) return;
+    const uint32_t o = a.qoff[qi];
+    const int L = (int) (a.qoff[qi + 1] - o);
+    const uint8_t *q = a.qres + o;
+    int aaBias = 0;
+    for (int i = 0; i < L; i++) {
+        const int minPos = max(0, i - 20), maxPos = min(L, i + 20);
+        const short *row = a.seedSub + q[i] * kAlph;
+        int sum = 0;
+        for (int j = minPos; j < maxPos; j++) sum += row[q[j]];
+        sum -= row[q[i]];
+        float d = (float) sum;
+        d = (float) ((double) d / (-1.0 * (double) (float) (maxPos - minPos)));
+        for (int x = 0; x < kAlph; x++) d = (float) ((double) d + a.seedBack[x] * (double) (float) row[x]);
+        a.biasf[o + i] = d;
+        float c = d;
+        c = (float) ((c < 0.0) ? (double) (c / 4) - 0.5 : (double) (c / 4) + 0.5);
+        const signed char cc = (signed char) c;
+        a.qcorr[o + i] = cc;
+        aaBias = (cc < aaBias) ? cc : aaBias;
+    }
+    if (aaBias > 0) aaBias = 0;
+    a.qbias[qi] = a.ungMinAbs + abs(aaBias);
+    // windows
+    for (int i = 0; i < L; i++) {
+        short t = -1;
+        if (i + kSpan <= L) {
+            float bc = 0; bool hasX = false;
+            const int pp[6] = {0, 1, 3, 4, 5, 7};
+#pragma unroll
+            for (int p = 0; p < 6; p++) { bc += a.biasf[o + i + pp[p]]; hasX |= (q[i + pp[p]] == kX); }
+            if (!hasX) {
+                const short b = (short) ((bc < 0.0) ? (double) bc - 0.5 : (double) bc + 0.5);
+                int v = a.kmerThr - b; if (v < 0) v = 0;
+                t = (short) v;
+            }
+        }
+        a.qthr[o + i] = t;
+    }
+    // self score on diagonal 0 (QueryMatcher::rescoreHits, prefiltering/QueryMatcher.cpp:489-494)
+    int mx = 0, sc = 0;
+    for (int i = 0; i < L; i++) { sc += a.ungSub[q[i] * kAlph + q[i]] + a.qcorr[o + i]; sc = sc < 0 ? 0 : sc; mx = sc > mx ? sc : mx; }
+    a.qself[qi] = mx;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K_match: one wavefront per query (persistent waves pulling queries from an atomic counter)
+//   similar k-mer lists        KmerGenerator::generateKmerList / calculateArrayProduct, KmerGenerator.cpp:107-216
+//   index lookup + hit stream  QueryMatcher::match, QueryMatcher.cpp:188-307
+//   double-hit detection       CacheFriendlyOperations::findDuplicates, CacheFriendlyOperations.cpp:146-235
+//
+// The reference scans the hit stream bin by bin with a byte array "previous 8-bit diagonal per target".  Per
+// target that is a sequential automaton over the target's hits in stream order, so here the hits of a query
+// are sorted by (target, stream position) in LDS and the automaton runs on adjacent elements:
+//   recorded(h)  <=>  diag8(h) == diag8(previous hit of the same target)   (previous := 0 for the first hit)
+//   kept(h)      <=>  recorded(h) and (no earlier recorded hit of the target, or diag8 differs from the last one)
+// Only windows [0, lastWindow) are scanned (CacheFriendlyOperations.cpp:43 with QueryMatcher.cpp:285-291).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kHitCap = 2048;        // hits per query held in LDS
+constexpr int kSpillCap = 65535;     // hits per query in the per-wave HBM scratch (16-bit stream index)
+constexpr int kATile = 256;
+constexpr int kBTile = 512;
+constexpr int kCntB = 384;
+constexpr uint32_t kMaxKmerResult = 262144u * 32u;   // KmerGenerator.h:45
+constexpr int kWavesPerBlock = 4;
+
+struct DiagRec { uint32_t seqId; uint16_t diag; uint16_t idx; };
+
+struct MatchArgs {
+    const uint8_t *qres; const uint32_t *qoff; uint32_t nq; const short *qthr;
+    const uint32_t *ext3;           // 8000 x 8000 packed (score+32768)<<16 | index
+    const uint32_t *ioff;           // 20^6 + 1
+    const uint64_t *ientries;       // seqId | pos << 32
+    uint64_t *spill;                // per-wave scratch: kSpillCap+1 keys (+ bitmap) each
+    uint32_t *queue;                // work counter
+    DiagRec *diagRec; uint32_t *diagQuery; uint32_t diagCap; uint32_t *diagCursor;
+    uint32_t *qDiagBase; uint32_t *qDiagCnt;
+    unsigned long long *counters;   // [0]=kmers [1]=dbMatches [2]=overflow queries
+};
+
+constexpr size_t kSpillWordsPerWave = 65536 + 65536 / 64;   // keys + kept-bitmap (as u64 words)
+
+__device__ void markKept(const uint64_t *keys, uint32_t M, uint32_t *bits, int lane) {
+    for (uint32_t base = 0; base < M; base += 64) {
+        const uint32_t t = base + lane;
+        if (t < M) {
+            const uint32_t id = (uint32_t) (keys[t] >> 32);
+            const bool head = (t == 0) || ((uint32_t) (keys[t - 1] >> 32) != id);
+            if (head) {
+                uint32_t prev = 0, lastRec = 0; bool hasRec = false;
+                for (uint32_t u = t; u < M; u++) {
+                    const uint64_t k = keys[u];
+                    if ((uint32_t) (k >> 32) != id) break;
+                    const uint32_t d = (uint32_t) (k & 0xFF);
+                    const bool rec = (d == prev);
+                    prev = d;
+                    if (rec) {
+                        if (!hasRec || lastRec != d) atomicOr(&bits[u >> 5], 1u << (u & 31));
+                        lastRec = d; hasRec = true;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
+    __shared__ uint64_t s_keys[kWavesPerBlock][kHitCap];
+    __shared__ uint32_t s_aStart[kWavesPerBlock][kATile + 1];
+    __shared__ uint16_t s_aIdx[kWavesPerBlock][kATile];
+    __shared__ uint16_t s_bIdx[kWavesPerBlock][kBTile];
+    __shared__ uint16_t s_cntB[kWavesPerBlock][kCntB];
+    __shared__ uint32_t s_bits[kWavesPerBlock][kHitCap / 32];
+
+    const int lane = laneId();
+    const int w = (int) (threadIdx.x >> 6);
+    uint64_t *keys = s_keys[w];
+    uint32_t *aStart = s_aStart[w];
+    uint16_t *aIdx = s_aIdx[w];
+    uint16_t *bIdx = s_bIdx[w];
+    uint16_t *cntB = s_cntB[w];
+    uint32_t *bitsL = s_bits[w];
+    const uint32_t waveGlobal = blockIdx.x * kWavesPerBlock + w;
+    uint64_t *spillKeys = a.spill + (size_t) waveGlobal * kSpillWordsPerWave;
+    uint32_t *spillBits = (uint32_t *) (spillKeys + 65536);
+    unsigned long long kmersTotal = 0, matchesTotal = 0;
+
+    for (;;) {
+        uint32_t qi = 0;
+        if (lane == 0) qi = atomicAdd(a.queue, 1u);
+        qi = __shfl(qi, 0);
+        if (qi >= a.nq) break;
+        const uint32_t qo = a.qoff[qi];
+        const int L = (int) (a.qoff[qi + 1] - qo);
+        const uint8_t *q = a.qres + qo;
+        const int nScan = L - kSpan;        // windows 0 .. L-9 ; the last window (L-8) is never scanned
+        uint32_t M = 0;
+        bool overflow = false;
+
+        for (int i = 0; i < nScan; i++) {
+            const int thr = a.qthr[qo + i];
+            if (thr < 0) continue;
+            const uint32_t ia = q[i] + 20u * q[i + 1] + 400u * q[i + 3];
+            const uint32_t ib = q[i + 4] + 20u * q[i + 5] + 400u * q[i + 7];
+            const uint32_t *rowA = a.ext3 + (size_t) ia * 8000u;
+            const uint32_t *rowB = a.ext3 + (size_t) ib * 8000u;
+            const int sB0 = extScore(rowB[0]);
+            const int sA0 = extScore(rowA[0]);
+            const int cutoff1 = (short) (thr - sB0);
+            if (sA0 < cutoff1) continue;
+            const int minCut2 = (short) (thr - sA0);
+            // ---- prefix of row B with score >= minCut2: partner indices + "how many b reach cutoff c" table
+            for (uint32_t p0 = 0;; p0 += 64) {
+                const uint32_t p = p0 + lane;
+                int s = -32768, sn = -32768; uint32_t v = 0;
+                if (p < 8000u) { v = rowB[p]; s = extScore(v); }
+                if (p + 1 < 8000u) sn = extScore(rowB[p + 1]);
+                const bool valid = s >= minCut2;
+                if (valid) {
+                    if (p < (uint32_t) kBTile) bIdx[p] = (uint16_t) extIndex(v);
+                    int cLo = sn + 1; if (cLo < minCut2) cLo = minCut2;
+                    for (int c = cLo; c <= s; c++) { const int at = c - minCut2; if (at < kCntB) cntB[at] = (uint16_t) (p + 1); }
+                }
+                if (__ballot(valid) != ~0ull) break;
+            }
+            waveSync();
+            // ---- tiles of row A, flattened (a, b) enumeration in the reference's list order
+            uint32_t kBase = 0;
+            bool lastTile = false;
+            for (uint32_t a0 = 0; a0 < 8000u && !lastTile; a0 += kATile) {
+                uint32_t tileK = 0, nATile = kATile;
+                for (int j = 0; j < kATile / 64; j++) {
+                    const uint32_t ai = a0 + j * 64 + lane;
+                    int s = -32768; uint32_t v = 0;
+                    if (ai < 8000u) { v = rowA[ai]; s = extScore(v); }
+                    const bool ok = s >= cutoff1;
+                    uint32_t nb = 0;
+                    if (ok) { const int at = (short) (thr - s) - minCut2; nb = (at >= 0 && at < kCntB) ? cntB[at] : 0; }
+                    const uint32_t incl = waveInclusiveScan(nb, lane);
+                    aStart[j * 64 + lane] = tileK + incl - nb;
+                    aIdx[j * 64 + lane] = (uint16_t) extIndex(v);
+                    tileK += __shfl(incl, 63);
+                    const uint64_t okMask = __ballot(ok);
+                    if (okMask != ~0ull) { lastTile = true; nATile = j * 64 + __popcll(okMask); break; }
+                }
+                if (lane == 0) aStart[nATile] = tileK;
+                waveSync();
+                if (kBase + tileK > kMaxKmerResult - 1) { tileK = kMaxKmerResult - 1 - kBase; lastTile = true; }
+                for (uint32_t k0 = 0; k0 < tileK; k0 += 64) {
+                    const uint32_t k = k0 + lane;
+                    uint32_t o0 = 0, len = 0;
+                    if (k < tileK) {
+                        // largest ai with aStart[ai] <= k
+                        uint32_t lo = 0, hi = nATile;
+                        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (aStart[mid] <= k) lo = mid; else hi = mid; }
+                        const uint32_t b = k - aStart[lo];
+                        const uint32_t bi = (b < (uint32_t) kBTile) ? bIdx[b] : extIndex(rowB[b]);
+                        const uint32_t kmer = aIdx[lo] + 8000u * bi;
+                        o0 = a.ioff[kmer];
+                        len = a.ioff[kmer + 1] - o0;
+                    }
+                    const uint32_t incl = waveInclusiveScan(len, lane);
+                    const uint32_t tot = __shfl(incl, 63);
+                    uint32_t h = M + incl - len;
+                    for (uint32_t e = 0; e < len; e++, h++) {
+                        const uint64_t ent = a.ientries[o0 + e];
+                        const uint32_t seqId = (uint32_t) ent;
+                        const uint32_t diag = (uint32_t) (i - (int) (uint32_t) ((ent >> 32) & 0xFFFF)) & 0xFFFFu;
+                        const uint64_t key = ((uint64_t) seqId << 32) | ((uint64_t) (h & 0xFFFFu) << 16) | diag;
+                        if (h < (uint32_t) kHitCap) keys[h] = key;
+                        else if (h < (uint32_t) kSpillCap) spillKeys[h] = key;
+                    }
+                    M += tot;
+                }
+                kBase += tileK;
+                waveSync();
+            }
+            kmersTotal += kBase;
+        }
+        matchesTotal += M;
+        if (M > (uint32_t) kSpillCap) { overflow = true; M = 0; }
+
+        uint32_t D = 0, dbase = 0;
+        if (M > 0) {
+            const bool inLds = M <= (uint32_t) kHitCap;
+            uint32_t n = 1; while (n < M) n <<= 1;
+            uint64_t *K = keys; uint32_t *B = bitsL;
+            if (!inLds) {
+                for (uint32_t t = lane; t < (uint32_t) kHitCap; t += 64) spillKeys[t] = keys[t];
+                K = spillKeys; B = spillBits;
+            }
+            for (uint32_t t = M + lane; t < n; t += 64) K[t] = ~0ull;
+            for (uint32_t t = lane; t < (n + 31) / 32; t += 64) B[t] = 0;
+            waveSync();
+            if (inLds) waveBitonicSort(keys, n, lane); else waveBitonicSort(spillKeys, n, lane);
+            if (inLds) markKept(keys, M, bitsL, lane); else markKept(spillKeys, M, spillBits, lane);
+            waveSync();
+            uint32_t cnt = 0;
+            for (uint32_t t = lane; t < (M + 31) / 32; t += 64) cnt += __popc(B[t]);
+            D = waveSum(cnt);
+            if (D > 0) {
+                if (lane == 0) dbase = atomicAdd(a.diagCursor, D);
+                dbase = __shfl(dbase, 0);
+                if ((uint64_t) dbase + D > a.diagCap) { overflow = true; D = 0; }
+            }
+            if (D > 0) {
+                uint32_t outPos = dbase;
+                for (uint32_t base = 0; base < M; base += 64) {
+                    const uint32_t t = base + lane;
+                    const bool kept = (t < M) && ((B[t >> 5] >> (t & 31)) & 1u);
+                    const uint64_t m = __ballot(kept);
+                    if (kept) {
+                        const uint64_t k = K[t];
+                        const uint32_t at = outPos + __popcll(m & laneMaskLt(lane));
+                        DiagRec r; r.seqId = (uint32_t) (k >> 32); r.diag = (uint16_t) (k & 0xFFFF); r.idx = (uint16_t) ((k >> 16) & 0xFFFF);
+                        a.diagRec[at] = r;
+                        a.diagQuery[at] = qi;
+                    }
+                    outPos += __popcll(m);
+                }
+            }
+            waveSync();
+        }
+        if (lane == 0) {
+            a.qDiagBase[qi] = dbase;
+            a.qDiagCnt[qi] = D;
+            if (overflow) atomicAdd(&a.counters[2], 1ull);
+        }
+    }
+    if (lane == 0) { atomicAdd(&a.counters[0], kmersTotal); atomicAdd(&a.counters[1], matchesTotal); }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K_score: one lane per double-hit diagonal -- ungapped local score along the diagonal of the MASKED target
+//   UngappedAlignment::scalarDiagonalScoring / computeSingelSequenceScores / computeLongScore
+//   prefiltering/UngappedAlignment.cpp:37-51, :216-233, :368-382.  The AVX2 u8-saturating path (:67-121) equals
+//   min(255 - bias, exact), so the exact score is kept and clamped where the reference clamps.
+// ---------------------------------------------------------------------------------------------------------------
+struct ScoreArgs {
+    const DiagRec *diagRec; const uint32_t *diagQuery; const uint32_t *diagCursor; uint32_t diagCap;
+    const uint8_t *qres; const uint32_t *qoff; const signed char *qcorr;
+    const uint8_t *tmasked; const uint64_t *toff;
+    const signed char *ungSub;
+    uint16_t *diagScore;
+    unsigned long long *counters;   // [3] += residues read
+};
+
+__device__ __forceinline__ int diagRun(const signed char *sub, const uint8_t *q, const signed char *corr, const uint8_t *db, uint32_t len) {
+    int mx = 0, sc = 0;
+    for (uint32_t p = 0; p < len; p++) {
+        sc += sub[q[p] * kAlph + db[p]] + corr[p];
+        sc = sc < 0 ? 0 : sc;
+        mx = sc > mx ? sc : mx;
+    }
+    return mx;
+}
+
+__device__ int singleDiag(const signed char *sub, const uint8_t *q, const signed char *corr, int qL, const uint8_t *db, uint32_t dbLen,
+                          int diagonal, uint32_t minDist, uint32_t &read) {
+    if (diagonal >= 0 && minDist < (uint32_t) qL) {
+        const uint32_t len = min(dbLen, (uint32_t) qL - minDist);
+        read += len;
+        return diagRun(sub, q + minDist, corr + minDist, db, len);
+    } else if (diagonal < 0 && minDist < dbLen) {
+        const uint32_t len = min(dbLen - minDist, (uint32_t) qL);
+        read += len;
+        return diagRun(sub, q, corr, db + minDist, len);
+    }
+    return 0;
+}
+
+__global__ void k_score(ScoreArgs a) {
+    __shared__ signed char s_sub[kAlph * kAlph];
+    for (int t = threadIdx.x; t < kAlph * kAlph; t += blockDim.x) s_sub[t] = a.ungSub[t];
+    __syncthreads();
+    uint32_t nDiag = *a.diagCursor; if (nDiag > a.diagCap) nDiag = a.diagCap;
+    uint32_t read = 0;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nDiag; r += gridDim.x * blockDim.x) {
+        const DiagRec rec = a.diagRec[r];
+        const uint32_t qi = a.diagQuery[r];
+        const uint32_t qo = a.qoff[qi];
+        const int qL = (int) (a.qoff[qi + 1] - qo);
+        const uint64_t to = a.toff[rec.seqId];
+        const uint32_t dbLen = (uint32_t) (a.toff[rec.seqId + 1] - to);
+        const uint8_t *db = a.tmasked + to;
+        int mx;
+        if (qL >= 32768 || dbLen >= 32768) {
+            mx = 0;
+            for (uint32_t d = 1; d <= 1 + dbLen / 32768; d++) {
+                const int real = (int) (-(long long) d * 65536 + rec.diag);
+                mx = max(mx, singleDiag(s_sub, a.qres + qo, a.qcorr + qo, qL, db, dbLen, real, (uint32_t) abs(real), read));
+            }
+            for (uint32_t d = 0; d <= (uint32_t) qL / 65536; d++) {
+                const int real = (int) (d * 65536 + rec.diag);
+                mx = max(mx, singleDiag(s_sub, a.qres + qo, a.qcorr + qo, qL, db, dbLen, real, (uint32_t) abs(real), read));
+            }
+        } else {
+            const uint16_t nd = (uint16_t) (0 - rec.diag);
+            const uint32_t minDist = nd < rec.diag ? nd : rec.diag;
+            mx = singleDiag(s_sub, a.qres + qo, a.qcorr + qo, qL, db, dbLen, (int) (short) rec.diag, minDist, read);
+        }
+        a.diagScore[r] = (uint16_t) (mx > 65535 ? 65535 : mx);
+    }
+    read = waveSum(read);
+    if (laneId() == 0 && read) atomicAdd(&a.counters[3], (unsigned long long) read);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K_select: one wavefront per query -- the tail of QueryMatcher::matchQuery
+//   min-score filter, per-target best, histogram threshold, top-N cut, final order
+//   prefiltering/QueryMatcher.cpp:100-186,318-381,459-505; QueryMatcher.h:199-209;
+//   CacheFriendlyOperations.cpp:311-341 (keepMaxElement)
+// Equivalent order-free statement used here (derivation in DESIGN.md): per target keep the diagonal with the
+// highest clamped score, ties -> earliest in the hit stream; candidates are ranked by
+// (score desc, seqId & (BINSIZE-1) asc, stream position asc); the first maxHits with score >= threshold survive;
+// output is sorted by (final score desc, seqId asc).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSelCap = 1024;
+
+struct SelectArgs {
+    uint32_t nq; const DiagRec *diagRec; const uint16_t *diagScore; const uint32_t *qDiagBase; const uint32_t *qDiagCnt;
+    const int *qbias; const int *qself; const uint32_t *qoff;
+    uint8_t *diagFlag;              // scratch, one byte per diagonal
+    uint64_t *selScratch;           // per-wave HBM key scratch (65536 keys) for oversized candidate lists
+    uint32_t *queue;                // work counter (persistent waves)
+    uint32_t binMask; int maxHits; int minDiagScore;
+    GpuHit *outHits; uint32_t *outCount;
+    unsigned long long *counters;   // [4] += hits
+};
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_select(SelectArgs a) {
+    __shared__ uint64_t s_keys[kWavesPerBlock][kSelCap];
+    __shared__ uint32_t s_hist[kWavesPerBlock][256];
+    const int lane = laneId();
+    const int w = (int) (threadIdx.x >> 6);
+    uint32_t *hist = s_hist[w];
+    uint64_t *keys = s_keys[w];
+    uint64_t *scratch = a.selScratch + (size_t) (blockIdx.x * kWavesPerBlock + w) * kSpillWordsPerWave;
+    for (;;) {
+    uint32_t qi = 0;
+    if (lane == 0) qi = atomicAdd(a.queue, 1u);
+    qi = __shfl(qi, 0);
+    if (qi >= a.nq) break;
+    const uint32_t D = a.qDiagCnt[qi];
+    if (D == 0) { if (lane == 0) a.outCount[qi] = 0; continue; }
+    const uint32_t base = a.qDiagBase[qi];
+    const DiagRec *rec = a.diagRec + base;
+    const uint16_t *exact = a.diagScore + base;
+    uint8_t *flag = a.diagFlag + base;
+    const int qL = (int) (a.qoff[qi + 1] - a.qoff[qi]);
+    const int bias = a.qbias[qi];
+    const int maxC = (qL >= 32768) ? 255 : 255 - bias;          // clamp applied by scoreDiagonalAndUpdateHits
+    const int truncAt = 255 - bias;                             // UCHAR_MAX - queryBias
+    for (int t = lane; t < 256; t += 64) hist[t] = 0;
+    for (uint32_t t = lane; t < D; t += 64) flag[t] = 0;
+    waveSync();
+    // per-target best (records arrive sorted by (seqId, stream position))
+    for (uint32_t b0 = 0; b0 < D; b0 += 64) {
+        const uint32_t t = b0 + lane;
+        if (t < D) {
+            const uint32_t id = rec[t].seqId;
+            if (t == 0 || rec[t - 1].seqId != id) {
+                int bestC = a.minDiagScore - 1; uint32_t best = 0xFFFFFFFFu;
+                for (uint32_t u = t; u < D && rec[u].seqId == id; u++) {
+                    const int c = min((int) exact[u], maxC);
+                    if (c > bestC) { bestC = c; best = u; }
+                }
+                if (best != 0xFFFFFFFFu) { flag[best] = 1; atomicAdd(&hist[bestC], 1u); }
+            }
+        }
+    }
+    waveSync();
+    // QueryMatcher::computeScoreThreshold (QueryMatcher.h:199-209)
+    uint32_t thr = 0;
+    if (lane == 0) {
+        uint32_t found = 0; int t;
+        for (t = 255; t > 0; t--) { found += hist[t]; if (found >= (uint32_t) a.maxHits) break; }
+        thr = (uint32_t) t;
+        if (thr < (uint32_t) a.minDiagScore) thr = (uint32_t) a.minDiagScore;
+    }
+    thr = __shfl(thr, 0);
+    const bool truncated = (int) thr >= truncAt;
+    uint32_t nC = 0;
+    for (int t = lane; t < 256; t += 64) if ((uint32_t) t >= thr) nC += hist[t];
+    nC = waveSum(nC);
+    if (nC == 0) { if (lane == 0) a.outCount[qi] = 0; continue; }
+    const bool inLds = nC <= (uint32_t) kSelCap;
+    uint64_t *K = inLds ? keys : scratch;
+    uint32_t n = 1; while (n < nC) n <<= 1;
+    // rescale factor of the saturated branch (QueryMatcher::rescoreHits, QueryMatcher.cpp:486-505)
+    int maxSelf = a.qself[qi] - truncAt; if (maxSelf < 1) maxSelf = 1; if (maxSelf > 65535) maxSelf = 65535;
+    const float fltMax = (float) maxSelf;
+    uint32_t wr = 0;
+    for (uint32_t b0 = 0; b0 < D; b0 += 64) {
+        const uint32_t t = b0 + lane;
+        bool take = false; uint64_t key = 0;
+        if (t < D && flag[t]) {
+            int c = min((int) exact[t], maxC);
+            if ((uint32_t) c >= thr) {
+                take = true;
+                if (truncated) {
+                    uint32_t ns = (uint32_t) exact[t] - (uint32_t) truncAt;
+                    const float sc = (float) (ns < 65535u ? ns : 65535u);
+                    c = (int) (unsigned char) ((double) ((sc / fltMax) * (float) 255) + 0.5);
+                }
+                key = ((uint64_t) (255 - c) << 48) | ((uint64_t) (rec[t].seqId & a.binMask) << 32) | ((uint64_t) rec[t].idx << 16) | (uint64_t) t;
+            }
+        }
+        const uint64_t m = __ballot(take);
+        if (take) K[wr + __popcll(m & laneMaskLt(lane))] = key;
+        wr += __popcll(m);
+    }
+    for (uint32_t t = nC + lane; t < n; t += 64) K[t] = ~0ull;
+    waveSync();
+    if (inLds) waveBitonicSort(keys, n, lane); else waveBitonicSort(K, n, lane);
+    const uint32_t nOut = min(nC, (uint32_t) a.maxHits);
+    // final score + final order (score desc, seqId asc)
+    for (uint32_t t = lane; t < n; t += 64) {
+        uint64_t key = ~0ull;
+        if (t < nOut) {
+            const uint64_t k2 = K[t];
+            const uint32_t r = (uint32_t) (k2 & 0xFFFF);
+            const int c = 255 - (int) (k2 >> 48);
+            int score;
+            if (truncated) score = truncAt + (int) ((uint32_t) c * (uint32_t) maxSelf / 255u);
+            else score = (c >= truncAt) ? (int) exact[r] : c;
+            if (score > 65535) score = 65535;
+            key = ((uint64_t) (65535 - score) << 48) | ((uint64_t) rec[r].seqId << 16) | (uint64_t) r;
+        }
+        // all lanes must have read K[t] of this round before anybody overwrites: rounds are disjoint in t
+        K[t] = key;
+    }
+    waveSync();
+    uint32_t n2 = 1; while (n2 < nOut) n2 <<= 1;
+    if (inLds) waveBitonicSort(keys, n2, lane); else waveBitonicSort(K, n2, lane);
+    for (uint32_t t = lane; t < nOut; t += 64) {
+        const uint64_t k3 = K[t];
+        const uint32_t r = (uint32_t) (k3 & 0xFFFF);
+        GpuHit h; h.seqId = rec[r].seqId; h.score = (uint16_t) (65535 - (uint32_t) (k3 >> 48)); h.diag = rec[r].diag;
+        a.outHits[(size_t) qi * a.maxHits + t] = h;
+    }
+    if (lane == 0) { a.outCount[qi] = nOut; atomicAdd(&a.counters[4], (unsigned long long) nOut); }
+    waveSync();
+    }
+}
+
+#include "sp_gpu_sw.inc"
+
+// ---------------------------------------------------------------------------------------------------------------
+// device context
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    bool ensure(size_t count, std::string &err) {
+        if (count <= n && p) return true;
+        if (p) (void) hipFree(p);
+        p = nullptr; n = 0;
+        size_t want = count + count / 8 + 64;
+        hipError_t e = hipMalloc((void **) &p, want * sizeof(T));
+        if (e != hipSuccess) { err = std::string("hipMalloc: ") + hipGetErrorString(e); return false; }
+        n = want;
+        return true;
+    }
+    void release() { if (p) (void) hipFree(p); p = nullptr; n = 0; }
+};
+
+struct Gpu::Impl {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    int numCU = 256;
+    // tables
+    DevBuf<uint32_t> ext3; DevBuf<short> seedSub; DevBuf<double> seedBack; DevBuf<signed char> ungSub; DevBuf<signed char> alnSub;
+    DevBuf<short> alnSub16; DevBuf<double> alnBack;
+    int ungMinAbs = 0;
+    // targets
+    DevBuf<uint32_t> ioff; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff;
+    size_t nTargets = 0;
+    // queries
+    DevBuf<uint8_t> qres; DevBuf<uint32_t> qoff; DevBuf<float> biasf; DevBuf<short> qthr; DevBuf<signed char> qcorr; DevBuf<int> qbias; DevBuf<int> qself;
+    size_t qTotal = 0; uint32_t maxQLen = 0;
+    std::vector<uint32_t> hQoff;
+    // match / select
+    DevBuf<uint64_t> spill; DevBuf<uint32_t> queue; DevBuf<DiagRec> diagRec; DevBuf<uint32_t> diagQuery; DevBuf<uint16_t> diagScore; DevBuf<uint8_t> diagFlag;
+    DevBuf<uint32_t> qDiagBase; DevBuf<uint32_t> qDiagCnt; DevBuf<unsigned long long> counters;
+    DevBuf<GpuHit> outHits; DevBuf<uint32_t> outCount;
+    uint32_t matchBlocks = 0;
+    SwState sw;
+};
+
+Gpu::Gpu() : d_(new Impl) {}
+Gpu::~Gpu() {
+    if (d_) {
+        if (d_->stream) (void) hipStreamDestroy(d_->stream);
+        for (hipEvent_t e : d_->ev) if (e) (void) hipEventDestroy(e);
+        delete d_;
+    }
+}
+
+int Gpu::deviceCount() const { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+bool Gpu::init(int device, std::string &err) {
+    int n = 0;
+    HIP_OK(hipGetDeviceCount(&n));
+    if (n <= 0) { err = "no HIP device visible"; return false; }
+    HIP_OK(hipSetDevice(device % n));
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, device % n));
+    name_ = prop.name;
+    d_->numCU = prop.multiProcessorCount;
+    HIP_OK(hipStreamCreateWithFlags(&d_->stream, hipStreamNonBlocking));
+    for (hipEvent_t &e : d_->ev) HIP_OK(hipEventCreate(&e));
+    stream_ = d_->stream;
+    return true;
+}
+
+void Gpu::sync() { (void) hipStreamSynchronize(d_->stream); }
+
+template <typename T>
+static bool upload(DevBuf<T> &b, const T *src, size_t n, hipStream_t s, std::string &err) {
+    if (!b.ensure(n ? n : 1, err)) return false;
+    if (n) HIP_OK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+    return true;
+}
+
+bool Gpu::uploadTables(const std::vector<uint32_t> &ext3, const SubMat &seed, const SubMat &ung, const SubMat &aln, std::string &err) {
+    Impl &d = *d_;
+    if (!upload(d.ext3, ext3.data(), ext3.size(), d.stream, err)) return false;
+    short s16[kAlph * kAlph]; signed char u8[kAlph * kAlph], a8[kAlph * kAlph]; short a16[kAlph * kAlph];
+    int mn = 0;
+    for (int i = 0; i < kAlph; i++) for (int j = 0; j < kAlph; j++) {
+        s16[i * kAlph + j] = seed.sub[i][j];
+        u8[i * kAlph + j] = (signed char) ung.sub[i][j];
+        a8[i * kAlph + j] = (signed char) aln.sub[i][j];
+        a16[i * kAlph + j] = aln.sub[i][j];
+        mn = std::min<int>(mn, ung.sub[i][j]);
+    }
+    d.ungMinAbs = std::abs(mn);
+    if (!upload(d.seedSub, s16, kAlph * kAlph, d.stream, err)) return false;
+    if (!upload(d.seedBack, seed.pBack, kAlph, d.stream, err)) return false;
+    if (!upload(d.ungSub, u8, kAlph * kAlph, d.stream, err)) return false;
+    if (!upload(d.alnSub, a8, kAlph * kAlph, d.stream, err)) return false;
+    if (!upload(d.alnSub16, a16, kAlph * kAlph, d.stream, err)) return false;
+    if (!upload(d.alnBack, aln.pBack, kAlph, d.stream, err)) return false;
+    HIP_OK(hipStreamSynchronize(d.stream));
+    return true;
+}
+
+bool Gpu::uploadTargets(const TargetSet &ts, const KmerIndex &idx, std::string &err) {
+    Impl &d = *d_;
+    d.nTargets = ts.n;
+    if (!upload(d.ioff, idx.offsets.data(), idx.offsets.size(), d.stream, err)) return false;
+    if (!upload(d.ientries, idx.entries.data(), idx.entries.size(), d.stream, err)) return false;
+    if (!upload(d.tmasked, ts.masked.data(), ts.masked.size(), d.stream, err)) return false;
+    if (!upload(d.tplain, ts.plain.data(), ts.plain.size(), d.stream, err)) return false;
+    if (!upload(d.tascii, ts.ascii.data(), ts.ascii.size(), d.stream, err)) return false;
+    if (!upload(d.toff, ts.offsets.data(), ts.offsets.size(), d.stream, err)) return false;
+    HIP_OK(hipStreamSynchronize(d.stream));
+    return true;
+}
+
+bool Gpu::uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std::string &err) {
+    Impl &d = *d_;
+    nq_ = nq;
+    d.qTotal = off[nq];
+    d.hQoff.assign(off, off + nq + 1);
+    d.maxQLen = 0;
+    for (size_t i = 0; i < nq; i++) d.maxQLen = std::max(d.maxQLen, off[i + 1] - off[i]);
+    if (!upload(d.qres, res, d.qTotal, d.stream, err)) return false;
+    if (!upload(d.qoff, off, nq + 1, d.stream, err)) return false;
+    if (!d.biasf.ensure(d.qTotal + 1, err) || !d.qthr.ensure(d.qTotal + 1, err) || !d.qcorr.ensure(d.qTotal + 1, err)) return false;
+    if (!d.qbias.ensure(nq + 1, err) || !d.qself.ensure(nq + 1, err) || !d.qDiagBase.ensure(nq + 1, err) || !d.qDiagCnt.ensure(nq + 1, err) || !d.outCount.ensure(nq + 1, err)) return false;
+    HIP_OK(hipStreamSynchronize(d.stream));
+    return true;
+}
+
+bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore, std::string &err) {
+    Impl &d = *d_;
+    if (!d.ext3.p || !d.ioff.p) { err = "tables/targets not resident"; return false; }
+    if (nq_ == 0) return true;
+    maxHits_ = maxHits;
+    // persistent match grid: 2 blocks (8 waves) per CU -- bounded by the 80 KiB of LDS a block takes
+    const uint32_t blocks = (uint32_t) std::min<size_t>((nq_ + kWavesPerBlock - 1) / kWavesPerBlock, (size_t) d.numCU * 2);
+    d.matchBlocks = blocks;
+    if (!d.spill.ensure((size_t) blocks * kWavesPerBlock * kSpillWordsPerWave, err)) return false;
+    if (!d.queue.ensure(4, err) || !d.counters.ensure(8, err)) return false;
+    // diagonal buffer: generous, HBM is plentiful (64 M records = 512 MB + side arrays)
+    const size_t diagCap = std::max<size_t>((size_t) 1 << 22, std::min<size_t>((size_t) 1 << 26, nq_ * 64));
+    if (!d.diagRec.ensure(diagCap, err) || !d.diagQuery.ensure(diagCap, err) || !d.diagScore.ensure(diagCap, err) || !d.diagFlag.ensure(diagCap, err)) return false;
+    if (!d.outHits.ensure(nq_ * (size_t) maxHits, err)) return false;
+    const uint32_t selBlocks = (uint32_t) ((nq_ + kWavesPerBlock - 1) / kWavesPerBlock);
+    (void) selBlocks;
+    HIP_OK(hipMemsetAsync(d.queue.p, 0, 4 * sizeof(uint32_t), d.stream));
+    HIP_OK(hipMemsetAsync(d.counters.p, 0, 8 * sizeof(unsigned long long), d.stream));
+
+    HIP_OK(hipEventRecord(d.ev[0], d.stream));
+    PrepArgs pa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.seedSub.p, d.seedBack.p, d.ungSub.p, kmerThr, d.ungMinAbs, d.biasf.p, d.qthr.p, d.qcorr.p, d.qbias.p, d.qself.p};
+    hipLaunchKernelGGL(k_prep, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, pa);
+    HIP_OK(hipEventRecord(d.ev[1], d.stream));
+    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ioff.p, d.ientries.p, d.spill.p, d.queue.p,
+                 d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p};
+    hipLaunchKernelGGL(k_match, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+    HIP_OK(hipEventRecord(d.ev[2], d.stream));
+    ScoreArgs sa{d.diagRec.p, d.diagQuery.p, d.queue.p + 1, (uint32_t) diagCap, d.qres.p, d.qoff.p, d.qcorr.p, d.tmasked.p, d.toff.p, d.ungSub.p, d.diagScore.p, d.counters.p};
+    hipLaunchKernelGGL(k_score, dim3((unsigned) d.numCU * 8), dim3(256), 0, d.stream, sa);
+    HIP_OK(hipEventRecord(d.ev[3], d.stream));
+    SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.queue.p + 2,
+                  binSize - 1, maxHits, minDiagScore, d.outHits.p, d.outCount.p, d.counters.p};
+    hipLaunchKernelGGL(k_select, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, se);
+    HIP_OK(hipEventRecord(d.ev[4], d.stream));
+    HIP_OK(hipGetLastError());
+    unsigned long long c[8]; uint32_t qv[4];
+    HIP_OK(hipMemcpyAsync(c, d.counters.p, sizeof(c), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipMemcpyAsync(qv, d.queue.p, sizeof(qv), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipStreamSynchronize(d.stream));
+    counters_.kmers = c[0]; counters_.dbMatches = c[1]; counters_.overflowQueries = c[2]; counters_.diagResidues = c[3]; counters_.hits = c[4];
+    counters_.diagonals = qv[1];
+    (void) hipEventElapsedTime(&times_.prep, d.ev[0], d.ev[1]);
+    (void) hipEventElapsedTime(&times_.match, d.ev[1], d.ev[2]);
+    (void) hipEventElapsedTime(&times_.score, d.ev[2], d.ev[3]);
+    (void) hipEventElapsedTime(&times_.select, d.ev[3], d.ev[4]);
+    if (counters_.overflowQueries) {
+        err = std::to_string(counters_.overflowQueries) + " queries produced more index hits or diagonals than the device buffers hold";
+        return false;
+    }
+    return true;
+}
+
+bool Gpu::downloadHits(std::vector<GpuHit> &hits, std::vector<uint32_t> &counts, std::string &err) {
+    Impl &d = *d_;
+    hits.resize(nq_ * (size_t) maxHits_);
+    counts.resize(nq_);
+    if (nq_ == 0) return true;
+    HIP_OK(hipMemcpyAsync(counts.data(), d.outCount.p, nq_ * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipMemcpyAsync(hits.data(), d.outHits.p, hits.size() * sizeof(GpuHit), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipStreamSynchronize(d.stream));
+    return true;
+}
+
+#include "sp_gpu_sw_host.inc"
+
+}  // namespace sp

@@ -1,0 +1,21 @@
+// Front-end binary: `spacepharer-amd <module> <args...>` with module in {prefilter, align, rescorediagonal}.
+// Point $MMSEQS at a wrapper that sends these three module names here and every other one to the stock
+// spacepharer binary, and the unmodified workflow scripts (lib/mmseqs/data/workflow/blastp.sh:33,41,48) land
+// in the MI355X implementation.
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/spacepharer_amd.h"
+
+int main(int argc, const char **argv) {
+    if (argc < 2) { fprintf(stderr, "usage: %s <prefilter|align|rescorediagonal> <args>\n", argv[0]); return 1; }
+    int rc;
+    if (sp_init(0) != SP_OK) { fprintf(stderr, "%s\n", sp_last_error()); return 1; }
+    if (!strcmp(argv[1], "prefilter")) rc = sp_prefilter_run(argc - 2, argv + 2);
+    else if (!strcmp(argv[1], "align")) rc = sp_align_run(argc - 2, argv + 2);
+    else if (!strcmp(argv[1], "rescorediagonal")) rc = sp_rescorediagonal_run(argc - 2, argv + 2);
+    else { fprintf(stderr, "unknown module %s\n", argv[1]); return 1; }
+    if (rc != 0) fprintf(stderr, "%s\n", sp_last_error());
+    sp_shutdown();
+    return rc;
+}
