@@ -1,0 +1,222 @@
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libspacepharer_amd.so"
+
+
+class SpError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(HERE, LIB_NAME)
+
+
+def build_library():
+    """Compile the HIP extension in-tree (hipcc --offload-arch=gfx950)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "csrc")])
+    return library_path()
+
+
+class SearchParams(C.Structure):
+    _fields_ = [("seed_sub_mat", C.c_char_p), ("sub_mat", C.c_char_p), ("sensitivity", C.c_float), ("kmer_score", C.c_int),
+                ("max_seqs", C.c_int), ("min_ungapped_score", C.c_int), ("mask", C.c_int), ("gap_open", C.c_int),
+                ("gap_extend", C.c_int), ("evalue", C.c_double), ("threads", C.c_int), ("bin_size", C.c_uint)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("seq_id", C.c_uint32), ("score", C.c_int32), ("diagonal", C.c_int16), ("pad", C.c_int16)]
+
+
+class Alignment(C.Structure):
+    _fields_ = [("db_key", C.c_uint32), ("bit_score", C.c_int32), ("raw_score", C.c_int32), ("seq_id", C.c_float),
+                ("evalue", C.c_double), ("q_start", C.c_int32), ("q_end", C.c_int32), ("q_len", C.c_uint32),
+                ("db_start", C.c_int32), ("db_end", C.c_int32), ("db_len", C.c_uint32), ("aln_len", C.c_uint32),
+                ("cigar_offset", C.c_uint32), ("passed", C.c_int32)]
+
+
+class Rescore(C.Structure):
+    _fields_ = [("score", C.c_int32), ("start_pos", C.c_int32), ("end_pos", C.c_int32), ("diagonal_len", C.c_int32),
+                ("diagonal", C.c_int32), ("dist_to_diagonal", C.c_uint32), ("evalue", C.c_double), ("bit_score", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load the in-tree shared library.  Fails loudly when it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise SpError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(or make -C spacepharer_amd/csrc); there is no CPU fallback" % path)
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.sp_init.argtypes = [C.c_int]
+    L.sp_last_error.restype = C.c_char_p
+    L.sp_version.restype = C.c_char_p
+    L.sp_default_params.argtypes = [C.POINTER(SearchParams)]
+    L.sp_ctx_create.restype = vp
+    L.sp_ctx_create.argtypes = [C.POINTER(SearchParams)]
+    L.sp_ctx_destroy.argtypes = [vp]
+    L.sp_ctx_set_targets.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint64]
+    L.sp_ctx_set_queries.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint64]
+    L.sp_ctx_prefilter.argtypes = [vp]
+    L.sp_ctx_get_hits.argtypes = [vp, C.POINTER(Hit), C.POINTER(C.c_uint32)]
+    L.sp_ctx_max_seqs.argtypes = [vp]
+    L.sp_ctx_align.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(Alignment), C.c_char_p,
+                               C.c_uint64, C.POINTER(C.c_uint64)]
+    L.sp_ctx_rescore.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int16), C.c_uint64, C.c_int,
+                                 C.POINTER(Rescore)]
+    L.sp_ctx_stat.restype = C.c_double
+    L.sp_ctx_stat.argtypes = [vp, C.c_char_p]
+    L.sp_ctx_stream.restype = vp
+    L.sp_ctx_stream.argtypes = [vp]
+    for f in ("sp_prefilter_run", "sp_align_run", "sp_rescorediagonal_run"):
+        getattr(L, f).argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise SpError("%s (code %d)" % (load_library().sp_last_error().decode(), rc))
+
+
+def _concat(seqs):
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    offs = (C.c_uint64 * (len(bs) + 1))()
+    t = 0
+    for i, b in enumerate(bs):
+        offs[i] = t
+        t += len(b)
+    offs[len(bs)] = t
+    return b"".join(bs), offs
+
+
+def _run_module(fn, args):
+    L = load_library()
+    _check(L.sp_init(0))
+    arr = (C.c_char_p * len(args))(*[a.encode() for a in args])
+    rc = getattr(L, fn)(len(args), arr)
+    if rc != 0:
+        raise SpError("%s failed: %s" % (fn, L.sp_last_error().decode()))
+    return rc
+
+
+def module_prefilter(args):
+    """`prefilter <queryDB> <targetDB> <outDB> [flags]` -- same argv as the reference module."""
+    return _run_module("sp_prefilter_run", list(args))
+
+
+def module_align(args):
+    return _run_module("sp_align_run", list(args))
+
+
+def module_rescorediagonal(args):
+    return _run_module("sp_rescorediagonal_run", list(args))
+
+
+class SearchContext:
+    """matrices -> target set (masked store + k-mer index in HBM) -> query batch -> prefilter / align."""
+
+    def __init__(self, device_mask=0, **kw):
+        self.L = load_library()
+        _check(self.L.sp_init(device_mask))
+        p = SearchParams()
+        self.L.sp_default_params(C.byref(p))
+        self._keep = []
+        for k, v in kw.items():
+            if isinstance(v, str):
+                v = v.encode()
+                self._keep.append(v)
+            setattr(p, k, v)
+        self.params = p
+        self.ctx = self.L.sp_ctx_create(C.byref(p))
+        if not self.ctx:
+            raise SpError(self.L.sp_last_error().decode())
+        self.n_targets = 0
+        self.n_queries = 0
+
+    def close(self):
+        if self.ctx:
+            self.L.sp_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_targets(self, seqs, keys=None):
+        buf, offs = _concat(seqs)
+        karr = (C.c_uint32 * len(seqs))(*keys) if keys is not None else None
+        _check(self.L.sp_ctx_set_targets(self.ctx, buf, offs, karr, len(seqs)))
+        self.n_targets = len(seqs)
+
+    def set_targets_raw(self, buf, offs_u64, n):
+        _check(self.L.sp_ctx_set_targets(self.ctx, buf, offs_u64, None, n))
+        self.n_targets = n
+
+    def set_queries(self, seqs):
+        buf, offs = _concat(seqs)
+        _check(self.L.sp_ctx_set_queries(self.ctx, buf, offs, len(seqs)))
+        self.n_queries = len(seqs)
+
+    def set_queries_raw(self, buf, offs_u64, n):
+        _check(self.L.sp_ctx_set_queries(self.ctx, buf, offs_u64, n))
+        self.n_queries = n
+
+    def prefilter(self):
+        _check(self.L.sp_ctx_prefilter(self.ctx))
+
+    def hits_raw(self):
+        ms = self.L.sp_ctx_max_seqs(self.ctx)
+        hits = (Hit * (max(1, self.n_queries * ms)))()
+        counts = (C.c_uint32 * max(1, self.n_queries))()
+        _check(self.L.sp_ctx_get_hits(self.ctx, hits, counts))
+        return hits, counts, ms
+
+    def hits(self):
+        hits, counts, ms = self.hits_raw()
+        return [[(hits[q * ms + i].seq_id, hits[q * ms + i].score, hits[q * ms + i].diagonal) for i in range(counts[q])]
+                for q in range(self.n_queries)]
+
+    def align(self, pairs):
+        n = len(pairs)
+        q = (C.c_uint32 * max(1, n))(*[p[0] for p in pairs])
+        t = (C.c_uint32 * max(1, n))(*[p[1] for p in pairs])
+        res = (Alignment * max(1, n))()
+        cap = 1 << 16
+        while True:
+            buf = C.create_string_buffer(cap)
+            used = C.c_uint64()
+            rc = self.L.sp_ctx_align(self.ctx, q, t, n, res, buf, cap, C.byref(used))
+            if rc == -5 and used.value > cap:
+                cap = int(used.value) + 16
+                continue
+            _check(rc)
+            break
+        out = []
+        for i in range(n):
+            r = res[i]
+            cig = C.string_at(C.addressof(buf) + r.cigar_offset).decode() if r.aln_len else ""
+            out.append((r, cig))
+        return out
+
+    def rescore(self, triples, mode):
+        n = len(triples)
+        q = (C.c_uint32 * max(1, n))(*[p[0] for p in triples])
+        t = (C.c_uint32 * max(1, n))(*[p[1] for p in triples])
+        d = (C.c_int16 * max(1, n))(*[p[2] for p in triples])
+        res = (Rescore * max(1, n))()
+        _check(self.L.sp_ctx_rescore(self.ctx, q, t, d, n, mode, res))
+        return [res[i] for i in range(n)]
+
+    def stat(self, name):
+        return self.L.sp_ctx_stat(self.ctx, name.encode())
