@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "sp_gpu.h"
@@ -47,10 +48,23 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, int lane) {
     return v;
 }
 
+// NOTE: every value that steers wave-uniform control flow is forced into an SGPR (readfirstlane/readlane).  Left
+// in VGPRs, the compiler structurises such loops as divergent and lanes can leave a loop one by one, which
+// deadlocks against the cross-lane operations inside it.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
+__device__ __forceinline__ uint32_t lane63(uint32_t v) { return (uint32_t) __builtin_amdgcn_readlane((int) v, 63); }
+
+// work-queue pop without a divergent `if (lane == 0)`: every lane issues the add (0 for all but lane 0); the
+// compiler's atomic optimiser folds it into one atomic per wave and lane 0 receives the old counter value
+__device__ __forceinline__ uint32_t popQueue(uint32_t *queue, int lane) {
+    const uint32_t v = atomicAdd(queue, lane == 0 ? 1u : 0u);
+    return uni(v);
+}
+
 __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-    return v;
+    return uni(v);
 }
 
 __device__ __forceinline__ uint64_t laneMaskLt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
@@ -222,26 +236,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     unsigned long long kmersTotal = 0, matchesTotal = 0;
 
     for (;;) {
-        uint32_t qi = 0;
-        if (lane == 0) qi = atomicAdd(a.queue, 1u);
-        qi = __shfl(qi, 0);
+        const uint32_t qi = popQueue(a.queue, lane);
         if (qi >= a.nq) break;
-        const uint32_t qo = a.qoff[qi];
-        const int L = (int) (a.qoff[qi + 1] - qo);
+        const uint32_t qo = uni(a.qoff[qi]);
+        const int L = (int) (uni(a.qoff[qi + 1]) - qo);
         const uint8_t *q = a.qres + qo;
         const int nScan = L - kSpan;        // windows 0 .. L-9 ; the last window (L-8) is never scanned
         uint32_t M = 0;
         bool overflow = false;
 
         for (int i = 0; i < nScan; i++) {
-            const int thr = a.qthr[qo + i];
+            const int thr = (int) uni((uint32_t) (int) a.qthr[qo + i]);
             if (thr < 0) continue;
-            const uint32_t ia = q[i] + 20u * q[i + 1] + 400u * q[i + 3];
-            const uint32_t ib = q[i + 4] + 20u * q[i + 5] + 400u * q[i + 7];
+            const uint32_t ia = uni(q[i] + 20u * q[i + 1] + 400u * q[i + 3]);
+            const uint32_t ib = uni(q[i + 4] + 20u * q[i + 5] + 400u * q[i + 7]);
             const uint32_t *rowA = a.ext3 + (size_t) ia * 8000u;
             const uint32_t *rowB = a.ext3 + (size_t) ib * 8000u;
-            const int sB0 = extScore(rowB[0]);
-            const int sA0 = extScore(rowA[0]);
+            const int sB0 = (int) uni((uint32_t) extScore(rowB[0]));
+            const int sA0 = (int) uni((uint32_t) extScore(rowA[0]));
             const int cutoff1 = (short) (thr - sB0);
             if (sA0 < cutoff1) continue;
             const int minCut2 = (short) (thr - sA0);
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                     const uint32_t incl = waveInclusiveScan(nb, lane);
                     aStart[j * 64 + lane] = tileK + incl - nb;
                     aIdx[j * 64 + lane] = (uint16_t) extIndex(v);
-                    tileK += __shfl(incl, 63);
+                    tileK += lane63(incl);
                     const uint64_t okMask = __ballot(ok);
                     if (okMask != ~0ull) { lastTile = true; nATile = j * 64 + __popcll(okMask); break; }
                 }
@@ -296,7 +308,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                         len = a.ioff[kmer + 1] - o0;
                     }
                     const uint32_t incl = waveInclusiveScan(len, lane);
-                    const uint32_t tot = __shfl(incl, 63);
+                    const uint32_t tot = lane63(incl);
                     uint32_t h = M + incl - len;
                     for (uint32_t e = 0; e < len; e++, h++) {
                         const uint64_t ent = a.ientries[o0 + e];
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
             D = waveSum(cnt);
             if (D > 0) {
                 if (lane == 0) dbase = atomicAdd(a.diagCursor, D);
-                dbase = __shfl(dbase, 0);
+                dbase = uni(dbase);
                 if ((uint64_t) dbase + D > a.diagCap) { overflow = true; D = 0; }
             }
             if (D > 0) {
@@ -464,27 +476,15 @@ struct SelectArgs {
     unsigned long long *counters;   // [4] += hits
 };
 
-__global__ __launch_bounds__(64 * kWavesPerBlock) void k_select(SelectArgs a) {
-    __shared__ uint64_t s_keys[kWavesPerBlock][kSelCap];
-    __shared__ uint32_t s_hist[kWavesPerBlock][256];
-    const int lane = laneId();
-    const int w = (int) (threadIdx.x >> 6);
-    uint32_t *hist = s_hist[w];
-    uint64_t *keys = s_keys[w];
-    uint64_t *scratch = a.selScratch + (size_t) (blockIdx.x * kWavesPerBlock + w) * kSpillWordsPerWave;
-    for (;;) {
-    uint32_t qi = 0;
-    if (lane == 0) qi = atomicAdd(a.queue, 1u);
-    qi = __shfl(qi, 0);
-    if (qi >= a.nq) break;
-    const uint32_t D = a.qDiagCnt[qi];
-    if (D == 0) { if (lane == 0) a.outCount[qi] = 0; continue; }
-    const uint32_t base = a.qDiagBase[qi];
+__device__ __noinline__ void selectOne(const SelectArgs &a, const uint32_t qi, uint32_t *hist, uint64_t *keys, uint64_t *scratch, const int lane) {
+    const uint32_t D = uni(a.qDiagCnt[qi]);
+    if (D == 0) { if (lane == 0) a.outCount[qi] = 0; return; }
+    const uint32_t base = uni(a.qDiagBase[qi]);
     const DiagRec *rec = a.diagRec + base;
     const uint16_t *exact = a.diagScore + base;
     uint8_t *flag = a.diagFlag + base;
-    const int qL = (int) (a.qoff[qi + 1] - a.qoff[qi]);
-    const int bias = a.qbias[qi];
+    const int qL = (int) uni(a.qoff[qi + 1] - a.qoff[qi]);
+    const int bias = (int) uni((uint32_t) a.qbias[qi]);
     const int maxC = (qL >= 32768) ? 255 : 255 - bias;          // clamp applied by scoreDiagonalAndUpdateHits
     const int truncAt = 255 - bias;                             // UCHAR_MAX - queryBias
     for (int t = lane; t < 256; t += 64) hist[t] = 0;
@@ -514,17 +514,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_select(SelectArgs a) {
         thr = (uint32_t) t;
         if (thr < (uint32_t) a.minDiagScore) thr = (uint32_t) a.minDiagScore;
     }
-    thr = __shfl(thr, 0);
+    thr = uni(thr);
     const bool truncated = (int) thr >= truncAt;
     uint32_t nC = 0;
     for (int t = lane; t < 256; t += 64) if ((uint32_t) t >= thr) nC += hist[t];
     nC = waveSum(nC);
-    if (nC == 0) { if (lane == 0) a.outCount[qi] = 0; continue; }
+    if (nC == 0) { if (lane == 0) a.outCount[qi] = 0; return; }
     const bool inLds = nC <= (uint32_t) kSelCap;
     uint64_t *K = inLds ? keys : scratch;
     uint32_t n = 1; while (n < nC) n <<= 1;
     // rescale factor of the saturated branch (QueryMatcher::rescoreHits, QueryMatcher.cpp:486-505)
-    int maxSelf = a.qself[qi] - truncAt; if (maxSelf < 1) maxSelf = 1; if (maxSelf > 65535) maxSelf = 65535;
+    int maxSelf = (int) uni((uint32_t) a.qself[qi]) - truncAt; if (maxSelf < 1) maxSelf = 1; if (maxSelf > 65535) maxSelf = 65535;
     const float fltMax = (float) maxSelf;
     uint32_t wr = 0;
     for (uint32_t b0 = 0; b0 < D; b0 += 64) {
@@ -577,6 +577,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_select(SelectArgs a) {
     }
     if (lane == 0) { a.outCount[qi] = nOut; atomicAdd(&a.counters[4], (unsigned long long) nOut); }
     waveSync();
+}
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_select(SelectArgs a) {
+    __shared__ uint64_t s_keys[kWavesPerBlock][kSelCap];
+    __shared__ uint32_t s_hist[kWavesPerBlock][256];
+    const int lane = laneId();
+    const int w = (int) (threadIdx.x >> 6);
+    uint64_t *scratch = a.selScratch + (size_t) (blockIdx.x * kWavesPerBlock + w) * kSpillWordsPerWave;
+    for (;;) {
+        const uint32_t qi = popQueue(a.queue, lane);
+        if (qi >= a.nq) break;
+        selectOne(a, qi, s_hist[w], s_keys[w], scratch, lane);
     }
 }
 
@@ -729,22 +741,27 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     HIP_OK(hipMemsetAsync(d.queue.p, 0, 4 * sizeof(uint32_t), d.stream));
     HIP_OK(hipMemsetAsync(d.counters.p, 0, 8 * sizeof(unsigned long long), d.stream));
 
+    const bool dbg = getenv("SP_DEBUG") != nullptr;
+#define SP_DBG_SYNC(tag) do { HIP_OK(hipGetLastError()); if (dbg) { HIP_OK(hipStreamSynchronize(d.stream)); fprintf(stderr, "[sp] %s done\n", tag); } } while (0)
     HIP_OK(hipEventRecord(d.ev[0], d.stream));
     PrepArgs pa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.seedSub.p, d.seedBack.p, d.ungSub.p, kmerThr, d.ungMinAbs, d.biasf.p, d.qthr.p, d.qcorr.p, d.qbias.p, d.qself.p};
     hipLaunchKernelGGL(k_prep, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, pa);
+    SP_DBG_SYNC("k_prep");
     HIP_OK(hipEventRecord(d.ev[1], d.stream));
     MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ioff.p, d.ientries.p, d.spill.p, d.queue.p,
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p};
     hipLaunchKernelGGL(k_match, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+    SP_DBG_SYNC("k_match");
     HIP_OK(hipEventRecord(d.ev[2], d.stream));
     ScoreArgs sa{d.diagRec.p, d.diagQuery.p, d.queue.p + 1, (uint32_t) diagCap, d.qres.p, d.qoff.p, d.qcorr.p, d.tmasked.p, d.toff.p, d.ungSub.p, d.diagScore.p, d.counters.p};
     hipLaunchKernelGGL(k_score, dim3((unsigned) d.numCU * 8), dim3(256), 0, d.stream, sa);
+    SP_DBG_SYNC("k_score");
     HIP_OK(hipEventRecord(d.ev[3], d.stream));
     SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.queue.p + 2,
                   binSize - 1, maxHits, minDiagScore, d.outHits.p, d.outCount.p, d.counters.p};
     hipLaunchKernelGGL(k_select, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, se);
+    SP_DBG_SYNC("k_select");
     HIP_OK(hipEventRecord(d.ev[4], d.stream));
-    HIP_OK(hipGetLastError());
     unsigned long long c[8]; uint32_t qv[4];
     HIP_OK(hipMemcpyAsync(c, d.counters.p, sizeof(c), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipMemcpyAsync(qv, d.queue.p, sizeof(qv), hipMemcpyDeviceToHost, d.stream));
