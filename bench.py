@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- spacer-queries/s through prefilter+align on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+A "step" is one pass of the hot path over one resident batch of synthetic spacer peptides:
+    k_prep -> k_match -> k_score -> k_select -> hit download -> SW forward -> E-value gate -> SW reverse + traceback
+with the target index / residues / similar-k-mer tables and the query batch already resident in HBM.
+
+Workload (BASELINE.json configs[2], SURVEY.md section 8d "synthetic proxy"): 10 000 synthetic 30-nt spacers =
+60 000 peptides of 10 aa (even index: window of a target with one substitution, odd: background i.i.d.) against
+50 000 synthetic phage ORFs x 200 aa = 1e7 residues drawn from the VTML40 background, seed 12345.
+N > 1 (torchrun): every rank holds the full target index and searches its own 10 000 spacers (weak scaling, query
+partition like the reference's default QUERY_DB_SPLIT; no data-path collective) -- value = all spacers / max time.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+AA = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+BG = np.array([0.0819, 0.0169, 0.0453, 0.0616, 0.0465, 0.0745, 0.0217, 0.0549, 0.0582, 0.0905, 0.0274, 0.0435,
+               0.0506, 0.0375, 0.0447, 0.0533, 0.0569, 0.081, 0.0132, 0.0329])
+BG = BG / BG.sum()
+
+
+def make_workload(n_spacers, n_targets, target_len, seed):
+    rng = np.random.default_rng(seed)
+    tres = AA[rng.choice(20, size=n_targets * target_len, p=BG)]
+    toff = np.arange(n_targets + 1, dtype=np.uint64) * np.uint64(target_len)
+    nq, ql = 6 * n_spacers, 10
+    q = AA[rng.choice(20, size=nq * ql, p=BG)].reshape(nq, ql)
+    tid = rng.integers(0, n_targets, size=nq)
+    pos = rng.integers(0, target_len - ql + 1, size=nq)
+    planted = tres.reshape(n_targets, target_len)[tid[:, None], pos[:, None] + np.arange(ql)[None, :]].copy()
+    sub = rng.integers(0, ql, size=nq)
+    planted[np.arange(nq), sub] = AA[rng.integers(0, 20, size=nq)]
+    q[0::2] = planted[0::2]
+    qoff = np.arange(nq + 1, dtype=np.uint64) * np.uint64(ql)
+    return tres, toff, np.ascontiguousarray(q).reshape(-1), qoff
+
+
+def u64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def cpu_baseline(tres, toff, qres, qoff, n_sample):
+    """The oracle (scalar C port of the reference algorithm, one thread) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Alp, Oracle
+    o = Oracle(sens=5.7, max_seqs=300)
+    n_t = len(toff) - 1
+    tl = int(toff[1])
+    o.set_targets([tres[i * tl:(i + 1) * tl].tobytes() for i in range(n_t)])
+    g = json.load(__import__("gzip").open(os.path.join(ROOT, "tests/golden/spacer.json.gz")))["ref"]
+    o.set_alp(Alp.from_ref(g["alpGapped"]), Alp.from_ref(g["alpGapless"]))
+    ql = int(qoff[1])
+    t0 = time.perf_counter()
+    pairs = 0
+    for i in range(n_sample):
+        q = qres[i * ql:(i + 1) * ql].tobytes().decode()
+        for h in o.prefilter_list(q):
+            o.align(q, h[0])
+            pairs += 1
+    dt = time.perf_counter() - t0
+    o.close()
+    return {"value": (n_sample / 6.0) / dt, "unit": "spacer-queries/s", "cores": 1, "kind": "port",
+            "sample": "%d of the workload's peptides (prefilter + %d SW alignments), oracle/sp_oracle.c, single thread, "
+                      "index build excluded" % (n_sample, pairs)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spacers", type=int, default=10000)
+    ap.add_argument("--targets", type=int, default=50000)
+    ap.add_argument("--target-len", type=int, default=200)
+    ap.add_argument("--stage", default="full", choices=["full", "prefilter"])
+    ap.add_argument("--cpu-sample", type=int, default=3000, help="peptides for the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+
+    import spacepharer_amd as sa
+    tres, toff, qres, qoff = make_workload(args.spacers, args.targets, args.target_len, 12345 + 7919 * rank)
+    if rank != 0:   # same target set on every rank, different spacers
+        tres, toff, _, _ = make_workload(1, args.targets, args.target_len, 12345)
+    ctx = sa.SearchContext(device_mask=1 << local_rank)
+    t0 = time.perf_counter()
+    ctx.set_targets_raw(tres.tobytes(), u64p(toff), len(toff) - 1)
+    t_index = time.perf_counter() - t0
+    nq = len(qoff) - 1
+    ctx.set_queries_raw(qres.tobytes(), u64p(qoff), nq)
+
+    def step():
+        ctx.prefilter()
+        hits, offs, npairs = ctx.hits_compact()
+        if args.stage == "full" and npairs:
+            off = np.ctypeslib.as_array(offs)
+            h = np.ctypeslib.as_array(C.cast(hits, C.POINTER(C.c_uint32)), shape=(npairs, 3))
+            qidx = np.repeat(np.arange(nq, dtype=np.uint32), np.diff(off).astype(np.int64))
+            tidx = np.ascontiguousarray(h[:, 0])
+            ctx.align_raw(qidx, tidx)
+        return npairs
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        step()
+    stats = {"ms_match": 0.0, "ms_prep": 0.0, "ms_score": 0.0, "ms_select": 0.0, "ms_sw_forward": 0.0, "ms_sw_reverse": 0.0, "ms_traceback": 0.0}
+    barrier()
+    t0 = time.perf_counter()
+    pairs = 0
+    for _ in range(args.steps):
+        pairs = step()
+        for k in stats:
+            v = ctx.stat(k)
+            stats[k] += 0.0 if v != v else v
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    K, M, D, R, H = (ctx.stat(k) for k in ("kmers", "db_matches", "diagonals", "diag_residues", "hits"))
+    ms_match = stats["ms_match"] / args.steps
+    # algorithmic bytes of the dominant kernel (k_match) per launch: 6 B similar-k-mer table entry + 16 B offsets pair
+    # per similar k-mer, 6 B per index entry fetched, 7 B per double-hit diagonal written
+    algo_bytes = 22.0 * K + 6.0 * M + 7.0 * D
+    achieved = algo_bytes / (ms_match * 1e-3) / 1e9 if ms_match > 0 else 0.0
+    out = {
+        "metric": "spacer-queries/sec through prefilter+align; achieved HBM GB/s vs roofline",
+        "value": args.spacers * world * args.steps / dt,
+        "unit": "spacer-queries/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8/i16 (integer k-mer lookup, u8/i16 Smith-Waterman)", "data": "synthetic",
+        "config": {"workload": "%d synthetic 30-nt spacers (= %d peptides of 10 aa) vs %d synthetic phage ORFs x %d aa "
+                               "(%.1e residues), 1xMI355X per rank, %s" % (args.spacers, nq, args.targets, args.target_len,
+                                                                         args.targets * args.target_len,
+                                                                         "prefilter + ungapped + banded-SW align" if args.stage == "full" else "prefilter only"),
+                   "stage": args.stage, "pairs_aligned_per_step": pairs, "sensitivity": 5.7, "max_seqs": 300,
+                   "parallelism": "query partition x%d, index replicated" % world,
+                   "index_build_s": round(t_index, 3)},
+        "kernels_ms_per_step": {k[3:]: round(v / args.steps, 4) for k, v in stats.items()},
+        "counters_per_step": {"similar_kmers": K, "index_entries_fetched": M, "diagonals_scored": D, "diag_residues": R, "hits": H},
+        "roofline": {"bound": "hbm", "kernel": "k_match", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                     "frac": achieved / 8000.0, "traffic": None,
+                     "algorithmic_bytes_per_launch": algo_bytes},
+    }
+    if args.cpu_sample > 0:
+        out["cpu_baseline"] = cpu_baseline(tres, toff, qres, qoff, min(args.cpu_sample, nq))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

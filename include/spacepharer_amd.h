@@ -110,6 +110,9 @@ int sp_ctx_prefilter(sp_ctx *c);
 /* hits: n_queries * max_seqs entries, counts: n_queries entries; seq_id = 0-based target index */
 int sp_ctx_get_hits(sp_ctx *c, sp_hit *hits, uint32_t *counts);
 int sp_ctx_max_seqs(const sp_ctx *c);
+/* compact form: total = sp_ctx_num_hits(); hits[total] grouped by query in query order, offsets[n_queries + 1] */
+uint64_t sp_ctx_num_hits(const sp_ctx *c);
+int sp_ctx_get_hits_compact(sp_ctx *c, sp_hit *hits, uint64_t *offsets);
 
 /* align (query index, target index) pairs of the resident batch.  results[n]; cigars: caller buffer of cigar_cap
    bytes, *cigar_used returns the bytes needed/used (SP_ERR_OVERFLOW if cigar_cap is too small). */
@@ -124,6 +127,8 @@ int sp_ctx_rescore(sp_ctx *c, const uint32_t *query_idx, const uint32_t *target_
    "ms_prep", "ms_match", "ms_score", "ms_select", "ms_sw_forward", "ms_sw_reverse", "ms_traceback",
    "ms_index_build", "ms_upload" */
 double sp_ctx_stat(const sp_ctx *c, const char *name);
+/* wait for everything queued on the context's stream */
+int sp_ctx_sync(sp_ctx *c);
 /* raw HIP stream the context launches on (hipStream_t), for callers that time with their own events */
 void *sp_ctx_stream(const sp_ctx *c);
 

@@ -68,12 +68,16 @@ def load_library():
     L.sp_ctx_prefilter.argtypes = [vp]
     L.sp_ctx_get_hits.argtypes = [vp, C.POINTER(Hit), C.POINTER(C.c_uint32)]
     L.sp_ctx_max_seqs.argtypes = [vp]
+    L.sp_ctx_num_hits.restype = C.c_uint64
+    L.sp_ctx_num_hits.argtypes = [vp]
+    L.sp_ctx_get_hits_compact.argtypes = [vp, C.POINTER(Hit), C.POINTER(C.c_uint64)]
     L.sp_ctx_align.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(Alignment), C.c_char_p,
                                C.c_uint64, C.POINTER(C.c_uint64)]
     L.sp_ctx_rescore.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int16), C.c_uint64, C.c_int,
                                  C.POINTER(Rescore)]
     L.sp_ctx_stat.restype = C.c_double
     L.sp_ctx_stat.argtypes = [vp, C.c_char_p]
+    L.sp_ctx_sync.argtypes = [vp]
     L.sp_ctx_stream.restype = vp
     L.sp_ctx_stream.argtypes = [vp]
     for f in ("sp_prefilter_run", "sp_align_run", "sp_rescorediagonal_run"):
@@ -182,9 +186,17 @@ class SearchContext:
         _check(self.L.sp_ctx_get_hits(self.ctx, hits, counts))
         return hits, counts, ms
 
+    def hits_compact(self):
+        """(Hit array of all hits grouped by query, uint64 offsets[n_queries+1])"""
+        total = int(self.L.sp_ctx_num_hits(self.ctx))
+        hits = (Hit * max(1, total))()
+        offs = (C.c_uint64 * (self.n_queries + 1))()
+        _check(self.L.sp_ctx_get_hits_compact(self.ctx, hits, offs))
+        return hits, offs, total
+
     def hits(self):
-        hits, counts, ms = self.hits_raw()
-        return [[(hits[q * ms + i].seq_id, hits[q * ms + i].score, hits[q * ms + i].diagonal) for i in range(counts[q])]
+        hits, offs, _ = self.hits_compact()
+        return [[(hits[i].seq_id, hits[i].score, hits[i].diagonal) for i in range(offs[q], offs[q + 1])]
                 for q in range(self.n_queries)]
 
     def align(self, pairs):
@@ -208,6 +220,29 @@ class SearchContext:
             cig = C.string_at(C.addressof(buf) + r.cigar_offset).decode() if r.aln_len else ""
             out.append((r, cig))
         return out
+
+    def sync(self):
+        _check(self.L.sp_ctx_sync(self.ctx))
+
+    def align_raw(self, qidx, tidx):
+        """numpy uint32 arrays in, (Alignment array, cigar buffer) out -- no per-pair Python work"""
+        n = len(qidx)
+        if getattr(self, "_aln_cap", 0) < n:
+            self._aln_cap = n + n // 4 + 16
+            self._aln = (Alignment * self._aln_cap)()
+            self._cig_cap = 64 * self._aln_cap
+            self._cig = C.create_string_buffer(self._cig_cap)
+        used = C.c_uint64()
+        u32p = C.POINTER(C.c_uint32)
+        while True:
+            rc = self.L.sp_ctx_align(self.ctx, qidx.ctypes.data_as(u32p), tidx.ctypes.data_as(u32p), n, self._aln, self._cig,
+                                     self._cig_cap, C.byref(used))
+            if rc == -5 and used.value > self._cig_cap:
+                self._cig_cap = int(used.value) * 2
+                self._cig = C.create_string_buffer(self._cig_cap)
+                continue
+            _check(rc)
+            return self._aln, self._cig
 
     def rescore(self, triples, mode):
         n = len(triples)

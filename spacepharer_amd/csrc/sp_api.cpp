@@ -170,16 +170,25 @@ int sp_ctx_prefilter(sp_ctx *c) {
     return SP_OK;
 }
 
+uint64_t sp_ctx_num_hits(const sp_ctx *c) { return (uint64_t) c->gpu.counters().hits; }
+
+int sp_ctx_get_hits_compact(sp_ctx *c, sp_hit *hits, uint64_t *offsets) {
+    std::vector<sp::GpuHit> h; std::vector<uint64_t> off; std::string err;
+    if (!c->gpu.downloadHits(h, off, err)) { g_err = err; return SP_ERR_DEVICE; }
+    memcpy(offsets, off.data(), off.size() * sizeof(uint64_t));
+    for (size_t i = 0; i < h.size(); i++) { hits[i].seq_id = h[i].seqId; hits[i].score = h[i].score; hits[i].diagonal = (int16_t) h[i].diag; hits[i].pad = 0; }
+    return SP_OK;
+}
+
 int sp_ctx_get_hits(sp_ctx *c, sp_hit *hits, uint32_t *counts) {
-    std::vector<sp::GpuHit> h; std::vector<uint32_t> cnt; std::string err;
-    if (!c->gpu.downloadHits(h, cnt, err)) { g_err = err; return SP_ERR_DEVICE; }
-    const size_t nq = cnt.size(); const int mh = c->gpu.maxHits();
+    std::vector<sp::GpuHit> h; std::vector<uint64_t> off; std::string err;
+    if (!c->gpu.downloadHits(h, off, err)) { g_err = err; return SP_ERR_DEVICE; }
+    const size_t nq = off.size() - 1; const int mh = c->gpu.maxHits();
     for (size_t q = 0; q < nq; q++) {
-        counts[q] = cnt[q];
-        for (uint32_t i = 0; i < cnt[q]; i++) {
-            const sp::GpuHit &g = h[q * mh + i];
-            sp_hit &o = hits[q * mh + i];
-            o.seq_id = g.seqId; o.score = g.score; o.diagonal = (int16_t) g.diag; o.pad = 0;
+        counts[q] = (uint32_t) (off[q + 1] - off[q]);
+        for (uint64_t i = off[q]; i < off[q + 1]; i++) {
+            sp_hit &o = hits[q * mh + (i - off[q])];
+            o.seq_id = h[i].seqId; o.score = h[i].score; o.diagonal = (int16_t) h[i].diag; o.pad = 0;
         }
     }
     return SP_OK;
@@ -266,6 +275,7 @@ double sp_ctx_stat(const sp_ctx *c, const char *name) {
 }
 
 void *sp_ctx_stream(const sp_ctx *c) { return c->gpu.stream(); }
+int sp_ctx_sync(sp_ctx *c) { c->gpu.sync(); return SP_OK; }
 
 int sp_prefilter_run(int argc, const char **argv) { return sp::runPrefilterModule(argc, argv); }
 int sp_align_run(int argc, const char **argv) { return sp::runAlignModule(argc, argv); }

@@ -50,7 +50,8 @@ public:
 
     // k-mer prefilter + ungapped diagonal scoring + selection for every resident query
     bool prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore, std::string &err);
-    bool downloadHits(std::vector<GpuHit> &hits, std::vector<uint32_t> &counts, std::string &err);
+    // hits grouped by query (query order); offsets has nq+1 entries
+    bool downloadHits(std::vector<GpuHit> &hits, std::vector<uint64_t> &offsets, std::string &err);
     PrefilterCounters counters() const { return counters_; }
     KernelTimes times() const { return times_; }
     int maxHits() const { return maxHits_; }

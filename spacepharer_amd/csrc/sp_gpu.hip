@@ -472,11 +472,11 @@ struct SelectArgs {
     uint64_t *selScratch;           // per-wave HBM key scratch (65536 keys) for oversized candidate lists
     uint32_t *queue;                // work counter (persistent waves)
     uint32_t binMask; int maxHits; int minDiagScore;
-    GpuHit *outHits; uint32_t *outCount;
+    GpuHit *outHits; uint32_t *outCount; uint32_t *outBase; uint32_t *outCursor;   // compact output: each query owns [outBase, outBase+outCount)
     unsigned long long *counters;   // [4] += hits
 };
 
-__device__ __noinline__ void selectOne(const SelectArgs &a, const uint32_t qi, uint32_t *hist, uint64_t *keys, uint64_t *scratch, const int lane) {
+__device__ __forceinline__ void selectOne(const SelectArgs &a, const uint32_t qi, uint32_t *hist, uint64_t *keys, uint64_t *scratch, const int lane) {
     const uint32_t D = uni(a.qDiagCnt[qi]);
     if (D == 0) { if (lane == 0) a.outCount[qi] = 0; return; }
     const uint32_t base = uni(a.qDiagBase[qi]);
@@ -569,13 +569,14 @@ __device__ __noinline__ void selectOne(const SelectArgs &a, const uint32_t qi, u
     waveSync();
     uint32_t n2 = 1; while (n2 < nOut) n2 <<= 1;
     if (inLds) waveBitonicSort(keys, n2, lane); else waveBitonicSort(K, n2, lane);
+    const uint32_t obase = uni(atomicAdd(a.outCursor, lane == 0 ? nOut : 0u));
     for (uint32_t t = lane; t < nOut; t += 64) {
         const uint64_t k3 = K[t];
         const uint32_t r = (uint32_t) (k3 & 0xFFFF);
         GpuHit h; h.seqId = rec[r].seqId; h.score = (uint16_t) (65535 - (uint32_t) (k3 >> 48)); h.diag = rec[r].diag;
-        a.outHits[(size_t) qi * a.maxHits + t] = h;
+        a.outHits[(size_t) obase + t] = h;
     }
-    if (lane == 0) { a.outCount[qi] = nOut; atomicAdd(&a.counters[4], (unsigned long long) nOut); }
+    if (lane == 0) { a.outCount[qi] = nOut; a.outBase[qi] = obase; }
     waveSync();
 }
 
@@ -631,7 +632,7 @@ struct Gpu::Impl {
     // match / select
     DevBuf<uint64_t> spill; DevBuf<uint32_t> queue; DevBuf<DiagRec> diagRec; DevBuf<uint32_t> diagQuery; DevBuf<uint16_t> diagScore; DevBuf<uint8_t> diagFlag;
     DevBuf<uint32_t> qDiagBase; DevBuf<uint32_t> qDiagCnt; DevBuf<unsigned long long> counters;
-    DevBuf<GpuHit> outHits; DevBuf<uint32_t> outCount;
+    DevBuf<GpuHit> outHits; DevBuf<uint32_t> outCount; DevBuf<uint32_t> outBase;
     uint32_t matchBlocks = 0;
     SwState sw;
 };
@@ -717,7 +718,7 @@ bool Gpu::uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std:
     if (!upload(d.qres, res, d.qTotal, d.stream, err)) return false;
     if (!upload(d.qoff, off, nq + 1, d.stream, err)) return false;
     if (!d.biasf.ensure(d.qTotal + 1, err) || !d.qthr.ensure(d.qTotal + 1, err) || !d.qcorr.ensure(d.qTotal + 1, err)) return false;
-    if (!d.qbias.ensure(nq + 1, err) || !d.qself.ensure(nq + 1, err) || !d.qDiagBase.ensure(nq + 1, err) || !d.qDiagCnt.ensure(nq + 1, err) || !d.outCount.ensure(nq + 1, err)) return false;
+    if (!d.qbias.ensure(nq + 1, err) || !d.qself.ensure(nq + 1, err) || !d.qDiagBase.ensure(nq + 1, err) || !d.qDiagCnt.ensure(nq + 1, err) || !d.outCount.ensure(nq + 1, err) || !d.outBase.ensure(nq + 1, err)) return false;
     HIP_OK(hipStreamSynchronize(d.stream));
     return true;
 }
@@ -758,7 +759,7 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     SP_DBG_SYNC("k_score");
     HIP_OK(hipEventRecord(d.ev[3], d.stream));
     SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.queue.p + 2,
-                  binSize - 1, maxHits, minDiagScore, d.outHits.p, d.outCount.p, d.counters.p};
+                  binSize - 1, maxHits, minDiagScore, d.outHits.p, d.outCount.p, d.outBase.p, d.queue.p + 3, d.counters.p};
     hipLaunchKernelGGL(k_select, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, se);
     SP_DBG_SYNC("k_select");
     HIP_OK(hipEventRecord(d.ev[4], d.stream));
@@ -766,7 +767,7 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     HIP_OK(hipMemcpyAsync(c, d.counters.p, sizeof(c), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipMemcpyAsync(qv, d.queue.p, sizeof(qv), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipStreamSynchronize(d.stream));
-    counters_.kmers = c[0]; counters_.dbMatches = c[1]; counters_.overflowQueries = c[2]; counters_.diagResidues = c[3]; counters_.hits = c[4];
+    counters_.kmers = c[0]; counters_.dbMatches = c[1]; counters_.overflowQueries = c[2]; counters_.diagResidues = c[3]; counters_.hits = qv[3];
     counters_.diagonals = qv[1];
     (void) hipEventElapsedTime(&times_.prep, d.ev[0], d.ev[1]);
     (void) hipEventElapsedTime(&times_.match, d.ev[1], d.ev[2]);
@@ -779,14 +780,21 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     return true;
 }
 
-bool Gpu::downloadHits(std::vector<GpuHit> &hits, std::vector<uint32_t> &counts, std::string &err) {
+bool Gpu::downloadHits(std::vector<GpuHit> &hits, std::vector<uint64_t> &offsets, std::string &err) {
     Impl &d = *d_;
-    hits.resize(nq_ * (size_t) maxHits_);
-    counts.resize(nq_);
+    offsets.assign(nq_ + 1, 0);
+    hits.clear();
     if (nq_ == 0) return true;
-    HIP_OK(hipMemcpyAsync(counts.data(), d.outCount.p, nq_ * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
-    HIP_OK(hipMemcpyAsync(hits.data(), d.outHits.p, hits.size() * sizeof(GpuHit), hipMemcpyDeviceToHost, d.stream));
+    const size_t total = (size_t) counters_.hits;
+    std::vector<uint32_t> cnt(nq_), base(nq_);
+    std::vector<GpuHit> raw(total);
+    HIP_OK(hipMemcpyAsync(cnt.data(), d.outCount.p, nq_ * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipMemcpyAsync(base.data(), d.outBase.p, nq_ * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    if (total) HIP_OK(hipMemcpyAsync(raw.data(), d.outHits.p, total * sizeof(GpuHit), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipStreamSynchronize(d.stream));
+    for (size_t q = 0; q < nq_; q++) offsets[q + 1] = offsets[q] + cnt[q];
+    hits.resize(total);
+    for (size_t q = 0; q < nq_; q++) if (cnt[q]) memcpy(&hits[offsets[q]], &raw[base[q]], cnt[q] * sizeof(GpuHit));
     return true;
 }
 
