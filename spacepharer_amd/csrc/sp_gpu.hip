@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 #include "sp_gpu.h"
 
@@ -614,6 +615,15 @@ struct DevBuf {
     void release() { if (p) (void) hipFree(p); p = nullptr; n = 0; }
 };
 
+struct SwDev {
+    DevBuf<SwPair> pairs; DevBuf<SwForward> fwd; DevBuf<uint32_t> list; DevBuf<int32_t> revRef, revRead, revScore;
+    DevBuf<signed char> qcomp; DevBuf<int> qbias;
+    DevBuf<uint64_t> dirOff, rowOff, btOff; DevBuf<uint32_t> dirCap, rowCap, btCap;
+    DevBuf<signed char> dirPool; DevBuf<int> rowPool; DevBuf<char> btPool; DevBuf<SwFull> full;
+    DevBuf<uint16_t> diag; DevBuf<DiagRescore> resc;
+    size_t preparedFor = (size_t) -1; const void *preparedPtr = nullptr;
+};
+
 struct Gpu::Impl {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
@@ -621,7 +631,7 @@ struct Gpu::Impl {
     // tables
     DevBuf<uint32_t> ext3; DevBuf<short> seedSub; DevBuf<double> seedBack; DevBuf<signed char> ungSub; DevBuf<signed char> alnSub;
     DevBuf<short> alnSub16; DevBuf<double> alnBack;
-    int ungMinAbs = 0;
+    int ungMinAbs = 0, alnMinAbs = 0;
     // targets
     DevBuf<uint32_t> ioff; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff;
     size_t nTargets = 0;
@@ -635,6 +645,7 @@ struct Gpu::Impl {
     DevBuf<GpuHit> outHits; DevBuf<uint32_t> outCount; DevBuf<uint32_t> outBase;
     uint32_t matchBlocks = 0;
     SwState sw;
+    SwDev swd;
 };
 
 Gpu::Gpu() : d_(new Impl) {}
@@ -676,15 +687,17 @@ bool Gpu::uploadTables(const std::vector<uint32_t> &ext3, const SubMat &seed, co
     Impl &d = *d_;
     if (!upload(d.ext3, ext3.data(), ext3.size(), d.stream, err)) return false;
     short s16[kAlph * kAlph]; signed char u8[kAlph * kAlph], a8[kAlph * kAlph]; short a16[kAlph * kAlph];
-    int mn = 0;
+    int mn = 0, mnAln = 0;
     for (int i = 0; i < kAlph; i++) for (int j = 0; j < kAlph; j++) {
         s16[i * kAlph + j] = seed.sub[i][j];
         u8[i * kAlph + j] = (signed char) ung.sub[i][j];
         a8[i * kAlph + j] = (signed char) aln.sub[i][j];
         a16[i * kAlph + j] = aln.sub[i][j];
         mn = std::min<int>(mn, ung.sub[i][j]);
+        mnAln = std::min<int>(mnAln, aln.sub[i][j]);
     }
     d.ungMinAbs = std::abs(mn);
+    d.alnMinAbs = std::abs(mnAln);
     if (!upload(d.seedSub, s16, kAlph * kAlph, d.stream, err)) return false;
     if (!upload(d.seedBack, seed.pBack, kAlph, d.stream, err)) return false;
     if (!upload(d.ungSub, u8, kAlph * kAlph, d.stream, err)) return false;

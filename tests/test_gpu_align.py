@@ -1,0 +1,95 @@
+"""GPU parity of the Smith-Waterman (align) and diagonal-rescoring kernels against the reference-generated golden
+vectors: integer scores, end/start positions, E-values (bit-identical doubles), acceptance and backtrace strings."""
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["small", "spacer", "family", "longq"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_align_matches_reference_golden(name):
+    import spacepharer_amd as sa
+    g = load_golden(name)
+    r = g["ref"]
+    ctx = sa.SearchContext(sensitivity=r["sens"], max_seqs=r["maxSeqs"])
+    ctx.set_targets(g["targets"])
+    ctx.set_queries(g["queries"])
+    pairs, exp = [], []
+    for a in r["aln"]:
+        for raw in a["raw"]:
+            pairs.append((a["id"], raw[0]))
+            exp.append(raw)
+    assert pairs
+    got = ctx.align(pairs)
+    gapped = word = 0
+    for (res, cig), raw in zip(got, exp):
+        dbKey, bits, qs, qe, ts, te, alnLen, ev, ok, bt = raw
+        assert res.db_key == dbKey
+        assert res.bit_score == bits, raw
+        assert (res.q_end, res.db_end) == (qe, te), raw
+        assert res.passed == ok, raw
+        if ok:
+            assert (res.q_start, res.db_start, res.aln_len) == (qs, ts, alnLen), raw
+            assert res.evalue == float.fromhex(ev)
+            assert cig == bt, raw
+            gapped += ("I" in bt) or ("D" in bt)
+        word += res.raw_score >= 255
+    if name in ("family", "longq"):
+        assert gapped > 0
+    if name == "longq":
+        assert word > 0          # exercises the 16-bit pass
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_rescorediagonal_matches_reference_golden(name):
+    import spacepharer_amd as sa
+    g = load_golden(name)
+    r = g["ref"]
+    ctx = sa.SearchContext(sensitivity=r["sens"], max_seqs=r["maxSeqs"])
+    ctx.set_targets(g["targets"])
+    ctx.set_queries(g["queries"])
+    triples, exp = [], []
+    for a, qh in zip(r["aln"], r["queries"]):
+        for raw, hit in zip(a["rescore"], qh["hits"]):
+            triples.append((a["id"], raw[0], hit[2]))
+            exp.append(raw)
+    m1 = ctx.rescore(triples, 1)
+    m2 = ctx.rescore(triples, 2)
+    for a, b, raw in zip(m1, m2, exp):
+        dbKey, s1, s2, st, en, dlen, dist, diag, ev, bits = raw
+        assert a.score == s1
+        assert (b.score, b.start_pos, b.end_pos, b.diagonal_len, b.dist_to_diagonal, b.diagonal) == (s2, st, en, dlen, dist, diag)
+        assert b.evalue == float.fromhex(ev)
+        assert b.bit_score == bits
+    ctx.close()
+
+
+def test_align_matches_oracle_on_fresh_inputs():
+    from golden.make_golden import make_case
+    from oracle_lib import Alp, Oracle
+    import spacepharer_amd as sa
+    g = load_golden("spacer")["ref"]
+    T, Q = make_case(seed=99, n_targets=1500, n_queries=600, tmin=30, tmax=350, qmin=9, qmax=31, families=2)
+    o = Oracle()
+    o.set_targets(T)
+    o.set_alp(Alp.from_ref(g["alpGapped"]), Alp.from_ref(g["alpGapless"]))
+    ctx = sa.SearchContext()
+    ctx.set_targets(T)
+    ctx.set_queries(Q)
+    ctx.prefilter()
+    hits = ctx.hits()
+    pairs = [(qi, h[0]) for qi, hs in enumerate(hits) for h in hs]
+    assert len(pairs) > 200
+    got = ctx.align(pairs)
+    for (qi, ti), (res, cig) in zip(pairs, got):
+        e = o.align(Q[qi], ti)
+        assert (res.raw_score, res.bit_score, res.q_end, res.db_end, res.passed) == (e.rawScore, e.score, e.qEndPos, e.dbEndPos, e.passed)
+        if e.passed:
+            assert (res.q_start, res.db_start, res.aln_len, res.evalue, cig) == (e.qStartPos, e.dbStartPos, e.alnLength, e.eval, e.backtrace.decode())
+            assert res.seq_id == e.seqId
+    ctx.close()
+    o.close()
