@@ -102,6 +102,8 @@ void sp_ctx_destroy(sp_ctx *c);
 /* target set: ASCII residues concatenated, offsets[n+1]; keys may be NULL (key = index).  Builds the masked
    sequence store and the k-mer index on the host and stages both into HBM. */
 int sp_ctx_set_targets(sp_ctx *c, const char *residues, const uint64_t *offsets, const uint32_t *keys, uint64_t n);
+/* flags: bit 0 = do not build / stage the k-mer index (align and rescorediagonal only need the residues) */
+int sp_ctx_set_targets_ex(sp_ctx *c, const char *residues, const uint64_t *offsets, const uint32_t *keys, uint64_t n, int flags);
 /* query batch: ASCII residues concatenated, offsets[n+1]; uploaded once, stays resident until replaced */
 int sp_ctx_set_queries(sp_ctx *c, const char *residues, const uint64_t *offsets, uint64_t n);
 
@@ -131,6 +133,16 @@ double sp_ctx_stat(const sp_ctx *c, const char *name);
 int sp_ctx_sync(sp_ctx *c);
 /* raw HIP stream the context launches on (hipStream_t), for callers that time with their own events */
 void *sp_ctx_stream(const sp_ctx *c);
+
+/* ---- host-side diagnostics: run the set-up code (matrices, masking, index construction, E-value statistics) without
+   a device so that it can be checked on any machine; digests are FNV-1a over the same byte streams the golden
+   fixtures hash (tests/test_host_logic.py) ---- */
+int sp_host_matrix(const char *spec, double bit_factor, double score_bias, int16_t *sub441, double *p_back21);
+int sp_host_ext3_digest(const char *seed_spec, uint64_t *digest, int16_t *score_head64, uint32_t *index_head64, uint32_t row);
+int sp_host_index_digest(const char *seed_spec, float sensitivity, int mask, const char *residues, const uint64_t *offsets, uint64_t n,
+                         uint64_t *entries, uint64_t *masked_residues, uint64_t *digest, char *masked_out);
+int sp_host_evalue(const char *matrix_name, int gap_open, int gap_extend, uint64_t db_residues, double score, double q_len,
+                   double *evalue, double *bit_score);
 
 #ifdef __cplusplus
 }

@@ -113,7 +113,12 @@ void sp_ctx_destroy(sp_ctx *c) { delete c; }
 int sp_ctx_max_seqs(const sp_ctx *c) { return (int) std::min<uint64_t>(c->targets.n, (uint64_t) c->par.max_seqs); }
 
 int sp_ctx_set_targets(sp_ctx *c, const char *residues, const uint64_t *offsets, const uint32_t *keys, uint64_t n) {
+    return sp_ctx_set_targets_ex(c, residues, offsets, keys, n, 0);
+}
+
+int sp_ctx_set_targets_ex(sp_ctx *c, const char *residues, const uint64_t *offsets, const uint32_t *keys, uint64_t n, int flags) {
     if (!c || !residues || !offsets) { g_err = "sp_ctx_set_targets: null argument"; return SP_ERR_ARG; }
+    const bool noIndex = (flags & 1) != 0;
     std::string err;
     double t0 = nowMs();
     if (!c->tablesUp) {
@@ -123,8 +128,9 @@ int sp_ctx_set_targets(sp_ctx *c, const char *residues, const uint64_t *offsets,
         c->tablesUp = true;
     }
     double t1 = nowMs();
-    sp::prepareTargets(c->seed, residues, offsets, keys, (size_t) n, c->par.mask != 0, c->threads, c->targets);
-    sp::buildIndex(c->seed, c->targets, c->kmerThr, c->threads, c->index);
+    sp::prepareTargets(c->seed, residues, offsets, keys, (size_t) n, c->par.mask != 0 && !noIndex, c->threads, c->targets);
+    if (noIndex) { c->index.offsets.assign(2, 0); c->index.entries.clear(); }
+    else sp::buildIndex(c->seed, c->targets, c->kmerThr, c->threads, c->index);
     c->indexEntries = c->index.entries.size();
     double t2 = nowMs();
     if (!c->gpu.uploadTargets(c->targets, c->index, err)) { g_err = err; return SP_ERR_DEVICE; }
@@ -158,6 +164,7 @@ int sp_ctx_set_queries(sp_ctx *c, const char *residues, const uint64_t *offsets,
 
 int sp_ctx_prefilter(sp_ctx *c) {
     if (!c || c->targets.n == 0) { g_err = "sp_ctx_prefilter: no target set"; return SP_ERR_STATE; }
+    if (c->indexEntries == 0) { g_err = "sp_ctx_prefilter: the target set has no k-mer index (no indexable k-mer, or staged without one)"; return SP_ERR_STATE; }
     std::string err;
     // maxResListLen = min(#targets, --max-seqs): prefiltering/Prefiltering.cpp:170
     const int maxHits = sp_ctx_max_seqs(c);
@@ -276,6 +283,60 @@ double sp_ctx_stat(const sp_ctx *c, const char *name) {
 
 void *sp_ctx_stream(const sp_ctx *c) { return c->gpu.stream(); }
 int sp_ctx_sync(sp_ctx *c) { c->gpu.sync(); return SP_OK; }
+
+/* ---- host-side diagnostics (no device needed): used by the CPU test-suite to check the set-up code ---- */
+static uint64_t fnv1a(const void *p, size_t n, uint64_t h) {
+    const unsigned char *c = (const unsigned char *) p;
+    if (h == 0) h = 1469598103934665603ULL;
+    for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 1099511628211ULL; }
+    return h;
+}
+
+int sp_host_matrix(const char *spec, double bitFactor, double scoreBias, int16_t *sub441, double *pBack21) {
+    sp::SubMat m; std::string err;
+    if (!m.load(spec, bitFactor, scoreBias, err)) { g_err = err; return SP_ERR_ARG; }
+    for (int i = 0; i < 21; i++) { for (int j = 0; j < 21; j++) sub441[i * 21 + j] = m.sub[i][j]; pBack21[i] = m.pBack[i]; }
+    return SP_OK;
+}
+
+int sp_host_ext3_digest(const char *seedSpec, uint64_t *digest, int16_t *scoreHead64, uint32_t *indexHead64, uint32_t row) {
+    sp::SubMat m; std::string err;
+    if (!m.load(seedSpec, (double) 8.0f, (double) -0.2f, err)) { g_err = err; return SP_ERR_ARG; }
+    std::vector<uint32_t> packed; sp::buildExt3(m, packed, (int) std::max(1u, std::thread::hardware_concurrency()));
+    uint64_t h = 0; std::vector<int16_t> sc(8000); std::vector<uint32_t> ix(8000);
+    for (size_t r = 0; r < 8000; r++) {
+        for (size_t z = 0; z < 8000; z++) { sc[z] = (int16_t) ((int) (packed[r * 8000 + z] >> 16) - 32768); ix[z] = packed[r * 8000 + z] & 0xFFFF; }
+        h = fnv1a(sc.data(), 16000, h); h = fnv1a(ix.data(), 32000, h);
+        if (r == row) for (int z = 0; z < 64; z++) { scoreHead64[z] = sc[z]; indexHead64[z] = ix[z]; }
+    }
+    *digest = h;
+    return SP_OK;
+}
+
+int sp_host_index_digest(const char *seedSpec, float sensitivity, int mask, const char *residues, const uint64_t *offsets, uint64_t n,
+                         uint64_t *entries, uint64_t *maskedResidues, uint64_t *digest, char *maskedOut) {
+    sp::SubMat m; std::string err;
+    if (!m.load(seedSpec, (double) 8.0f, (double) -0.2f, err)) { g_err = err; return SP_ERR_ARG; }
+    const int threads = (int) std::max(1u, std::thread::hardware_concurrency());
+    sp::TargetSet ts; sp::KmerIndex idx;
+    sp::prepareTargets(m, residues, offsets, nullptr, (size_t) n, mask != 0, threads, ts);
+    sp::buildIndex(m, ts, sp::kmerThreshold(sensitivity, INT_MAX, sp::kKmer), threads, idx);
+    uint64_t h = 0;
+    for (size_t k = 0; k < sp::kTableSize; k++) for (uint32_t e = idx.offsets[k]; e < idx.offsets[k + 1]; e++) {
+        uint32_t rec[3] = {(uint32_t) k, (uint32_t) idx.entries[e], (uint32_t) (idx.entries[e] >> 32)};
+        h = fnv1a(rec, sizeof(rec), h);
+    }
+    *entries = idx.entries.size(); *maskedResidues = ts.maskedCount; *digest = h;
+    if (maskedOut) for (uint64_t i = 0; i < ts.residues(); i++) maskedOut[i] = m.num2aa[ts.masked[i]];
+    return SP_OK;
+}
+
+int sp_host_evalue(const char *matrixName, int gapOpen, int gapExtend, uint64_t dbResidues, double score, double qLen, double *evalue, double *bitScore) {
+    sp::Evaluer e; std::string err;
+    if (!e.init(matrixName, gapOpen, gapExtend, dbResidues, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
+    *evalue = e.evalue(score, qLen); *bitScore = e.bitScore(score);
+    return SP_OK;
+}
 
 int sp_prefilter_run(int argc, const char **argv) { return sp::runPrefilterModule(argc, argv); }
 int sp_align_run(int argc, const char **argv) { return sp::runAlignModule(argc, argv); }

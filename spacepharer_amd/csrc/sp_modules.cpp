@@ -1,6 +1,448 @@
+// Module drivers: `prefilter`, `align`, `rescorediagonal` with the reference's command lines on MMseqs2 DB triples
+// (SURVEY.md Appendix A/B).  They replace the bodies of
+//   lib/mmseqs/src/prefiltering/Main.cpp:13-68            (prefilter)
+//   lib/mmseqs/src/alignment/Main.cpp:12-32               (align)
+//   lib/mmseqs/src/alignment/rescorediagonal.cpp:381-431  (rescorediagonal)
+// Host orchestration only: every score comes from the HIP kernels behind the in-memory C ABI.
 #include "sp_modules.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <set>
+#include <sstream>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+#include "../../include/spacepharer_amd.h"
+
 namespace sp {
-int runPrefilterModule(int, const char **) { setLastError("not implemented"); return 1; }
-int runAlignModule(int, const char **) { setLastError("not implemented"); return 1; }
-int runRescoreDiagonalModule(int, const char **) { setLastError("not implemented"); return 1; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// MMseqs2 DB triple: <p> (or <p>.0 .. <p>.N), <p>.index, <p>.dbtype     (commons/DBReader.cpp, DBWriter.cpp)
+// ---------------------------------------------------------------------------------------------------------------
+struct DbEntry { uint32_t key; uint64_t offset; uint64_t length; };   // length includes the terminating NUL
+
+struct Db {
+    std::vector<char> data;
+    std::vector<DbEntry> entries;     // sorted by data offset (DBReader::LINEAR_ACCCESS)
+    int dbtype = -1;
+    bool compressed() const { return dbtype >= 0 && (dbtype & (1 << 31)); }
+    int type() const { return dbtype & 0x7FFFFFFF; }
+
+    bool load(const std::string &path, std::string &err) {
+        std::ifstream idx(path + ".index");
+        if (!idx.good()) { err = "cannot open " + path + ".index"; return false; }
+        std::string line;
+        while (std::getline(idx, line)) {
+            if (line.empty()) continue;
+            DbEntry e; unsigned long long k, o, l;
+            if (sscanf(line.c_str(), "%llu\t%llu\t%llu", &k, &o, &l) != 3) { err = "malformed index line in " + path + ".index"; return false; }
+            e.key = (uint32_t) k; e.offset = o; e.length = l;
+            entries.push_back(e);
+        }
+        std::vector<std::string> files;
+        struct stat st;
+        if (stat(path.c_str(), &st) == 0) files.push_back(path);
+        else for (int i = 0;; i++) { std::string f = path + "." + std::to_string(i); if (stat(f.c_str(), &st) != 0) break; files.push_back(f); }
+        if (files.empty()) { err = "cannot open data file of " + path; return false; }
+        for (const std::string &f : files) {
+            std::ifstream in(f, std::ios::binary);
+            if (!in.good()) { err = "cannot read " + f; return false; }
+            in.seekg(0, std::ios::end); size_t sz = (size_t) in.tellg(); in.seekg(0);
+            size_t at = data.size(); data.resize(at + sz);
+            in.read(data.data() + at, (std::streamsize) sz);
+        }
+        std::ifstream t(path + ".dbtype", std::ios::binary);
+        if (t.good()) { int32_t v = 0; t.read((char *) &v, 4); dbtype = v; }
+        for (const DbEntry &e : entries) if (e.offset + e.length > data.size()) { err = "index of " + path + " points past the data file"; return false; }
+        std::sort(entries.begin(), entries.end(), [](const DbEntry &a, const DbEntry &b) { return a.offset < b.offset; });
+        return true;
+    }
+    // sequence entry = residues + '\n' + '\0'  (DBReader.h:191-211)
+    uint64_t seqLen(size_t i) const { return entries[i].length >= 2 ? entries[i].length - 2 : 0; }
+    const char *ptr(size_t i) const { return data.data() + entries[i].offset; }
+};
+
+struct DbWriter {
+    std::string path; int dbtype;
+    std::vector<char> data; std::vector<DbEntry> entries;
+    void add(uint32_t key, const std::string &payload) {
+        DbEntry e; e.key = key; e.offset = data.size(); e.length = payload.size() + 1;
+        data.insert(data.end(), payload.begin(), payload.end());
+        data.push_back('\0');
+        entries.push_back(e);
+    }
+    bool close(std::string &err) {
+        { std::ofstream o(path, std::ios::binary); if (!o.good()) { err = "cannot write " + path; return false; } o.write(data.data(), (std::streamsize) data.size()); }
+        std::sort(entries.begin(), entries.end(), [](const DbEntry &a, const DbEntry &b) { return a.key < b.key; });   // DBWriter.cpp:645-660
+        { std::ofstream o(path + ".index"); if (!o.good()) { err = "cannot write " + path + ".index"; return false; }
+          for (const DbEntry &e : entries) o << e.key << '\t' << e.offset << '\t' << e.length << '\n'; }
+        // .dbtype is written LAST so that a crashed step is re-run by the workflow scripts (DBWriter.cpp:243)
+        { std::ofstream o(path + ".dbtype", std::ios::binary); int32_t v = dbtype; o.write((const char *) &v, 4); if (!o.good()) { err = "cannot write " + path + ".dbtype"; return false; } }
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// flags (commons/Parameters.cpp:338-437): every flag of the module's list is accepted; values this implementation
+// cannot honour are rejected loudly rather than ignored
+// ---------------------------------------------------------------------------------------------------------------
+struct Flags {
+    std::vector<std::string> positional;
+    std::map<std::string, std::string> kv;
+    bool has(const std::string &k) const { return kv.count(k) != 0; }
+    std::string str(const std::string &k, const std::string &d) const { auto it = kv.find(k); return it == kv.end() ? d : it->second; }
+    long num(const std::string &k, long d) const { auto it = kv.find(k); return it == kv.end() ? d : strtol(it->second.c_str(), NULL, 10); }
+    double real(const std::string &k, double d) const { auto it = kv.find(k); return it == kv.end() ? d : strtod(it->second.c_str(), NULL); }
+};
+
+static const char *kBoolFlags[] = {"-a", "--add-self-matches", "--realign", "--wrapped-scoring", "--filter-hits", NULL};
+
+static bool parseFlags(int argc, const char **argv, const std::set<std::string> &allowed, size_t nPositional, Flags &f, std::string &err) {
+    for (int i = 0; i < argc; i++) {
+        std::string a = argv[i];
+        if (a.size() >= 2 && a[0] == '-' && !(a.size() > 1 && (isdigit((unsigned char) a[1])))) {
+            if (!allowed.count(a)) { err = "Unrecognized parameter \"" + a + "\""; return false; }      // fatal in the reference too (Parameters.cpp:1663-1666)
+            bool isBool = false;
+            for (const char **b = kBoolFlags; *b; b++) if (a == *b) isBool = true;
+            if (isBool) {
+                if (i + 1 < argc && (!strcmp(argv[i + 1], "0") || !strcmp(argv[i + 1], "1") || !strcmp(argv[i + 1], "true") || !strcmp(argv[i + 1], "false"))) {
+                    std::string v = argv[++i]; f.kv[a] = (v == "1" || v == "true") ? "1" : "0";
+                } else f.kv[a] = "1";
+            } else {
+                if (i + 1 >= argc) { err = "Missing argument for " + a; return false; }
+                f.kv[a] = argv[++i];
+            }
+        } else f.positional.push_back(a);
+    }
+    if (f.positional.size() != nPositional) { err = "expected " + std::to_string(nPositional) + " database arguments, got " + std::to_string(f.positional.size()); return false; }
+    return true;
 }
+
+// MultiParam "nucl:X,aa:Y" (commons/MultiParam.cpp:22-95): the amino-acid part
+static std::string aaPart(const std::string &v) {
+    size_t p = v.find("aa:");
+    if (p == std::string::npos) return v;
+    size_t e = v.find(',', p);
+    return v.substr(p + 3, e == std::string::npos ? std::string::npos : e - p - 3);
+}
+
+static bool requireValue(const Flags &f, const char *flag, const std::vector<std::string> &ok, std::string &err) {
+    if (!f.has(flag)) return true;
+    std::string v = aaPart(f.str(flag, ""));
+    for (const std::string &o : ok) if (v == o) return true;
+    err = std::string("unsupported value for ") + flag + ": " + v + " (the MI355X path implements SpacePHARER's search configuration only)";
+    return false;
+}
+
+static const std::set<std::string> kPrefilterFlags = {
+    "--sub-mat", "--seed-sub-mat", "-s", "-k", "--k-score", "--alph-size", "--max-seq-len", "--max-seqs", "--split", "--split-mode",
+    "--split-memory-limit", "-c", "--cov-mode", "--comp-bias-corr", "--diag-score", "--exact-kmer-matching", "--mask", "--mask-lower-case",
+    "--min-ungapped-score", "--add-self-matches", "--spaced-kmer-mode", "--db-load-mode", "--pca", "--pcb", "--spaced-kmer-pattern",
+    "--local-tmp", "--threads", "--compressed", "-v"};
+static const std::set<std::string> kAlignFlags = {
+    "--sub-mat", "-a", "--alignment-mode", "--alignment-output-mode", "--wrapped-scoring", "-e", "--min-seq-id", "--min-aln-len", "--seq-id-mode",
+    "--alt-ali", "-c", "--cov-mode", "--max-seq-len", "--comp-bias-corr", "--max-rejected", "--max-accept", "--add-self-matches", "--db-load-mode",
+    "--pca", "--pcb", "--score-bias", "--realign", "--realign-score-bias", "--realign-max-seqs", "--gap-open", "--gap-extend", "--zdrop",
+    "--threads", "--compressed", "-v"};
+static const std::set<std::string> kRescoreFlags = {
+    "--sub-mat", "--rescore-mode", "--wrapped-scoring", "--filter-hits", "-e", "-c", "-a", "--cov-mode", "--min-seq-id", "--min-aln-len",
+    "--seq-id-mode", "--add-self-matches", "--sort-results", "--db-load-mode", "--threads", "--compressed", "-v"};
+
+static char *u32toa(uint32_t v, char *p) { char t[12]; int n = 0; do { t[n++] = (char) ('0' + v % 10); v /= 10; } while (v); while (n) *p++ = t[--n]; return p; }
+static char *i32toa(int32_t v, char *p) { if (v < 0) { *p++ = '-'; return u32toa((uint32_t) (-(int64_t) v), p); } return u32toa((uint32_t) v, p); }
+
+struct Ctx {
+    sp_ctx *c = nullptr;
+    ~Ctx() { if (c) sp_ctx_destroy(c); }
+};
+
+static bool loadSeqDb(const std::string &path, Db &db, std::string &err) {
+    if (!db.load(path, err)) return false;
+    if (db.type() != 0) { err = path + ": only amino-acid sequence DBs (dbtype 0) are supported, got " + std::to_string(db.type()); return false; }
+    if (db.compressed()) { err = path + ": compressed DBs are not supported (the workflows pass --compressed 0)"; return false; }
+    return true;
+}
+
+static void flatten(const Db &db, std::vector<char> &res, std::vector<uint64_t> &off, std::vector<uint32_t> &keys) {
+    off.assign(1, 0); keys.clear(); res.clear();
+    for (size_t i = 0; i < db.entries.size(); i++) {
+        const char *p = db.ptr(i); uint64_t L = db.seqLen(i);
+        uint64_t l = 0; while (l < L && p[l] != '\n' && p[l] != '\0') l++;        // Sequence::mapSequence stops at \n / \0
+        res.insert(res.end(), p, p + l);
+        off.push_back(res.size()); keys.push_back(db.entries[i].key);
+    }
+    if (res.empty()) res.push_back('X');
+}
+
+static int fail(const std::string &e) { setLastError(e); fprintf(stderr, "%s\n", e.c_str()); return 1; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// prefilter <queryDB> <targetDB> <outDB>
+// ---------------------------------------------------------------------------------------------------------------
+int runPrefilterModule(int argc, const char **argv) {
+    Flags f; std::string err;
+    if (!parseFlags(argc, argv, kPrefilterFlags, 3, f, err)) return fail("prefilter: " + err);
+    if (!requireValue(f, "-k", {"6", "0"}, err) || !requireValue(f, "--alph-size", {"21"}, err) || !requireValue(f, "--comp-bias-corr", {"1"}, err) ||
+        !requireValue(f, "--diag-score", {"1"}, err) || !requireValue(f, "--exact-kmer-matching", {"0"}, err) || !requireValue(f, "--spaced-kmer-mode", {"1"}, err) ||
+        !requireValue(f, "--spaced-kmer-pattern", {"11011101", ""}, err) || !requireValue(f, "--mask-lower-case", {"0"}, err) || !requireValue(f, "--compressed", {"0"}, err) ||
+        !requireValue(f, "--add-self-matches", {"0"}, err) || !requireValue(f, "--split", {"0", "1"}, err) || !requireValue(f, "-c", {"0", "0.0", "0.000"}, err))
+        return fail("prefilter: " + err);
+    Db qdb, tdb;
+    if (!loadSeqDb(f.positional[0], qdb, err) || !loadSeqDb(f.positional[1], tdb, err)) return fail("prefilter: " + err);
+    sp_search_params p; sp_default_params(&p);
+    std::string seed = aaPart(f.str("--seed-sub-mat", "VTML80.out")), sub = aaPart(f.str("--sub-mat", "VTML40.out"));
+    p.seed_sub_mat = seed.c_str(); p.sub_mat = sub.c_str();
+    p.sensitivity = (float) f.real("-s", 5.7);
+    p.kmer_score = (int) f.num("--k-score", INT_MAX);
+    p.max_seqs = (int) f.num("--max-seqs", 300);
+    p.min_ungapped_score = (int) f.num("--min-ungapped-score", 15);
+    p.mask = (int) f.num("--mask", 1);
+    p.threads = (int) f.num("--threads", 0);
+    Ctx ctx; ctx.c = sp_ctx_create(&p);
+    if (!ctx.c) return fail(std::string("prefilter: ") + sp_last_error());
+    std::vector<char> tres, qres; std::vector<uint64_t> toff, qoff; std::vector<uint32_t> tkeys, qkeys;
+    flatten(tdb, tres, toff, tkeys);
+    if (sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) return fail(std::string("prefilter: ") + sp_last_error());
+    flatten(qdb, qres, qoff, qkeys);
+    DbWriter w; w.path = f.positional[2]; w.dbtype = 7;      // DBTYPE_PREFILTER_RES
+    const size_t nq = qkeys.size(), batch = 1u << 20;
+    std::string payload; char buf[64];
+    for (size_t b0 = 0; b0 < nq; b0 += batch) {
+        const size_t b1 = std::min(nq, b0 + batch);
+        std::vector<uint64_t> off(qoff.begin() + b0, qoff.begin() + b1 + 1);
+        for (uint64_t &o : off) o -= qoff[b0];
+        if (sp_ctx_set_queries(ctx.c, qres.data() + qoff[b0], off.data(), b1 - b0) != SP_OK || sp_ctx_prefilter(ctx.c) != SP_OK) return fail(std::string("prefilter: ") + sp_last_error());
+        std::vector<sp_hit> hits(std::max<uint64_t>(1, sp_ctx_num_hits(ctx.c))); std::vector<uint64_t> ho(b1 - b0 + 1);
+        if (sp_ctx_get_hits_compact(ctx.c, hits.data(), ho.data()) != SP_OK) return fail(std::string("prefilter: ") + sp_last_error());
+        for (size_t q = b0; q < b1; q++) {
+            payload.clear();
+            for (uint64_t h = ho[q - b0]; h < ho[q - b0 + 1]; h++) {       // QueryMatcher::prefilterHitToBuffer, QueryMatcher.h:114-126
+                char *e = u32toa(tkeys[hits[h].seq_id], buf); *e++ = '\t';
+                e = i32toa(hits[h].score, e); *e++ = '\t';
+                e = i32toa((int32_t) hits[h].diagonal, e); *e++ = '\n';
+                payload.append(buf, e - buf);
+            }
+            w.add(qkeys[q], payload);     // every query key gets an entry, empty ones too
+        }
+    }
+    if (!w.close(err)) return fail("prefilter: " + err);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// shared by align / rescorediagonal: parse a prefilter result DB into (query index, target index, diagonal) triples
+// ---------------------------------------------------------------------------------------------------------------
+struct Triples { std::vector<uint32_t> q, t; std::vector<int16_t> d; std::vector<uint64_t> perQuery; /* offsets per result entry */ std::vector<uint32_t> entryQuery; std::vector<uint32_t> entryKey; };
+
+static bool collectTriples(const Db &res, const std::map<uint32_t, uint32_t> &qIndex, const std::map<uint32_t, uint32_t> &tIndex, Triples &tr, std::string &err) {
+    tr.perQuery.assign(1, 0);
+    for (size_t i = 0; i < res.entries.size(); i++) {
+        const uint32_t key = res.entries[i].key;
+        const char *p = res.ptr(i);
+        uint32_t qi = 0xFFFFFFFFu;
+        if (*p != '\0') {
+            auto it = qIndex.find(key);
+            if (it == qIndex.end()) { err = "query " + std::to_string(key) + " of the result DB is not in the query DB"; return false; }
+            qi = it->second;
+        }
+        while (*p != '\0') {
+            char *e; unsigned long tk = strtoul(p, &e, 10);
+            long score = 0, diag = 0; int cols = 1;
+            if (*e == '\t') { score = strtol(e + 1, &e, 10); cols++; }
+            if (*e == '\t') { diag = strtol(e + 1, &e, 10); cols++; }
+            (void) score;
+            auto it = tIndex.find((uint32_t) tk);
+            if (it == tIndex.end()) { err = "target " + std::to_string(tk) + " of the result DB is not in the target DB"; return false; }
+            tr.q.push_back(qi); tr.t.push_back(it->second); tr.d.push_back(cols == 3 ? (int16_t) diag : 0);
+            while (*e != '\n' && *e != '\0') e++;
+            p = (*e == '\n') ? e + 1 : e;
+        }
+        tr.perQuery.push_back(tr.q.size()); tr.entryQuery.push_back(qi); tr.entryKey.push_back(key);
+    }
+    return true;
+}
+
+static void appendAlnLine(std::string &out, const sp_alignment &r, const char *cigar, bool addBacktrace) {
+    char buf[256]; char *p = buf;
+    p = u32toa(r.db_key, p); *p++ = '\t';
+    p = i32toa(r.bit_score, p); *p++ = '\t';
+    // Util::fastSeqIdToBuffer (Util.cpp:278-306): for 1.0 the caller overwrites the third '0' with the tab
+    if (r.seq_id == 1.0) { memcpy(p, "1.00", 4); p += 4; }
+    else { *p++ = '0'; *p++ = '.'; if (r.seq_id < 0.10) *p++ = '0'; if (r.seq_id < 0.01) *p++ = '0'; p = i32toa((int) (r.seq_id * 1000), p); }
+    *p++ = '\t';
+    p += sprintf(p, "%.3E", r.evalue); *p++ = '\t';
+    p = i32toa(r.q_start, p); *p++ = '\t'; p = i32toa(r.q_end, p); *p++ = '\t'; p = i32toa((int) r.q_len, p); *p++ = '\t';
+    p = i32toa(r.db_start, p); *p++ = '\t'; p = i32toa(r.db_end, p); *p++ = '\t'; p = i32toa((int) r.db_len, p);
+    out.append(buf, p - buf);
+    if (addBacktrace) {          // Matcher::compressAlignment (Matcher.cpp:211-230)
+        out.push_back('\t');
+        char state = 'M'; size_t counter = 0; char nb[16];
+        for (const char *c = cigar; *c; c++) { if (*c != state) { char *e = u32toa((uint32_t) counter, nb); out.append(nb, e - nb); out.push_back(state); state = *c; counter = 1; } else counter++; }
+        char *e = u32toa((uint32_t) counter, nb); out.append(nb, e - nb); out.push_back(state);
+    }
+    out.push_back('\n');
+}
+
+static bool alnLess(const sp_alignment &a, const sp_alignment &b) {      // Matcher::compareHits, Matcher.h:156-167
+    if (a.evalue != b.evalue) return a.evalue < b.evalue;
+    if (a.bit_score != b.bit_score) return a.bit_score > b.bit_score;
+    if (a.db_len != b.db_len) return a.db_len < b.db_len;
+    return a.db_key < b.db_key;
+}
+
+
+static bool openSearch(const Flags &f, const char *module, bool gapped, Ctx &ctx, Db &qdb, Db &tdb, std::vector<uint32_t> &qkeys, std::vector<uint32_t> &tkeys,
+                       std::vector<char> &qres, std::vector<uint64_t> &qoff, std::string &err) {
+    if (!loadSeqDb(f.positional[0], qdb, err) || !loadSeqDb(f.positional[1], tdb, err)) return false;
+    sp_search_params p; sp_default_params(&p);
+    static std::string sub; sub = aaPart(f.str("--sub-mat", "VTML40.out"));
+    p.sub_mat = sub.c_str();
+    p.evalue = f.real("-e", 0.001);
+    p.threads = (int) f.num("--threads", 0);
+    if (gapped) { p.gap_open = (int) strtol(aaPart(f.str("--gap-open", "11")).c_str(), NULL, 10); p.gap_extend = (int) strtol(aaPart(f.str("--gap-extend", "1")).c_str(), NULL, 10); }
+    ctx.c = sp_ctx_create(&p);
+    if (!ctx.c) { err = sp_last_error(); return false; }
+    std::vector<char> tres; std::vector<uint64_t> toff;
+    flatten(tdb, tres, toff, tkeys);
+    if (sp_ctx_set_targets_ex(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size(), 1 /* no k-mer index needed */) != SP_OK) { err = sp_last_error(); return false; }
+    flatten(qdb, qres, qoff, qkeys);
+    if (sp_ctx_set_queries(ctx.c, qres.data(), qoff.data(), qkeys.size()) != SP_OK) { err = sp_last_error(); return false; }
+    (void) module;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// align <queryDB> <targetDB> <prefilterDB> <outDB>          (alignment/Alignment.cpp:255-549)
+// ---------------------------------------------------------------------------------------------------------------
+int runAlignModule(int argc, const char **argv) {
+    Flags f; std::string err;
+    if (!parseFlags(argc, argv, kAlignFlags, 4, f, err)) return fail("align: " + err);
+    if (!requireValue(f, "--alignment-mode", {"0", "1", "2", "3"}, err) || !requireValue(f, "--comp-bias-corr", {"1"}, err) || !requireValue(f, "--compressed", {"0"}, err) ||
+        !requireValue(f, "--alt-ali", {"0"}, err) || !requireValue(f, "--realign", {"0"}, err) || !requireValue(f, "--wrapped-scoring", {"0"}, err) ||
+        !requireValue(f, "--add-self-matches", {"0"}, err) || !requireValue(f, "--alignment-output-mode", {"0"}, err) || !requireValue(f, "--score-bias", {"0", "0.0", "0.000"}, err) ||
+        !requireValue(f, "-c", {"0", "0.0", "0.000"}, err) || !requireValue(f, "--seq-id-mode", {"0"}, err))
+        return fail("align: " + err);
+    if (f.num("-a", 0) != 1) return fail("align: only -a 1 (backtrace => score, coverage and sequence identity) is implemented, which is what predictmatch passes");
+    Ctx ctx; Db qdb, tdb, rdb; std::vector<uint32_t> qkeys, tkeys; std::vector<char> qres; std::vector<uint64_t> qoff;
+    if (!openSearch(f, "align", true, ctx, qdb, tdb, qkeys, tkeys, qres, qoff, err)) return fail("align: " + err);
+    if (!rdb.load(f.positional[2], err)) return fail("align: " + err);
+    std::map<uint32_t, uint32_t> qIndex, tIndex;
+    for (size_t i = 0; i < qkeys.size(); i++) qIndex[qkeys[i]] = (uint32_t) i;
+    for (size_t i = 0; i < tkeys.size(); i++) tIndex[tkeys[i]] = (uint32_t) i;
+    Triples tr;
+    if (!collectTriples(rdb, qIndex, tIndex, tr, err)) return fail("align: " + err);
+    const double minSeqId = f.real("--min-seq-id", 0.0); const long minAlnLen = f.num("--min-aln-len", 0);
+    const long maxAccept = f.num("--max-accept", INT_MAX), maxRejected = f.num("--max-rejected", INT_MAX);
+    std::vector<sp_alignment> res(std::max<size_t>(1, tr.q.size()));
+    std::vector<char> cig(64 * (tr.q.size() + 16)); uint64_t used = 0;
+    int rc = sp_ctx_align(ctx.c, tr.q.data(), tr.t.data(), tr.q.size(), res.data(), cig.data(), cig.size(), &used);
+    if (rc == SP_ERR_OVERFLOW && used > cig.size()) { cig.resize(used + 16); rc = sp_ctx_align(ctx.c, tr.q.data(), tr.t.data(), tr.q.size(), res.data(), cig.data(), cig.size(), &used); }
+    if (rc != SP_OK) return fail(std::string("align: ") + sp_last_error());
+    DbWriter w; w.path = f.positional[3]; w.dbtype = 5;       // DBTYPE_ALIGNMENT_RES
+    std::string payload;
+    for (size_t e = 0; e + 1 < tr.perQuery.size(); e++) {
+        std::vector<std::pair<sp_alignment, const char *>> ok;
+        long passed = 0, rejected = 0;
+        for (uint64_t i = tr.perQuery[e]; i < tr.perQuery[e + 1] && passed < maxAccept && rejected < maxRejected; i++) {
+            const sp_alignment &r = res[i];
+            const bool good = r.passed && r.seq_id >= minSeqId && (long) r.aln_len >= minAlnLen;    // Alignment::checkCriteria, Alignment.cpp:555-574
+            if (good) { ok.push_back({r, cig.data() + r.cigar_offset}); passed++; rejected = 0; } else rejected++;
+        }
+        std::sort(ok.begin(), ok.end(), [](const std::pair<sp_alignment, const char *> &a, const std::pair<sp_alignment, const char *> &b) { return alnLess(a.first, b.first); });
+        payload.clear();
+        for (auto &x : ok) appendAlnLine(payload, x.first, x.second, true);
+        w.add(tr.entryKey[e], payload);
+    }
+    if (!w.close(err)) return fail("align: " + err);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// rescorediagonal <queryDB> <targetDB> <prefilterDB> <outDB>     (alignment/rescorediagonal.cpp:45-379), modes 1 and 2
+// ---------------------------------------------------------------------------------------------------------------
+int runRescoreDiagonalModule(int argc, const char **argv) {
+    Flags f; std::string err;
+    if (!parseFlags(argc, argv, kRescoreFlags, 4, f, err)) return fail("rescorediagonal: " + err);
+    if (!requireValue(f, "--rescore-mode", {"1", "2"}, err) || !requireValue(f, "--wrapped-scoring", {"0"}, err) || !requireValue(f, "--filter-hits", {"0"}, err) ||
+        !requireValue(f, "--compressed", {"0"}, err) || !requireValue(f, "--add-self-matches", {"0"}, err) || !requireValue(f, "-c", {"0", "0.0", "0.000"}, err) ||
+        !requireValue(f, "--seq-id-mode", {"0"}, err))
+        return fail("rescorediagonal: " + err);
+    const int mode = (int) f.num("--rescore-mode", 0);
+    if (mode != 1 && mode != 2) return fail("rescorediagonal: only --rescore-mode 1 and 2 are implemented");
+    Ctx ctx; Db qdb, tdb, rdb; std::vector<uint32_t> qkeys, tkeys; std::vector<char> qres; std::vector<uint64_t> qoff;
+    if (!openSearch(f, "rescorediagonal", false, ctx, qdb, tdb, qkeys, tkeys, qres, qoff, err)) return fail("rescorediagonal: " + err);
+    if (!rdb.load(f.positional[2], err)) return fail("rescorediagonal: " + err);
+    std::map<uint32_t, uint32_t> qIndex, tIndex;
+    for (size_t i = 0; i < qkeys.size(); i++) qIndex[qkeys[i]] = (uint32_t) i;
+    for (size_t i = 0; i < tkeys.size(); i++) tIndex[tkeys[i]] = (uint32_t) i;
+    Triples tr;
+    if (!collectTriples(rdb, qIndex, tIndex, tr, err)) return fail("rescorediagonal: " + err);
+    std::vector<sp_rescore> res(std::max<size_t>(1, tr.q.size()));
+    if (sp_ctx_rescore(ctx.c, tr.q.data(), tr.t.data(), tr.d.data(), tr.q.size(), mode, res.data()) != SP_OK) return fail(std::string("rescorediagonal: ") + sp_last_error());
+    const double evalThr = f.real("-e", 0.001), seqIdThr = f.real("--min-seq-id", 0.0); const long alnLenThr = f.num("--min-aln-len", 0);
+    const bool addBt = f.num("-a", 0) == 1; const bool sortRes = f.num("--sort-results", 0) > 0;
+    // target ASCII for the identity count of mode 2 (rescorediagonal.cpp:283-290 compares letters case-insensitively)
+    std::vector<char> tres; std::vector<uint64_t> toff; std::vector<uint32_t> tk2; flatten(tdb, tres, toff, tk2);
+    DbWriter w; w.path = f.positional[3]; w.dbtype = (mode == 2) ? 5 : (rdb.type() > 0 ? rdb.type() : 7);
+    std::string payload; char buf[64];
+    for (size_t e = 0; e + 1 < tr.perQuery.size(); e++) {
+        std::vector<std::pair<sp_alignment, std::string>> alns;
+        struct Short { uint32_t key; int score; int diag; }; std::vector<Short> shorts;
+        for (uint64_t i = tr.perQuery[e]; i < tr.perQuery[e + 1]; i++) {
+            const sp_rescore &r = res[i];
+            const uint32_t qi = tr.q[i], ti = tr.t[i];
+            const int qLen = (int) (qoff[qi + 1] - qoff[qi]), dbLen = (int) (toff[ti + 1] - toff[ti]);
+            double seqId = 0; int alnLen = 0;
+            const bool hasEvalue = r.evalue <= evalThr;
+            sp_alignment a; memset(&a, 0, sizeof(a));
+            std::string bt;
+            if (mode == 2) {
+                alnLen = (r.end_pos - r.start_pos) + 1;
+                int qs, qe, ts, te;
+                if (r.diagonal >= 0) { qs = r.start_pos + (int) r.dist_to_diagonal; qe = r.end_pos + (int) r.dist_to_diagonal; ts = r.start_pos; te = r.end_pos; }
+                else { qs = r.start_pos; qe = r.end_pos; ts = r.start_pos + (int) r.dist_to_diagonal; te = r.end_pos + (int) r.dist_to_diagonal; }
+                if (hasEvalue) {
+                    int ids = 0;
+                    for (int x = qs; x <= qe; x++) { char ql = qres[qoff[qi] + x] & (char) ~0x20, tl = tres[toff[ti] + ts + (x - qs)] & (char) ~0x20; ids += (ql == tl); }
+                    seqId = (double) ((float) ids / (float) alnLen);
+                }
+                if (addBt) { char *e2 = i32toa(alnLen, buf); bt.assign(buf, e2 - buf); bt.push_back('M'); }
+                a.db_key = tkeys[ti]; a.bit_score = r.bit_score; a.seq_id = (float) seqId; a.evalue = r.evalue; a.q_start = qs; a.q_end = qe; a.q_len = (uint32_t) qLen;
+                a.db_start = ts; a.db_end = te; a.db_len = (uint32_t) dbLen; a.aln_len = (uint32_t) alnLen;
+            }
+            const bool hasSeqId = seqId >= (seqIdThr - 1.1920929e-07), hasAlnLen = alnLen >= alnLenThr;
+            if (!(hasAlnLen && hasSeqId && hasEvalue)) continue;
+            if (mode == 2) alns.push_back({a, bt});
+            else shorts.push_back({tkeys[ti], r.bit_score, r.diagonal});
+        }
+        payload.clear();
+        if (mode == 2) {
+            if (sortRes) std::sort(alns.begin(), alns.end(), [](const std::pair<sp_alignment, std::string> &x, const std::pair<sp_alignment, std::string> &y) { return alnLess(x.first, y.first); });
+            for (auto &x : alns) {
+                // the reference prints the run-length string itself here (resultToBuffer(..., compress=false))
+                std::string line; appendAlnLine(line, x.first, "", false);
+                if (addBt) { line.pop_back(); line.push_back('\t'); line += x.second; line.push_back('\n'); }
+                payload += line;
+            }
+        } else {
+            if (sortRes) std::sort(shorts.begin(), shorts.end(), [](const Short &x, const Short &y) { int ax = abs(x.score), ay = abs(y.score); if (ax != ay) return ax > ay; return x.key < y.key; });
+            for (const Short &s : shorts) {
+                char *p = u32toa(s.key, buf); *p++ = '\t'; p = i32toa(s.score, p); *p++ = '\t'; p = i32toa((int32_t) (short) (uint16_t) s.diag, p); *p++ = '\n';
+                payload.append(buf, p - buf);
+            }
+        }
+        w.add(tr.entryKey[e], payload);
+    }
+    if (!w.close(err)) return fail("rescorediagonal: " + err);
+    return 0;
+}
+
+}  // namespace sp

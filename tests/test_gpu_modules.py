@@ -1,0 +1,105 @@
+"""GPU: the module drop-ins (`prefilter`, `align`, `rescorediagonal`) run with the exact command lines SpacePHARER's
+workflow issues on MMseqs2 DB triples and must write byte-identical entries to what the
+reference modules produce (golden `pref` / `text` strings come from QueryMatcher::prefilterHitToBuffer and
+Matcher::resultToBuffer of the real reference)."""
+import os
+import struct
+
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+PREF_FLAGS = ("--sub-mat nucl:nucleotide.out,aa:VTML40.out --seed-sub-mat nucl:nucleotide.out,aa:VTML80.out -k 6 --k-score 2147483647 "
+              "--alph-size nucl:5,aa:21 --max-seq-len 65535 --max-seqs %d --split 0 --split-mode 2 --split-memory-limit 0 -c 0 --cov-mode 0 "
+              "--comp-bias-corr 1 --diag-score 1 --exact-kmer-matching 0 --mask 1 --mask-lower-case 0 --min-ungapped-score 15 "
+              "--add-self-matches 0 --spaced-kmer-mode 1 --db-load-mode 0 --pca 1 --pcb 1.5 --spaced-kmer-pattern 11011101 --threads 8 "
+              "--compressed 0 -v 3 -s 5.7")
+ALN_FLAGS = ("--sub-mat nucl:nucleotide.out,aa:VTML40.out -a 1 --alignment-mode 2 --alignment-output-mode 0 --wrapped-scoring 0 -e 200 "
+             "--min-seq-id 0 --min-aln-len 0 --seq-id-mode 0 --alt-ali 0 -c 0 --cov-mode 0 --max-seq-len 65535 --comp-bias-corr 1 "
+             "--max-rejected 2147483647 --max-accept 2147483647 --add-self-matches 0 --db-load-mode 0 --pca 1 --pcb 1.5 --score-bias 0 "
+             "--realign 0 --realign-score-bias -0.2 --realign-max-seqs 2147483647 --gap-open nucl:10,aa:16 --gap-extend 2 --zdrop 40 "
+             "--threads 8 --compressed 0 -v 3")
+
+
+def write_seq_db(path, seqs, key0=0, split=False):
+    """MMseqs2 sequence DB: residues + '\\n' + NUL per entry; index key\\toffset\\tlength; 4-byte dbtype (0 = amino acids)."""
+    data = b"".join(s.encode() + b"\n\0" for s in seqs)
+    if split:     # exercise the <p>.0 / <p>.1 split data files the real workflow leaves behind
+        half = len(data) // 2
+        open(path + ".0", "wb").write(data[:half])
+        open(path + ".1", "wb").write(data[half:])
+    else:
+        open(path, "wb").write(data)
+    off = 0
+    with open(path + ".index", "w") as f:
+        for i, s in enumerate(seqs):
+            f.write("%d\t%d\t%d\n" % (key0 + i, off, len(s) + 2))
+            off += len(s) + 2
+    open(path + ".dbtype", "wb").write(struct.pack("<i", 0))
+
+
+def read_db(path):
+    data = open(path, "rb").read()
+    out = {}
+    for line in open(path + ".index"):
+        k, o, l = (int(x) for x in line.split("\t"))
+        out[k] = data[o:o + l - 1].decode()
+        assert data[o + l - 1] == 0
+    return out, struct.unpack("<i", open(path + ".dbtype", "rb").read(4))[0]
+
+
+@pytest.mark.parametrize("name", ["small", "family"])
+def test_prefilter_align_modules_on_db_triples(name, tmp_path):
+    import spacepharer_amd as sa
+    g = load_golden(name)
+    r = g["ref"]
+    q, t, pref, aln = (str(tmp_path / x) for x in ("qdb", "tdb", "pref", "aln"))
+    write_seq_db(q, g["queries"])
+    write_seq_db(t, g["targets"], split=True)
+    sa.module_prefilter([q, t, pref] + (PREF_FLAGS % r["maxSeqs"]).split())
+    got, dbtype = read_db(pref)
+    assert dbtype == 7
+    assert sorted(got) == list(range(len(g["queries"])))            # every query key present, empty ones too
+    for qq in r["queries"]:
+        assert got[qq["id"]] == qq["pref"], qq["id"]
+    sa.module_align([q, t, pref, aln] + ALN_FLAGS.split())
+    got, dbtype = read_db(aln)
+    assert dbtype == 5
+    for a in r["aln"]:
+        assert got[a["id"]] == a["text"], a["id"]
+    # index is sorted by key and .dbtype exists only after the data is complete
+    keys = [int(l.split("\t")[0]) for l in open(aln + ".index")]
+    assert keys == sorted(keys)
+
+
+def test_rescorediagonal_module(tmp_path):
+    import spacepharer_amd as sa
+    g = load_golden("small")
+    r = g["ref"]
+    q, t, pref, out1 = (str(tmp_path / x) for x in ("qdb", "tdb", "pref", "resc1"))
+    write_seq_db(q, g["queries"])
+    write_seq_db(t, g["targets"])
+    sa.module_prefilter([q, t, pref] + (PREF_FLAGS % r["maxSeqs"]).split())
+    sa.module_rescorediagonal([q, t, pref, out1, "--sub-mat", "nucl:nucleotide.out,aa:VTML40.out", "--rescore-mode", "1", "-e", "200",
+                               "-c", "0", "--min-seq-id", "0", "--threads", "4", "--compressed", "0", "-v", "3"])
+    got, dbtype = read_db(out1)
+    assert dbtype == 7
+    for a in r["aln"]:
+        exp = ""
+        for raw in a["rescore"]:
+            dbKey, s1, s2, st, en, dlen, dist, diag, ev, bits = raw
+            if float.fromhex(ev) <= 200.0:
+                d16 = ((diag + 32768) % 65536) - 32768
+                exp += "%d\t%d\t%d\n" % (dbKey, bits, d16)
+        assert got[a["id"]] == exp, a["id"]
+
+
+def test_module_fails_without_touching_dbtype_on_error(tmp_path):
+    import spacepharer_amd as sa
+    q, t, pref = (str(tmp_path / x) for x in ("qdb", "tdb", "pref"))
+    write_seq_db(q, ["ACDEFGHIKL"])
+    with pytest.raises(sa.SpError):
+        sa.module_prefilter([q, t, pref])          # target DB missing
+    assert not os.path.exists(pref + ".dbtype")

@@ -1,0 +1,106 @@
+"""CPU-side checks of the PRODUCT library (no GPU, no compute calls on the device): the shared object loads, exports every
+symbol the public header declares, rejects bad command lines, and its host set-up code (matrices, similar-k-mer table,
+tantan masking, k-mer index, E-value statistics) reproduces the reference-generated golden digests."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import spacepharer_amd as sa
+    if not os.path.exists(sa.library_path()):
+        sa.build_library()
+    return sa.load_library()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "spacepharer_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(sp_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), n
+    assert b"gfx950" in lib.sp_version()
+
+
+def test_modules_reject_bad_command_lines(lib):
+    def run(fn, args):
+        arr = (C.c_char_p * len(args))(*[a.encode() for a in args])
+        return getattr(lib, fn)(len(args), arr), lib.sp_last_error().decode()
+    rc, err = run("sp_prefilter_run", ["q", "t", "o", "--no-such-flag", "1"])
+    assert rc != 0 and "Unrecognized parameter" in err
+    rc, err = run("sp_prefilter_run", ["q", "t"])
+    assert rc != 0 and "database arguments" in err
+    rc, err = run("sp_prefilter_run", ["q", "t", "o", "--exact-kmer-matching", "1"])
+    assert rc != 0 and "unsupported value" in err
+    rc, err = run("sp_align_run", ["q", "t", "r", "o", "--alt-ali", "3"])
+    assert rc != 0 and "unsupported value" in err
+    rc, err = run("sp_rescorediagonal_run", ["q", "t", "r", "o", "--rescore-mode", "0"])
+    assert rc != 0
+    rc, err = run("sp_prefilter_run", ["/nonexistent/q", "/nonexistent/t", "/tmp/o"])
+    assert rc != 0 and "cannot open" in err
+
+
+def test_host_matrices(lib):
+    g = load_golden("small")["ref"]
+    lib.sp_host_matrix.argtypes = [C.c_char_p, C.c_double, C.c_double, C.POINTER(C.c_int16), C.POINTER(C.c_double)]
+    for spec, bf, sb, key in ((b"VTML80.out", 8.0, float(C.c_float(-0.2).value), "seedMat"),
+                              (b"VTML40.out", 2.0, float(C.c_float(-0.2).value), "ungappedMat"), (b"VTML40.out", 2.0, 0.0, "alnMat")):
+        sub = (C.c_int16 * 441)()
+        pb = (C.c_double * 21)()
+        assert lib.sp_host_matrix(spec, bf, sb, sub, pb) == 0
+        assert list(sub) == g[key]["sub"]
+        assert list(pb) == [float.fromhex(x) for x in g[key]["pBack"]]
+    assert lib.sp_host_matrix(b"NOPE.out", 2.0, 0.0, (C.c_int16 * 441)(), (C.c_double * 21)()) != 0
+
+
+def test_host_ext3_table(lib):
+    g = load_golden("small")["ref"]["ext3"]
+    lib.sp_host_ext3_digest.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int16), C.POINTER(C.c_uint32), C.c_uint32]
+    dig = C.c_uint64()
+    sc = (C.c_int16 * 64)()
+    ix = (C.c_uint32 * 64)()
+    assert lib.sp_host_ext3_digest(b"VTML80.out", C.byref(dig), sc, ix, 4321) == 0
+    assert "%016x" % dig.value == g["digest"]
+    assert list(sc) == g["rows"]["4321"]["score"] and list(ix) == g["rows"]["4321"]["index"]
+
+
+@pytest.mark.parametrize("name", ["small", "spacer", "family", "longq"])
+def test_host_masking_and_index(lib, name):
+    g = load_golden(name)
+    r = g["ref"]
+    lib.sp_host_index_digest.argtypes = [C.c_char_p, C.c_float, C.c_int, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint64,
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p]
+    T = [t.encode() for t in g["targets"]]
+    offs = (C.c_uint64 * (len(T) + 1))()
+    for i, t in enumerate(T):
+        offs[i + 1] = offs[i] + len(t)
+    buf = b"".join(T)
+    ent, msk, dig = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    masked = C.create_string_buffer(len(buf) + 1)
+    assert lib.sp_host_index_digest(b"VTML80.out", r["sens"], 1, buf, offs, len(T), C.byref(ent), C.byref(msk), C.byref(dig), masked) == 0
+    assert ent.value == r["index"]["entries"]
+    assert msk.value == r["maskedResidues"]
+    assert "%016x" % dig.value == r["index"]["digest"]
+    assert masked.raw[:len(buf)].decode() == "".join(r["masked"])
+
+
+def test_host_evalues(lib):
+    r = load_golden("spacer")["ref"]
+    lib.sp_host_evalue.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    for key, v in r["evalueProbe"].items():
+        ql, s = (int(x) for x in key.split("_"))
+        ev, bits, evg, bitsg = (float.fromhex(x) for x in v)
+        e, b = C.c_double(), C.c_double()
+        assert lib.sp_host_evalue(b"VTML40.out", 16, 2, r["aaDbSize"], float(s), float(ql), C.byref(e), C.byref(b)) == 0
+        assert (e.value, b.value) == (ev, bits)
+        assert lib.sp_host_evalue(b"VTML40.out", -1, -1, r["aaDbSize"], float(s), float(ql), C.byref(e), C.byref(b)) == 0
+        assert (e.value, b.value) == (evg, bitsg)
+    assert lib.sp_host_evalue(b"VTML40.out", 11, 1, 1000, 10.0, 10.0, C.byref(e), C.byref(b)) != 0   # untabulated combination: loud failure

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 make -s -C oracle liboracle.so
-timeout 400 python -m pytest tests/test_gpu_align.py -x -q -m gpu --timeout 120 2>&1 | tail -30
+timeout 600 python -m pytest tests -x -q -m gpu --timeout 200 2>&1 | tail -30
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
