@@ -109,13 +109,9 @@ def main():
 
     def step():
         ctx.prefilter()
-        hits, offs, npairs = ctx.hits_compact()
+        hits, offs, npairs = ctx.hits_compact()           # prefilter result DB content (hit_t triples per query)
         if args.stage == "full" and npairs:
-            off = np.ctypeslib.as_array(offs)
-            h = np.ctypeslib.as_array(C.cast(hits, C.POINTER(C.c_uint32)), shape=(npairs, 3))
-            qidx = np.repeat(np.arange(nq, dtype=np.uint32), np.diff(off).astype(np.int64))
-            tidx = np.ascontiguousarray(h[:, 0])
-            ctx.align_raw(qidx, tidx)
+            ctx.align_hits_raw()                          # alignment result DB content (result_t + backtraces per hit)
         return npairs
 
     def barrier():

@@ -120,6 +120,9 @@ int sp_ctx_get_hits_compact(sp_ctx *c, sp_hit *hits, uint64_t *offsets);
    bytes, *cigar_used returns the bytes needed/used (SP_ERR_OVERFLOW if cigar_cap is too small). */
 int sp_ctx_align(sp_ctx *c, const uint32_t *query_idx, const uint32_t *target_idx, uint64_t n, sp_alignment *results,
                  char *cigars, uint64_t cigar_cap, uint64_t *cigar_used);
+/* align every hit of the last sp_ctx_prefilter() without a host round trip in between; results[i] belongs to hit i of
+   sp_ctx_get_hits_compact() (n = sp_ctx_num_hits()) */
+int sp_ctx_align_hits(sp_ctx *c, sp_alignment *results, char *cigars, uint64_t cigar_cap, uint64_t *cigar_used);
 /* rescorediagonal core: mode 1 = substitution score, 2 = score + start/end */
 int sp_ctx_rescore(sp_ctx *c, const uint32_t *query_idx, const uint32_t *target_idx, const int16_t *diagonal, uint64_t n,
                    int mode, sp_rescore *results);

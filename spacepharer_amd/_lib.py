@@ -73,6 +73,7 @@ def load_library():
     L.sp_ctx_get_hits_compact.argtypes = [vp, C.POINTER(Hit), C.POINTER(C.c_uint64)]
     L.sp_ctx_align.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(Alignment), C.c_char_p,
                                C.c_uint64, C.POINTER(C.c_uint64)]
+    L.sp_ctx_align_hits.argtypes = [vp, C.POINTER(Alignment), C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.sp_ctx_rescore.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int16), C.c_uint64, C.c_int,
                                  C.POINTER(Rescore)]
     L.sp_ctx_stat.restype = C.c_double
@@ -243,6 +244,24 @@ class SearchContext:
                 continue
             _check(rc)
             return self._aln, self._cig
+
+    def align_hits_raw(self):
+        """align all hits of the last prefilter(); results follow hits_compact() order"""
+        n = int(self.L.sp_ctx_num_hits(self.ctx))
+        if getattr(self, "_aln_cap", 0) < n or not hasattr(self, "_aln"):
+            self._aln_cap = n + n // 4 + 16
+            self._aln = (Alignment * self._aln_cap)()
+            self._cig_cap = 64 * self._aln_cap
+            self._cig = C.create_string_buffer(self._cig_cap)
+        used = C.c_uint64()
+        while True:
+            rc = self.L.sp_ctx_align_hits(self.ctx, self._aln, self._cig, self._cig_cap, C.byref(used))
+            if rc == -5 and used.value > self._cig_cap:
+                self._cig_cap = int(used.value) * 2
+                self._cig = C.create_string_buffer(self._cig_cap)
+                continue
+            _check(rc)
+            return self._aln, self._cig, n
 
     def rescore(self, triples, mode):
         n = len(triples)

@@ -50,6 +50,9 @@ struct sp_ctx {
     sp::Evaluer evGapped, evGapless;
     bool haveGapped = false, haveGapless = false;
     std::map<std::string, double> stats;
+    std::map<uint32_t, std::vector<uint8_t>> gateRows;     // E-value gate rows per query length (for this target set / -e)
+    std::map<uint32_t, std::vector<double>> evalRows;      // evalue(score, qLen) per query length
+    std::vector<int32_t> bitRow;                           // int(bitScore(score) + 0.5)
     bool tablesUp = false;
 };
 
@@ -145,6 +148,7 @@ int sp_ctx_set_targets_ex(sp_ctx *c, const char *residues, const uint64_t *offse
     c->stats["target_residues"] = (double) c->targets.residues();
     c->stats["bin_size"] = c->binSize;
     c->haveGapped = c->haveGapless = false;
+    c->gateRows.clear(); c->evalRows.clear(); c->bitRow.clear();
     return SP_OK;
 }
 
@@ -207,55 +211,97 @@ static bool ensureEvaluers(sp_ctx *c, bool gapped, std::string &err) {
     return true;
 }
 
-int sp_ctx_align(sp_ctx *c, const uint32_t *qidx, const uint32_t *tidx, uint64_t n, sp_alignment *res, char *cigars, uint64_t cigarCap, uint64_t *cigarUsed) {
-    if (!c || c->targets.n == 0) { g_err = "sp_ctx_align: no target set"; return SP_ERR_STATE; }
-    std::string err;
-    if (!ensureEvaluers(c, true, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
-    std::vector<sp::SwPair> pairs(n);
-    for (uint64_t i = 0; i < n; i++) { pairs[i].query = qidx[i]; pairs[i].target = tidx[i]; }
-    std::vector<sp::SwForward> fwd;
-    if (!c->gpu.swForward(pairs.data(), (size_t) n, c->par.gap_open, c->par.gap_extend, fwd, err)) { g_err = err; return SP_ERR_DEVICE; }
-    // E-value gate between the passes (StripedSmithWaterman.cpp:188-200); scores repeat a lot, so memoise per (qLen, score)
-    std::vector<uint8_t> pass(n, 0);
-    std::map<uint64_t, double> memo;
-    for (uint64_t i = 0; i < n; i++) {
-        sp_alignment &r = res[i];
-        memset(&r, 0, sizeof(r));
-        const uint32_t qL = c->qoff[qidx[i] + 1] - c->qoff[qidx[i]];
-        const uint32_t tL = (uint32_t) (c->targets.offsets[tidx[i] + 1] - c->targets.offsets[tidx[i]]);
-        r.db_key = c->targets.keys[tidx[i]];
-        r.raw_score = fwd[i].score; r.q_len = qL; r.db_len = tL;
-        r.q_start = -1; r.db_start = -1; r.q_end = fwd[i].readEnd; r.db_end = fwd[i].refEnd;
-        r.bit_score = (int) (c->evGapped.bitScore(fwd[i].score) + 0.5);
-        if (fwd[i].refEnd == -1) continue;
-        const uint64_t mk = ((uint64_t) qL << 32) | (uint32_t) fwd[i].score;
-        auto it = memo.find(mk);
-        if (it == memo.end()) it = memo.emplace(mk, c->evGapped.evalue(fwd[i].score, qL)).first;
-        r.evalue = it->second;
-        pass[i] = !(r.evalue > c->par.evalue);
+// E-value gate table for the query lengths of the resident batch: pass[slot(qLen)][score] = !(evalue(score, qLen) > -e)
+// evaluated with the exact double arithmetic of EvalueComputation::computeEvalue; rows are cached per length
+static void buildGate(sp_ctx *c, sp::GateTable &g) {
+    const uint32_t maxL = c->gpu.maxQueryLen();
+    g.stride = std::min<uint32_t>(65536u, maxL * 32u + 2u);
+    g.slotOf.assign(maxL + 2, 0);
+    std::vector<uint32_t> lens;
+    { std::vector<uint8_t> seen(maxL + 2, 0); for (size_t q = 0; q + 1 < c->qoff.size(); q++) { uint32_t L = c->qoff[q + 1] - c->qoff[q]; if (!seen[L]) { seen[L] = 1; lens.push_back(L); } } }
+    g.pass.assign((lens.size() + 1) * (size_t) g.stride, 0);
+    for (size_t s = 0; s < lens.size(); s++) {
+        const uint32_t L = lens[s];
+        g.slotOf[L] = (uint16_t) s;
+        std::vector<uint8_t> &row = c->gateRows[L];
+        if (row.size() != g.stride) {
+            row.assign(g.stride, 0);
+            std::vector<double> &ev = c->evalRows[L];
+            const uint32_t lim = std::min<uint32_t>(g.stride, L * 32u + 2u);       // scores above qLen * max matrix entry cannot occur
+            ev.assign(lim, 0.0);
+            for (uint32_t sc = 0; sc < lim; sc++) { ev[sc] = c->evGapped.evalue((double) sc, (double) L); row[sc] = !(ev[sc] > c->par.evalue); }
+            for (uint32_t sc = lim; sc < g.stride; sc++) row[sc] = lim ? row[lim - 1] : 0;
+        }
+        memcpy(&g.pass[s * (size_t) g.stride], row.data(), g.stride);
     }
-    std::vector<sp::SwFull> full; std::vector<char> bt;
-    if (!c->gpu.swFinish(pass.data(), full, bt, err)) { g_err = err; return SP_ERR_DEVICE; }
+    if (c->bitRow.size() != g.stride) { c->bitRow.resize(g.stride); for (uint32_t sc = 0; sc < g.stride; sc++) c->bitRow[sc] = (int) (c->evGapped.bitScore((double) sc) + 0.5); }
+}
+
+static int finishAlign(sp_ctx *c, const std::vector<sp::SwPair> &pairs, const std::vector<sp::SwForward> &fwd, const std::vector<uint8_t> &pass,
+                       const std::vector<sp::SwFull> &full, const std::vector<char> &bt, const std::vector<uint32_t> *order,
+                       sp_alignment *res, char *cigars, uint64_t cigarCap, uint64_t *cigarUsed) {
+    const size_t n = pairs.size();
     uint64_t used = 0;
-    for (uint64_t i = 0; i < n; i++) if (pass[i]) used += (uint64_t) full[i].alnLen + 1;
+    for (size_t i = 0; i < n; i++) if (pass[i]) used += (uint64_t) full[i].alnLen + 1;
     if (cigarUsed) *cigarUsed = used;
     if (used > cigarCap) { g_err = "sp_ctx_align: cigar buffer too small"; return SP_ERR_OVERFLOW; }
+    std::vector<const std::vector<double> *> evRow(c->gpu.maxQueryLen() + 2, nullptr);
+    for (auto &kv : c->evalRows) if (kv.first < evRow.size()) evRow[kv.first] = &kv.second;
     uint64_t at = 0;
-    for (uint64_t i = 0; i < n; i++) {
+    for (size_t o = 0; o < n; o++) {
+        const size_t i = order ? (*order)[o] : o;
+        sp_alignment &r = res[o];
+        memset(&r, 0, sizeof(r));
+        const uint32_t q = pairs[i].query, t = pairs[i].target;
+        const uint32_t qL = c->qoff[q + 1] - c->qoff[q];
+        r.db_key = c->targets.keys[t];
+        r.raw_score = fwd[i].score; r.q_len = qL; r.db_len = (uint32_t) (c->targets.offsets[t + 1] - c->targets.offsets[t]);
+        r.q_start = -1; r.db_start = -1; r.q_end = fwd[i].readEnd; r.db_end = fwd[i].refEnd;
+        const uint32_t sc = (uint32_t) fwd[i].score;
+        r.bit_score = sc < c->bitRow.size() ? c->bitRow[sc] : (int) (c->evGapped.bitScore(fwd[i].score) + 0.5);
+        if (fwd[i].refEnd == -1) continue;
+        const std::vector<double> *er = qL < evRow.size() ? evRow[qL] : nullptr;
+        r.evalue = (er && sc < er->size()) ? (*er)[sc] : c->evGapped.evalue(fwd[i].score, qL);
         if (!pass[i]) continue;
-        sp_alignment &r = res[i];
-        if (full[i].status != 0) { g_err = "sp_ctx_align: traceback failed for a pair (status " + std::to_string(full[i].status) + ")"; return SP_ERR_OVERFLOW; }
         r.q_start = full[i].qStart; r.db_start = full[i].dbStart; r.aln_len = (uint32_t) full[i].alnLen;
         r.seq_id = (float) full[i].identities / (float) full[i].alnLen;     // Util::computeSeqId, SEQ_ID_ALN_LEN
         r.cigar_offset = (uint32_t) at;
         memcpy(cigars + at, bt.data() + full[i].btOffset, (size_t) full[i].alnLen);
-        cigars[at + full[i].alnLen] = '\0';
+        cigars[at + full[i].alnLen] = 0;
         at += (uint64_t) full[i].alnLen + 1;
         r.passed = (r.evalue <= c->par.evalue) && (r.seq_id >= 0.0);     // Alignment::checkCriteria, -c 0 --min-seq-id 0 --min-aln-len 0
     }
     sp::KernelTimes kt = c->gpu.times();
     c->stats["ms_sw_forward"] = kt.swForward; c->stats["ms_sw_reverse"] = kt.swReverse; c->stats["ms_traceback"] = kt.traceback;
     return SP_OK;
+}
+
+int sp_ctx_align(sp_ctx *c, const uint32_t *qidx, const uint32_t *tidx, uint64_t n, sp_alignment *res, char *cigars, uint64_t cigarCap, uint64_t *cigarUsed) {
+    if (!c || c->targets.n == 0) { g_err = "sp_ctx_align: no target set"; return SP_ERR_STATE; }
+    std::string err;
+    if (!ensureEvaluers(c, true, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
+    std::vector<sp::SwPair> pairs(n), unused;
+    for (uint64_t i = 0; i < n; i++) { pairs[i].query = qidx[i]; pairs[i].target = tidx[i]; }
+    sp::GateTable gate; buildGate(c, gate);
+    std::vector<sp::SwForward> fwd; std::vector<uint8_t> pass; std::vector<sp::SwFull> full; std::vector<char> bt;
+    if (!c->gpu.align(pairs.data(), (size_t) n, c->par.gap_open, c->par.gap_extend, gate, unused, fwd, pass, full, bt, err)) { g_err = err; return SP_ERR_DEVICE; }
+    return finishAlign(c, pairs, fwd, pass, full, bt, nullptr, res, cigars, cigarCap, cigarUsed);
+}
+
+/* align every hit of the last sp_ctx_prefilter(): results[i] belongs to hit i of sp_ctx_get_hits_compact() */
+int sp_ctx_align_hits(sp_ctx *c, sp_alignment *res, char *cigars, uint64_t cigarCap, uint64_t *cigarUsed) {
+    if (!c || c->targets.n == 0) { g_err = "sp_ctx_align_hits: no target set"; return SP_ERR_STATE; }
+    std::string err;
+    if (!ensureEvaluers(c, true, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
+    sp::GateTable gate; buildGate(c, gate);
+    std::vector<sp::SwPair> pairs; std::vector<sp::SwForward> fwd; std::vector<uint8_t> pass; std::vector<sp::SwFull> full; std::vector<char> bt;
+    if (!c->gpu.align(nullptr, 0, c->par.gap_open, c->par.gap_extend, gate, pairs, fwd, pass, full, bt, err)) { g_err = err; return SP_ERR_DEVICE; }
+    // device order (allocation order of k_select) -> hits grouped by query in query order
+    std::vector<uint32_t> base, count;
+    if (!c->gpu.downloadHitLayout(base, count, err)) { g_err = err; return SP_ERR_DEVICE; }
+    std::vector<uint32_t> order; order.reserve(pairs.size());
+    for (size_t q = 0; q < base.size(); q++) for (uint32_t k = 0; k < count[q]; k++) order.push_back(base[q] + k);
+    return finishAlign(c, pairs, fwd, pass, full, bt, &order, res, cigars, cigarCap, cigarUsed);
 }
 
 int sp_ctx_rescore(sp_ctx *c, const uint32_t *qidx, const uint32_t *tidx, const int16_t *diag, uint64_t n, int mode, sp_rescore *res) {

@@ -19,6 +19,8 @@ struct SwFull {
     uint32_t btOffset;            // into the backtrace byte pool
     int32_t status;               // 0 ok
 };
+// E-value gate as a lookup table filled by the host with the exact double-precision test: pass[slotOf[qLen] * stride + min(score, stride-1)]
+struct GateTable { uint32_t stride = 0; std::vector<uint16_t> slotOf; std::vector<uint8_t> pass; };
 struct DiagRescore { int32_t score, startPos, endPos, diagonalLen, diagonal; uint32_t distToDiagonal; };
 
 struct PrefilterCounters {       // the K, M, D, H terms of the roofline formula
@@ -60,6 +62,16 @@ public:
     // the pairs whose flag is set (the host applies the E-value gate in between)
     bool swForward(const SwPair *pairs, size_t n, int gapOpen, int gapExtend, std::vector<SwForward> &out, std::string &err);
     bool swFinish(const uint8_t *passMask, std::vector<SwFull> &out, std::vector<char> &backtraces, std::string &err);
+    bool traceHostDriven(const uint8_t *passMask, std::vector<SwFull> &out, std::vector<char> &backtraces, std::string &err);
+    bool reverseAndTrace(const uint8_t *passMask, bool runReverse, std::vector<SwFull> &out, std::vector<char> &backtraces, std::string &err);
+
+    // device-driven align: forward pass, E-value gate (table), 16-bit redo, reverse pass, banded traceback without host
+    // round trips.  hostPairs == nullptr aligns every hit of the last prefilter() (pairs come back in compact hit order).
+    bool align(const SwPair *hostPairs, size_t n, int gapOpen, int gapExtend, const GateTable &gate, std::vector<SwPair> &pairsOut,
+               std::vector<SwForward> &fwd, std::vector<uint8_t> &passMask, std::vector<SwFull> &full, std::vector<char> &bt, std::string &err);
+    // per-query base/count of the compact hit array of the last prefilter()
+    bool downloadHitLayout(std::vector<uint32_t> &base, std::vector<uint32_t> &count, std::string &err);
+    uint32_t maxQueryLen() const;
 
     // rescorediagonal: ungapped score on one diagonal of the UNMASKED residues, align matrix, no composition bias
     bool rescoreDiagonals(const SwPair *pairs, const uint16_t *diags, size_t n, int mode, std::vector<DiagRescore> &out, std::string &err);

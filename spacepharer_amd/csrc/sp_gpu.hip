@@ -167,7 +167,6 @@ __global__ void k_prep(PrepArgs a) {
 //   kept(h)      <=>  recorded(h) and (no earlier recorded hit of the target, or diag8 differs from the last one)
 // Only windows [0, lastWindow) are scanned (CacheFriendlyOperations.cpp:43 with QueryMatcher.cpp:285-291).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kHitCap = 2048;        // hits per query held in LDS
 constexpr int kSpillCap = 65535;     // hits per query in the per-wave HBM scratch (16-bit stream index)
 constexpr int kATile = 256;
 constexpr int kBTile = 512;
@@ -215,6 +214,8 @@ __device__ void markKept(const uint64_t *keys, uint32_t M, uint32_t *bits, int l
     }
 }
 
+// HITCAP = hits per query held in LDS; more spill to the per-wave HBM scratch.  Smaller HITCAP = more resident waves.
+template <int kHitCap>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     __shared__ uint64_t s_keys[kWavesPerBlock][kHitCap];
     __shared__ uint32_t s_aStart[kWavesPerBlock][kATile + 1];
@@ -465,6 +466,7 @@ __global__ void k_score(ScoreArgs a) {
 // output is sorted by (final score desc, seqId asc).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kSelCap = 1024;
+constexpr int kSelChunk = 16;     // queries per work-queue pop
 
 struct SelectArgs {
     uint32_t nq; const DiagRec *diagRec; const uint16_t *diagScore; const uint32_t *qDiagBase; const uint32_t *qDiagCnt;
@@ -473,13 +475,13 @@ struct SelectArgs {
     uint64_t *selScratch;           // per-wave HBM key scratch (65536 keys) for oversized candidate lists
     uint32_t *queue;                // work counter (persistent waves)
     uint32_t binMask; int maxHits; int minDiagScore;
-    GpuHit *outHits; uint32_t *outCount; uint32_t *outBase; uint32_t *outCursor;   // compact output: each query owns [outBase, outBase+outCount)
+    GpuHit *outHits; uint32_t *outQuery; uint32_t *outCount; uint32_t *outBase; uint32_t *outCursor;   // compact output: each query owns [outBase, outBase+outCount)
     unsigned long long *counters;   // [4] += hits
 };
 
 __device__ __forceinline__ void selectOne(const SelectArgs &a, const uint32_t qi, uint32_t *hist, uint64_t *keys, uint64_t *scratch, const int lane) {
     const uint32_t D = uni(a.qDiagCnt[qi]);
-    if (D == 0) { if (lane == 0) a.outCount[qi] = 0; return; }
+    if (D == 0) { if (lane == 0) { a.outCount[qi] = 0; a.outBase[qi] = 0; } return; }
     const uint32_t base = uni(a.qDiagBase[qi]);
     const DiagRec *rec = a.diagRec + base;
     const uint16_t *exact = a.diagScore + base;
@@ -520,7 +522,7 @@ __device__ __forceinline__ void selectOne(const SelectArgs &a, const uint32_t qi
     uint32_t nC = 0;
     for (int t = lane; t < 256; t += 64) if ((uint32_t) t >= thr) nC += hist[t];
     nC = waveSum(nC);
-    if (nC == 0) { if (lane == 0) a.outCount[qi] = 0; return; }
+    if (nC == 0) { if (lane == 0) { a.outCount[qi] = 0; a.outBase[qi] = 0; } return; }
     const bool inLds = nC <= (uint32_t) kSelCap;
     uint64_t *K = inLds ? keys : scratch;
     uint32_t n = 1; while (n < nC) n <<= 1;
@@ -576,6 +578,7 @@ __device__ __forceinline__ void selectOne(const SelectArgs &a, const uint32_t qi
         const uint32_t r = (uint32_t) (k3 & 0xFFFF);
         GpuHit h; h.seqId = rec[r].seqId; h.score = (uint16_t) (65535 - (uint32_t) (k3 >> 48)); h.diag = rec[r].diag;
         a.outHits[(size_t) obase + t] = h;
+        a.outQuery[(size_t) obase + t] = qi;
     }
     if (lane == 0) { a.outCount[qi] = nOut; a.outBase[qi] = obase; }
     waveSync();
@@ -587,10 +590,41 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_select(SelectArgs a) {
     const int lane = laneId();
     const int w = (int) (threadIdx.x >> 6);
     uint64_t *scratch = a.selScratch + (size_t) (blockIdx.x * kWavesPerBlock + w) * kSpillWordsPerWave;
+    // 64 queries per pop: queries with a single double-hit diagonal (the common case for spacer peptides) are
+    // finished lane-parallel; the others are handled one at a time by the whole wave
     for (;;) {
-        const uint32_t qi = popQueue(a.queue, lane);
-        if (qi >= a.nq) break;
-        selectOne(a, qi, s_hist[w], s_keys[w], scratch, lane);
+        const uint32_t chunk = popQueue(a.queue, lane);
+        if ((uint64_t) chunk * kSelChunk >= a.nq) break;
+        const uint32_t qi = chunk * kSelChunk + lane;
+        const uint32_t D = (lane < kSelChunk && qi < a.nq) ? a.qDiagCnt[qi] : 0;
+        const bool fast = (D == 1) && a.maxHits > 1;
+        bool hit = false; GpuHit h{0, 0, 0};
+        if (fast) {
+            const uint32_t b = a.qDiagBase[qi];
+            const int qL = (int) (a.qoff[qi + 1] - a.qoff[qi]);
+            const int bias = a.qbias[qi];
+            const int maxC = (qL >= 32768) ? 255 : 255 - bias;
+            const int ex = a.diagScore[b];
+            const int c = min(ex, maxC);
+            if (c >= a.minDiagScore) {
+                hit = true;
+                const DiagRec r = a.diagRec[b];
+                int score = (c >= 255 - bias) ? ex : c;
+                h.seqId = r.seqId; h.score = (uint16_t) (score > 65535 ? 65535 : score); h.diag = r.diag;
+            }
+        }
+        const uint64_t hm = __ballot(hit);
+        const uint32_t nh = (uint32_t) __popcll(hm);
+        uint32_t ob = 0;
+        if (nh) ob = uni(atomicAdd(a.outCursor, lane == 0 ? nh : 0u));
+        if (hit) { const uint32_t at = ob + (uint32_t) __popcll(hm & laneMaskLt(lane)); a.outHits[at] = h; a.outQuery[at] = qi; a.outBase[qi] = at; a.outCount[qi] = 1; }
+        else if (lane < kSelChunk && qi < a.nq && (D == 0 || fast)) { a.outCount[qi] = 0; a.outBase[qi] = 0; }
+        uint64_t slow = __ballot(D > 0 && !fast);
+        while (slow) {
+            const int bit = __builtin_ctzll(slow);
+            slow &= slow - 1;
+            selectOne(a, chunk * kSelChunk + (uint32_t) bit, s_hist[w], s_keys[w], scratch, lane);
+        }
     }
 }
 
@@ -621,6 +655,7 @@ struct SwDev {
     DevBuf<uint64_t> dirOff, rowOff, btOff; DevBuf<uint32_t> dirCap, rowCap, btCap;
     DevBuf<signed char> dirPool; DevBuf<int> rowPool; DevBuf<char> btPool; DevBuf<SwFull> full;
     DevBuf<uint16_t> diag; DevBuf<DiagRescore> resc;
+    DevBuf<uint32_t> passList, redoList, counters; DevBuf<unsigned long long> cursors; DevBuf<uint8_t> gatePass; DevBuf<uint16_t> gateSlot;
     size_t preparedFor = (size_t) -1; const void *preparedPtr = nullptr;
 };
 
@@ -634,7 +669,7 @@ struct Gpu::Impl {
     int ungMinAbs = 0, alnMinAbs = 0;
     // targets
     DevBuf<uint32_t> ioff; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff;
-    size_t nTargets = 0;
+    size_t nTargets = 0; size_t indexEntries = 0;
     // queries
     DevBuf<uint8_t> qres; DevBuf<uint32_t> qoff; DevBuf<float> biasf; DevBuf<short> qthr; DevBuf<signed char> qcorr; DevBuf<int> qbias; DevBuf<int> qself;
     size_t qTotal = 0; uint32_t maxQLen = 0;
@@ -642,7 +677,7 @@ struct Gpu::Impl {
     // match / select
     DevBuf<uint64_t> spill; DevBuf<uint32_t> queue; DevBuf<DiagRec> diagRec; DevBuf<uint32_t> diagQuery; DevBuf<uint16_t> diagScore; DevBuf<uint8_t> diagFlag;
     DevBuf<uint32_t> qDiagBase; DevBuf<uint32_t> qDiagCnt; DevBuf<unsigned long long> counters;
-    DevBuf<GpuHit> outHits; DevBuf<uint32_t> outCount; DevBuf<uint32_t> outBase;
+    DevBuf<GpuHit> outHits; DevBuf<uint32_t> outQuery; DevBuf<uint32_t> outCount; DevBuf<uint32_t> outBase;
     uint32_t matchBlocks = 0;
     SwState sw;
     SwDev swd;
@@ -710,7 +745,7 @@ bool Gpu::uploadTables(const std::vector<uint32_t> &ext3, const SubMat &seed, co
 
 bool Gpu::uploadTargets(const TargetSet &ts, const KmerIndex &idx, std::string &err) {
     Impl &d = *d_;
-    d.nTargets = ts.n;
+    d.nTargets = ts.n; d.indexEntries = idx.entries.size();
     if (!upload(d.ioff, idx.offsets.data(), idx.offsets.size(), d.stream, err)) return false;
     if (!upload(d.ientries, idx.entries.data(), idx.entries.size(), d.stream, err)) return false;
     if (!upload(d.tmasked, ts.masked.data(), ts.masked.size(), d.stream, err)) return false;
@@ -741,15 +776,21 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     if (!d.ext3.p || !d.ioff.p) { err = "tables/targets not resident"; return false; }
     if (nq_ == 0) return true;
     maxHits_ = maxHits;
-    // persistent match grid: 2 blocks (8 waves) per CU -- bounded by the 80 KiB of LDS a block takes
-    const uint32_t blocks = (uint32_t) std::min<size_t>((nq_ + kWavesPerBlock - 1) / kWavesPerBlock, (size_t) d.numCU * 2);
+    // persistent match grid: as many blocks per CU as the LDS footprint of the chosen hit-buffer size admits.
+    // Expected hits per query ~ (similar k-mers per query) x (index entries per k-mer slot); keep 4x headroom.
+    int hitCap = ((double) d.indexEntries / (double) kTableSize * 1300.0 * 4.0 < 512.0) ? 512 : 2048;
+    if (const char *e = getenv("SP_HITCAP")) hitCap = atoi(e) <= 512 ? 512 : 2048;
+    int perCU = 2;
+    if (hitCap == 512) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_match<512>, 64 * kWavesPerBlock, 0) != hipSuccess || perCU < 1) perCU = 2; }
+    else { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_match<2048>, 64 * kWavesPerBlock, 0) != hipSuccess || perCU < 1) perCU = 2; }
+    const uint32_t blocks = (uint32_t) std::min<size_t>((nq_ + kWavesPerBlock - 1) / kWavesPerBlock, (size_t) d.numCU * perCU);
     d.matchBlocks = blocks;
     if (!d.spill.ensure((size_t) blocks * kWavesPerBlock * kSpillWordsPerWave, err)) return false;
     if (!d.queue.ensure(4, err) || !d.counters.ensure(8, err)) return false;
     // diagonal buffer: generous, HBM is plentiful (64 M records = 512 MB + side arrays)
     const size_t diagCap = std::max<size_t>((size_t) 1 << 22, std::min<size_t>((size_t) 1 << 26, nq_ * 64));
     if (!d.diagRec.ensure(diagCap, err) || !d.diagQuery.ensure(diagCap, err) || !d.diagScore.ensure(diagCap, err) || !d.diagFlag.ensure(diagCap, err)) return false;
-    if (!d.outHits.ensure(nq_ * (size_t) maxHits, err)) return false;
+    if (!d.outHits.ensure(nq_ * (size_t) maxHits, err) || !d.outQuery.ensure(nq_ * (size_t) maxHits, err)) return false;
     const uint32_t selBlocks = (uint32_t) ((nq_ + kWavesPerBlock - 1) / kWavesPerBlock);
     (void) selBlocks;
     HIP_OK(hipMemsetAsync(d.queue.p, 0, 4 * sizeof(uint32_t), d.stream));
@@ -764,7 +805,8 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     HIP_OK(hipEventRecord(d.ev[1], d.stream));
     MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ioff.p, d.ientries.p, d.spill.p, d.queue.p,
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p};
-    hipLaunchKernelGGL(k_match, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+    if (hitCap == 512) hipLaunchKernelGGL(k_match<512>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+    else hipLaunchKernelGGL(k_match<2048>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     SP_DBG_SYNC("k_match");
     HIP_OK(hipEventRecord(d.ev[2], d.stream));
     ScoreArgs sa{d.diagRec.p, d.diagQuery.p, d.queue.p + 1, (uint32_t) diagCap, d.qres.p, d.qoff.p, d.qcorr.p, d.tmasked.p, d.toff.p, d.ungSub.p, d.diagScore.p, d.counters.p};
@@ -772,7 +814,7 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     SP_DBG_SYNC("k_score");
     HIP_OK(hipEventRecord(d.ev[3], d.stream));
     SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.queue.p + 2,
-                  binSize - 1, maxHits, minDiagScore, d.outHits.p, d.outCount.p, d.outBase.p, d.queue.p + 3, d.counters.p};
+                  binSize - 1, maxHits, minDiagScore, d.outHits.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.queue.p + 3, d.counters.p};
     hipLaunchKernelGGL(k_select, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, se);
     SP_DBG_SYNC("k_select");
     HIP_OK(hipEventRecord(d.ev[4], d.stream));

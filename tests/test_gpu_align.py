@@ -93,3 +93,27 @@ def test_align_matches_oracle_on_fresh_inputs():
             assert res.seq_id == e.seqId
     ctx.close()
     o.close()
+
+
+def test_align_hits_equals_align_pairs():
+    """the fused prefilter -> align path (pairs built on the device) returns exactly what aligning the downloaded hits does"""
+    import spacepharer_amd as sa
+    g = load_golden("family")
+    r = g["ref"]
+    ctx = sa.SearchContext(sensitivity=r["sens"], max_seqs=r["maxSeqs"])
+    ctx.set_targets(g["targets"])
+    ctx.set_queries(g["queries"])
+    ctx.prefilter()
+    hits = ctx.hits()
+    pairs = [(qi, h[0]) for qi, hs in enumerate(hits) for h in hs]
+    a = ctx.align(pairs)
+    aln, cig, n = ctx.align_hits_raw()
+    assert n == len(pairs)
+    import ctypes as C
+    for i, (res, c1) in enumerate(a):
+        b = aln[i]
+        assert (b.db_key, b.bit_score, b.raw_score, b.q_start, b.q_end, b.db_start, b.db_end, b.aln_len, b.passed, b.evalue) == \
+               (res.db_key, res.bit_score, res.raw_score, res.q_start, res.q_end, res.db_start, res.db_end, res.aln_len, res.passed, res.evalue)
+        if b.aln_len:
+            assert C.string_at(C.addressof(cig) + b.cigar_offset).decode() == c1
+    ctx.close()
