@@ -88,6 +88,8 @@ __device__ void waveBitonicSort(uint64_t *keys, uint32_t n, int lane) {
     }
 }
 
+struct __attribute__((packed, aligned(4))) Off2 { uint32_t lo, hi; };   // ioff[k], ioff[k+1] with one 8-byte load
+
 __device__ __forceinline__ int extScore(uint32_t packed) { return (int) (packed >> 16) - 32768; }
 __device__ __forceinline__ uint32_t extIndex(uint32_t packed) { return packed & 0xFFFFu; }
 
@@ -180,6 +182,7 @@ struct MatchArgs {
     const uint8_t *qres; const uint32_t *qoff; uint32_t nq; const short *qthr;
     const uint32_t *ext3;           // 8000 x 8000 packed (score+32768)<<16 | index
     const uint32_t *ioff;           // 20^6 + 1
+    const uint32_t *ibits;          // 20^6 bits: k-mer slot has entries (nullptr = do not use; pays off for sparse indices)
     const uint64_t *ientries;       // seqId | pos << 32
     uint64_t *spill;                // per-wave scratch: kSpillCap+1 keys (+ bitmap) each
     uint32_t *queue;                // work counter
@@ -296,18 +299,29 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                 if (lane == 0) aStart[nATile] = tileK;
                 waveSync();
                 if (kBase + tileK > kMaxKmerResult - 1) { tileK = kMaxKmerResult - 1 - kBase; lastTile = true; }
+                // Flattened (a, b) enumeration, 64 similar k-mers per round.  Lane L owns k = k0 + L and needs the largest a
+                // with aStart[a] <= k.  The a's are consecutive and every a contributes >= 1 k-mer, so the a's that START
+                // inside this round are aCur+1 .. aCur+63 at most: lane j looks at candidate aCur+1+j, the start positions
+                // are OR-reduced into a 64-bit mask and a popcount below the own position gives the offset -- no search.
+                uint32_t aCur = 0;
                 for (uint32_t k0 = 0; k0 < tileK; k0 += 64) {
                     const uint32_t k = k0 + lane;
                     uint32_t o0 = 0, len = 0;
+                    const uint32_t cand = aCur + 1u + (uint32_t) lane;
+                    unsigned long long startBit = 0;
+                    if (cand < nATile) { const uint32_t st = aStart[cand]; if (st - k0 < 64u) startBit = 1ull << (st - k0); }
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) startBit |= __shfl_xor(startBit, d);
+                    const uint32_t ai = aCur + (uint32_t) __popcll(startBit & (~0ull >> (63 - lane)));
+                    aCur = uni(aCur + (uint32_t) __popcll(startBit));       // a of the last position of this round
                     if (k < tileK) {
-                        // largest ai with aStart[ai] <= k
-                        uint32_t lo = 0, hi = nATile;
-                        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (aStart[mid] <= k) lo = mid; else hi = mid; }
-                        const uint32_t b = k - aStart[lo];
+                        const uint32_t b = k - aStart[ai];
                         const uint32_t bi = (b < (uint32_t) kBTile) ? bIdx[b] : extIndex(rowB[b]);
-                        const uint32_t kmer = aIdx[lo] + 8000u * bi;
-                        o0 = a.ioff[kmer];
-                        len = a.ioff[kmer + 1] - o0;
+                        const uint32_t kmer = aIdx[ai] + 8000u * bi;
+                        // sparse index: 1 bit from an 8 MB (L2/MALL-resident) bitmap decides whether the offsets pair -- a
+                        // random sector of the 256 MB table -- has to be fetched at all
+                        const bool occupied = a.ibits ? ((a.ibits[kmer >> 5] >> (kmer & 31)) & 1u) : true;
+                        if (occupied) { const Off2 o = *reinterpret_cast<const Off2 *>(a.ioff + kmer); o0 = o.lo; len = o.hi - o.lo; }
                     }
                     const uint32_t incl = waveInclusiveScan(len, lane);
                     const uint32_t tot = lane63(incl);
@@ -668,7 +682,7 @@ struct Gpu::Impl {
     DevBuf<short> alnSub16; DevBuf<double> alnBack;
     int ungMinAbs = 0, alnMinAbs = 0;
     // targets
-    DevBuf<uint32_t> ioff; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff;
+    DevBuf<uint32_t> ioff; DevBuf<uint32_t> ibits; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff;
     size_t nTargets = 0; size_t indexEntries = 0;
     // queries
     DevBuf<uint8_t> qres; DevBuf<uint32_t> qoff; DevBuf<float> biasf; DevBuf<short> qthr; DevBuf<signed char> qcorr; DevBuf<int> qbias; DevBuf<int> qself;
@@ -747,6 +761,13 @@ bool Gpu::uploadTargets(const TargetSet &ts, const KmerIndex &idx, std::string &
     Impl &d = *d_;
     d.nTargets = ts.n; d.indexEntries = idx.entries.size();
     if (!upload(d.ioff, idx.offsets.data(), idx.offsets.size(), d.stream, err)) return false;
+    {
+        std::vector<uint32_t> bits((kTableSize + 31) / 32, 0);
+        if (idx.offsets.size() == (size_t) kTableSize + 1)
+            for (uint32_t k = 0; k < kTableSize; k++) if (idx.offsets[k + 1] != idx.offsets[k]) bits[k >> 5] |= 1u << (k & 31);
+        if (!upload(d.ibits, bits.data(), bits.size(), d.stream, err)) return false;
+        HIP_OK(hipStreamSynchronize(d.stream));
+    }
     if (!upload(d.ientries, idx.entries.data(), idx.entries.size(), d.stream, err)) return false;
     if (!upload(d.tmasked, ts.masked.data(), ts.masked.size(), d.stream, err)) return false;
     if (!upload(d.tplain, ts.plain.data(), ts.plain.size(), d.stream, err)) return false;
@@ -778,11 +799,13 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     maxHits_ = maxHits;
     // persistent match grid: as many blocks per CU as the LDS footprint of the chosen hit-buffer size admits.
     // Expected hits per query ~ (similar k-mers per query) x (index entries per k-mer slot); keep 4x headroom.
-    int hitCap = ((double) d.indexEntries / (double) kTableSize * 1300.0 * 4.0 < 512.0) ? 512 : 2048;
+    int hitCap = ((double) d.indexEntries / (double) kTableSize * 1300.0 * 2.5 < 512.0) ? 512 : 2048;
     if (const char *e = getenv("SP_HITCAP")) hitCap = atoi(e) <= 512 ? 512 : 2048;
     int perCU = 2;
     if (hitCap == 512) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_match<512>, 64 * kWavesPerBlock, 0) != hipSuccess || perCU < 1) perCU = 2; }
     else { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_match<2048>, 64 * kWavesPerBlock, 0) != hipSuccess || perCU < 1) perCU = 2; }
+    if (const char *e = getenv("SP_MATCH_PERCU")) perCU = std::max(1, atoi(e));
+    if (getenv("SP_DEBUG")) fprintf(stderr, "[sp] k_match hitCap=%d blocks/CU=%d\n", hitCap, perCU);
     const uint32_t blocks = (uint32_t) std::min<size_t>((nq_ + kWavesPerBlock - 1) / kWavesPerBlock, (size_t) d.numCU * perCU);
     d.matchBlocks = blocks;
     if (!d.spill.ensure((size_t) blocks * kWavesPerBlock * kSpillWordsPerWave, err)) return false;
@@ -803,7 +826,9 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     hipLaunchKernelGGL(k_prep, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, pa);
     SP_DBG_SYNC("k_prep");
     HIP_OK(hipEventRecord(d.ev[1], d.stream));
-    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ioff.p, d.ientries.p, d.spill.p, d.queue.p,
+    // the occupancy bitmap pays off while most k-mer slots are empty (phage-scale DBs); a dense index skips it
+    const bool useBits = getenv("SP_NO_BITMAP") == nullptr && (double) d.indexEntries < 0.5 * (double) kTableSize;
+    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ioff.p, useBits ? d.ibits.p : nullptr, d.ientries.p, d.spill.p, d.queue.p,
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p};
     if (hitCap == 512) hipLaunchKernelGGL(k_match<512>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     else hipLaunchKernelGGL(k_match<2048>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);

@@ -1,0 +1,117 @@
+"""GPU, BASELINE.json's full single-GPU size (10 000 spacers = 60 000 peptides vs 1e7 target residues): size-independent
+properties of the whole path + bit-exact comparison with the oracle on a random sample of the queries."""
+import ctypes as C
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def full():
+    import bench
+    import spacepharer_amd as sa
+    tres, toff, qres, qoff = bench.make_workload(10000, 50000, 200, 12345)
+    ctx = sa.SearchContext()
+    ctx.set_targets_raw(tres.tobytes(), bench.u64p(toff), len(toff) - 1)
+    nq = len(qoff) - 1
+    ctx.set_queries_raw(qres.tobytes(), bench.u64p(qoff), nq)
+    ctx.prefilter()
+    hits, offs, n = ctx.hits_compact()
+    h = np.ctypeslib.as_array(C.cast(hits, C.POINTER(C.c_int32)), shape=(max(1, n), 3))[:n].copy()
+    off = np.ctypeslib.as_array(offs).astype(np.int64).copy()
+    yield dict(ctx=ctx, tres=tres, qres=qres, nq=nq, h=h, off=off, n=n)
+    ctx.close()
+
+
+def test_counters_and_shapes(full):
+    ctx, h, off, nq, n = full["ctx"], full["h"], full["off"], full["nq"], full["n"]
+    assert off[0] == 0 and off[-1] == n and np.all(np.diff(off) >= 0) and np.all(np.diff(off) <= 300)
+    assert int(ctx.stat("hits")) == n
+    assert ctx.stat("index_entries") > 9e6          # ~9.6e6 at 1e7 residues
+    assert ctx.stat("db_matches") > ctx.stat("diagonals") >= n * 0.9
+    seq = h[:, 0]; score = h[:, 1]; diag = (h[:, 2] << 16) >> 16
+    assert seq.min() >= 0 and seq.max() < 50000
+    assert score.min() >= 15                         # --min-ungapped-score
+    assert np.all(np.abs(diag) < 200 + 10)
+
+
+def test_order_and_uniqueness_per_query(full):
+    h, off, nq = full["h"], full["off"], full["nq"]
+    for q in range(0, nq, 7):
+        s = h[off[q]:off[q + 1]]
+        if len(s) < 2:
+            continue
+        key = list(zip((-s[:, 1]).tolist(), s[:, 0].tolist()))
+        assert key == sorted(key)                    # (score desc, seqId asc)
+        assert len(set(s[:, 0].tolist())) == len(s)  # one diagonal per target
+
+
+def test_planted_windows_are_found(full):
+    """even-indexed peptides are windows of a target with one substitution: whenever the reference algorithm can see them
+    (two scanned windows with a double k-mer hit) the source target must be in the list with the planted diagonal"""
+    import bench
+    rng = np.random.default_rng(12345)
+    # regenerate the planting decisions exactly as make_workload does
+    n_targets, tl, nq, ql = 50000, 200, 60000, 10
+    rng.choice(20, size=n_targets * tl, p=bench.BG)
+    rng.choice(20, size=nq * ql, p=bench.BG)
+    tid = rng.integers(0, n_targets, size=nq)
+    pos = rng.integers(0, tl - ql + 1, size=nq)
+    h, off = full["h"], full["off"]
+    found = 0
+    for q in range(0, nq, 2):
+        s = h[off[q]:off[q + 1]]
+        m = s[s[:, 0] == tid[q]]
+        if len(m) and (((int(m[0, 2]) << 16) >> 16) & 0xFFFF) == ((-int(pos[q])) & 0xFFFF):
+            found += 1
+    assert found > 0.5 * (nq // 2)                   # most planted windows survive prefilter (the rest lose their k-mer pair to the substitution)
+
+
+def test_idempotent(full):
+    ctx, h, off = full["ctx"], full["h"], full["off"]
+    ctx.prefilter()
+    hits, offs, n = ctx.hits_compact()
+    h2 = np.ctypeslib.as_array(C.cast(hits, C.POINTER(C.c_int32)), shape=(max(1, n), 3))[:n]
+    assert n == full["n"] and np.array_equal(h2, h) and np.array_equal(np.ctypeslib.as_array(offs).astype(np.int64), off)
+
+
+def test_sample_against_oracle_at_full_size(full):
+    import gzip
+    from oracle_lib import Alp, Oracle
+    tres, qres, h, off, nq, ctx = full["tres"], full["qres"], full["h"], full["off"], full["nq"], full["ctx"]
+    o = Oracle()
+    o.set_targets([tres[i * 200:(i + 1) * 200].tobytes() for i in range(50000)])
+    g = json.load(gzip.open(os.path.join(ROOT, "tests/golden/spacer.json.gz")))["ref"]
+    o.set_alp(Alp.from_ref(g["alpGapped"]), Alp.from_ref(g["alpGapless"]))
+    assert int(ctx.stat("index_entries")) == lib_entries(o)
+    rnd = random.Random(7)
+    sample = rnd.sample(range(nq), 400)
+    aln, cig, n = ctx.align_hits_raw()
+    checked = 0
+    for q in sample:
+        qs = qres[q * 10:(q + 1) * 10].tobytes().decode()
+        exp = o.prefilter_list(qs)
+        got = [[int(x[0]), int(x[1]), ((int(x[2]) & 0xFFFF) ^ 0x8000) - 0x8000] for x in h[off[q]:off[q + 1]]]
+        assert got == exp, q
+        for k, e in enumerate(exp):
+            r = aln[off[q] + k]
+            a = o.align(qs, e[0])
+            assert (r.raw_score, r.bit_score, r.q_end, r.db_end, r.passed) == (a.rawScore, a.score, a.qEndPos, a.dbEndPos, a.passed)
+            if a.passed:
+                assert (r.q_start, r.db_start, r.evalue) == (a.qStartPos, a.dbStartPos, a.eval)
+                assert C.string_at(C.addressof(cig) + r.cigar_offset).decode() == a.backtrace.decode()
+            checked += 1
+    assert checked > 100
+    o.close()
+
+
+def lib_entries(o):
+    from oracle_lib import lib
+    return lib().spo_index_entries(o.ctx)
