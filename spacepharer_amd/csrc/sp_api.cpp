@@ -5,6 +5,7 @@
 #include <chrono>
 #include <climits>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -247,29 +248,39 @@ static int finishAlign(sp_ctx *c, const std::vector<sp::SwPair> &pairs, const st
     if (used > cigarCap) { g_err = "sp_ctx_align: cigar buffer too small"; return SP_ERR_OVERFLOW; }
     std::vector<const std::vector<double> *> evRow(c->gpu.maxQueryLen() + 2, nullptr);
     for (auto &kv : c->evalRows) if (kv.first < evRow.size()) evRow[kv.first] = &kv.second;
-    uint64_t at = 0;
-    for (size_t o = 0; o < n; o++) {
-        const size_t i = order ? (*order)[o] : o;
-        sp_alignment &r = res[o];
-        memset(&r, 0, sizeof(r));
-        const uint32_t q = pairs[i].query, t = pairs[i].target;
-        const uint32_t qL = c->qoff[q + 1] - c->qoff[q];
-        r.db_key = c->targets.keys[t];
-        r.raw_score = fwd[i].score; r.q_len = qL; r.db_len = (uint32_t) (c->targets.offsets[t + 1] - c->targets.offsets[t]);
-        r.q_start = -1; r.db_start = -1; r.q_end = fwd[i].readEnd; r.db_end = fwd[i].refEnd;
-        const uint32_t sc = (uint32_t) fwd[i].score;
-        r.bit_score = sc < c->bitRow.size() ? c->bitRow[sc] : (int) (c->evGapped.bitScore(fwd[i].score) + 0.5);
-        if (fwd[i].refEnd == -1) continue;
-        const std::vector<double> *er = qL < evRow.size() ? evRow[qL] : nullptr;
-        r.evalue = (er && sc < er->size()) ? (*er)[sc] : c->evGapped.evalue(fwd[i].score, qL);
-        if (!pass[i]) continue;
-        r.q_start = full[i].qStart; r.db_start = full[i].dbStart; r.aln_len = (uint32_t) full[i].alnLen;
-        r.seq_id = (float) full[i].identities / (float) full[i].alnLen;     // Util::computeSeqId, SEQ_ID_ALN_LEN
-        r.cigar_offset = (uint32_t) at;
-        memcpy(cigars + at, bt.data() + full[i].btOffset, (size_t) full[i].alnLen);
-        cigars[at + full[i].alnLen] = 0;
-        at += (uint64_t) full[i].alnLen + 1;
-        r.passed = (r.evalue <= c->par.evalue) && (r.seq_id >= 0.0);     // Alignment::checkCriteria, -c 0 --min-seq-id 0 --min-aln-len 0
+    // cigar offsets first (serial, cheap), then the records in parallel
+    std::vector<uint64_t> cigAt(n + 1, 0);
+    for (size_t o = 0; o < n; o++) { const size_t i = order ? (*order)[o] : o; cigAt[o + 1] = cigAt[o] + (pass[i] ? (uint64_t) full[i].alnLen + 1 : 0); }
+    auto fill = [&](size_t from, size_t to) {
+        for (size_t o = from; o < to; o++) {
+            const size_t i = order ? (*order)[o] : o;
+            sp_alignment &r = res[o];
+            memset(&r, 0, sizeof(r));
+            const uint32_t q = pairs[i].query, t = pairs[i].target;
+            const uint32_t qL = c->qoff[q + 1] - c->qoff[q];
+            r.db_key = c->targets.keys[t];
+            r.raw_score = fwd[i].score; r.q_len = qL; r.db_len = (uint32_t) (c->targets.offsets[t + 1] - c->targets.offsets[t]);
+            r.q_start = -1; r.db_start = -1; r.q_end = fwd[i].readEnd; r.db_end = fwd[i].refEnd;
+            const uint32_t sc = (uint32_t) fwd[i].score;
+            r.bit_score = sc < c->bitRow.size() ? c->bitRow[sc] : (int) (c->evGapped.bitScore(fwd[i].score) + 0.5);
+            if (fwd[i].refEnd == -1) continue;
+            const std::vector<double> *er = qL < evRow.size() ? evRow[qL] : nullptr;
+            r.evalue = (er && sc < er->size()) ? (*er)[sc] : c->evGapped.evalue(fwd[i].score, qL);
+            if (!pass[i]) continue;
+            r.q_start = full[i].qStart; r.db_start = full[i].dbStart; r.aln_len = (uint32_t) full[i].alnLen;
+            r.seq_id = (float) full[i].identities / (float) full[i].alnLen;     // Util::computeSeqId, SEQ_ID_ALN_LEN
+            r.cigar_offset = (uint32_t) cigAt[o];
+            memcpy(cigars + cigAt[o], bt.data() + full[i].btOffset, (size_t) full[i].alnLen);
+            cigars[cigAt[o] + full[i].alnLen] = 0;
+            r.passed = (r.evalue <= c->par.evalue) && (r.seq_id >= 0.0);     // Alignment::checkCriteria, -c 0 --min-seq-id 0 --min-aln-len 0
+        }
+    };
+    const size_t nThreads = n > 20000 ? (size_t) std::min(8, std::max(1, c->threads)) : 1;
+    if (nThreads == 1) fill(0, n);
+    else {
+        std::vector<std::thread> pool; const size_t chunk = (n + nThreads - 1) / nThreads;
+        for (size_t t = 0; t < nThreads; t++) { const size_t a = std::min(n, t * chunk), b = std::min(n, a + chunk); pool.emplace_back(fill, a, b); }
+        for (auto &th : pool) th.join();
     }
     sp::KernelTimes kt = c->gpu.times();
     c->stats["ms_sw_forward"] = kt.swForward; c->stats["ms_sw_reverse"] = kt.swReverse; c->stats["ms_traceback"] = kt.traceback;
@@ -293,15 +304,17 @@ int sp_ctx_align_hits(sp_ctx *c, sp_alignment *res, char *cigars, uint64_t cigar
     if (!c || c->targets.n == 0) { g_err = "sp_ctx_align_hits: no target set"; return SP_ERR_STATE; }
     std::string err;
     if (!ensureEvaluers(c, true, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
+    const bool dbg = getenv("SP_DEBUG") != nullptr;
+    double t0 = nowMs();
     sp::GateTable gate; buildGate(c, gate);
+    double t1 = nowMs();
     std::vector<sp::SwPair> pairs; std::vector<sp::SwForward> fwd; std::vector<uint8_t> pass; std::vector<sp::SwFull> full; std::vector<char> bt;
     if (!c->gpu.align(nullptr, 0, c->par.gap_open, c->par.gap_extend, gate, pairs, fwd, pass, full, bt, err)) { g_err = err; return SP_ERR_DEVICE; }
-    // device order (allocation order of k_select) -> hits grouped by query in query order
-    std::vector<uint32_t> base, count;
-    if (!c->gpu.downloadHitLayout(base, count, err)) { g_err = err; return SP_ERR_DEVICE; }
-    std::vector<uint32_t> order; order.reserve(pairs.size());
-    for (size_t q = 0; q < base.size(); q++) for (uint32_t k = 0; k < count[q]; k++) order.push_back(base[q] + k);
-    return finishAlign(c, pairs, fwd, pass, full, bt, &order, res, cigars, cigarCap, cigarUsed);
+    double t2 = nowMs();
+    double t3 = nowMs();
+    int rc = finishAlign(c, pairs, fwd, pass, full, bt, nullptr, res, cigars, cigarCap, cigarUsed);
+    if (dbg) fprintf(stderr, "[sp] align_hits: gate %.3f  gpu.align %.3f  layout %.3f  finish %.3f ms\n", t1 - t0, t2 - t1, t3 - t2, nowMs() - t3);
+    return rc;
 }
 
 int sp_ctx_rescore(sp_ctx *c, const uint32_t *qidx, const uint32_t *tidx, const int16_t *diag, uint64_t n, int mode, sp_rescore *res) {

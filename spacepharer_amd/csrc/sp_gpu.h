@@ -66,11 +66,9 @@ public:
     bool reverseAndTrace(const uint8_t *passMask, bool runReverse, std::vector<SwFull> &out, std::vector<char> &backtraces, std::string &err);
 
     // device-driven align: forward pass, E-value gate (table), 16-bit redo, reverse pass, banded traceback without host
-    // round trips.  hostPairs == nullptr aligns every hit of the last prefilter() (pairs come back in compact hit order).
+    // round trips.  hostPairs == nullptr aligns every hit of the last prefilter(), in the order of downloadHits().
     bool align(const SwPair *hostPairs, size_t n, int gapOpen, int gapExtend, const GateTable &gate, std::vector<SwPair> &pairsOut,
                std::vector<SwForward> &fwd, std::vector<uint8_t> &passMask, std::vector<SwFull> &full, std::vector<char> &bt, std::string &err);
-    // per-query base/count of the compact hit array of the last prefilter()
-    bool downloadHitLayout(std::vector<uint32_t> &base, std::vector<uint32_t> &count, std::string &err);
     uint32_t maxQueryLen() const;
 
     // rescorediagonal: ungapped score on one diagonal of the UNMASKED residues, align matrix, no composition bias

@@ -642,6 +642,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_select(SelectArgs a) {
     }
 }
 
+// query-ordered output: exclusive scan of the per-query hit counts (one block), then move the hits from the staging
+// array (allocation order of k_select) to their final place; everything downstream (download, align) is sequential
+__global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t *count, uint32_t n, uint32_t *offset /* n+1 */) {
+    __shared__ uint32_t s_part[1024];
+    const uint32_t per = (n + 1023) / 1024, from = min(n, threadIdx.x * per), to = min(n, from + per);
+    uint32_t sum = 0;
+    for (uint32_t i = from; i < to; i++) sum += count[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[threadIdx.x] - sum;
+    for (uint32_t i = from; i < to; i++) { offset[i] = run; run += count[i]; }
+    if (threadIdx.x == 1023) offset[n] = s_part[1023];
+}
+
+__global__ void k_reorder_hits(const GpuHit *staging, const uint32_t *base, const uint32_t *count, const uint32_t *offset, uint32_t nq, GpuHit *out, uint32_t *outQuery) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t b = base[q], o = offset[q], c = count[q];
+    for (uint32_t k = 0; k < c; k++) { out[o + k] = staging[b + k]; outQuery[o + k] = q; }
+}
+
 #include "sp_gpu_sw.inc"
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -691,7 +718,7 @@ struct Gpu::Impl {
     // match / select
     DevBuf<uint64_t> spill; DevBuf<uint32_t> queue; DevBuf<DiagRec> diagRec; DevBuf<uint32_t> diagQuery; DevBuf<uint16_t> diagScore; DevBuf<uint8_t> diagFlag;
     DevBuf<uint32_t> qDiagBase; DevBuf<uint32_t> qDiagCnt; DevBuf<unsigned long long> counters;
-    DevBuf<GpuHit> outHits; DevBuf<uint32_t> outQuery; DevBuf<uint32_t> outCount; DevBuf<uint32_t> outBase;
+    DevBuf<GpuHit> outHits; DevBuf<GpuHit> outStage; DevBuf<uint32_t> outQuery; DevBuf<uint32_t> outCount; DevBuf<uint32_t> outBase; DevBuf<uint32_t> outOffset;
     uint32_t matchBlocks = 0;
     SwState sw;
     SwDev swd;
@@ -787,7 +814,7 @@ bool Gpu::uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std:
     if (!upload(d.qres, res, d.qTotal, d.stream, err)) return false;
     if (!upload(d.qoff, off, nq + 1, d.stream, err)) return false;
     if (!d.biasf.ensure(d.qTotal + 1, err) || !d.qthr.ensure(d.qTotal + 1, err) || !d.qcorr.ensure(d.qTotal + 1, err)) return false;
-    if (!d.qbias.ensure(nq + 1, err) || !d.qself.ensure(nq + 1, err) || !d.qDiagBase.ensure(nq + 1, err) || !d.qDiagCnt.ensure(nq + 1, err) || !d.outCount.ensure(nq + 1, err) || !d.outBase.ensure(nq + 1, err)) return false;
+    if (!d.qbias.ensure(nq + 1, err) || !d.qself.ensure(nq + 1, err) || !d.qDiagBase.ensure(nq + 1, err) || !d.qDiagCnt.ensure(nq + 1, err) || !d.outCount.ensure(nq + 1, err) || !d.outBase.ensure(nq + 1, err) || !d.outOffset.ensure(nq + 2, err)) return false;
     HIP_OK(hipStreamSynchronize(d.stream));
     return true;
 }
@@ -813,7 +840,7 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     // diagonal buffer: generous, HBM is plentiful (64 M records = 512 MB + side arrays)
     const size_t diagCap = std::max<size_t>((size_t) 1 << 22, std::min<size_t>((size_t) 1 << 26, nq_ * 64));
     if (!d.diagRec.ensure(diagCap, err) || !d.diagQuery.ensure(diagCap, err) || !d.diagScore.ensure(diagCap, err) || !d.diagFlag.ensure(diagCap, err)) return false;
-    if (!d.outHits.ensure(nq_ * (size_t) maxHits, err) || !d.outQuery.ensure(nq_ * (size_t) maxHits, err)) return false;
+    if (!d.outHits.ensure(nq_ * (size_t) maxHits, err) || !d.outStage.ensure(nq_ * (size_t) maxHits, err) || !d.outQuery.ensure(nq_ * (size_t) maxHits, err)) return false;
     const uint32_t selBlocks = (uint32_t) ((nq_ + kWavesPerBlock - 1) / kWavesPerBlock);
     (void) selBlocks;
     HIP_OK(hipMemsetAsync(d.queue.p, 0, 4 * sizeof(uint32_t), d.stream));
@@ -839,8 +866,10 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     SP_DBG_SYNC("k_score");
     HIP_OK(hipEventRecord(d.ev[3], d.stream));
     SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.queue.p + 2,
-                  binSize - 1, maxHits, minDiagScore, d.outHits.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.queue.p + 3, d.counters.p};
+                  binSize - 1, maxHits, minDiagScore, d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.queue.p + 3, d.counters.p};
     hipLaunchKernelGGL(k_select, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, se);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d.stream, d.outCount.p, (uint32_t) nq_, d.outOffset.p);
+    hipLaunchKernelGGL(k_reorder_hits, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.outStage.p, d.outBase.p, d.outCount.p, d.outOffset.p, (uint32_t) nq_, d.outHits.p, d.outQuery.p);
     SP_DBG_SYNC("k_select");
     HIP_OK(hipEventRecord(d.ev[4], d.stream));
     unsigned long long c[8]; uint32_t qv[4];
@@ -866,15 +895,12 @@ bool Gpu::downloadHits(std::vector<GpuHit> &hits, std::vector<uint64_t> &offsets
     hits.clear();
     if (nq_ == 0) return true;
     const size_t total = (size_t) counters_.hits;
-    std::vector<uint32_t> cnt(nq_), base(nq_);
-    std::vector<GpuHit> raw(total);
-    HIP_OK(hipMemcpyAsync(cnt.data(), d.outCount.p, nq_ * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
-    HIP_OK(hipMemcpyAsync(base.data(), d.outBase.p, nq_ * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
-    if (total) HIP_OK(hipMemcpyAsync(raw.data(), d.outHits.p, total * sizeof(GpuHit), hipMemcpyDeviceToHost, d.stream));
-    HIP_OK(hipStreamSynchronize(d.stream));
-    for (size_t q = 0; q < nq_; q++) offsets[q + 1] = offsets[q] + cnt[q];
+    std::vector<uint32_t> off(nq_ + 1);
     hits.resize(total);
-    for (size_t q = 0; q < nq_; q++) if (cnt[q]) memcpy(&hits[offsets[q]], &raw[base[q]], cnt[q] * sizeof(GpuHit));
+    HIP_OK(hipMemcpyAsync(off.data(), d.outOffset.p, (nq_ + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    if (total) HIP_OK(hipMemcpyAsync(hits.data(), d.outHits.p, total * sizeof(GpuHit), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipStreamSynchronize(d.stream));
+    for (size_t q = 0; q <= nq_; q++) offsets[q] = off[q];
     return true;
 }
 

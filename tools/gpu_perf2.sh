@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python tools/host_prof.py 2>&1 | tail -6
+SP_DEBUG=1 timeout 300 python tools/host_prof.py 2>&1 | grep 'align_hits:' | tail -3
