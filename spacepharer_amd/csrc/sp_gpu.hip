@@ -172,15 +172,20 @@ __global__ void k_prep(PrepArgs a) {
 constexpr int kSpillCap = 65535;     // hits per query in the per-wave HBM scratch (16-bit stream index)
 constexpr int kATile = 256;
 constexpr int kBTile = 512;
-constexpr int kCntB = 384;
+constexpr int kCntW = 320;         // width of a row of the count table: cutoffs cntMin .. cntMin + 319
 constexpr uint32_t kMaxKmerResult = 262144u * 32u;   // KmerGenerator.h:45
 constexpr int kWavesPerBlock = 4;
+constexpr uint32_t kDiagChunk = 64;   // diagonal records reserved per atomic in k_match
+constexpr uint32_t kQueryChunk = 4;
+constexpr int kSuper = 1024;         // similar k-mers per enumeration super-round in k_match   // queries per work-queue pop in k_match
 
 struct DiagRec { uint32_t seqId; uint16_t diag; uint16_t idx; };
 
 struct MatchArgs {
     const uint8_t *qres; const uint32_t *qoff; uint32_t nq; const short *qthr;
     const uint32_t *ext3;           // 8000 x 8000 packed (score+32768)<<16 | index
+    const uint16_t *ext3cnt;        // 8000 x kCntW: [row][c - cntMin] = number of partners with score >= c
+    int cntMin;
     const uint32_t *ioff;           // 20^6 + 1
     const uint32_t *ibits;          // 20^6 bits: k-mer slot has entries (nullptr = do not use; pays off for sparse indices)
     const uint64_t *ientries;       // seqId | pos << 32
@@ -189,6 +194,7 @@ struct MatchArgs {
     DiagRec *diagRec; uint32_t *diagQuery; uint32_t diagCap; uint32_t *diagCursor;
     uint32_t *qDiagBase; uint32_t *qDiagCnt;
     unsigned long long *counters;   // [0]=kmers [1]=dbMatches [2]=overflow queries
+    int ablate;                     // experiments only: 1 = skip the offsets gather, 2 = skip the per-window prologue reuse
 };
 
 constexpr size_t kSpillWordsPerWave = 65536 + 65536 / 64;   // keys + kept-bitmap (as u64 words)
@@ -224,8 +230,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     __shared__ uint32_t s_aStart[kWavesPerBlock][kATile + 1];
     __shared__ uint16_t s_aIdx[kWavesPerBlock][kATile];
     __shared__ uint16_t s_bIdx[kWavesPerBlock][kBTile];
-    __shared__ uint16_t s_cntB[kWavesPerBlock][kCntB];
+    __shared__ uint16_t s_cntB[kWavesPerBlock][kCntW];
     __shared__ uint32_t s_bits[kWavesPerBlock][kHitCap / 32];
+    __shared__ uint32_t s_occ[kWavesPerBlock][kSuper];
 
     const int lane = laneId();
     const int w = (int) (threadIdx.x >> 6);
@@ -235,13 +242,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     uint16_t *bIdx = s_bIdx[w];
     uint16_t *cntB = s_cntB[w];
     uint32_t *bitsL = s_bits[w];
+    uint32_t *occList = s_occ[w];
     const uint32_t waveGlobal = blockIdx.x * kWavesPerBlock + w;
     uint64_t *spillKeys = a.spill + (size_t) waveGlobal * kSpillWordsPerWave;
     uint32_t *spillBits = (uint32_t *) (spillKeys + 65536);
-    unsigned long long kmersTotal = 0, matchesTotal = 0;
+    unsigned long long kmersTotal = 0, matchesTotal = 0, diagTotal = 0;
+    uint32_t dChunkBase = 0, dChunkUsed = 0, dChunkCap = 0;
 
-    for (;;) {
-        const uint32_t qi = popQueue(a.queue, lane);
+    // one atomic pops kQueryChunk queries: a single counter word serialises at ~12 ns per atomic (60 000 pops = 0.7 ms)
+    for (uint32_t qc = 0, qcEnd = 0;;) {
+        if (qc == qcEnd) { qc = popQueue(a.queue, lane) * kQueryChunk; qcEnd = qc + kQueryChunk; if (qc >= a.nq) break; }
+        const uint32_t qi = qc++;
         if (qi >= a.nq) break;
         const uint32_t qo = uni(a.qoff[qi]);
         const int L = (int) (uni(a.qoff[qi + 1]) - qo);
@@ -249,46 +260,66 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
         const int nScan = L - kSpan;        // windows 0 .. L-9 ; the last window (L-8) is never scanned
         uint32_t M = 0;
         bool overflow = false;
+        // the wave is bound by chains of dependent memory round trips, so: residues and thresholds of the first 64
+        // positions are fetched once per query into lanes (readlane per window), and all loads of a window's
+        // prologue (row A tile, head of row B, count-table row) are issued together
+        const int myRes = lane < L ? (int) q[lane] : 0;
+        const int myThr = lane < L ? (int) a.qthr[qo + lane] : -1;
 
         for (int i = 0; i < nScan; i++) {
-            const int thr = (int) uni((uint32_t) (int) a.qthr[qo + i]);
+            if (a.ablate == 3) break;
+            int thr; uint32_t ia, ib;
+            if (i + kSpan <= 64) {
+                thr = __builtin_amdgcn_readlane(myThr, i);
+                ia = (uint32_t) __builtin_amdgcn_readlane(myRes, i) + 20u * (uint32_t) __builtin_amdgcn_readlane(myRes, i + 1) + 400u * (uint32_t) __builtin_amdgcn_readlane(myRes, i + 3);
+                ib = (uint32_t) __builtin_amdgcn_readlane(myRes, i + 4) + 20u * (uint32_t) __builtin_amdgcn_readlane(myRes, i + 5) + 400u * (uint32_t) __builtin_amdgcn_readlane(myRes, i + 7);
+            } else {
+                thr = (int) uni((uint32_t) (int) a.qthr[qo + i]);
+                ia = uni(q[i] + 20u * q[i + 1] + 400u * q[i + 3]);
+                ib = uni(q[i + 4] + 20u * q[i + 5] + 400u * q[i + 7]);
+            }
             if (thr < 0) continue;
-            const uint32_t ia = uni(q[i] + 20u * q[i + 1] + 400u * q[i + 3]);
-            const uint32_t ib = uni(q[i + 4] + 20u * q[i + 5] + 400u * q[i + 7]);
             const uint32_t *rowA = a.ext3 + (size_t) ia * 8000u;
             const uint32_t *rowB = a.ext3 + (size_t) ib * 8000u;
-            const int sB0 = (int) uni((uint32_t) extScore(rowB[0]));
-            const int sA0 = (int) uni((uint32_t) extScore(rowA[0]));
+            const uint16_t *cntRow = a.ext3cnt + (size_t) ib * kCntW;
+            // ---- one batch of independent loads
+            uint32_t vA0[kATile / 64];
+#pragma unroll
+            for (int j = 0; j < kATile / 64; j++) vA0[j] = rowA[j * 64 + lane];
+            const uint32_t vB0 = rowB[lane], vB1 = rowB[64 + lane];
+            uint16_t cw[kCntW / 64];
+#pragma unroll
+            for (int j = 0; j < kCntW / 64; j++) cw[j] = cntRow[j * 64 + lane];
+            const int sB0 = (int) uni((uint32_t) extScore(vB0));
+            const int sA0 = (int) uni((uint32_t) extScore(vA0[0]));
             const int cutoff1 = (short) (thr - sB0);
             if (sA0 < cutoff1) continue;
             const int minCut2 = (short) (thr - sA0);
-            // ---- prefix of row B with score >= minCut2: partner indices + "how many b reach cutoff c" table
-            for (uint32_t p0 = 0;; p0 += 64) {
-                const uint32_t p = p0 + lane;
-                int s = -32768, sn = -32768; uint32_t v = 0;
-                if (p < 8000u) { v = rowB[p]; s = extScore(v); }
-                if (p + 1 < 8000u) sn = extScore(rowB[p + 1]);
-                const bool valid = s >= minCut2;
-                if (valid) {
-                    if (p < (uint32_t) kBTile) bIdx[p] = (uint16_t) extIndex(v);
-                    int cLo = sn + 1; if (cLo < minCut2) cLo = minCut2;
-                    for (int c = cLo; c <= s; c++) { const int at = c - minCut2; if (at < kCntB) cntB[at] = (uint16_t) (p + 1); }
-                }
-                if (__ballot(valid) != ~0ull) break;
-            }
+            // "how many b reach cutoff c": precomputed per-row count table
+#pragma unroll
+            for (int j = 0; j < kCntW / 64; j++) cntB[j * 64 + lane] = cw[j];
+            bIdx[lane] = (uint16_t) extIndex(vB0); bIdx[64 + lane] = (uint16_t) extIndex(vB1);
+            waveSync();
+            int cAt = minCut2 - a.cntMin; cAt = cAt < 0 ? 0 : (cAt >= kCntW ? kCntW - 1 : cAt);
+            const uint32_t nBmax = uni((uint32_t) cntB[cAt]);
+            for (uint32_t p = 128 + lane; p < nBmax && p < (uint32_t) kBTile; p += 64) bIdx[p] = (uint16_t) extIndex(rowB[p]);
             waveSync();
             // ---- tiles of row A, flattened (a, b) enumeration in the reference's list order
             uint32_t kBase = 0;
             bool lastTile = false;
             for (uint32_t a0 = 0; a0 < 8000u && !lastTile; a0 += kATile) {
                 uint32_t tileK = 0, nATile = kATile;
+                uint32_t vA[kATile / 64];
+#pragma unroll
+                for (int j = 0; j < kATile / 64; j++) { const uint32_t ai = a0 + j * 64 + lane; vA[j] = a0 == 0 ? vA0[j] : (ai < 8000u ? rowA[ai] : 0u); }
+#pragma unroll
                 for (int j = 0; j < kATile / 64; j++) {
                     const uint32_t ai = a0 + j * 64 + lane;
-                    int s = -32768; uint32_t v = 0;
-                    if (ai < 8000u) { v = rowA[ai]; s = extScore(v); }
+                    const uint32_t v = vA[j];
+                    const int s = ai < 8000u ? extScore(v) : -32768;
                     const bool ok = s >= cutoff1;
                     uint32_t nb = 0;
-                    if (ok) { const int at = (short) (thr - s) - minCut2; nb = (at >= 0 && at < kCntB) ? cntB[at] : 0; }
+                    if (ok) { int at = (short) (thr - s) - a.cntMin; at = at < 0 ? 0 : (at >= kCntW ? kCntW - 1 : at); nb = cntB[at]; }
                     const uint32_t incl = waveInclusiveScan(nb, lane);
                     aStart[j * 64 + lane] = tileK + incl - nb;
                     aIdx[j * 64 + lane] = (uint16_t) extIndex(v);
@@ -299,42 +330,83 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                 if (lane == 0) aStart[nATile] = tileK;
                 waveSync();
                 if (kBase + tileK > kMaxKmerResult - 1) { tileK = kMaxKmerResult - 1 - kBase; lastTile = true; }
+                if (a.ablate == 2) { kBase += tileK; waveSync(); continue; }
                 // Flattened (a, b) enumeration, 64 similar k-mers per round.  Lane L owns k = k0 + L and needs the largest a
                 // with aStart[a] <= k.  The a's are consecutive and every a contributes >= 1 k-mer, so the a's that START
                 // inside this round are aCur+1 .. aCur+63 at most: lane j looks at candidate aCur+1+j, the start positions
                 // are OR-reduced into a 64-bit mask and a popcount below the own position gives the offset -- no search.
                 uint32_t aCur = 0;
-                for (uint32_t k0 = 0; k0 < tileK; k0 += 64) {
-                    const uint32_t k = k0 + lane;
-                    uint32_t o0 = 0, len = 0;
-                    const uint32_t cand = aCur + 1u + (uint32_t) lane;
-                    unsigned long long startBit = 0;
-                    if (cand < nATile) { const uint32_t st = aStart[cand]; if (st - k0 < 64u) startBit = 1ull << (st - k0); }
+                // Enumeration in super-rounds of 1024 similar k-mers so that memory round trips are paid per 1024, not per 64:
+                //   phase 1: map the 16 x 64 flattened positions to k-mer ids (registers), fetch their occupancy bits with 16
+                //            independent loads, compact the occupied ids (14 % for a phage-scale index) into LDS in list order
+                //   phase 2: 256 occupied ids at a time: 4 independent offset-pair loads per lane, then the index entries
+                for (uint32_t s0 = 0; s0 < tileK; s0 += kSuper) {
+                    uint32_t kmerR[kSuper / 64];
 #pragma unroll
-                    for (int d = 32; d > 0; d >>= 1) startBit |= __shfl_xor(startBit, d);
-                    const uint32_t ai = aCur + (uint32_t) __popcll(startBit & (~0ull >> (63 - lane)));
-                    aCur = uni(aCur + (uint32_t) __popcll(startBit));       // a of the last position of this round
-                    if (k < tileK) {
-                        const uint32_t b = k - aStart[ai];
-                        const uint32_t bi = (b < (uint32_t) kBTile) ? bIdx[b] : extIndex(rowB[b]);
-                        const uint32_t kmer = aIdx[ai] + 8000u * bi;
-                        // sparse index: 1 bit from an 8 MB (L2/MALL-resident) bitmap decides whether the offsets pair -- a
-                        // random sector of the 256 MB table -- has to be fetched at all
-                        const bool occupied = a.ibits ? ((a.ibits[kmer >> 5] >> (kmer & 31)) & 1u) : true;
-                        if (occupied) { const Off2 o = *reinterpret_cast<const Off2 *>(a.ioff + kmer); o0 = o.lo; len = o.hi - o.lo; }
+                    for (int r = 0; r < kSuper / 64; r++) {
+                        const uint32_t kr0 = s0 + 64u * r;
+                        kmerR[r] = 0xFFFFFFFFu;
+                        if (kr0 < tileK) {
+                            const uint32_t k = kr0 + lane;
+                            const uint32_t cand = aCur + 1u + (uint32_t) lane;
+                            unsigned long long startBit = 0;
+                            if (cand < nATile) { const uint32_t st = aStart[cand]; if (st - kr0 < 64u) startBit = 1ull << (st - kr0); }
+#pragma unroll
+                            for (int d = 32; d > 0; d >>= 1) startBit |= __shfl_xor(startBit, d);
+                            const uint32_t ai = aCur + (uint32_t) __popcll(startBit & (~0ull >> (63 - lane)));
+                            aCur = uni(aCur + (uint32_t) __popcll(startBit));       // a of the last position of this round
+                            if (k < tileK) {
+                                const uint32_t bb = k - aStart[ai];
+                                const uint32_t bi = (bb < (uint32_t) kBTile) ? bIdx[bb] : extIndex(rowB[bb]);
+                                kmerR[r] = aIdx[ai] + 8000u * bi;
+                            }
+                        }
                     }
-                    const uint32_t incl = waveInclusiveScan(len, lane);
-                    const uint32_t tot = lane63(incl);
-                    uint32_t h = M + incl - len;
-                    for (uint32_t e = 0; e < len; e++, h++) {
-                        const uint64_t ent = a.ientries[o0 + e];
-                        const uint32_t seqId = (uint32_t) ent;
-                        const uint32_t diag = (uint32_t) (i - (int) (uint32_t) ((ent >> 32) & 0xFFFF)) & 0xFFFFu;
-                        const uint64_t key = ((uint64_t) seqId << 32) | ((uint64_t) (h & 0xFFFFu) << 16) | diag;
-                        if (h < (uint32_t) kHitCap) keys[h] = key;
-                        else if (h < (uint32_t) kSpillCap) spillKeys[h] = key;
+                    uint32_t wordR[kSuper / 64];
+#pragma unroll
+                    for (int r = 0; r < kSuper / 64; r++) wordR[r] = (a.ibits && kmerR[r] != 0xFFFFFFFFu) ? a.ibits[kmerR[r] >> 5] : 0xFFFFFFFFu;
+                    uint32_t nOcc = 0;
+#pragma unroll
+                    for (int r = 0; r < kSuper / 64; r++) {
+                        const bool occ = kmerR[r] != 0xFFFFFFFFu && ((wordR[r] >> (kmerR[r] & 31)) & 1u) && a.ablate != 1;
+                        const uint64_t m = __ballot(occ);
+                        if (occ) occList[nOcc + (uint32_t) __popcll(m & laneMaskLt(lane))] = kmerR[r];
+                        nOcc += (uint32_t) __popcll(m);
                     }
-                    M += tot;
+                    waveSync();
+                    for (uint32_t ob = 0; ob < nOcc; ob += 256) {
+                        uint32_t o0R[4] = {0, 0, 0, 0}, lenR[4] = {0, 0, 0, 0}, hR[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const uint32_t at = ob + 64u * r + lane;
+                            if (at < nOcc) { const Off2 o = *reinterpret_cast<const Off2 *>(a.ioff + occList[at]); o0R[r] = o.lo; lenR[r] = o.hi - o.lo; }
+                        }
+                        uint32_t lenMax = 0, run = M;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const uint32_t incl = waveInclusiveScan(lenR[r], lane);
+                            hR[r] = run + incl - lenR[r];
+                            run += lane63(incl);
+                            if (a.ablate == 4) lenR[r] = 0;
+                            lenMax = lenR[r] > lenMax ? lenR[r] : lenMax;
+                        }
+                        for (uint32_t e = 0; e < lenMax; e++) {
+                            uint64_t ent[4] = {0, 0, 0, 0};
+#pragma unroll
+                            for (int r = 0; r < 4; r++) if (e < lenR[r]) ent[r] = a.ientries[o0R[r] + e];
+#pragma unroll
+                            for (int r = 0; r < 4; r++) if (e < lenR[r]) {
+                                const uint32_t seqId = (uint32_t) ent[r];
+                                const uint32_t diag = (uint32_t) (i - (int) (uint32_t) ((ent[r] >> 32) & 0xFFFF)) & 0xFFFFu;
+                                const uint32_t h = hR[r] + e;
+                                const uint64_t key = ((uint64_t) seqId << 32) | ((uint64_t) (h & 0xFFFFu) << 16) | diag;
+                                if (h < (uint32_t) kHitCap) keys[h] = key;
+                                else if (h < (uint32_t) kSpillCap) spillKeys[h] = key;
+                            }
+                        }
+                        M = run;
+                    }
+                    waveSync();
                 }
                 kBase += tileK;
                 waveSync();
@@ -343,10 +415,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
         }
         matchesTotal += M;
         if (M > (uint32_t) kSpillCap) { overflow = true; M = 0; }
+        const bool spilled = M > (uint32_t) kHitCap;
 
         uint32_t D = 0, dbase = 0;
+        if (a.ablate == 5 || a.ablate == 4) M = 0;
+        if (M > 0 && M <= (uint32_t) kHitCap) {
+            // Cheap exact pre-filter before the sort: a target hit only once in this query can only be recorded when its
+            // 8-bit diagonal is 0 (previous := 0).  Count hits per hashed target in LDS, keep hits whose bucket saw >= 2
+            // hits or whose diag8 == 0; bucket collisions merely let a few extra hits through to the exact automaton.
+            uint32_t *hcnt = aStart;                                   // 256 counters; the tile arrays are free now
+            for (uint32_t t = lane; t < 256; t += 64) hcnt[t] = 0;
+            waveSync();
+            for (uint32_t t = lane; t < M; t += 64) atomicAdd(&hcnt[((uint32_t) (keys[t] >> 32) * 2654435761u) >> 24], 1u);
+            waveSync();
+            uint32_t wr = 0;
+            for (uint32_t base = 0; base < M; base += 64) {
+                const uint32_t t = base + lane;
+                const uint64_t k = t < M ? keys[t] : 0ull;
+                const bool keep = t < M && (hcnt[((uint32_t) (k >> 32) * 2654435761u) >> 24] >= 2u || (k & 0xFF) == 0);
+                const uint64_t m = __ballot(keep);
+                if (keep) keys[wr + (uint32_t) __popcll(m & laneMaskLt(lane))] = k;
+                wr += (uint32_t) __popcll(m);
+            }
+            waveSync();
+            M = wr;
+        }
         if (M > 0) {
-            const bool inLds = M <= (uint32_t) kHitCap;
+            const bool inLds = !spilled;
             uint32_t n = 1; while (n < M) n <<= 1;
             uint64_t *K = keys; uint32_t *B = bitsL;
             if (!inLds) {
@@ -363,9 +458,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
             for (uint32_t t = lane; t < (M + 31) / 32; t += 64) cnt += __popc(B[t]);
             D = waveSum(cnt);
             if (D > 0) {
-                if (lane == 0) dbase = atomicAdd(a.diagCursor, D);
-                dbase = uni(dbase);
-                if ((uint64_t) dbase + D > a.diagCap) { overflow = true; D = 0; }
+                // diagonal records are reserved kDiagChunk at a time per wave (one atomic per query on a single word
+                // would serialise); unused slots of a chunk stay marked invalid (diagQuery == ~0)
+                if (dChunkUsed + D > dChunkCap) {
+                    dChunkCap = D > kDiagChunk ? D : kDiagChunk;
+                    dChunkBase = uni(atomicAdd(a.diagCursor, lane == 0 ? dChunkCap : 0u));
+                    dChunkUsed = 0;
+                }
+                dbase = dChunkBase + dChunkUsed;
+                dChunkUsed += D;
+                diagTotal += D;
+                if ((uint64_t) dChunkBase + dChunkCap > a.diagCap) { overflow = true; D = 0; }
             }
             if (D > 0) {
                 uint32_t outPos = dbase;
@@ -391,7 +494,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
             if (overflow) atomicAdd(&a.counters[2], 1ull);
         }
     }
-    if (lane == 0) { atomicAdd(&a.counters[0], kmersTotal); atomicAdd(&a.counters[1], matchesTotal); }
+    if (lane == 0) { atomicAdd(&a.counters[0], kmersTotal); atomicAdd(&a.counters[1], matchesTotal); atomicAdd(&a.counters[5], diagTotal); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -440,8 +543,9 @@ __global__ void k_score(ScoreArgs a) {
     uint32_t nDiag = *a.diagCursor; if (nDiag > a.diagCap) nDiag = a.diagCap;
     uint32_t read = 0;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nDiag; r += gridDim.x * blockDim.x) {
-        const DiagRec rec = a.diagRec[r];
         const uint32_t qi = a.diagQuery[r];
+        if (qi == 0xFFFFFFFFu) continue;            // unused slot of a reservation chunk
+        const DiagRec rec = a.diagRec[r];
         const uint32_t qo = a.qoff[qi];
         const int qL = (int) (a.qoff[qi + 1] - qo);
         const uint64_t to = a.toff[rec.seqId];
@@ -705,7 +809,7 @@ struct Gpu::Impl {
     hipEvent_t ev[8] = {};
     int numCU = 256;
     // tables
-    DevBuf<uint32_t> ext3; DevBuf<short> seedSub; DevBuf<double> seedBack; DevBuf<signed char> ungSub; DevBuf<signed char> alnSub;
+    DevBuf<uint32_t> ext3; DevBuf<uint16_t> ext3cnt; int cntMin = 0; DevBuf<short> seedSub; DevBuf<double> seedBack; DevBuf<signed char> ungSub; DevBuf<signed char> alnSub;
     DevBuf<short> alnSub16; DevBuf<double> alnBack;
     int ungMinAbs = 0, alnMinAbs = 0;
     // targets
@@ -752,6 +856,8 @@ bool Gpu::init(int device, std::string &err) {
 
 void Gpu::sync() { (void) hipStreamSynchronize(d_->stream); }
 
+static inline int extScoreHost(uint32_t packed) { return (int) (packed >> 16) - 32768; }
+
 template <typename T>
 static bool upload(DevBuf<T> &b, const T *src, size_t n, hipStream_t s, std::string &err) {
     if (!b.ensure(n ? n : 1, err)) return false;
@@ -762,6 +868,20 @@ static bool upload(DevBuf<T> &b, const T *src, size_t n, hipStream_t s, std::str
 bool Gpu::uploadTables(const std::vector<uint32_t> &ext3, const SubMat &seed, const SubMat &ung, const SubMat &aln, std::string &err) {
     Impl &d = *d_;
     if (!upload(d.ext3, ext3.data(), ext3.size(), d.stream, err)) return false;
+    {   // count table: for every row and every cutoff c in [cntMin, cntMin + kCntW): how many partners score >= c
+        int lo = 1 << 20, hi = -(1 << 20);
+        for (size_t r = 0; r < 8000; r++) { lo = std::min(lo, extScoreHost(ext3[r * 8000 + 7999])); hi = std::max(hi, extScoreHost(ext3[r * 8000])); }
+        if (hi - lo + 2 > kCntW) { err = "seed matrix 3-mer score range " + std::to_string(hi - lo) + " exceeds the count-table width"; return false; }
+        d.cntMin = lo;
+        std::vector<uint16_t> cnt((size_t) 8000 * kCntW);
+        for (size_t r = 0; r < 8000; r++) {
+            const uint32_t *row = ext3.data() + r * 8000; uint16_t *out = cnt.data() + r * kCntW;
+            size_t p = 0;      // entries are sorted by score descending: walk cutoffs from high to low
+            for (int x = kCntW - 1; x >= 0; x--) { const int c = lo + x; while (p < 8000 && extScoreHost(row[p]) >= c) p++; out[x] = (uint16_t) p; }
+        }
+        if (!upload(d.ext3cnt, cnt.data(), cnt.size(), d.stream, err)) return false;
+        HIP_OK(hipStreamSynchronize(d.stream));
+    }
     short s16[kAlph * kAlph]; signed char u8[kAlph * kAlph], a8[kAlph * kAlph]; short a16[kAlph * kAlph];
     int mn = 0, mnAln = 0;
     for (int i = 0; i < kAlph; i++) for (int j = 0; j < kAlph; j++) {
@@ -845,6 +965,7 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     (void) selBlocks;
     HIP_OK(hipMemsetAsync(d.queue.p, 0, 4 * sizeof(uint32_t), d.stream));
     HIP_OK(hipMemsetAsync(d.counters.p, 0, 8 * sizeof(unsigned long long), d.stream));
+    HIP_OK(hipMemsetAsync(d.diagQuery.p, 0xFF, diagCap * sizeof(uint32_t), d.stream));
 
     const bool dbg = getenv("SP_DEBUG") != nullptr;
 #define SP_DBG_SYNC(tag) do { HIP_OK(hipGetLastError()); if (dbg) { HIP_OK(hipStreamSynchronize(d.stream)); fprintf(stderr, "[sp] %s done\n", tag); } } while (0)
@@ -855,8 +976,9 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     HIP_OK(hipEventRecord(d.ev[1], d.stream));
     // the occupancy bitmap pays off while most k-mer slots are empty (phage-scale DBs); a dense index skips it
     const bool useBits = getenv("SP_NO_BITMAP") == nullptr && (double) d.indexEntries < 0.5 * (double) kTableSize;
-    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ioff.p, useBits ? d.ibits.p : nullptr, d.ientries.p, d.spill.p, d.queue.p,
-                 d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p};
+    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.ioff.p, useBits ? d.ibits.p : nullptr, d.ientries.p, d.spill.p, d.queue.p,
+                 d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
+                 getenv("SP_ABLATE") ? atoi(getenv("SP_ABLATE")) : 0};
     if (hitCap == 512) hipLaunchKernelGGL(k_match<512>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     else hipLaunchKernelGGL(k_match<2048>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     SP_DBG_SYNC("k_match");
@@ -877,7 +999,7 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     HIP_OK(hipMemcpyAsync(qv, d.queue.p, sizeof(qv), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipStreamSynchronize(d.stream));
     counters_.kmers = c[0]; counters_.dbMatches = c[1]; counters_.overflowQueries = c[2]; counters_.diagResidues = c[3]; counters_.hits = qv[3];
-    counters_.diagonals = qv[1];
+    counters_.diagonals = c[5];
     (void) hipEventElapsedTime(&times_.prep, d.ev[0], d.ev[1]);
     (void) hipEventElapsedTime(&times_.match, d.ev[1], d.ev[2]);
     (void) hipEventElapsedTime(&times_.score, d.ev[2], d.ev[3]);
