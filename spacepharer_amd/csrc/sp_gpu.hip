@@ -40,14 +40,28 @@ __device__ __forceinline__ void waveSync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// DPP data movement (gfx9 family): row_shr:n shifts inside a row of 16 lanes, row_bcast15/31 forward a row's last lane
+// to the following rows, wave_shr:1 shifts the whole wave by one lane.  One VALU op each -- no trip through the LDS
+// crossbar like ds_bpermute (__shfl*), which matters because the kernels here are latency-bound.
+#define SP_DPP_ROW_SHR(n) (0x110 | (n))
+#define SP_DPP_ROW_BCAST15 0x142
+#define SP_DPP_ROW_BCAST31 0x143
+#define SP_DPP_WAVE_SHR1 0x138
+
 __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
-    return v;
+    (void) lane;
+    int x = (int) v;
+    x += __builtin_amdgcn_update_dpp(0, x, SP_DPP_ROW_SHR(1), 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, SP_DPP_ROW_SHR(2), 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, SP_DPP_ROW_SHR(4), 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, SP_DPP_ROW_SHR(8), 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, SP_DPP_ROW_BCAST15, 0xA, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, SP_DPP_ROW_BCAST31, 0xC, 0xF, false);
+    return (uint32_t) x;
 }
+
+// value of the previous lane (0 for lane 0)
+__device__ __forceinline__ int waveShiftUp1(int v) { return __builtin_amdgcn_update_dpp(0, v, SP_DPP_WAVE_SHR1, 0xF, 0xF, false); }
 
 // NOTE: every value that steers wave-uniform control flow is forced into an SGPR (readfirstlane/readlane).  Left
 // in VGPRs, the compiler structurises such loops as divergent and lanes can leave a loop one by one, which
@@ -233,6 +247,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     __shared__ uint16_t s_cntB[kWavesPerBlock][kCntW];
     __shared__ uint32_t s_bits[kWavesPerBlock][kHitCap / 32];
     __shared__ uint32_t s_occ[kWavesPerBlock][kSuper];
+    __shared__ uint32_t s_stamp[kWavesPerBlock][64];
 
     const int lane = laneId();
     const int w = (int) (threadIdx.x >> 6);
@@ -243,6 +258,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     uint16_t *cntB = s_cntB[w];
     uint32_t *bitsL = s_bits[w];
     uint32_t *occList = s_occ[w];
+    uint32_t *stamp = s_stamp[w];
+    stamp[lane] = 0;
+    uint32_t stampId = 0;
     const uint32_t waveGlobal = blockIdx.x * kWavesPerBlock + w;
     uint64_t *spillKeys = a.spill + (size_t) waveGlobal * kSpillWordsPerWave;
     uint32_t *spillBits = (uint32_t *) (spillKeys + 65536);
@@ -348,13 +366,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                         kmerR[r] = 0xFFFFFFFFu;
                         if (kr0 < tileK) {
                             const uint32_t k = kr0 + lane;
+                            // which of the 64 positions of this round start a new a?  candidates aCur+1+lane stamp their start
+                            // position in LDS, every lane then reads the stamp of its own position, a ballot gives the mask
                             const uint32_t cand = aCur + 1u + (uint32_t) lane;
-                            unsigned long long startBit = 0;
-                            if (cand < nATile) { const uint32_t st = aStart[cand]; if (st - kr0 < 64u) startBit = 1ull << (st - kr0); }
-#pragma unroll
-                            for (int d = 32; d > 0; d >>= 1) startBit |= __shfl_xor(startBit, d);
+                            stampId++;
+                            if (cand < nATile) { const uint32_t st = aStart[cand]; if (st - kr0 < 64u) stamp[st - kr0] = stampId; }
+                            waveSync();
+                            const unsigned long long startBit = __ballot(stamp[lane] == stampId);
                             const uint32_t ai = aCur + (uint32_t) __popcll(startBit & (~0ull >> (63 - lane)));
-                            aCur = uni(aCur + (uint32_t) __popcll(startBit));       // a of the last position of this round
+                            aCur = aCur + (uint32_t) __popcll(startBit);            // a of the last position of this round
                             if (k < tileK) {
                                 const uint32_t bb = k - aStart[ai];
                                 const uint32_t bi = (bb < (uint32_t) kBTile) ? bIdx[bb] : extIndex(rowB[bb]);
