@@ -74,6 +74,24 @@ def cpu_baseline(tres, toff, qres, qoff, n_sample):
                       "index build excluded" % (n_sample, pairs)}
 
 
+def default_workload(args):
+    return (args.spacers, args.targets, args.target_len) == (10000, 50000, 200)
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the newest committed counter pass (profiles/rNN_pmc_traffic.json, made by
+    tools/gpu_pmc.sh on this same workload: FETCH_SIZE corrected by the calibration reads + WRITE_SIZE); None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))["kernels"][kernel]
+        return k["fetch_bytes_corrected"] + k.get("write_bytes_raw", 0.0), "profiles/" + os.path.basename(files[-1])
+    except (KeyError, ValueError):
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,6 +163,7 @@ def main():
     # per similar k-mer, 6 B per index entry fetched, 7 B per double-hit diagonal written
     algo_bytes = 22.0 * K + 6.0 * M + 7.0 * D
     achieved = algo_bytes / (ms_match * 1e-3) / 1e9 if ms_match > 0 else 0.0
+    traffic, traffic_src = pmc_traffic("k_match") if default_workload(args) else (None, None)
     out = {
         "metric": "spacer-queries/sec through prefilter+align; achieved HBM GB/s vs roofline",
         "value": args.spacers * world * args.steps / dt,
@@ -163,8 +182,8 @@ def main():
         "kernels_ms_per_step": {k[3:]: round(v / args.steps, 4) for k, v in stats.items()},
         "counters_per_step": {"similar_kmers": K, "index_entries_fetched": M, "diagonals_scored": D, "diag_residues": R, "hits": H},
         "roofline": {"bound": "hbm", "kernel": "k_match", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                     "frac": achieved / 8000.0, "traffic": None,
-                     "algorithmic_bytes_per_launch": algo_bytes},
+                     "frac": achieved / 8000.0, "traffic": traffic,
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes},
     }
     if args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(tres, toff, qres, qoff, min(args.cpu_sample, nq))

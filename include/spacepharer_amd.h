@@ -136,6 +136,9 @@ double sp_ctx_stat(const sp_ctx *c, const char *name);
 int sp_ctx_sync(sp_ctx *c);
 /* raw HIP stream the context launches on (hipStream_t), for callers that time with their own events */
 void *sp_ctx_stream(const sp_ctx *c);
+/* profiling aid: one streaming read of `bytes` with lane_bytes (4, 8 or 16) per lane per load on the context's stream;
+   tools/pmc_traffic.py uses it to calibrate rocprofv3's FETCH_SIZE before quoting it for the search kernels */
+int sp_ctx_diag_stream_read(sp_ctx *c, uint64_t bytes, int lane_bytes, double *ms);
 
 /* ---- host-side diagnostics: run the set-up code (matrices, masking, index construction, E-value statistics) without
    a device so that it can be checked on any machine; digests are FNV-1a over the same byte streams the golden

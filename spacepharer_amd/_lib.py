@@ -81,6 +81,7 @@ def load_library():
     L.sp_ctx_sync.argtypes = [vp]
     L.sp_ctx_stream.restype = vp
     L.sp_ctx_stream.argtypes = [vp]
+    L.sp_ctx_diag_stream_read.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     for f in ("sp_prefilter_run", "sp_align_run", "sp_rescorediagonal_run"):
         getattr(L, f).argtypes = [C.c_int, C.POINTER(C.c_char_p)]
     _lib = L
@@ -224,6 +225,12 @@ class SearchContext:
 
     def sync(self):
         _check(self.L.sp_ctx_sync(self.ctx))
+
+    def diag_stream_read(self, nbytes, lane_bytes):
+        """profiling aid: milliseconds of one streaming read of nbytes (FETCH_SIZE calibration)"""
+        ms = C.c_double()
+        _check(self.L.sp_ctx_diag_stream_read(self.ctx, nbytes, lane_bytes, C.byref(ms)))
+        return ms.value
 
     def align_raw(self, qidx, tidx):
         """numpy uint32 arrays in, (Alignment array, cigar buffer) out -- no per-pair Python work"""

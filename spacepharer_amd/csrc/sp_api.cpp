@@ -342,6 +342,12 @@ double sp_ctx_stat(const sp_ctx *c, const char *name) {
 
 void *sp_ctx_stream(const sp_ctx *c) { return c->gpu.stream(); }
 int sp_ctx_sync(sp_ctx *c) { c->gpu.sync(); return SP_OK; }
+int sp_ctx_diag_stream_read(sp_ctx *c, uint64_t bytes, int laneBytes, double *ms) {
+    std::string err; double t = 0;
+    if (!c->gpu.diagStreamRead(bytes, laneBytes, t, err)) { g_err = err; return SP_ERR_DEVICE; }
+    if (ms) *ms = t;
+    return SP_OK;
+}
 
 /* ---- host-side diagnostics (no device needed): used by the CPU test-suite to check the set-up code ---- */
 static uint64_t fnv1a(const void *p, size_t n, uint64_t h) {

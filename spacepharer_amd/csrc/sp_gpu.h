@@ -74,6 +74,9 @@ public:
     // rescorediagonal: ungapped score on one diagonal of the UNMASKED residues, align matrix, no composition bias
     bool rescoreDiagonals(const SwPair *pairs, const uint16_t *diags, size_t n, int mode, std::vector<DiagRescore> &out, std::string &err);
 
+    // profiling aid: streaming read of `bytes` with laneBytes (4/8/16) per lane, to calibrate the FETCH_SIZE counter
+    bool diagStreamRead(uint64_t bytes, int laneBytes, double &ms, std::string &err);
+
     void sync();
     void *stream() const { return stream_; }
 

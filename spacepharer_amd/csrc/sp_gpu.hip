@@ -876,6 +876,39 @@ bool Gpu::init(int device, std::string &err) {
 
 void Gpu::sync() { (void) hipStreamSynchronize(d_->stream); }
 
+// ---- counter calibration (profiles/ only): streaming read of a known byte count, W bytes per lane per load.  The
+// rocprofv3 FETCH_SIZE counter is calibrated against these launches before it is quoted for k_match.
+template <typename T>
+__global__ __launch_bounds__(256) void k_diag_read(const T *src, size_t n, unsigned long long *sink) {
+    unsigned long long acc = 0;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
+        const T v = src[i];
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&v);
+#pragma unroll
+        for (unsigned j = 0; j < sizeof(T) / 4; j++) acc += w[j];
+    }
+    if (acc == 0x9E3779B97F4A7C15ull) *sink = acc;     // never true for the zero-filled buffer; keeps the loads alive
+}
+
+bool Gpu::diagStreamRead(uint64_t bytes, int laneBytes, double &ms, std::string &err) {
+    void *buf = nullptr; unsigned long long *sink = nullptr;
+    if (hipMalloc(&buf, bytes) != hipSuccess || hipMalloc((void **) &sink, 8) != hipSuccess) { err = "diagStreamRead: hipMalloc failed"; return false; }
+    (void) hipMemsetAsync(buf, 0, bytes, d_->stream);
+    hipEvent_t e0, e1; (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
+    const int blocks = 256 * 16;
+    (void) hipEventRecord(e0, d_->stream);
+    if (laneBytes == 16) hipLaunchKernelGGL(k_diag_read<uint4>, dim3(blocks), dim3(256), 0, d_->stream, (const uint4 *) buf, (size_t) (bytes / 16), sink);
+    else if (laneBytes == 8) hipLaunchKernelGGL(k_diag_read<uint2>, dim3(blocks), dim3(256), 0, d_->stream, (const uint2 *) buf, (size_t) (bytes / 8), sink);
+    else hipLaunchKernelGGL(k_diag_read<uint32_t>, dim3(blocks), dim3(256), 0, d_->stream, (const uint32_t *) buf, (size_t) (bytes / 4), sink);
+    (void) hipEventRecord(e1, d_->stream);
+    (void) hipStreamSynchronize(d_->stream);
+    float t = 0; (void) hipEventElapsedTime(&t, e0, e1); ms = t;
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    (void) hipFree(buf); (void) hipFree(sink);
+    if (hipGetLastError() != hipSuccess) { err = "diagStreamRead: launch failed"; return false; }
+    return true;
+}
+
 static inline int extScoreHost(uint32_t packed) { return (int) (packed >> 16) - 32768; }
 
 template <typename T>
