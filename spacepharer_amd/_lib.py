@@ -3,7 +3,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_NAME = "libspacepharer_amd.so"
+LIB_NAME = os.environ.get("SP_LIB_NAME", "libspacepharer_amd.so")    # override: instrumented builds (tools/)
 
 
 class SpError(RuntimeError):

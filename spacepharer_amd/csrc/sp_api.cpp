@@ -55,6 +55,8 @@ struct sp_ctx {
     std::map<uint32_t, std::vector<double>> evalRows;      // evalue(score, qLen) per query length
     std::vector<int32_t> bitRow;                           // int(bitScore(score) + 0.5)
     bool tablesUp = false;
+    sp::AlignHost alnHost;                                 // pinned staging, reused; declared last = released before the device context
+    sp::PinVec<sp::GpuHit> hitStage; sp::PinVec<uint32_t> hitOffStage;
 };
 
 extern "C" {
@@ -185,15 +187,15 @@ int sp_ctx_prefilter(sp_ctx *c) {
 uint64_t sp_ctx_num_hits(const sp_ctx *c) { return (uint64_t) c->gpu.counters().hits; }
 
 int sp_ctx_get_hits_compact(sp_ctx *c, sp_hit *hits, uint64_t *offsets) {
-    std::vector<sp::GpuHit> h; std::vector<uint64_t> off; std::string err;
+    sp::PinVec<sp::GpuHit> &h = c->hitStage; sp::PinVec<uint32_t> &off = c->hitOffStage; std::string err;
     if (!c->gpu.downloadHits(h, off, err)) { g_err = err; return SP_ERR_DEVICE; }
-    memcpy(offsets, off.data(), off.size() * sizeof(uint64_t));
+    for (size_t q = 0; q < off.size(); q++) offsets[q] = off[q];
     for (size_t i = 0; i < h.size(); i++) { hits[i].seq_id = h[i].seqId; hits[i].score = h[i].score; hits[i].diagonal = (int16_t) h[i].diag; hits[i].pad = 0; }
     return SP_OK;
 }
 
 int sp_ctx_get_hits(sp_ctx *c, sp_hit *hits, uint32_t *counts) {
-    std::vector<sp::GpuHit> h; std::vector<uint64_t> off; std::string err;
+    sp::PinVec<sp::GpuHit> &h = c->hitStage; sp::PinVec<uint32_t> &off = c->hitOffStage; std::string err;
     if (!c->gpu.downloadHits(h, off, err)) { g_err = err; return SP_ERR_DEVICE; }
     const size_t nq = off.size() - 1; const int mh = c->gpu.maxHits();
     for (size_t q = 0; q < nq; q++) {
@@ -238,9 +240,10 @@ static void buildGate(sp_ctx *c, sp::GateTable &g) {
     if (c->bitRow.size() != g.stride) { c->bitRow.resize(g.stride); for (uint32_t sc = 0; sc < g.stride; sc++) c->bitRow[sc] = (int) (c->evGapped.bitScore((double) sc) + 0.5); }
 }
 
-static int finishAlign(sp_ctx *c, const std::vector<sp::SwPair> &pairs, const std::vector<sp::SwForward> &fwd, const std::vector<uint8_t> &pass,
-                       const std::vector<sp::SwFull> &full, const std::vector<char> &bt, const std::vector<uint32_t> *order,
+static int finishAlign(sp_ctx *c, const sp::AlignHost &ah, const std::vector<uint32_t> *order,
                        sp_alignment *res, char *cigars, uint64_t cigarCap, uint64_t *cigarUsed) {
+    const sp::PinVec<sp::SwPair> &pairs = ah.pairs; const sp::PinVec<sp::SwForward> &fwd = ah.fwd; const std::vector<uint8_t> &pass = ah.pass;
+    const sp::PinVec<sp::SwFull> &full = ah.full; const sp::PinVec<char> &bt = ah.bt;
     const size_t n = pairs.size();
     uint64_t used = 0;
     for (size_t i = 0; i < n; i++) if (pass[i]) used += (uint64_t) full[i].alnLen + 1;
@@ -291,12 +294,11 @@ int sp_ctx_align(sp_ctx *c, const uint32_t *qidx, const uint32_t *tidx, uint64_t
     if (!c || c->targets.n == 0) { g_err = "sp_ctx_align: no target set"; return SP_ERR_STATE; }
     std::string err;
     if (!ensureEvaluers(c, true, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
-    std::vector<sp::SwPair> pairs(n), unused;
+    std::vector<sp::SwPair> pairs(n);
     for (uint64_t i = 0; i < n; i++) { pairs[i].query = qidx[i]; pairs[i].target = tidx[i]; }
     sp::GateTable gate; buildGate(c, gate);
-    std::vector<sp::SwForward> fwd; std::vector<uint8_t> pass; std::vector<sp::SwFull> full; std::vector<char> bt;
-    if (!c->gpu.align(pairs.data(), (size_t) n, c->par.gap_open, c->par.gap_extend, gate, unused, fwd, pass, full, bt, err)) { g_err = err; return SP_ERR_DEVICE; }
-    return finishAlign(c, pairs, fwd, pass, full, bt, nullptr, res, cigars, cigarCap, cigarUsed);
+    if (!c->gpu.align(pairs.data(), (size_t) n, c->par.gap_open, c->par.gap_extend, gate, c->alnHost, err)) { g_err = err; return SP_ERR_DEVICE; }
+    return finishAlign(c, c->alnHost, nullptr, res, cigars, cigarCap, cigarUsed);
 }
 
 /* align every hit of the last sp_ctx_prefilter(): results[i] belongs to hit i of sp_ctx_get_hits_compact() */
@@ -308,12 +310,10 @@ int sp_ctx_align_hits(sp_ctx *c, sp_alignment *res, char *cigars, uint64_t cigar
     double t0 = nowMs();
     sp::GateTable gate; buildGate(c, gate);
     double t1 = nowMs();
-    std::vector<sp::SwPair> pairs; std::vector<sp::SwForward> fwd; std::vector<uint8_t> pass; std::vector<sp::SwFull> full; std::vector<char> bt;
-    if (!c->gpu.align(nullptr, 0, c->par.gap_open, c->par.gap_extend, gate, pairs, fwd, pass, full, bt, err)) { g_err = err; return SP_ERR_DEVICE; }
+    if (!c->gpu.align(nullptr, 0, c->par.gap_open, c->par.gap_extend, gate, c->alnHost, err)) { g_err = err; return SP_ERR_DEVICE; }
     double t2 = nowMs();
-    double t3 = nowMs();
-    int rc = finishAlign(c, pairs, fwd, pass, full, bt, nullptr, res, cigars, cigarCap, cigarUsed);
-    if (dbg) fprintf(stderr, "[sp] align_hits: gate %.3f  gpu.align %.3f  layout %.3f  finish %.3f ms\n", t1 - t0, t2 - t1, t3 - t2, nowMs() - t3);
+    int rc = finishAlign(c, c->alnHost, nullptr, res, cigars, cigarCap, cigarUsed);
+    if (dbg) fprintf(stderr, "[sp] align_hits: gate %.3f  gpu.align %.3f  finish %.3f ms\n", t1 - t0, t2 - t1, nowMs() - t2);
     return rc;
 }
 

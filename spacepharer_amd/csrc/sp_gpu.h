@@ -23,6 +23,27 @@ struct SwFull {
 struct GateTable { uint32_t stride = 0; std::vector<uint16_t> slotOf; std::vector<uint8_t> pass; };
 struct DiagRescore { int32_t score, startPos, endPos, diagonalLen, diagonal; uint32_t distToDiagonal; };
 
+// page-locked host memory for device<->host copies (pageable std::vector memory costs a staging copy per transfer)
+void *pinnedAlloc(size_t bytes);
+void pinnedFree(void *p);
+template <typename T>
+struct PinnedAlloc {
+    using value_type = T;
+    PinnedAlloc() = default;
+    template <typename U> PinnedAlloc(const PinnedAlloc<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(pinnedAlloc(n * sizeof(T))); }
+    void deallocate(T *p, size_t) { pinnedFree(p); }
+    template <typename U> bool operator==(const PinnedAlloc<U> &) const { return true; }
+    template <typename U> bool operator!=(const PinnedAlloc<U> &) const { return false; }
+};
+template <typename T> using PinVec = std::vector<T, PinnedAlloc<T>>;
+
+// host side of one align() call; the buffers are reused from call to call
+struct AlignHost {
+    PinVec<SwPair> pairs; PinVec<SwForward> fwd; PinVec<SwFull> full; PinVec<char> bt;
+    std::vector<uint8_t> pass;
+};
+
 struct PrefilterCounters {       // the K, M, D, H terms of the roofline formula
     uint64_t kmers;              // similar k-mers generated (scanned windows only)
     uint64_t dbMatches;          // index entries fetched
@@ -53,7 +74,7 @@ public:
     // k-mer prefilter + ungapped diagonal scoring + selection for every resident query
     bool prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore, std::string &err);
     // hits grouped by query (query order); offsets has nq+1 entries
-    bool downloadHits(std::vector<GpuHit> &hits, std::vector<uint64_t> &offsets, std::string &err);
+    bool downloadHits(PinVec<GpuHit> &hits, PinVec<uint32_t> &offsets, std::string &err);
     PrefilterCounters counters() const { return counters_; }
     KernelTimes times() const { return times_; }
     int maxHits() const { return maxHits_; }
@@ -67,8 +88,7 @@ public:
 
     // device-driven align: forward pass, E-value gate (table), 16-bit redo, reverse pass, banded traceback without host
     // round trips.  hostPairs == nullptr aligns every hit of the last prefilter(), in the order of downloadHits().
-    bool align(const SwPair *hostPairs, size_t n, int gapOpen, int gapExtend, const GateTable &gate, std::vector<SwPair> &pairsOut,
-               std::vector<SwForward> &fwd, std::vector<uint8_t> &passMask, std::vector<SwFull> &full, std::vector<char> &bt, std::string &err);
+    bool align(const SwPair *hostPairs, size_t n, int gapOpen, int gapExtend, const GateTable &gate, AlignHost &out, std::string &err);
     uint32_t maxQueryLen() const;
 
     // rescorediagonal: ungapped score on one diagonal of the UNMASKED residues, align matrix, no composition bias

@@ -102,7 +102,6 @@ __device__ void waveBitonicSort(uint64_t *keys, uint32_t n, int lane) {
     }
 }
 
-struct __attribute__((packed, aligned(4))) Off2 { uint32_t lo, hi; };   // ioff[k], ioff[k+1] with one 8-byte load
 
 __device__ __forceinline__ int extScore(uint32_t packed) { return (int) (packed >> 16) - 32768; }
 __device__ __forceinline__ uint32_t extIndex(uint32_t packed) { return packed & 0xFFFFu; }
@@ -200,16 +199,27 @@ struct MatchArgs {
     const uint32_t *ext3;           // 8000 x 8000 packed (score+32768)<<16 | index
     const uint16_t *ext3cnt;        // 8000 x kCntW: [row][c - cntMin] = number of partners with score >= c
     int cntMin;
-    const uint32_t *ioff;           // 20^6 + 1
-    const uint32_t *ibits;          // 20^6 bits: k-mer slot has entries (nullptr = do not use; pays off for sparse indices)
-    const uint64_t *ientries;       // seqId | pos << 32
+    const uint2 *probe;             // per 32 k-mer slots: {occupancy bits, number of occupied slots before this word}
+    const uint64_t *slots;          // per OCCUPIED slot (rank order): the entry itself (seqId | pos << 32) when the list has one
+                                    // entry, else bit 63 | len << 32 | offset into ientries
+    const uint64_t *ientries;       // seqId | pos << 32, lists concatenated in k-mer order
     uint64_t *spill;                // per-wave scratch: kSpillCap+1 keys (+ bitmap) each
     uint32_t *queue;                // work counter
     DiagRec *diagRec; uint32_t *diagQuery; uint32_t diagCap; uint32_t *diagCursor;
     uint32_t *qDiagBase; uint32_t *qDiagCnt;
     unsigned long long *counters;   // [0]=kmers [1]=dbMatches [2]=overflow queries
-    int ablate;                     // experiments only: 1 = skip the offsets gather, 2 = skip the per-window prologue reuse
 };
+
+// phase timers (build with -DSP_PHASE_TIMERS): shader-clock ticks per phase, summed over waves into counters[8 + phase]
+#ifdef SP_PHASE_TIMERS
+#define SP_T_DECL unsigned long long tPh[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tLast = __builtin_amdgcn_s_memtime();
+#define SP_T(ph) do { const unsigned long long tNow = __builtin_amdgcn_s_memtime(); tPh[ph] += tNow - tLast; tLast = tNow; } while (0)
+#define SP_T_FLUSH(ctr) do { if (lane == 0) for (int ph = 0; ph < 8; ph++) atomicAdd(&(ctr)[8 + ph], tPh[ph]); } while (0)
+#else
+#define SP_T_DECL
+#define SP_T(ph) do { } while (0)
+#define SP_T_FLUSH(ctr) do { } while (0)
+#endif
 
 constexpr size_t kSpillWordsPerWave = 65536 + 65536 / 64;   // keys + kept-bitmap (as u64 words)
 
@@ -266,6 +276,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     uint32_t *spillBits = (uint32_t *) (spillKeys + 65536);
     unsigned long long kmersTotal = 0, matchesTotal = 0, diagTotal = 0;
     uint32_t dChunkBase = 0, dChunkUsed = 0, dChunkCap = 0;
+    SP_T_DECL
 
     // one atomic pops kQueryChunk queries: a single counter word serialises at ~12 ns per atomic (60 000 pops = 0.7 ms)
     for (uint32_t qc = 0, qcEnd = 0;;) {
@@ -283,9 +294,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
         // prologue (row A tile, head of row B, count-table row) are issued together
         const int myRes = lane < L ? (int) q[lane] : 0;
         const int myThr = lane < L ? (int) a.qthr[qo + lane] : -1;
+        SP_T(0);
 
         for (int i = 0; i < nScan; i++) {
-            if (a.ablate == 3) break;
             int thr; uint32_t ia, ib;
             if (i + kSpan <= 64) {
                 thr = __builtin_amdgcn_readlane(myThr, i);
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
             const int cutoff1 = (short) (thr - sB0);
             if (sA0 < cutoff1) continue;
             const int minCut2 = (short) (thr - sA0);
+            SP_T(1);
             // "how many b reach cutoff c": precomputed per-row count table
 #pragma unroll
             for (int j = 0; j < kCntW / 64; j++) cntB[j * 64 + lane] = cw[j];
@@ -348,16 +360,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                 if (lane == 0) aStart[nATile] = tileK;
                 waveSync();
                 if (kBase + tileK > kMaxKmerResult - 1) { tileK = kMaxKmerResult - 1 - kBase; lastTile = true; }
-                if (a.ablate == 2) { kBase += tileK; waveSync(); continue; }
+                SP_T(2);
                 // Flattened (a, b) enumeration, 64 similar k-mers per round.  Lane L owns k = k0 + L and needs the largest a
                 // with aStart[a] <= k.  The a's are consecutive and every a contributes >= 1 k-mer, so the a's that START
                 // inside this round are aCur+1 .. aCur+63 at most: lane j looks at candidate aCur+1+j, the start positions
                 // are OR-reduced into a 64-bit mask and a popcount below the own position gives the offset -- no search.
                 uint32_t aCur = 0;
                 // Enumeration in super-rounds of 1024 similar k-mers so that memory round trips are paid per 1024, not per 64:
-                //   phase 1: map the 16 x 64 flattened positions to k-mer ids (registers), fetch their occupancy bits with 16
-                //            independent loads, compact the occupied ids (14 % for a phage-scale index) into LDS in list order
-                //   phase 2: 256 occupied ids at a time: 4 independent offset-pair loads per lane, then the index entries
+                //   phase 1: map the 16 x 64 flattened positions to k-mer ids (registers), fetch their probe words with 16
+                //            independent loads, compact the ranks of the occupied slots (14 % for a phage-scale index) into LDS
+                //            in list order
+                //   phase 2: 256 occupied slots at a time: 4 independent slot-word loads per lane; one-entry lists are
+                //            finished by that load, longer lists walk the entry array
                 for (uint32_t s0 = 0; s0 < tileK; s0 += kSuper) {
                     uint32_t kmerR[kSuper / 64];
 #pragma unroll
@@ -382,51 +396,59 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                             }
                         }
                     }
-                    uint32_t wordR[kSuper / 64];
+                    SP_T(3);
+                    uint2 prR[kSuper / 64];
 #pragma unroll
-                    for (int r = 0; r < kSuper / 64; r++) wordR[r] = (a.ibits && kmerR[r] != 0xFFFFFFFFu) ? a.ibits[kmerR[r] >> 5] : 0xFFFFFFFFu;
+                    for (int r = 0; r < kSuper / 64; r++) prR[r] = (kmerR[r] != 0xFFFFFFFFu) ? a.probe[kmerR[r] >> 5] : make_uint2(0u, 0u);
                     uint32_t nOcc = 0;
 #pragma unroll
                     for (int r = 0; r < kSuper / 64; r++) {
-                        const bool occ = kmerR[r] != 0xFFFFFFFFu && ((wordR[r] >> (kmerR[r] & 31)) & 1u) && a.ablate != 1;
+                        const uint32_t bit = kmerR[r] & 31u;
+                        const bool occ = kmerR[r] != 0xFFFFFFFFu && ((prR[r].x >> bit) & 1u);
                         const uint64_t m = __ballot(occ);
-                        if (occ) occList[nOcc + (uint32_t) __popcll(m & laneMaskLt(lane))] = kmerR[r];
+                        if (occ) occList[nOcc + (uint32_t) __popcll(m & laneMaskLt(lane))] = prR[r].y + (uint32_t) __popc(prR[r].x & ((1u << bit) - 1u));
                         nOcc += (uint32_t) __popcll(m);
                     }
                     waveSync();
+                    SP_T(4);
                     for (uint32_t ob = 0; ob < nOcc; ob += 256) {
-                        uint32_t o0R[4] = {0, 0, 0, 0}, lenR[4] = {0, 0, 0, 0}, hR[4];
+                        uint64_t slotR[4] = {0, 0, 0, 0}; uint32_t lenR[4] = {0, 0, 0, 0}, hR[4];
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             const uint32_t at = ob + 64u * r + lane;
-                            if (at < nOcc) { const Off2 o = *reinterpret_cast<const Off2 *>(a.ioff + occList[at]); o0R[r] = o.lo; lenR[r] = o.hi - o.lo; }
+                            if (at < nOcc) { slotR[r] = a.slots[occList[at]]; lenR[r] = (slotR[r] >> 63) ? ((uint32_t) (slotR[r] >> 32) & 0x7FFFFFFFu) : 1u; }
                         }
-                        uint32_t lenMax = 0, run = M;
+                        uint32_t lenMulti = 0, run = M;
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             const uint32_t incl = waveInclusiveScan(lenR[r], lane);
                             hR[r] = run + incl - lenR[r];
                             run += lane63(incl);
-                            if (a.ablate == 4) lenR[r] = 0;
-                            lenMax = lenR[r] > lenMax ? lenR[r] : lenMax;
+                            if ((slotR[r] >> 63) && lenR[r] > lenMulti) lenMulti = lenR[r];
                         }
-                        for (uint32_t e = 0; e < lenMax; e++) {
-                            uint64_t ent[4] = {0, 0, 0, 0};
+                        auto emit = [&](uint64_t ent, uint32_t h) {
+                            const uint32_t seqId = (uint32_t) ent;
+                            const uint32_t diag = (uint32_t) (i - (int) (uint32_t) ((ent >> 32) & 0xFFFF)) & 0xFFFFu;
+                            const uint64_t key = ((uint64_t) seqId << 32) | ((uint64_t) (h & 0xFFFFu) << 16) | diag;
+                            if (h < (uint32_t) kHitCap) keys[h] = key;
+                            else if (h < (uint32_t) kSpillCap) spillKeys[h] = key;
+                        };
+                        // one-entry lists (the rule while the index is sparse) are complete with the slot word
 #pragma unroll
-                            for (int r = 0; r < 4; r++) if (e < lenR[r]) ent[r] = a.ientries[o0R[r] + e];
+                        for (int r = 0; r < 4; r++) if (lenR[r] == 1u && !(slotR[r] >> 63)) emit(slotR[r], hR[r]);
+                        if (__ballot(lenMulti != 0u)) {
+                            for (uint32_t e = 0; e < lenMulti; e++) {
+                                uint64_t ent[4] = {0, 0, 0, 0};
 #pragma unroll
-                            for (int r = 0; r < 4; r++) if (e < lenR[r]) {
-                                const uint32_t seqId = (uint32_t) ent[r];
-                                const uint32_t diag = (uint32_t) (i - (int) (uint32_t) ((ent[r] >> 32) & 0xFFFF)) & 0xFFFFu;
-                                const uint32_t h = hR[r] + e;
-                                const uint64_t key = ((uint64_t) seqId << 32) | ((uint64_t) (h & 0xFFFFu) << 16) | diag;
-                                if (h < (uint32_t) kHitCap) keys[h] = key;
-                                else if (h < (uint32_t) kSpillCap) spillKeys[h] = key;
+                                for (int r = 0; r < 4; r++) if ((slotR[r] >> 63) && e < lenR[r]) ent[r] = a.ientries[(uint32_t) slotR[r] + e];
+#pragma unroll
+                                for (int r = 0; r < 4; r++) if ((slotR[r] >> 63) && e < lenR[r]) emit(ent[r], hR[r] + e);
                             }
                         }
                         M = run;
                     }
                     waveSync();
+                    SP_T(5);
                 }
                 kBase += tileK;
                 waveSync();
@@ -438,7 +460,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
         const bool spilled = M > (uint32_t) kHitCap;
 
         uint32_t D = 0, dbase = 0;
-        if (a.ablate == 5 || a.ablate == 4) M = 0;
         if (M > 0 && M <= (uint32_t) kHitCap) {
             // Cheap exact pre-filter before the sort: a target hit only once in this query can only be recorded when its
             // 8-bit diagonal is 0 (previous := 0).  Count hits per hashed target in LDS, keep hits whose bucket saw >= 2
@@ -474,6 +495,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
             if (inLds) waveBitonicSort(keys, n, lane); else waveBitonicSort(spillKeys, n, lane);
             if (inLds) markKept(keys, M, bitsL, lane); else markKept(spillKeys, M, spillBits, lane);
             waveSync();
+            SP_T(6);
             uint32_t cnt = 0;
             for (uint32_t t = lane; t < (M + 31) / 32; t += 64) cnt += __popc(B[t]);
             D = waveSum(cnt);
@@ -513,7 +535,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
             a.qDiagCnt[qi] = D;
             if (overflow) atomicAdd(&a.counters[2], 1ull);
         }
+        SP_T(7);
     }
+    SP_T_FLUSH(a.counters);
     if (lane == 0) { atomicAdd(&a.counters[0], kmersTotal); atomicAdd(&a.counters[1], matchesTotal); atomicAdd(&a.counters[5], diagTotal); }
 }
 
@@ -833,7 +857,7 @@ struct Gpu::Impl {
     DevBuf<short> alnSub16; DevBuf<double> alnBack;
     int ungMinAbs = 0, alnMinAbs = 0;
     // targets
-    DevBuf<uint32_t> ioff; DevBuf<uint32_t> ibits; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff;
+    DevBuf<uint2> probe; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff;
     size_t nTargets = 0; size_t indexEntries = 0;
     // queries
     DevBuf<uint8_t> qres; DevBuf<uint32_t> qoff; DevBuf<float> biasf; DevBuf<short> qthr; DevBuf<signed char> qcorr; DevBuf<int> qbias; DevBuf<int> qself;
@@ -960,12 +984,30 @@ bool Gpu::uploadTables(const std::vector<uint32_t> &ext3, const SubMat &seed, co
 bool Gpu::uploadTargets(const TargetSet &ts, const KmerIndex &idx, std::string &err) {
     Impl &d = *d_;
     d.nTargets = ts.n; d.indexEntries = idx.entries.size();
-    if (!upload(d.ioff, idx.offsets.data(), idx.offsets.size(), d.stream, err)) return false;
     {
-        std::vector<uint32_t> bits((kTableSize + 31) / 32, 0);
-        if (idx.offsets.size() == (size_t) kTableSize + 1)
-            for (uint32_t k = 0; k < kTableSize; k++) if (idx.offsets[k + 1] != idx.offsets[k]) bits[k >> 5] |= 1u << (k & 31);
-        if (!upload(d.ibits, bits.data(), bits.size(), d.stream, err)) return false;
+        // rank-compressed slot table: one 8-byte probe word per 32 k-mer slots (occupancy bits + rank of the word's first
+        // occupied slot) and one 8-byte word per occupied slot.  A lookup is probe -> slot; the entry array is only touched
+        // for slots with more than one entry.  16 MB + 8 B x occupied slots instead of the 256 MB offsets table.
+        const size_t words = (kTableSize + 31) / 32;
+        std::vector<uint2> probe(words, make_uint2(0u, 0u));
+        std::vector<uint64_t> slots;
+        if (idx.offsets.size() == (size_t) kTableSize + 1) {
+            slots.reserve(idx.entries.size());
+            for (size_t w = 0; w < words; w++) {
+                uint32_t bits = 0;
+                probe[w].y = (uint32_t) slots.size();
+                const uint32_t k1 = (uint32_t) std::min<size_t>(kTableSize, (w + 1) * 32);
+                for (uint32_t k = (uint32_t) (w * 32); k < k1; k++) {
+                    const uint32_t o = idx.offsets[k], len = idx.offsets[k + 1] - o;
+                    if (len == 0) continue;
+                    bits |= 1u << (k & 31);
+                    slots.push_back(len == 1 ? idx.entries[o] : ((1ull << 63) | ((uint64_t) (len & 0x7FFFFFFFu) << 32) | o));
+                }
+                probe[w].x = bits;
+            }
+        }
+        if (!upload(d.probe, probe.data(), probe.size(), d.stream, err)) return false;
+        if (!upload(d.slots, slots.data(), slots.size(), d.stream, err)) return false;
         HIP_OK(hipStreamSynchronize(d.stream));
     }
     if (!upload(d.ientries, idx.entries.data(), idx.entries.size(), d.stream, err)) return false;
@@ -994,7 +1036,7 @@ bool Gpu::uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std:
 
 bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore, std::string &err) {
     Impl &d = *d_;
-    if (!d.ext3.p || !d.ioff.p) { err = "tables/targets not resident"; return false; }
+    if (!d.ext3.p || !d.probe.p) { err = "tables/targets not resident"; return false; }
     if (nq_ == 0) return true;
     maxHits_ = maxHits;
     // persistent match grid: as many blocks per CU as the LDS footprint of the chosen hit-buffer size admits.
@@ -1009,7 +1051,7 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     const uint32_t blocks = (uint32_t) std::min<size_t>((nq_ + kWavesPerBlock - 1) / kWavesPerBlock, (size_t) d.numCU * perCU);
     d.matchBlocks = blocks;
     if (!d.spill.ensure((size_t) blocks * kWavesPerBlock * kSpillWordsPerWave, err)) return false;
-    if (!d.queue.ensure(4, err) || !d.counters.ensure(8, err)) return false;
+    if (!d.queue.ensure(4, err) || !d.counters.ensure(16, err)) return false;
     // diagonal buffer: generous, HBM is plentiful (64 M records = 512 MB + side arrays)
     const size_t diagCap = std::max<size_t>((size_t) 1 << 22, std::min<size_t>((size_t) 1 << 26, nq_ * 64));
     if (!d.diagRec.ensure(diagCap, err) || !d.diagQuery.ensure(diagCap, err) || !d.diagScore.ensure(diagCap, err) || !d.diagFlag.ensure(diagCap, err)) return false;
@@ -1017,7 +1059,7 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     const uint32_t selBlocks = (uint32_t) ((nq_ + kWavesPerBlock - 1) / kWavesPerBlock);
     (void) selBlocks;
     HIP_OK(hipMemsetAsync(d.queue.p, 0, 4 * sizeof(uint32_t), d.stream));
-    HIP_OK(hipMemsetAsync(d.counters.p, 0, 8 * sizeof(unsigned long long), d.stream));
+    HIP_OK(hipMemsetAsync(d.counters.p, 0, 16 * sizeof(unsigned long long), d.stream));
     HIP_OK(hipMemsetAsync(d.diagQuery.p, 0xFF, diagCap * sizeof(uint32_t), d.stream));
 
     const bool dbg = getenv("SP_DEBUG") != nullptr;
@@ -1027,11 +1069,8 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     hipLaunchKernelGGL(k_prep, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, pa);
     SP_DBG_SYNC("k_prep");
     HIP_OK(hipEventRecord(d.ev[1], d.stream));
-    // the occupancy bitmap pays off while most k-mer slots are empty (phage-scale DBs); a dense index skips it
-    const bool useBits = getenv("SP_NO_BITMAP") == nullptr && (double) d.indexEntries < 0.5 * (double) kTableSize;
-    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.ioff.p, useBits ? d.ibits.p : nullptr, d.ientries.p, d.spill.p, d.queue.p,
-                 d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
-                 getenv("SP_ABLATE") ? atoi(getenv("SP_ABLATE")) : 0};
+    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.probe.p, d.slots.p, d.ientries.p, d.spill.p, d.queue.p,
+                 d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p};
     if (hitCap == 512) hipLaunchKernelGGL(k_match<512>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     else hipLaunchKernelGGL(k_match<2048>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     SP_DBG_SYNC("k_match");
@@ -1047,12 +1086,20 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     hipLaunchKernelGGL(k_reorder_hits, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.outStage.p, d.outBase.p, d.outCount.p, d.outOffset.p, (uint32_t) nq_, d.outHits.p, d.outQuery.p);
     SP_DBG_SYNC("k_select");
     HIP_OK(hipEventRecord(d.ev[4], d.stream));
-    unsigned long long c[8]; uint32_t qv[4];
+    unsigned long long c[16]; uint32_t qv[4];
     HIP_OK(hipMemcpyAsync(c, d.counters.p, sizeof(c), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipMemcpyAsync(qv, d.queue.p, sizeof(qv), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipStreamSynchronize(d.stream));
     counters_.kmers = c[0]; counters_.dbMatches = c[1]; counters_.overflowQueries = c[2]; counters_.diagResidues = c[3]; counters_.hits = qv[3];
     counters_.diagonals = c[5];
+#ifdef SP_PHASE_TIMERS
+    {
+        unsigned long long tot = 0; for (int ph = 0; ph < 8; ph++) tot += c[8 + ph];
+        fprintf(stderr, "[sp] k_match phase share:");
+        for (int ph = 0; ph < 8; ph++) fprintf(stderr, " p%d=%.1f%%", ph, tot ? 100.0 * (double) c[8 + ph] / (double) tot : 0.0);
+        fprintf(stderr, "  (ticks/wave %.0f)\n", (double) tot / (double) (d.matchBlocks * kWavesPerBlock));
+    }
+#endif
     (void) hipEventElapsedTime(&times_.prep, d.ev[0], d.ev[1]);
     (void) hipEventElapsedTime(&times_.match, d.ev[1], d.ev[2]);
     (void) hipEventElapsedTime(&times_.score, d.ev[2], d.ev[3]);
@@ -1064,18 +1111,22 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     return true;
 }
 
-bool Gpu::downloadHits(std::vector<GpuHit> &hits, std::vector<uint64_t> &offsets, std::string &err) {
+void *pinnedAlloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { fprintf(stderr, "spacepharer_amd: hipHostMalloc(%zu) failed\n", bytes); abort(); }
+    return p;
+}
+void pinnedFree(void *p) { if (p) (void) hipHostFree(p); }
+
+bool Gpu::downloadHits(PinVec<GpuHit> &hits, PinVec<uint32_t> &offsets, std::string &err) {
     Impl &d = *d_;
-    offsets.assign(nq_ + 1, 0);
-    hits.clear();
+    offsets.resize(nq_ + 1);
+    offsets[0] = 0;
+    hits.resize((size_t) counters_.hits);
     if (nq_ == 0) return true;
-    const size_t total = (size_t) counters_.hits;
-    std::vector<uint32_t> off(nq_ + 1);
-    hits.resize(total);
-    HIP_OK(hipMemcpyAsync(off.data(), d.outOffset.p, (nq_ + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
-    if (total) HIP_OK(hipMemcpyAsync(hits.data(), d.outHits.p, total * sizeof(GpuHit), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipMemcpyAsync(offsets.data(), d.outOffset.p, (nq_ + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    if (!hits.empty()) HIP_OK(hipMemcpyAsync(hits.data(), d.outHits.p, hits.size() * sizeof(GpuHit), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipStreamSynchronize(d.stream));
-    for (size_t q = 0; q <= nq_; q++) offsets[q] = off[q];
     return true;
 }
 
