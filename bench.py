@@ -10,6 +10,10 @@ Workload (BASELINE.json configs[2], SURVEY.md section 8d "synthetic proxy"): 10 
 50 000 synthetic phage ORFs x 200 aa = 1e7 residues drawn from the VTML40 background, seed 12345.
 N > 1 (torchrun): every rank holds the full target index and searches its own 10 000 spacers (weak scaling, query
 partition like the reference's default QUERY_DB_SPLIT; no data-path collective) -- value = all spacers / max time.
+
+--shard targets selects the target-sharded path instead (BASELINE.json configs[3]): the SAME 10 000
+spacers on every rank, rank g indexes target range g, the per-shard candidates are all-gathered over RCCL/xGMI and each
+rank finishes (selection on the union + align) its slice of the queries -- strong scaling, value = spacers / max time.
 """
 import argparse
 import ctypes as C
@@ -102,31 +106,56 @@ def main():
     ap.add_argument("--target-len", type=int, default=200)
     ap.add_argument("--stage", default="full", choices=["full", "prefilter"])
     ap.add_argument("--cpu-sample", type=int, default=3000, help="peptides for the CPU baseline (0 = skip)")
+    ap.add_argument("--shard", default="queries", choices=["queries", "targets"],
+                    help="N>1 decomposition: query partition with replicated index (default) or target shards + RCCL all-gather")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    sharded = args.shard == "targets"
+    if world > 1 or sharded:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        if world == 1:      # single-GPU run of the sharded path: a one-rank RCCL group
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl")
 
     import spacepharer_amd as sa
-    tres, toff, qres, qoff = make_workload(args.spacers, args.targets, args.target_len, 12345 + 7919 * rank)
-    if rank != 0:   # same target set on every rank, different spacers
-        tres, toff, _, _ = make_workload(1, args.targets, args.target_len, 12345)
+    from spacepharer_amd.dist import decompose_by_residues, sharded_prefilter
+    if sharded:
+        tres, toff, qres, qoff = make_workload(args.spacers, args.targets, args.target_len, 12345)
+    else:
+        tres, toff, qres, qoff = make_workload(args.spacers, args.targets, args.target_len, 12345 + 7919 * rank)
+        if rank != 0:   # same target set on every rank, different spacers
+            tres, toff, _, _ = make_workload(1, args.targets, args.target_len, 12345)
     ctx = sa.SearchContext(device_mask=1 << local_rank)
-    t0 = time.perf_counter()
-    ctx.set_targets_raw(tres.tobytes(), u64p(toff), len(toff) - 1)
-    t_index = time.perf_counter() - t0
     nq = len(qoff) - 1
+    q_from, q_to = 0, nq
+    t0 = time.perf_counter()
+    if sharded:
+        t_from, t_cnt = decompose_by_residues(np.diff(toff).astype(np.int64) + 2, rank, world)
+        ctx.set_targets_shard_raw(tres.tobytes(), u64p(toff), len(toff) - 1, t_from, t_from + t_cnt)
+        q_from, q_cnt = decompose_by_residues(np.diff(qoff).astype(np.int64) + 2, rank, world)
+        q_to = q_from + q_cnt
+    else:
+        ctx.set_targets_raw(tres.tobytes(), u64p(toff), len(toff) - 1)
+    t_index = time.perf_counter() - t0
     ctx.set_queries_raw(qres.tobytes(), u64p(qoff), nq)
+    gpu_dev = None
+    if dist is not None:
+        gpu_dev = torch.device("cuda", local_rank)
 
     def step():
-        ctx.prefilter()
+        if sharded:
+            sharded_prefilter(ctx, q_from, q_to, device=gpu_dev)   # own shard -> RCCL all-gather -> selection on the union
+        else:
+            ctx.prefilter()
         hits, offs, npairs = ctx.hits_compact()           # prefilter result DB content (hit_t triples per query)
         if args.stage == "full" and npairs:
             ctx.align_hits_raw()                          # alignment result DB content (result_t + backtraces per hit)
@@ -135,6 +164,7 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
+            torch.cuda.synchronize()
         ctx.sync()
 
     for _ in range(args.warmup):
@@ -151,10 +181,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        import torch
-        t = torch.tensor([dt], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([dt, float(pairs)], device="cuda")
+        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+        dt, pairs = float(t[0].item()), int(t[1].item())
+        dist.destroy_process_group()
     if rank != 0:
         return
     K, M, D, R, H = (ctx.stat(k) for k in ("kmers", "db_matches", "diagonals", "diag_residues", "hits"))
@@ -166,18 +197,19 @@ def main():
     traffic, traffic_src = pmc_traffic("k_match") if default_workload(args) else (None, None)
     out = {
         "metric": "spacer-queries/sec through prefilter+align; achieved HBM GB/s vs roofline",
-        "value": args.spacers * world * args.steps / dt,
+        "value": args.spacers * (1 if sharded else world) * args.steps / dt,
         "unit": "spacer-queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
         "dtype": "u8/i16 (integer k-mer lookup, u8/i16 Smith-Waterman)", "data": "synthetic",
         "config": {"workload": "%d synthetic 30-nt spacers (= %d peptides of 10 aa) vs %d synthetic phage ORFs x %d aa "
                                "(%.1e residues), 1xMI355X per rank, %s" % (args.spacers, nq, args.targets, args.target_len,
                                                                          args.targets * args.target_len,
                                                                          "prefilter + ungapped + banded-SW align" if args.stage == "full" else "prefilter only"),
                    "stage": args.stage, "pairs_aligned_per_step": pairs, "sensitivity": 5.7, "max_seqs": 300,
-                   "parallelism": "query partition x%d, index replicated" % world,
+                   "parallelism": ("target shards x%d, RCCL all-gather of candidates, selection + align by query slice" % world) if sharded
+                                  else ("query partition x%d, index replicated" % world),
                    "index_build_s": round(t_index, 3)},
         "kernels_ms_per_step": {k[3:]: round(v / args.steps, 4) for k, v in stats.items()},
         "counters_per_step": {"similar_kmers": K, "index_entries_fetched": M, "diagonals_scored": D, "diag_residues": R, "hits": H},
@@ -187,7 +219,8 @@ def main():
     }
     if args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(tres, toff, qres, qoff, min(args.cpu_sample, nq))
-    print(json.dumps(out))
+    C.CDLL(None).fflush(None)      # library chatter buffered in C stdio (RCCL prints its path) goes out BEFORE the result line
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -127,6 +127,25 @@ int sp_ctx_align_hits(sp_ctx *c, sp_alignment *results, char *cigars, uint64_t c
 int sp_ctx_rescore(sp_ctx *c, const uint32_t *query_idx, const uint32_t *target_idx, const int16_t *diagonal, uint64_t n,
                    int mode, sp_rescore *results);
 
+/* ---- target-sharded search (one context per GPU) ----
+ * Every GPU holds all target residues (align needs them) but masks and indexes only targets [shard_from, shard_to);
+ * sequence ids stay global.  Per query batch: sp_ctx_prefilter_candidates() on every shard, gather the candidate lists of
+ * all shards (RCCL all-gather of the device buffers, or any host transport), then sp_ctx_merge_candidates() runs the
+ * selection tail of QueryMatcher::matchQuery (prefiltering/QueryMatcher.cpp:100-186) over the union -- the result equals
+ * the unsplit search bit for bit (unlike Prefiltering::mergeTargetSplits, prefiltering/Prefiltering.cpp:300-420, whose
+ * per-split quota changes the hit set).  Afterwards the context is in the state sp_ctx_prefilter() leaves:
+ * sp_ctx_get_hits_compact() / sp_ctx_align_hits() work, restricted to queries [q_from, q_to). */
+typedef struct { uint32_t query; uint32_t seq_id; uint32_t kmer_ordinal; uint16_t diagonal; uint16_t score; } sp_candidate;   /* 16 bytes */
+int sp_ctx_set_targets_shard(sp_ctx *c, const char *residues, const uint64_t *offsets, const uint32_t *keys, uint64_t n,
+                             uint64_t shard_from, uint64_t shard_to);
+int sp_ctx_prefilter_candidates(sp_ctx *c);
+uint64_t sp_ctx_num_candidates(const sp_ctx *c);
+int sp_ctx_get_candidates(sp_ctx *c, sp_candidate *out);            /* copy of this shard's candidates; `out` may be host or
+                                                                       device memory (e.g. the send buffer of the all-gather) */
+const void *sp_ctx_candidates_device(const sp_ctx *c);              /* the same list in HBM (sp_candidate[num]) */
+/* candidates: the union (host or device memory, on_device says which); records with query == 0xFFFFFFFF are padding */
+int sp_ctx_merge_candidates(sp_ctx *c, const sp_candidate *candidates, uint64_t n, int on_device, uint64_t q_from, uint64_t q_to);
+
 /* counters / timings of the last call, by name: "kmers", "db_matches", "diagonals", "diag_residues",
    "hits", "index_entries", "masked_residues", "target_residues", "kmer_thr", "bin_size",
    "ms_prep", "ms_match", "ms_score", "ms_select", "ms_sw_forward", "ms_sw_reverse", "ms_traceback",

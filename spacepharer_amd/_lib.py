@@ -37,6 +37,11 @@ class Alignment(C.Structure):
                 ("cigar_offset", C.c_uint32), ("passed", C.c_int32)]
 
 
+class Candidate(C.Structure):
+    """sp_candidate: best double-hit diagonal of one (query, target), exchanged between target shards"""
+    _fields_ = [("query", C.c_uint32), ("seq_id", C.c_uint32), ("kmer_ordinal", C.c_uint32), ("diagonal", C.c_uint16), ("score", C.c_uint16)]
+
+
 class Rescore(C.Structure):
     _fields_ = [("score", C.c_int32), ("start_pos", C.c_int32), ("end_pos", C.c_int32), ("diagonal_len", C.c_int32),
                 ("diagonal", C.c_int32), ("dist_to_diagonal", C.c_uint32), ("evalue", C.c_double), ("bit_score", C.c_int32)]
@@ -76,6 +81,14 @@ def load_library():
     L.sp_ctx_align_hits.argtypes = [vp, C.POINTER(Alignment), C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.sp_ctx_rescore.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int16), C.c_uint64, C.c_int,
                                  C.POINTER(Rescore)]
+    L.sp_ctx_set_targets_shard.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint64, C.c_uint64, C.c_uint64]
+    L.sp_ctx_prefilter_candidates.argtypes = [vp]
+    L.sp_ctx_num_candidates.restype = C.c_uint64
+    L.sp_ctx_num_candidates.argtypes = [vp]
+    L.sp_ctx_get_candidates.argtypes = [vp, C.c_void_p]
+    L.sp_ctx_candidates_device.restype = vp
+    L.sp_ctx_candidates_device.argtypes = [vp]
+    L.sp_ctx_merge_candidates.argtypes = [vp, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64]
     L.sp_ctx_stat.restype = C.c_double
     L.sp_ctx_stat.argtypes = [vp, C.c_char_p]
     L.sp_ctx_sync.argtypes = [vp]
@@ -168,6 +181,46 @@ class SearchContext:
     def set_targets_raw(self, buf, offs_u64, n):
         _check(self.L.sp_ctx_set_targets(self.ctx, buf, offs_u64, None, n))
         self.n_targets = n
+
+    # ---- target-sharded search: this context indexes targets [shard_from, shard_to) of the full set
+    def set_targets_shard(self, seqs, shard_from, shard_to, keys=None):
+        buf, offs = _concat(seqs)
+        karr = (C.c_uint32 * len(seqs))(*keys) if keys is not None else None
+        _check(self.L.sp_ctx_set_targets_shard(self.ctx, buf, offs, karr, len(seqs), shard_from, shard_to))
+        self.n_targets = len(seqs)
+
+    def set_targets_shard_raw(self, buf, offs_u64, n, shard_from, shard_to):
+        _check(self.L.sp_ctx_set_targets_shard(self.ctx, buf, offs_u64, None, n, shard_from, shard_to))
+        self.n_targets = n
+
+    def prefilter_candidates(self):
+        """match + ungapped scoring against this shard; returns the number of candidates left in HBM"""
+        _check(self.L.sp_ctx_prefilter_candidates(self.ctx))
+        return int(self.L.sp_ctx_num_candidates(self.ctx))
+
+    def candidates(self):
+        """numpy uint8[n, 16] view of this shard's sp_candidate records (host copy)"""
+        import numpy as np
+        n = int(self.L.sp_ctx_num_candidates(self.ctx))
+        out = np.zeros((max(1, n), C.sizeof(Candidate)), dtype=np.uint8)
+        _check(self.L.sp_ctx_get_candidates(self.ctx, out.ctypes.data))
+        return out[:n]
+
+    def candidates_into(self, ptr):
+        """copy this shard's candidates to `ptr` (host or device address with room for num_candidates * 16 bytes)"""
+        _check(self.L.sp_ctx_get_candidates(self.ctx, ptr))
+
+    def candidates_device(self):
+        return self.L.sp_ctx_candidates_device(self.ctx), int(self.L.sp_ctx_num_candidates(self.ctx))
+
+    def merge_candidates(self, cands, q_from=0, q_to=None):
+        """cands: numpy uint8[n, 16] (host) -- the union of all shards' candidates"""
+        import numpy as np
+        cands = np.ascontiguousarray(cands, dtype=np.uint8)
+        _check(self.L.sp_ctx_merge_candidates(self.ctx, cands.ctypes.data, len(cands), 0, q_from, self.n_queries if q_to is None else q_to))
+
+    def merge_candidates_device(self, ptr, n, q_from=0, q_to=None):
+        _check(self.L.sp_ctx_merge_candidates(self.ctx, ptr, n, 1, q_from, self.n_queries if q_to is None else q_to))
 
     def set_queries(self, seqs):
         buf, offs = _concat(seqs)

@@ -122,7 +122,18 @@ int sp_ctx_set_targets(sp_ctx *c, const char *residues, const uint64_t *offsets,
     return sp_ctx_set_targets_ex(c, residues, offsets, keys, n, 0);
 }
 
+static int setTargets(sp_ctx *c, const char *residues, const uint64_t *offsets, const uint32_t *keys, uint64_t n, int flags, uint64_t from, uint64_t to);
+
 int sp_ctx_set_targets_ex(sp_ctx *c, const char *residues, const uint64_t *offsets, const uint32_t *keys, uint64_t n, int flags) {
+    return setTargets(c, residues, offsets, keys, n, flags, 0, n);
+}
+
+int sp_ctx_set_targets_shard(sp_ctx *c, const char *residues, const uint64_t *offsets, const uint32_t *keys, uint64_t n, uint64_t from, uint64_t to) {
+    if (from > to || to > n) { g_err = "sp_ctx_set_targets_shard: bad shard range"; return SP_ERR_ARG; }
+    return setTargets(c, residues, offsets, keys, n, 0, from, to);
+}
+
+static int setTargets(sp_ctx *c, const char *residues, const uint64_t *offsets, const uint32_t *keys, uint64_t n, int flags, uint64_t from, uint64_t to) {
     if (!c || !residues || !offsets) { g_err = "sp_ctx_set_targets: null argument"; return SP_ERR_ARG; }
     const bool noIndex = (flags & 1) != 0;
     std::string err;
@@ -134,9 +145,9 @@ int sp_ctx_set_targets_ex(sp_ctx *c, const char *residues, const uint64_t *offse
         c->tablesUp = true;
     }
     double t1 = nowMs();
-    sp::prepareTargets(c->seed, residues, offsets, keys, (size_t) n, c->par.mask != 0 && !noIndex, c->threads, c->targets);
+    sp::prepareTargets(c->seed, residues, offsets, keys, (size_t) n, c->par.mask != 0 && !noIndex, c->threads, c->targets, (size_t) from, (size_t) to);
     if (noIndex) { c->index.offsets.assign(2, 0); c->index.entries.clear(); }
-    else sp::buildIndex(c->seed, c->targets, c->kmerThr, c->threads, c->index);
+    else sp::buildIndex(c->seed, c->targets, c->kmerThr, c->threads, c->index, (size_t) from, (size_t) to);
     c->indexEntries = c->index.entries.size();
     double t2 = nowMs();
     if (!c->gpu.uploadTargets(c->targets, c->index, err)) { g_err = err; return SP_ERR_DEVICE; }
@@ -169,6 +180,8 @@ int sp_ctx_set_queries(sp_ctx *c, const char *residues, const uint64_t *offsets,
     return SP_OK;
 }
 
+static void prefilterStats(sp_ctx *c);
+
 int sp_ctx_prefilter(sp_ctx *c) {
     if (!c || c->targets.n == 0) { g_err = "sp_ctx_prefilter: no target set"; return SP_ERR_STATE; }
     if (c->indexEntries == 0) { g_err = "sp_ctx_prefilter: the target set has no k-mer index (no indexable k-mer, or staged without one)"; return SP_ERR_STATE; }
@@ -176,11 +189,45 @@ int sp_ctx_prefilter(sp_ctx *c) {
     // maxResListLen = min(#targets, --max-seqs): prefiltering/Prefiltering.cpp:170
     const int maxHits = sp_ctx_max_seqs(c);
     if (!c->gpu.prefilter(c->kmerThr, c->binSize, maxHits, c->par.min_ungapped_score, err)) { g_err = err; return SP_ERR_OVERFLOW; }
+    prefilterStats(c);
+    return SP_OK;
+}
+
+static void prefilterStats(sp_ctx *c) {
     sp::PrefilterCounters pc = c->gpu.counters();
     sp::KernelTimes kt = c->gpu.times();
     c->stats["kmers"] = (double) pc.kmers; c->stats["db_matches"] = (double) pc.dbMatches; c->stats["diagonals"] = (double) pc.diagonals;
     c->stats["diag_residues"] = (double) pc.diagResidues; c->stats["hits"] = (double) pc.hits;
     c->stats["ms_prep"] = kt.prep; c->stats["ms_match"] = kt.match; c->stats["ms_score"] = kt.score; c->stats["ms_select"] = kt.select;
+}
+
+int sp_ctx_prefilter_candidates(sp_ctx *c) {
+    if (!c || c->targets.n == 0) { g_err = "sp_ctx_prefilter_candidates: no target set"; return SP_ERR_STATE; }
+    std::string err;
+    if (!c->gpu.prefilterCandidates(c->kmerThr, c->par.min_ungapped_score, err)) { g_err = err; return SP_ERR_OVERFLOW; }
+    prefilterStats(c);
+    c->stats["candidates"] = (double) c->gpu.numCandidates();
+    return SP_OK;
+}
+
+uint64_t sp_ctx_num_candidates(const sp_ctx *c) { return (uint64_t) c->gpu.numCandidates(); }
+const void *sp_ctx_candidates_device(const sp_ctx *c) { return c->gpu.candidatesDevice(); }
+
+int sp_ctx_get_candidates(sp_ctx *c, sp_candidate *out) {
+    static_assert(sizeof(sp_candidate) == sizeof(sp::Candidate), "candidate layout");
+    std::string err;
+    if (!c->gpu.downloadCandidates(reinterpret_cast<sp::Candidate *>(out), err)) { g_err = err; return SP_ERR_DEVICE; }
+    return SP_OK;
+}
+
+int sp_ctx_merge_candidates(sp_ctx *c, const sp_candidate *cands, uint64_t n, int onDevice, uint64_t qFrom, uint64_t qTo) {
+    if (!c || c->targets.n == 0) { g_err = "sp_ctx_merge_candidates: no target set"; return SP_ERR_STATE; }
+    if (n && !cands) { g_err = "sp_ctx_merge_candidates: null candidate list"; return SP_ERR_ARG; }
+    std::string err;
+    if (!c->gpu.mergeCandidates(reinterpret_cast<const sp::Candidate *>(cands), (size_t) n, onDevice != 0, (size_t) qFrom, (size_t) qTo, c->binSize,
+                                sp_ctx_max_seqs(c), c->par.min_ungapped_score, err)) { g_err = err; return SP_ERR_OVERFLOW; }
+    sp::KernelTimes kt = c->gpu.times();
+    c->stats["hits"] = (double) c->gpu.counters().hits; c->stats["ms_select"] = kt.select;
     return SP_OK;
 }
 

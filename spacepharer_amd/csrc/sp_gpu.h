@@ -9,6 +9,9 @@
 namespace sp {
 
 struct GpuHit { uint32_t seqId; uint16_t score; uint16_t diag; };
+// target-sharded search: best double-hit diagonal of one (query, target) as exchanged between shards.  ord = ordinal of
+// the similar k-mer whose index hit recorded the diagonal, counted over the query's k-mer enumeration (shard independent).
+struct Candidate { uint32_t query; uint32_t seqId; uint32_t ord; uint16_t diag; uint16_t exact; };
 
 struct SwPair { uint32_t query; uint32_t target; };          // indices into the resident query batch / target set
 struct SwForward { int32_t score; int32_t refEnd; int32_t readEnd; int32_t word; };
@@ -73,6 +76,13 @@ public:
 
     // k-mer prefilter + ungapped diagonal scoring + selection for every resident query
     bool prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore, std::string &err);
+    // target-sharded search (every GPU indexes a target range, all queries resident): candidates of this shard, then the
+    // selection over the union of all shards' candidates (gathered by the caller, e.g. RCCL all-gather)
+    bool prefilterCandidates(int kmerThr, int minDiagScore, std::string &err);
+    size_t numCandidates() const;
+    const Candidate *candidatesDevice() const;
+    bool downloadCandidates(Candidate *out, std::string &err);
+    bool mergeCandidates(const Candidate *src, size_t n, bool onDevice, size_t qFrom, size_t qTo, unsigned binSize, int maxHits, int minDiagScore, std::string &err);
     // hits grouped by query (query order); offsets has nq+1 entries
     bool downloadHits(PinVec<GpuHit> &hits, PinVec<uint32_t> &offsets, std::string &err);
     PrefilterCounters counters() const { return counters_; }
@@ -101,6 +111,8 @@ public:
     void *stream() const { return stream_; }
 
 private:
+    bool matchAndScore(int kmerThr, bool withOrd, std::string &err);
+    bool finishPrefilter(bool matched, std::string &err);
     struct Impl;
     Impl *d_;
     void *stream_ = nullptr;

@@ -208,6 +208,9 @@ struct MatchArgs {
     DiagRec *diagRec; uint32_t *diagQuery; uint32_t diagCap; uint32_t *diagCursor;
     uint32_t *qDiagBase; uint32_t *qDiagCnt;
     unsigned long long *counters;   // [0]=kmers [1]=dbMatches [2]=overflow queries
+    // target-sharded search only (kOrd): ordinal of the similar k-mer that produced the recording hit, counted over the
+    // query's whole k-mer enumeration -- identical on every shard, so (ordinal, seqId) orders records globally
+    uint32_t *diagOrd; uint32_t *spillOrd;
 };
 
 // phase timers (build with -DSP_PHASE_TIMERS): shader-clock ticks per phase, summed over waves into counters[8 + phase]
@@ -248,8 +251,10 @@ __device__ void markKept(const uint64_t *keys, uint32_t M, uint32_t *bits, int l
 }
 
 // HITCAP = hits per query held in LDS; more spill to the per-wave HBM scratch.  Smaller HITCAP = more resident waves.
-template <int kHitCap>
+template <int kHitCap, bool kOrd>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
+    __shared__ uint16_t s_occOrd[kWavesPerBlock][kOrd ? kSuper : 1];
+    __shared__ uint32_t s_ordL[kWavesPerBlock][kOrd ? kHitCap : 1];
     __shared__ uint64_t s_keys[kWavesPerBlock][kHitCap];
     __shared__ uint32_t s_aStart[kWavesPerBlock][kATile + 1];
     __shared__ uint16_t s_aIdx[kWavesPerBlock][kATile];
@@ -269,11 +274,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     uint32_t *bitsL = s_bits[w];
     uint32_t *occList = s_occ[w];
     uint32_t *stamp = s_stamp[w];
+    uint16_t *occOrd = s_occOrd[w];
+    uint32_t *ordL = s_ordL[w];
     stamp[lane] = 0;
     uint32_t stampId = 0;
     const uint32_t waveGlobal = blockIdx.x * kWavesPerBlock + w;
     uint64_t *spillKeys = a.spill + (size_t) waveGlobal * kSpillWordsPerWave;
     uint32_t *spillBits = (uint32_t *) (spillKeys + 65536);
+    uint32_t *spillOrd = kOrd ? a.spillOrd + (size_t) waveGlobal * 65536 : nullptr;
     unsigned long long kmersTotal = 0, matchesTotal = 0, diagTotal = 0;
     uint32_t dChunkBase = 0, dChunkUsed = 0, dChunkCap = 0;
     SP_T_DECL
@@ -288,6 +296,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
         const uint8_t *q = a.qres + qo;
         const int nScan = L - kSpan;        // windows 0 .. L-9 ; the last window (L-8) is never scanned
         uint32_t M = 0;
+        uint32_t qK0 = 0;                   // similar k-mers of the windows before the current one
         bool overflow = false;
         // the wave is bound by chains of dependent memory round trips, so: residues and thresholds of the first 64
         // positions are fetched once per query into lanes (readlane per window), and all loads of a window's
@@ -406,17 +415,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                         const uint32_t bit = kmerR[r] & 31u;
                         const bool occ = kmerR[r] != 0xFFFFFFFFu && ((prR[r].x >> bit) & 1u);
                         const uint64_t m = __ballot(occ);
-                        if (occ) occList[nOcc + (uint32_t) __popcll(m & laneMaskLt(lane))] = prR[r].y + (uint32_t) __popc(prR[r].x & ((1u << bit) - 1u));
+                        if (occ) {
+                            const uint32_t at = nOcc + (uint32_t) __popcll(m & laneMaskLt(lane));
+                            occList[at] = prR[r].y + (uint32_t) __popc(prR[r].x & ((1u << bit) - 1u));
+                            if (kOrd) occOrd[at] = (uint16_t) (r * 64 + lane);
+                        }
                         nOcc += (uint32_t) __popcll(m);
                     }
                     waveSync();
                     SP_T(4);
                     for (uint32_t ob = 0; ob < nOcc; ob += 256) {
-                        uint64_t slotR[4] = {0, 0, 0, 0}; uint32_t lenR[4] = {0, 0, 0, 0}, hR[4];
+                        uint64_t slotR[4] = {0, 0, 0, 0}; uint32_t lenR[4] = {0, 0, 0, 0}, hR[4], ordR[4] = {0, 0, 0, 0};
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             const uint32_t at = ob + 64u * r + lane;
-                            if (at < nOcc) { slotR[r] = a.slots[occList[at]]; lenR[r] = (slotR[r] >> 63) ? ((uint32_t) (slotR[r] >> 32) & 0x7FFFFFFFu) : 1u; }
+                            if (at < nOcc) {
+                                slotR[r] = a.slots[occList[at]]; lenR[r] = (slotR[r] >> 63) ? ((uint32_t) (slotR[r] >> 32) & 0x7FFFFFFFu) : 1u;
+                                if (kOrd) ordR[r] = qK0 + kBase + s0 + occOrd[at];
+                            }
                         }
                         uint32_t lenMulti = 0, run = M;
 #pragma unroll
@@ -426,23 +442,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                             run += lane63(incl);
                             if ((slotR[r] >> 63) && lenR[r] > lenMulti) lenMulti = lenR[r];
                         }
-                        auto emit = [&](uint64_t ent, uint32_t h) {
+                        auto emit = [&](uint64_t ent, uint32_t h, uint32_t ord) {
                             const uint32_t seqId = (uint32_t) ent;
                             const uint32_t diag = (uint32_t) (i - (int) (uint32_t) ((ent >> 32) & 0xFFFF)) & 0xFFFFu;
                             const uint64_t key = ((uint64_t) seqId << 32) | ((uint64_t) (h & 0xFFFFu) << 16) | diag;
-                            if (h < (uint32_t) kHitCap) keys[h] = key;
-                            else if (h < (uint32_t) kSpillCap) spillKeys[h] = key;
+                            if (h < (uint32_t) kHitCap) { keys[h] = key; if (kOrd) ordL[h] = ord; }
+                            else if (h < (uint32_t) kSpillCap) { spillKeys[h] = key; if (kOrd) spillOrd[h] = ord; }
                         };
                         // one-entry lists (the rule while the index is sparse) are complete with the slot word
 #pragma unroll
-                        for (int r = 0; r < 4; r++) if (lenR[r] == 1u && !(slotR[r] >> 63)) emit(slotR[r], hR[r]);
+                        for (int r = 0; r < 4; r++) if (lenR[r] == 1u && !(slotR[r] >> 63)) emit(slotR[r], hR[r], ordR[r]);
                         if (__ballot(lenMulti != 0u)) {
                             for (uint32_t e = 0; e < lenMulti; e++) {
                                 uint64_t ent[4] = {0, 0, 0, 0};
 #pragma unroll
                                 for (int r = 0; r < 4; r++) if ((slotR[r] >> 63) && e < lenR[r]) ent[r] = a.ientries[(uint32_t) slotR[r] + e];
 #pragma unroll
-                                for (int r = 0; r < 4; r++) if ((slotR[r] >> 63) && e < lenR[r]) emit(ent[r], hR[r] + e);
+                                for (int r = 0; r < 4; r++) if ((slotR[r] >> 63) && e < lenR[r]) emit(ent[r], hR[r] + e, ordR[r]);
                             }
                         }
                         M = run;
@@ -454,6 +470,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                 waveSync();
             }
             kmersTotal += kBase;
+            qK0 += kBase;
         }
         matchesTotal += M;
         if (M > (uint32_t) kSpillCap) { overflow = true; M = 0; }
@@ -524,6 +541,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                         DiagRec r; r.seqId = (uint32_t) (k >> 32); r.diag = (uint16_t) (k & 0xFFFF); r.idx = (uint16_t) ((k >> 16) & 0xFFFF);
                         a.diagRec[at] = r;
                         a.diagQuery[at] = qi;
+                        if (kOrd) a.diagOrd[at] = r.idx < (uint32_t) kHitCap ? ordL[r.idx] : spillOrd[r.idx];
                     }
                     outPos += __popcll(m);
                 }
@@ -817,6 +835,196 @@ __global__ void k_reorder_hits(const GpuHit *staging, const uint32_t *base, cons
     for (uint32_t k = 0; k < c; k++) { out[o + k] = staging[b + k]; outQuery[o + k] = q; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Target-sharded search: every GPU matches all queries against the index of ITS target range and
+// exports, per (query, target), the best double-hit diagonal as a 16-byte candidate; the union of all shards' candidates
+// goes through the same selection tail as the unsplit search (NOT Prefiltering::mergeTargetSplits, which applies a
+// per-split quota -- prefiltering/Prefiltering.cpp:343-346 -- and therefore differs from the unsplit result).
+// ---------------------------------------------------------------------------------------------------------------
+struct CandArgs {
+    const DiagRec *diagRec; const uint32_t *diagQuery; const uint16_t *diagScore; const uint32_t *diagOrd; const uint32_t *diagCursor; uint32_t diagCap;
+    const uint32_t *qDiagBase; const uint32_t *qDiagCnt; const int *qbias; const uint32_t *qoff; int minDiagScore;
+    Candidate *out; uint32_t *outCursor; uint32_t outCap;
+};
+
+// one lane per diagonal record: keep it iff it is its target's best (clamped score, ties -> earliest in the stream)
+__global__ void k_candidates(CandArgs a) {
+    uint32_t nDiag = *a.diagCursor; if (nDiag > a.diagCap) nDiag = a.diagCap;
+    const int lane = laneId();
+    for (uint32_t r0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; r0 < nDiag; r0 += gridDim.x * blockDim.x) {
+        const uint32_t r = r0 + lane;
+        bool keep = false; Candidate c{0, 0, 0, 0, 0};
+        if (r < nDiag) {
+            const uint32_t qi = a.diagQuery[r];
+            if (qi != 0xFFFFFFFFu) {
+                const uint32_t base = a.qDiagBase[qi], end = base + a.qDiagCnt[qi];
+                const int qL = (int) (a.qoff[qi + 1] - a.qoff[qi]);
+                const int maxC = (qL >= 32768) ? 255 : 255 - a.qbias[qi];
+                const DiagRec me = a.diagRec[r];
+                const int cMe = min((int) a.diagScore[r], maxC);
+                keep = cMe >= a.minDiagScore;
+                for (uint32_t u = r; keep && u > base && a.diagRec[u - 1].seqId == me.seqId; u--) if (min((int) a.diagScore[u - 1], maxC) >= cMe) keep = false;
+                for (uint32_t u = r + 1; keep && u < end && a.diagRec[u].seqId == me.seqId; u++) if (min((int) a.diagScore[u], maxC) > cMe) keep = false;
+                c.query = qi; c.seqId = me.seqId; c.ord = a.diagOrd[r]; c.diag = me.diag; c.exact = a.diagScore[r];
+            }
+        }
+        const uint64_t m = __ballot(keep);
+        if (m) {
+            const uint32_t ob = uni(atomicAdd(a.outCursor, lane == 0 ? (uint32_t) __popcll(m) : 0u));
+            if (keep) { const uint32_t at = ob + (uint32_t) __popcll(m & laneMaskLt(lane)); if (at < a.outCap) a.out[at] = c; }
+        }
+    }
+}
+
+// union of candidates -> grouped by query (counting sort; the order inside a query is irrelevant, the selection ranks
+// by a total order)
+__global__ void k_cand_count(const Candidate *c, uint32_t n, uint32_t qFrom, uint32_t qTo, uint32_t *cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint32_t q = c[i].query; if (q >= qFrom && q < qTo) atomicAdd(&cnt[q], 1u); }
+}
+__global__ void k_cand_scatter(const Candidate *c, uint32_t n, uint32_t qFrom, uint32_t qTo, const uint32_t *offset, uint32_t *fill, Candidate *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const Candidate v = c[i]; if (v.query >= qFrom && v.query < qTo) out[offset[v.query] + atomicAdd(&fill[v.query], 1u)] = v; }
+}
+
+struct MergeArgs {
+    uint32_t nq; const Candidate *cand; const uint32_t *candOffset;     // candidates grouped by query, candOffset[nq + 1]
+    const int *qbias; const int *qself; const uint32_t *qoff;
+    uint64_t *scratch;              // per wave: 65536 u64 keys + 65536 u32 indices
+    uint32_t *queue;
+    uint32_t binMask; int maxHits; int minDiagScore;
+    GpuHit *outHits; uint32_t *outQuery; uint32_t *outCount; uint32_t *outBase; uint32_t *outCursor;
+    unsigned long long *counters;   // [2] += queries with more candidates than the scratch holds
+};
+constexpr size_t kMergeScratchWords = 65536 + 65536 / 2;
+constexpr int kMergeIdxLds = 1024;
+
+// bitonic sort of candidate indices by the selection order (rank key desc, bin asc, k-mer ordinal asc, seqId asc)
+template <typename Less>
+__device__ __forceinline__ void waveBitonicSortIdx(uint32_t *idx, uint32_t n, int lane, Less less) {
+    for (uint32_t k = 2; k <= n; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = lane; t < (n >> 1); t += 64) {
+                const uint32_t lo = t & (j - 1);
+                const uint32_t i = ((t - lo) << 1) | lo;
+                const uint32_t p = i | j;
+                const uint32_t x = idx[i], y = idx[p];
+                const bool up = ((i & k) == 0);
+                if (less(y, x) == up) { idx[i] = y; idx[p] = x; }
+            }
+            waveSync();
+        }
+    }
+}
+
+// the tail of QueryMatcher::matchQuery on the union of all shards' candidates; same statement as selectOne() with the
+// global stream order (k-mer ordinal, seqId) in place of the shard-local stream index
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_select_merged(MergeArgs a) {
+    __shared__ uint64_t s_keys[kWavesPerBlock][kSelCap];
+    __shared__ uint32_t s_idx[kWavesPerBlock][kMergeIdxLds];
+    __shared__ uint32_t s_hist[kWavesPerBlock][256];
+    const int lane = laneId();
+    const int w = (int) (threadIdx.x >> 6);
+    uint32_t *hist = s_hist[w];
+    uint64_t *scratchK = a.scratch + (size_t) (blockIdx.x * kWavesPerBlock + w) * kMergeScratchWords;
+    uint32_t *scratchI = (uint32_t *) (scratchK + 65536);
+    for (;;) {
+        const uint32_t qi = popQueue(a.queue, lane);
+        if (qi >= a.nq) break;
+        const uint32_t c0 = uni(a.candOffset[qi]);
+        uint32_t D = uni(a.candOffset[qi + 1]) - c0;
+        if (D > 65535u) { if (lane == 0) atomicAdd(&a.counters[2], 1ull); D = 0; }
+        if (D == 0) { if (lane == 0) { a.outCount[qi] = 0; a.outBase[qi] = 0; } continue; }
+        const Candidate *cand = a.cand + c0;
+        const int qL = (int) uni(a.qoff[qi + 1] - a.qoff[qi]);
+        const int bias = (int) uni((uint32_t) a.qbias[qi]);
+        const int maxC = (qL >= 32768) ? 255 : 255 - bias;
+        const int truncAt = 255 - bias;
+        for (int t = lane; t < 256; t += 64) hist[t] = 0;
+        waveSync();
+        for (uint32_t t = lane; t < D; t += 64) atomicAdd(&hist[min((int) cand[t].exact, maxC)], 1u);
+        waveSync();
+        uint32_t thr = 0;
+        if (lane == 0) {
+            uint32_t found = 0; int t;
+            for (t = 255; t > 0; t--) { found += hist[t]; if (found >= (uint32_t) a.maxHits) break; }
+            thr = (uint32_t) t;
+            if (thr < (uint32_t) a.minDiagScore) thr = (uint32_t) a.minDiagScore;
+        }
+        thr = uni(thr);
+        const bool truncated = (int) thr >= truncAt;
+        uint32_t nC = 0;
+        for (int t = lane; t < 256; t += 64) if ((uint32_t) t >= thr) nC += hist[t];
+        nC = waveSum(nC);
+        if (nC == 0) { if (lane == 0) { a.outCount[qi] = 0; a.outBase[qi] = 0; } continue; }
+        uint32_t n = 1; while (n < nC) n <<= 1;
+        const bool idxLds = n <= (uint32_t) kMergeIdxLds;
+        uint32_t *I = idxLds ? s_idx[w] : scratchI;
+        int maxSelf = (int) uni((uint32_t) a.qself[qi]) - truncAt; if (maxSelf < 1) maxSelf = 1; if (maxSelf > 65535) maxSelf = 65535;
+        const float fltMax = (float) maxSelf;
+        // rank value of a candidate: its clamped score, or the rescaled one in the saturated branch (QueryMatcher.cpp:486-505)
+        auto rankC = [&](const Candidate &c) -> int {
+            int v = min((int) c.exact, maxC);
+            if (truncated) {
+                const uint32_t ns = (uint32_t) c.exact - (uint32_t) truncAt;
+                const float sc = (float) (ns < 65535u ? ns : 65535u);
+                v = (int) (unsigned char) ((double) ((sc / fltMax) * (float) 255) + 0.5);
+            }
+            return v;
+        };
+        uint32_t wr = 0;
+        for (uint32_t b0 = 0; b0 < D; b0 += 64) {
+            const uint32_t t = b0 + lane;
+            const bool take = t < D && (uint32_t) min((int) cand[t].exact, maxC) >= thr;
+            const uint64_t m = __ballot(take);
+            if (take) I[wr + (uint32_t) __popcll(m & laneMaskLt(lane))] = t;
+            wr += (uint32_t) __popcll(m);
+        }
+        for (uint32_t t = nC + lane; t < n; t += 64) I[t] = 0xFFFFFFFFu;
+        waveSync();
+        auto less = [&](uint32_t x, uint32_t y) -> bool {       // strict order; the padding index sorts last
+            if (x == 0xFFFFFFFFu || y == 0xFFFFFFFFu) return x != 0xFFFFFFFFu && y == 0xFFFFFFFFu;
+            const Candidate cx = cand[x], cy = cand[y];
+            const int rx = rankC(cx), ry = rankC(cy);
+            if (rx != ry) return rx > ry;
+            const uint32_t bx = cx.seqId & a.binMask, by = cy.seqId & a.binMask;
+            if (bx != by) return bx < by;
+            if (cx.ord != cy.ord) return cx.ord < cy.ord;
+            return cx.seqId < cy.seqId;
+        };
+        if (idxLds) waveBitonicSortIdx(s_idx[w], n, lane, less); else waveBitonicSortIdx(scratchI, n, lane, less);
+        const uint32_t nOut = min(nC, (uint32_t) a.maxHits);
+        uint32_t n2 = 1; while (n2 < nOut) n2 <<= 1;
+        const bool keyLds = n2 <= (uint32_t) kSelCap;
+        uint64_t *K = keyLds ? s_keys[w] : scratchK;
+        for (uint32_t t = lane; t < n2; t += 64) {
+            uint64_t key = ~0ull;
+            if (t < nOut) {
+                const Candidate c = cand[I[t]];
+                const int v = rankC(c);
+                int score;
+                if (truncated) score = truncAt + (int) ((uint32_t) v * (uint32_t) maxSelf / 255u);
+                else score = (v >= truncAt) ? (int) c.exact : v;
+                if (score > 65535) score = 65535;
+                key = ((uint64_t) (65535 - score) << 48) | ((uint64_t) c.seqId << 16) | (uint64_t) t;
+            }
+            K[t] = key;
+        }
+        waveSync();
+        if (keyLds) waveBitonicSort(s_keys[w], n2, lane); else waveBitonicSort(scratchK, n2, lane);
+        const uint32_t obase = uni(atomicAdd(a.outCursor, lane == 0 ? nOut : 0u));
+        for (uint32_t t = lane; t < nOut; t += 64) {
+            const uint64_t k3 = K[t];
+            const Candidate c = cand[I[(uint32_t) (k3 & 0xFFFF)]];
+            GpuHit h; h.seqId = c.seqId; h.score = (uint16_t) (65535 - (uint32_t) (k3 >> 48)); h.diag = c.diag;
+            a.outHits[(size_t) obase + t] = h;
+            a.outQuery[(size_t) obase + t] = qi;
+        }
+        if (lane == 0) { a.outCount[qi] = nOut; a.outBase[qi] = obase; }
+        waveSync();
+    }
+}
+
 #include "sp_gpu_sw.inc"
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -868,6 +1076,11 @@ struct Gpu::Impl {
     DevBuf<uint32_t> qDiagBase; DevBuf<uint32_t> qDiagCnt; DevBuf<unsigned long long> counters;
     DevBuf<GpuHit> outHits; DevBuf<GpuHit> outStage; DevBuf<uint32_t> outQuery; DevBuf<uint32_t> outCount; DevBuf<uint32_t> outBase; DevBuf<uint32_t> outOffset;
     uint32_t matchBlocks = 0;
+    size_t diagCap = 0;
+    // target-sharded search
+    DevBuf<uint32_t> diagOrd; DevBuf<uint32_t> spillOrd; DevBuf<Candidate> cand; DevBuf<Candidate> candUnion; DevBuf<Candidate> candByQuery;
+    DevBuf<uint32_t> candCnt; DevBuf<uint32_t> candFill; DevBuf<uint32_t> candOffset; DevBuf<uint64_t> mergeScratch;
+    uint32_t nCand = 0;
     SwState sw;
     SwDev swd;
 };
@@ -1034,81 +1247,171 @@ bool Gpu::uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std:
     return true;
 }
 
-bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore, std::string &err) {
+#define SP_DBG_SYNC(tag) do { HIP_OK(hipGetLastError()); if (dbg) { HIP_OK(hipStreamSynchronize(d.stream)); fprintf(stderr, "[sp] %s done\n", tag); } } while (0)
+
+// k_prep, k_match, k_score for every resident query; leaves the scored double-hit diagonals in HBM (events 0..3)
+bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     Impl &d = *d_;
     if (!d.ext3.p || !d.probe.p) { err = "tables/targets not resident"; return false; }
-    if (nq_ == 0) return true;
-    maxHits_ = maxHits;
     // persistent match grid: as many blocks per CU as the LDS footprint of the chosen hit-buffer size admits.
     // Expected hits per query ~ (similar k-mers per query) x (index entries per k-mer slot); keep 4x headroom.
     int hitCap = ((double) d.indexEntries / (double) kTableSize * 1300.0 * 2.5 < 512.0) ? 512 : 2048;
     if (const char *e = getenv("SP_HITCAP")) hitCap = atoi(e) <= 512 ? 512 : 2048;
+    const void *fn = hitCap == 512 ? (withOrd ? (const void *) k_match<512, true> : (const void *) k_match<512, false>)
+                                   : (withOrd ? (const void *) k_match<2048, true> : (const void *) k_match<2048, false>);
     int perCU = 2;
-    if (hitCap == 512) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_match<512>, 64 * kWavesPerBlock, 0) != hipSuccess || perCU < 1) perCU = 2; }
-    else { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_match<2048>, 64 * kWavesPerBlock, 0) != hipSuccess || perCU < 1) perCU = 2; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, fn, 64 * kWavesPerBlock, 0) != hipSuccess || perCU < 1) perCU = 2;
     if (const char *e = getenv("SP_MATCH_PERCU")) perCU = std::max(1, atoi(e));
-    if (getenv("SP_DEBUG")) fprintf(stderr, "[sp] k_match hitCap=%d blocks/CU=%d\n", hitCap, perCU);
+    const bool dbg = getenv("SP_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[sp] k_match hitCap=%d ord=%d blocks/CU=%d\n", hitCap, (int) withOrd, perCU);
     const uint32_t blocks = (uint32_t) std::min<size_t>((nq_ + kWavesPerBlock - 1) / kWavesPerBlock, (size_t) d.numCU * perCU);
     d.matchBlocks = blocks;
     if (!d.spill.ensure((size_t) blocks * kWavesPerBlock * kSpillWordsPerWave, err)) return false;
-    if (!d.queue.ensure(4, err) || !d.counters.ensure(16, err)) return false;
+    if (!d.queue.ensure(8, err) || !d.counters.ensure(16, err)) return false;
     // diagonal buffer: generous, HBM is plentiful (64 M records = 512 MB + side arrays)
     const size_t diagCap = std::max<size_t>((size_t) 1 << 22, std::min<size_t>((size_t) 1 << 26, nq_ * 64));
+    d.diagCap = diagCap;
     if (!d.diagRec.ensure(diagCap, err) || !d.diagQuery.ensure(diagCap, err) || !d.diagScore.ensure(diagCap, err) || !d.diagFlag.ensure(diagCap, err)) return false;
-    if (!d.outHits.ensure(nq_ * (size_t) maxHits, err) || !d.outStage.ensure(nq_ * (size_t) maxHits, err) || !d.outQuery.ensure(nq_ * (size_t) maxHits, err)) return false;
-    const uint32_t selBlocks = (uint32_t) ((nq_ + kWavesPerBlock - 1) / kWavesPerBlock);
-    (void) selBlocks;
-    HIP_OK(hipMemsetAsync(d.queue.p, 0, 4 * sizeof(uint32_t), d.stream));
+    if (withOrd && (!d.diagOrd.ensure(diagCap, err) || !d.spillOrd.ensure((size_t) blocks * kWavesPerBlock * 65536, err))) return false;
+    HIP_OK(hipMemsetAsync(d.queue.p, 0, 8 * sizeof(uint32_t), d.stream));
     HIP_OK(hipMemsetAsync(d.counters.p, 0, 16 * sizeof(unsigned long long), d.stream));
     HIP_OK(hipMemsetAsync(d.diagQuery.p, 0xFF, diagCap * sizeof(uint32_t), d.stream));
 
-    const bool dbg = getenv("SP_DEBUG") != nullptr;
-#define SP_DBG_SYNC(tag) do { HIP_OK(hipGetLastError()); if (dbg) { HIP_OK(hipStreamSynchronize(d.stream)); fprintf(stderr, "[sp] %s done\n", tag); } } while (0)
     HIP_OK(hipEventRecord(d.ev[0], d.stream));
     PrepArgs pa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.seedSub.p, d.seedBack.p, d.ungSub.p, kmerThr, d.ungMinAbs, d.biasf.p, d.qthr.p, d.qcorr.p, d.qbias.p, d.qself.p};
     hipLaunchKernelGGL(k_prep, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, pa);
     SP_DBG_SYNC("k_prep");
     HIP_OK(hipEventRecord(d.ev[1], d.stream));
     MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.probe.p, d.slots.p, d.ientries.p, d.spill.p, d.queue.p,
-                 d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p};
-    if (hitCap == 512) hipLaunchKernelGGL(k_match<512>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
-    else hipLaunchKernelGGL(k_match<2048>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+                 d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
+                 withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr};
+    if (hitCap == 512) { if (withOrd) hipLaunchKernelGGL((k_match<512, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+                         else hipLaunchKernelGGL((k_match<512, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma); }
+    else { if (withOrd) hipLaunchKernelGGL((k_match<2048, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+           else hipLaunchKernelGGL((k_match<2048, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma); }
     SP_DBG_SYNC("k_match");
     HIP_OK(hipEventRecord(d.ev[2], d.stream));
     ScoreArgs sa{d.diagRec.p, d.diagQuery.p, d.queue.p + 1, (uint32_t) diagCap, d.qres.p, d.qoff.p, d.qcorr.p, d.tmasked.p, d.toff.p, d.ungSub.p, d.diagScore.p, d.counters.p};
     hipLaunchKernelGGL(k_score, dim3((unsigned) d.numCU * 8), dim3(256), 0, d.stream, sa);
     SP_DBG_SYNC("k_score");
     HIP_OK(hipEventRecord(d.ev[3], d.stream));
-    SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.queue.p + 2,
-                  binSize - 1, maxHits, minDiagScore, d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.queue.p + 3, d.counters.p};
-    hipLaunchKernelGGL(k_select, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, se);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d.stream, d.outCount.p, (uint32_t) nq_, d.outOffset.p);
-    hipLaunchKernelGGL(k_reorder_hits, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.outStage.p, d.outBase.p, d.outCount.p, d.outOffset.p, (uint32_t) nq_, d.outHits.p, d.outQuery.p);
-    SP_DBG_SYNC("k_select");
-    HIP_OK(hipEventRecord(d.ev[4], d.stream));
-    unsigned long long c[16]; uint32_t qv[4];
+    return true;
+}
+
+// counters + HIP-event times after the selection kernels were queued (event 4 recorded)
+bool Gpu::finishPrefilter(bool matched, std::string &err) {
+    Impl &d = *d_;
+    unsigned long long c[16]; uint32_t qv[8];
     HIP_OK(hipMemcpyAsync(c, d.counters.p, sizeof(c), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipMemcpyAsync(qv, d.queue.p, sizeof(qv), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipStreamSynchronize(d.stream));
-    counters_.kmers = c[0]; counters_.dbMatches = c[1]; counters_.overflowQueries = c[2]; counters_.diagResidues = c[3]; counters_.hits = qv[3];
-    counters_.diagonals = c[5];
+    if (matched) { counters_.kmers = c[0]; counters_.dbMatches = c[1]; counters_.diagResidues = c[3]; counters_.diagonals = c[5]; }
+    counters_.overflowQueries = c[2]; counters_.hits = qv[3];
+    d.nCand = qv[4];
 #ifdef SP_PHASE_TIMERS
-    {
+    if (matched) {
         unsigned long long tot = 0; for (int ph = 0; ph < 8; ph++) tot += c[8 + ph];
         fprintf(stderr, "[sp] k_match phase share:");
         for (int ph = 0; ph < 8; ph++) fprintf(stderr, " p%d=%.1f%%", ph, tot ? 100.0 * (double) c[8 + ph] / (double) tot : 0.0);
         fprintf(stderr, "  (ticks/wave %.0f)\n", (double) tot / (double) (d.matchBlocks * kWavesPerBlock));
     }
 #endif
-    (void) hipEventElapsedTime(&times_.prep, d.ev[0], d.ev[1]);
-    (void) hipEventElapsedTime(&times_.match, d.ev[1], d.ev[2]);
-    (void) hipEventElapsedTime(&times_.score, d.ev[2], d.ev[3]);
+    if (matched) {
+        (void) hipEventElapsedTime(&times_.prep, d.ev[0], d.ev[1]);
+        (void) hipEventElapsedTime(&times_.match, d.ev[1], d.ev[2]);
+        (void) hipEventElapsedTime(&times_.score, d.ev[2], d.ev[3]);
+    }
     (void) hipEventElapsedTime(&times_.select, d.ev[3], d.ev[4]);
     if (counters_.overflowQueries) {
-        err = std::to_string(counters_.overflowQueries) + " queries produced more index hits or diagonals than the device buffers hold";
+        err = std::to_string(counters_.overflowQueries) + " queries produced more index hits, diagonals or candidates than the device buffers hold";
         return false;
     }
     return true;
+}
+
+bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore, std::string &err) {
+    Impl &d = *d_;
+    if (nq_ == 0) return true;
+    maxHits_ = maxHits;
+    if (!d.outHits.ensure(nq_ * (size_t) maxHits, err) || !d.outStage.ensure(nq_ * (size_t) maxHits, err) || !d.outQuery.ensure(nq_ * (size_t) maxHits, err)) return false;
+    if (!matchAndScore(kmerThr, false, err)) return false;
+    const bool dbg = getenv("SP_DEBUG") != nullptr;
+    SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.queue.p + 2,
+                  binSize - 1, maxHits, minDiagScore, d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.queue.p + 3, d.counters.p};
+    hipLaunchKernelGGL(k_select, dim3(d.matchBlocks), dim3(64 * kWavesPerBlock), 0, d.stream, se);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d.stream, d.outCount.p, (uint32_t) nq_, d.outOffset.p);
+    hipLaunchKernelGGL(k_reorder_hits, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.outStage.p, d.outBase.p, d.outCount.p, d.outOffset.p, (uint32_t) nq_, d.outHits.p, d.outQuery.p);
+    SP_DBG_SYNC("k_select");
+    HIP_OK(hipEventRecord(d.ev[4], d.stream));
+    return finishPrefilter(true, err);
+}
+
+// sharded search, step 1: this shard's candidates (per query and target the best double-hit diagonal with score >= min)
+bool Gpu::prefilterCandidates(int kmerThr, int minDiagScore, std::string &err) {
+    Impl &d = *d_;
+    d.nCand = 0;
+    if (nq_ == 0) return true;
+    if (!matchAndScore(kmerThr, true, err)) return false;
+    const bool dbg = getenv("SP_DEBUG") != nullptr;
+    if (!d.cand.ensure(d.diagCap, err)) return false;
+    CandArgs ca{d.diagRec.p, d.diagQuery.p, d.diagScore.p, d.diagOrd.p, d.queue.p + 1, (uint32_t) d.diagCap, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qoff.p, minDiagScore,
+                d.cand.p, d.queue.p + 4, (uint32_t) d.diagCap};
+    hipLaunchKernelGGL(k_candidates, dim3((unsigned) d.numCU * 8), dim3(256), 0, d.stream, ca);
+    SP_DBG_SYNC("k_candidates");
+    HIP_OK(hipEventRecord(d.ev[4], d.stream));
+    if (!finishPrefilter(true, err)) return false;
+    counters_.hits = 0;
+    return true;
+}
+
+const Candidate *Gpu::candidatesDevice() const { return d_->cand.p; }
+size_t Gpu::numCandidates() const { return d_->nCand; }
+
+bool Gpu::downloadCandidates(Candidate *out, std::string &err) {
+    Impl &d = *d_;
+    if (d.nCand == 0) return true;
+    HIP_OK(hipMemcpyAsync(out, d.cand.p, (size_t) d.nCand * sizeof(Candidate), hipMemcpyDefault, d.stream));     // host or device destination
+    HIP_OK(hipStreamSynchronize(d.stream));
+    return true;
+}
+
+// sharded search, step 2: the selection tail over the union of all shards' candidates, for queries [qFrom, qTo); leaves
+// the context as prefilter() does (downloadHits(), align() work).  Needs the per-query bias / self scores of a preceding
+// prefilterCandidates() on the same query batch.
+bool Gpu::mergeCandidates(const Candidate *src, size_t n, bool onDevice, size_t qFrom, size_t qTo, unsigned binSize, int maxHits, int minDiagScore, std::string &err) {
+    Impl &d = *d_;
+    if (nq_ == 0) return true;
+    if (!d.qbias.p || !d.queue.p) { err = "mergeCandidates: run prefilterCandidates() on this query batch first"; return false; }
+    if (n >= (1ull << 32)) { err = "mergeCandidates: more than 2^32 candidates"; return false; }
+    qTo = std::min(qTo, nq_); qFrom = std::min(qFrom, qTo);
+    maxHits_ = maxHits;
+    const bool dbg = getenv("SP_DEBUG") != nullptr;
+    if (!d.outHits.ensure(nq_ * (size_t) maxHits, err) || !d.outStage.ensure(nq_ * (size_t) maxHits, err) || !d.outQuery.ensure(nq_ * (size_t) maxHits, err)) return false;
+    if (!d.candCnt.ensure(nq_ + 1, err) || !d.candFill.ensure(nq_ + 1, err) || !d.candOffset.ensure(nq_ + 2, err) || !d.candByQuery.ensure(n + 1, err)) return false;
+    const uint32_t blocks = (uint32_t) std::min<size_t>((nq_ + kWavesPerBlock - 1) / kWavesPerBlock, (size_t) d.numCU * 2);
+    if (!d.mergeScratch.ensure((size_t) blocks * kWavesPerBlock * kMergeScratchWords, err)) return false;
+    const Candidate *u = src;
+    if (!onDevice) {
+        if (!d.candUnion.ensure(n + 1, err)) return false;
+        if (n) HIP_OK(hipMemcpyAsync(d.candUnion.p, src, n * sizeof(Candidate), hipMemcpyHostToDevice, d.stream));
+        u = d.candUnion.p;
+    }
+    HIP_OK(hipMemsetAsync(d.queue.p + 2, 0, 2 * sizeof(uint32_t), d.stream));          // select queue + hit cursor
+    HIP_OK(hipMemsetAsync(d.counters.p + 2, 0, sizeof(unsigned long long), d.stream));
+    HIP_OK(hipMemsetAsync(d.candCnt.p, 0, (nq_ + 1) * sizeof(uint32_t), d.stream));
+    HIP_OK(hipMemsetAsync(d.candFill.p, 0, (nq_ + 1) * sizeof(uint32_t), d.stream));
+    HIP_OK(hipEventRecord(d.ev[3], d.stream));
+    if (n) hipLaunchKernelGGL(k_cand_count, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, u, (uint32_t) n, (uint32_t) qFrom, (uint32_t) qTo, d.candCnt.p);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d.stream, d.candCnt.p, (uint32_t) nq_, d.candOffset.p);
+    if (n) hipLaunchKernelGGL(k_cand_scatter, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, u, (uint32_t) n, (uint32_t) qFrom, (uint32_t) qTo, d.candOffset.p, d.candFill.p, d.candByQuery.p);
+    MergeArgs me{(uint32_t) nq_, d.candByQuery.p, d.candOffset.p, d.qbias.p, d.qself.p, d.qoff.p, d.mergeScratch.p, d.queue.p + 2, binSize - 1, maxHits, minDiagScore,
+                 d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.queue.p + 3, d.counters.p};
+    hipLaunchKernelGGL(k_select_merged, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, me);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d.stream, d.outCount.p, (uint32_t) nq_, d.outOffset.p);
+    hipLaunchKernelGGL(k_reorder_hits, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.outStage.p, d.outBase.p, d.outCount.p, d.outOffset.p, (uint32_t) nq_, d.outHits.p, d.outQuery.p);
+    SP_DBG_SYNC("k_select_merged");
+    HIP_OK(hipEventRecord(d.ev[4], d.stream));
+    return finishPrefilter(false, err);
 }
 
 void *pinnedAlloc(size_t bytes) {

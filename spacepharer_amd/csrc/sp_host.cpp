@@ -252,7 +252,8 @@ int tantanMask(const TantanModel &tm, uint8_t *seq, int L, std::vector<float> &p
 // targets + index
 // ---------------------------------------------------------------------------------------------------------------
 void prepareTargets(const SubMat &seed, const char *residues, const uint64_t *offsets, const uint32_t *keys, size_t n,
-                    bool mask, int threads, TargetSet &ts) {
+                    bool mask, int threads, TargetSet &ts, size_t from, size_t to) {
+    to = std::min(to, n); from = std::min(from, to);
     ts.n = n;
     ts.offsets.assign(offsets, offsets + n + 1);
     ts.keys.resize(n);
@@ -271,14 +272,15 @@ void prepareTargets(const SubMat &seed, const char *residues, const uint64_t *of
             const uint64_t o = offsets[t]; const int L = (int) (offsets[t + 1] - o);
             for (int i = 0; i < L; i++) ts.plain[o + i] = seed.aa2num[(uint8_t) residues[o + i]];
             memcpy(ts.masked.data() + o, ts.plain.data() + o, (size_t) L);
-            if (mask) local += (uint64_t) tantanMask(tm, ts.masked.data() + o, L, probs, scale);
+            if (mask && t >= from && t < to) local += (uint64_t) tantanMask(tm, ts.masked.data() + o, L, probs, scale);
         }
         maskedTotal += local;
     });
     ts.maskedCount = maskedTotal.load();
 }
 
-void buildIndex(const SubMat &seed, const TargetSet &ts, int kmerThr, int threads, KmerIndex &idx) {
+void buildIndex(const SubMat &seed, const TargetSet &ts, int kmerThr, int threads, KmerIndex &idx, size_t from, size_t to) {
+    to = std::min(to, ts.n); from = std::min(from, to);
     struct KP { uint32_t kmer; uint16_t pos; };
     // per target: distinct indexable k-mers, each at its smallest position (IndexTable.h:130-170,341-394)
     std::vector<std::vector<uint64_t>> perThread(std::max(1, threads));     // kmer<<32 | seq-local (count<<16|pos) is not needed; store kmer<<16|pos
@@ -286,7 +288,8 @@ void buildIndex(const SubMat &seed, const TargetSet &ts, int kmerThr, int thread
     std::vector<std::vector<uint32_t>> counts(std::max(1, threads));        // #entries per target of the range
     signed char self[kAlph];
     for (int a = 0; a < kAlph; a++) self[a] = (signed char) seed.sub[a][a];   // getScoreLookup, IndexBuilder.cpp:8-19
-    parallelFor(ts.n, threads, [&](int tid, size_t a, size_t b) {
+    parallelFor(to - from, threads, [&](int tid, size_t a, size_t b) {
+        a += from; b += from;
         ranges[tid] = {a, b};
         std::vector<KP> buf;
         std::vector<uint64_t> &out = perThread[tid];

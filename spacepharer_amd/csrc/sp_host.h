@@ -65,9 +65,10 @@ struct KmerIndex {
 };
 
 // prefiltering/IndexBuilder.cpp:53-256 + IndexTable.h (addKmerCount / addSequence / sortDBSeqLists)
+// [from, to) = the target range that is masked / indexed (a shard of a target-sharded search); seqIds stay global
 void prepareTargets(const SubMat &seed, const char *residues, const uint64_t *offsets, const uint32_t *keys, size_t n,
-                    bool mask, int threads, TargetSet &ts);
-void buildIndex(const SubMat &seed, const TargetSet &ts, int kmerThr, int threads, KmerIndex &idx);
+                    bool mask, int threads, TargetSet &ts, size_t from = 0, size_t to = (size_t) -1);
+void buildIndex(const SubMat &seed, const TargetSet &ts, int kmerThr, int threads, KmerIndex &idx, size_t from = 0, size_t to = (size_t) -1);
 
 // Prefiltering::getKmerThreshold (prefiltering/Prefiltering.cpp:987-1021), sequence search
 int kmerThreshold(float sensitivity, int kmerScore, int kmerSize);

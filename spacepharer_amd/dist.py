@@ -7,6 +7,12 @@ Prefiltering.cpp:273-281,735-740), which keeps results identical to the unsplit 
 Prefiltering.cpp:343-346 applies a per-split hit quota).  No data-path collective is needed; the only exchange is
 the variable-length all-gather of the per-rank hit lists so that every rank (or just rank 0) can write the result
 DB / feed the host-side aggregation steps.
+
+Target-sharded mode (for target sets that should be split across GPUs): rank g indexes the target
+range decompose_by_residues(target_lengths, g, world), all ranks search all queries, `allgather_candidates` exchanges
+the 16-byte per-(query, target) candidates (RCCL all-gather of device buffers over xGMI; gloo/host in the CPU tests) and
+every rank runs the selection on the union for its slice of the queries (SearchContext.merge_candidates*), which
+reproduces the unsplit result exactly.
 """
 import math
 
@@ -76,3 +82,55 @@ def allgather_hits(query_offset, offsets, hits, group=None, device=None):
     go[1:] = np.cumsum(gc).astype(np.uint64)
     gh = np.concatenate(all_hits) if all_hits else np.zeros((0, 3), dtype=np.int64)
     return go, gh
+
+
+CAND_BYTES = 16     # sizeof(sp_candidate)
+
+
+def allgather_candidates(local, group=None, device=None):
+    """All-gather of the per-shard candidate lists.
+
+    local : uint8[n, 16] -- numpy array (host exchange) or torch tensor (on `device`: RCCL moves HBM to HBM)
+    Returns a torch uint8 tensor [world * max_n, 16] on `device`; unused rows are 0xFF (query == 0xFFFFFFFF = padding,
+    ignored by sp_ctx_merge_candidates).  Two collectives: the counts, then the padded payloads."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = device if device is not None else torch.device("cpu")
+    if not torch.is_tensor(local):
+        local = torch.from_numpy(np.ascontiguousarray(local, dtype=np.uint8).reshape(-1, CAND_BYTES))
+    local = local.to(dev)
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    ns = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(ns, n, group=group)
+    max_n = max(1, max(int(x.item()) for x in ns))
+    pad = torch.full((max_n, CAND_BYTES), 0xFF, dtype=torch.uint8, device=dev)
+    if local.shape[0]:
+        pad[:local.shape[0]] = local
+    out = torch.empty((world * max_n, CAND_BYTES), dtype=torch.uint8, device=dev)
+    if hasattr(dist, "all_gather_into_tensor") and dev.type != "cpu":
+        dist.all_gather_into_tensor(out, pad, group=group)
+    else:
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group)
+        out = torch.cat(parts, dim=0)
+    return out
+
+
+def sharded_prefilter(ctx, q_from=0, q_to=None, group=None, device=None):
+    """One target-sharded prefilter pass on this rank's context (targets staged with set_targets_shard*): candidates of
+    the own shard -> all-gather (RCCL when `device` is the GPU: the payload goes HBM -> xGMI -> HBM) -> selection on the
+    union for queries [q_from, q_to).  Afterwards ctx.hits_compact() / ctx.align_hits_raw() see the merged hits."""
+    import torch
+    n = ctx.prefilter_candidates()
+    dev = device if device is not None else torch.device("cpu")
+    local = torch.empty((n, CAND_BYTES), dtype=torch.uint8, device=dev)
+    if n:
+        ctx.candidates_into(local.data_ptr())          # synchronises the context's stream
+    union = allgather_candidates(local, group=group, device=dev)
+    if dev.type != "cpu":
+        torch.cuda.synchronize(dev)                     # the collective ran on torch's stream
+        ctx.merge_candidates_device(union.data_ptr(), union.shape[0], q_from, q_to)
+    else:
+        ctx.merge_candidates(union.numpy(), q_from, q_to)
+    return int(union.shape[0])

@@ -65,3 +65,37 @@ def test_decompose_matches_reference_arithmetic():
     assert sum(c for _, c in parts) == len(lens)
     assert decompose_by_residues(lens, 0, 1) == (0, 10)
     assert decompose_by_residues([5, 5], 1, 4) == (1, 1) and decompose_by_residues([5, 5], 3, 4) == (0, 0)
+
+
+def _cand_records(rank):
+    """deterministic stand-in for a shard's sp_candidate list: rank r contributes 37*r records (rank 0: none)"""
+    n = 37 * rank
+    rng = np.random.default_rng(1000 + rank)
+    rec = np.zeros((n, 4), dtype=np.uint32)
+    rec[:, 0] = rng.integers(0, 500, n)            # query
+    rec[:, 1] = rank * 10000 + np.arange(n)        # seq_id inside the rank's target range
+    rec[:, 2] = rng.integers(0, 1 << 20, n)        # k-mer ordinal
+    rec[:, 3] = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)   # diagonal | score << 16
+    return rec.view(np.uint8).reshape(n, 16)
+
+
+def _cand_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from spacepharer_amd.dist import allgather_candidates
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    got = allgather_candidates(_cand_records(rank)).numpy()
+    keep = got[got.view(np.uint32).reshape(-1, 4)[:, 0] != 0xFFFFFFFF]       # what sp_ctx_merge_candidates keeps
+    exp = np.concatenate([_cand_records(r) for r in range(world)], axis=0)
+    ok = got.shape[1] == 16 and got.shape[0] == world * 37 * (world - 1) and keep.tolist() == exp.tolist()
+    open("%s.%d" % (out, rank), "w").write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_candidate_allgather_gloo(tmp_path):
+    """target-sharded mode: ragged candidate lists (one rank empty) -> padded all-gather, padding rows are 0xFF"""
+    out = str(tmp_path / "cand")
+    mp.spawn(_cand_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    assert [open("%s.%d" % (out, r)).read() for r in range(3)] == ["ok"] * 3

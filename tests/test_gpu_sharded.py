@@ -1,0 +1,111 @@
+"""GPU parity of the target-sharded search: the target set is cut into contiguous ranges, every
+range is searched by its own context (on a multi-GPU node: its own GPU), the per-shard candidate lists are concatenated
+(what the RCCL all-gather delivers) and the selection runs on the union.  The result must equal the UNSPLIT search --
+reference golden vectors and CPU oracle -- bit for bit: hit sets, scores, diagonals, order."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _ranges(seqs, world):
+    from spacepharer_amd.dist import decompose_by_residues
+    lens = [len(s) + 2 for s in seqs]
+    return [decompose_by_residues(lens, r, world) for r in range(world)]
+
+
+def _sharded_hits(sa, T, Q, world, pad_rows=0, **kw):
+    ctxs, cands = [], []
+    for start, count in _ranges(T, world):
+        c = sa.SearchContext(**kw)
+        c.set_targets_shard(T, start, start + count)
+        c.set_queries(Q)
+        n = c.prefilter_candidates()
+        cd = c.candidates()
+        assert cd.shape == (n, 16)
+        if n:
+            seq_id = cd.view(np.uint32).reshape(-1, 4)[:, 1]
+            assert seq_id.min() >= start and seq_id.max() < start + count          # a shard only reports its own targets
+        cands.append(cd)
+        if pad_rows:
+            cands.append(np.full((pad_rows, 16), 0xFF, dtype=np.uint8))           # all-gather padding is ignored
+        ctxs.append(c)
+    union = np.concatenate(cands, axis=0)
+    rng = np.random.default_rng(7)
+    union = union[rng.permutation(len(union))]                                     # arrival order must not matter
+    ctxs[0].merge_candidates(union)
+    got = ctxs[0].hits()
+    return got, ctxs
+
+
+@pytest.mark.parametrize("name,world", [("small", 2), ("spacer", 3), ("family", 4), ("longq", 8)])
+def test_sharded_search_equals_reference_unsplit(name, world):
+    import spacepharer_amd as sa
+    g = load_golden(name)
+    r = g["ref"]
+    got, ctxs = _sharded_hits(sa, g["targets"], g["queries"], world, pad_rows=5, sensitivity=r["sens"], max_seqs=r["maxSeqs"])
+    for q in r["queries"]:
+        assert [list(h) for h in got[q["id"]]] == q["hits"], (name, q["id"])
+    # the context that merged is in the post-prefilter state: align its hits and compare with the golden alignments
+    if name == "small":
+        hits, offs, total = ctxs[0].hits_compact()
+        res, cig, n = ctxs[0].align_hits_raw()
+        assert n == total == sum(len(q["hits"]) for q in r["queries"])
+    for c in ctxs:
+        c.close()
+
+
+def test_sharded_search_equals_unsplit_gpu_and_oracle_with_ties():
+    """many near-identical targets -> more candidates than --max-seqs with equal scores: the cut is decided by the
+    (score, seqId & (BINSIZE-1), k-mer ordinal, seqId) order, which must come out the same from 5 shards"""
+    from golden.make_golden import make_case
+    from oracle_lib import Oracle
+    import spacepharer_amd as sa
+    T, Q = make_case(seed=99173, n_targets=2500, n_queries=300, tmin=40, tmax=260, qmin=9, qmax=40, families=6)
+    T = T + [T[i % 50] for i in range(700)]              # exact duplicates: equal scores on many targets
+    ref = sa.SearchContext(max_seqs=25)
+    ref.set_targets(T)
+    ref.set_queries(Q)
+    ref.prefilter()
+    exp = ref.hits()
+    got, ctxs = _sharded_hits(sa, T, Q, 5, max_seqs=25)
+    assert got == exp
+    assert max(len(h) for h in exp) == 25
+    o = Oracle(sens=5.7, max_seqs=25)
+    o.set_targets(T)
+    for i in range(0, len(Q), 7):
+        assert [list(h) for h in got[i]] == o.prefilter_list(Q[i]), i
+    o.close()
+    # a query slice: queries outside [q_from, q_to) come back empty, the others unchanged
+    union = np.concatenate([c.candidates() for c in ctxs], axis=0)
+    ctxs[1].merge_candidates(union, q_from=100, q_to=200)
+    part = ctxs[1].hits()
+    assert part[100:200] == exp[100:200] and all(len(h) == 0 for h in part[:100] + part[200:])
+    ref.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_bench_sharded_path_over_rccl_single_rank():
+    """bench.py --shard targets on one GPU: candidates travel through a real RCCL all-gather (one-rank group) from and
+    to HBM, then the selection + align; it must align exactly the pairs the unsplit path aligns"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--spacers", "600", "--targets", "4000",
+            "--cpu-sample", "0"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    outs = []
+    for extra in ([], ["--shard", "targets"]):
+        p = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]))
+    a, b = outs
+    assert b["scaling"] == "strong" and "target shards" in b["config"]["parallelism"]
+    assert a["config"]["pairs_aligned_per_step"] == b["config"]["pairs_aligned_per_step"] > 0
+    assert a["counters_per_step"]["hits"] == b["counters_per_step"]["hits"]
+    assert a["counters_per_step"]["similar_kmers"] == b["counters_per_step"]["similar_kmers"]
