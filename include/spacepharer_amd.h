@@ -148,13 +148,17 @@ int sp_ctx_merge_candidates(sp_ctx *c, const sp_candidate *candidates, uint64_t 
 
 /* counters / timings of the last call, by name: "kmers", "db_matches", "diagonals", "diag_residues",
    "hits", "index_entries", "masked_residues", "target_residues", "kmer_thr", "bin_size",
-   "ms_prep", "ms_match", "ms_score", "ms_select", "ms_sw_forward", "ms_sw_reverse", "ms_traceback",
+   "ms_prep", "ms_match", "ms_score", "ms_select", "ms_sw_forward", "ms_sw_reverse", "ms_traceback", "ms_assemble",
    "ms_index_build", "ms_upload" */
 double sp_ctx_stat(const sp_ctx *c, const char *name);
 /* wait for everything queued on the context's stream */
 int sp_ctx_sync(sp_ctx *c);
 /* raw HIP stream the context launches on (hipStream_t), for callers that time with their own events */
 void *sp_ctx_stream(const sp_ctx *c);
+/* page-locked host memory for result buffers (hits, alignment records, cigars): device-to-host copies into such memory
+   run at full PCIe rate; ordinary memory works too, only slower.  Needs an initialised device (sp_init). */
+void *sp_host_alloc(uint64_t bytes);
+void sp_host_free(void *p);
 /* profiling aid: one streaming read of `bytes` with lane_bytes (4, 8 or 16) per lane per load on the context's stream;
    tools/pmc_traffic.py uses it to calibrate rocprofv3's FETCH_SIZE before quoting it for the search kernels */
 int sp_ctx_diag_stream_read(sp_ctx *c, uint64_t bytes, int lane_bytes, double *ms);

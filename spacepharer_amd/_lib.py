@@ -94,6 +94,9 @@ def load_library():
     L.sp_ctx_sync.argtypes = [vp]
     L.sp_ctx_stream.restype = vp
     L.sp_ctx_stream.argtypes = [vp]
+    L.sp_host_alloc.restype = vp
+    L.sp_host_alloc.argtypes = [C.c_uint64]
+    L.sp_host_free.argtypes = [vp]
     L.sp_ctx_diag_stream_read.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     for f in ("sp_prefilter_run", "sp_align_run", "sp_rescorediagonal_run"):
         getattr(L, f).argtypes = [C.c_int, C.POINTER(C.c_char_p)]
@@ -163,8 +166,29 @@ class SearchContext:
 
     def close(self):
         if self.ctx:
+            for p in getattr(self, "_pinned", []):
+                self.L.sp_host_free(p)
+            self._pinned = []
+            self._aln = self._cig = None
+            self._aln_cap = 0
             self.L.sp_ctx_destroy(self.ctx)
             self.ctx = None
+
+    def _result_buffers(self, n):
+        """page-locked result buffers (sp_host_alloc), grown on demand and reused"""
+        if getattr(self, "_aln_cap", 0) < n or getattr(self, "_aln", None) is None:
+            self._aln_cap = n + n // 4 + 16
+            self._cig_cap = 64 * self._aln_cap
+            self._new_pinned_results()
+
+    def _new_pinned_results(self):
+        if not hasattr(self, "_pinned"):
+            self._pinned = []
+        pa = self.L.sp_host_alloc(C.sizeof(Alignment) * self._aln_cap)
+        pc = self.L.sp_host_alloc(self._cig_cap)
+        self._pinned += [pa, pc]
+        self._aln = (Alignment * self._aln_cap).from_address(pa)
+        self._cig = (C.c_char * self._cig_cap).from_address(pc)
 
     def __del__(self):
         try:
@@ -288,19 +312,15 @@ class SearchContext:
     def align_raw(self, qidx, tidx):
         """numpy uint32 arrays in, (Alignment array, cigar buffer) out -- no per-pair Python work"""
         n = len(qidx)
-        if getattr(self, "_aln_cap", 0) < n:
-            self._aln_cap = n + n // 4 + 16
-            self._aln = (Alignment * self._aln_cap)()
-            self._cig_cap = 64 * self._aln_cap
-            self._cig = C.create_string_buffer(self._cig_cap)
+        self._result_buffers(n)
         used = C.c_uint64()
-        u32p = C.POINTER(C.c_uint32)
+        qp = qidx.ctypes.data_as(C.POINTER(C.c_uint32))
+        tp = tidx.ctypes.data_as(C.POINTER(C.c_uint32))
         while True:
-            rc = self.L.sp_ctx_align(self.ctx, qidx.ctypes.data_as(u32p), tidx.ctypes.data_as(u32p), n, self._aln, self._cig,
-                                     self._cig_cap, C.byref(used))
+            rc = self.L.sp_ctx_align(self.ctx, qp, tp, n, self._aln, C.cast(self._cig, C.c_char_p), self._cig_cap, C.byref(used))
             if rc == -5 and used.value > self._cig_cap:
                 self._cig_cap = int(used.value) * 2
-                self._cig = C.create_string_buffer(self._cig_cap)
+                self._new_pinned_results()
                 continue
             _check(rc)
             return self._aln, self._cig
@@ -308,17 +328,13 @@ class SearchContext:
     def align_hits_raw(self):
         """align all hits of the last prefilter(); results follow hits_compact() order"""
         n = int(self.L.sp_ctx_num_hits(self.ctx))
-        if getattr(self, "_aln_cap", 0) < n or not hasattr(self, "_aln"):
-            self._aln_cap = n + n // 4 + 16
-            self._aln = (Alignment * self._aln_cap)()
-            self._cig_cap = 64 * self._aln_cap
-            self._cig = C.create_string_buffer(self._cig_cap)
+        self._result_buffers(n)
         used = C.c_uint64()
         while True:
-            rc = self.L.sp_ctx_align_hits(self.ctx, self._aln, self._cig, self._cig_cap, C.byref(used))
+            rc = self.L.sp_ctx_align_hits(self.ctx, self._aln, C.cast(self._cig, C.c_char_p), self._cig_cap, C.byref(used))
             if rc == -5 and used.value > self._cig_cap:
                 self._cig_cap = int(used.value) * 2
-                self._cig = C.create_string_buffer(self._cig_cap)
+                self._new_pinned_results()
                 continue
             _check(rc)
             return self._aln, self._cig, n

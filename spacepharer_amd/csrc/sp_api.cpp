@@ -55,6 +55,7 @@ struct sp_ctx {
     std::map<uint32_t, std::vector<double>> evalRows;      // evalue(score, qLen) per query length
     std::vector<int32_t> bitRow;                           // int(bitScore(score) + 0.5)
     bool tablesUp = false;
+    sp::GateTable gate; bool gateValid = false; uint64_t gateSerial = 0;    // E-value tables of the resident query batch / target set
     sp::AlignHost alnHost;                                 // pinned staging, reused; declared last = released before the device context
     sp::PinVec<sp::GpuHit> hitStage; sp::PinVec<uint32_t> hitOffStage;
 };
@@ -162,7 +163,7 @@ static int setTargets(sp_ctx *c, const char *residues, const uint64_t *offsets, 
     c->stats["target_residues"] = (double) c->targets.residues();
     c->stats["bin_size"] = c->binSize;
     c->haveGapped = c->haveGapless = false;
-    c->gateRows.clear(); c->evalRows.clear(); c->bitRow.clear();
+    c->gateRows.clear(); c->evalRows.clear(); c->bitRow.clear(); c->gateValid = false;
     return SP_OK;
 }
 
@@ -171,6 +172,7 @@ int sp_ctx_set_queries(sp_ctx *c, const char *residues, const uint64_t *offsets,
     if (offsets[n] >= (1ull << 32)) { g_err = "query batch larger than 4 GiB of residues"; return SP_ERR_ARG; }
     c->qres.resize(offsets[n]);
     c->qoff.resize(n + 1);
+    c->gateValid = false;
     c->qascii.assign(residues, residues + offsets[n]);
     c->qasciiOff.assign(offsets, offsets + n + 1);
     for (uint64_t i = 0; i <= n; i++) c->qoff[i] = (uint32_t) offsets[i];
@@ -263,13 +265,16 @@ static bool ensureEvaluers(sp_ctx *c, bool gapped, std::string &err) {
 
 // E-value gate table for the query lengths of the resident batch: pass[slot(qLen)][score] = !(evalue(score, qLen) > -e)
 // evaluated with the exact double arithmetic of EvalueComputation::computeEvalue; rows are cached per length
-static void buildGate(sp_ctx *c, sp::GateTable &g) {
+static void buildGate(sp_ctx *c) {
+    if (c->gateValid) return;
+    sp::GateTable &g = c->gate;
     const uint32_t maxL = c->gpu.maxQueryLen();
     g.stride = std::min<uint32_t>(65536u, maxL * 32u + 2u);
     g.slotOf.assign(maxL + 2, 0);
     std::vector<uint32_t> lens;
     { std::vector<uint8_t> seen(maxL + 2, 0); for (size_t q = 0; q + 1 < c->qoff.size(); q++) { uint32_t L = c->qoff[q + 1] - c->qoff[q]; if (!seen[L]) { seen[L] = 1; lens.push_back(L); } } }
     g.pass.assign((lens.size() + 1) * (size_t) g.stride, 0);
+    g.evalue.assign((lens.size() + 1) * (size_t) g.stride, 0.0);
     for (size_t s = 0; s < lens.size(); s++) {
         const uint32_t L = lens[s];
         g.slotOf[L] = (uint16_t) s;
@@ -283,8 +288,14 @@ static void buildGate(sp_ctx *c, sp::GateTable &g) {
             for (uint32_t sc = lim; sc < g.stride; sc++) row[sc] = lim ? row[lim - 1] : 0;
         }
         memcpy(&g.pass[s * (size_t) g.stride], row.data(), g.stride);
+        const std::vector<double> &ev = c->evalRows[L];
+        for (uint32_t sc = 0; sc < g.stride; sc++) g.evalue[s * (size_t) g.stride + sc] = sc < ev.size() ? ev[sc] : c->evGapped.evalue((double) sc, (double) L);
     }
     if (c->bitRow.size() != g.stride) { c->bitRow.resize(g.stride); for (uint32_t sc = 0; sc < g.stride; sc++) c->bitRow[sc] = (int) (c->evGapped.bitScore((double) sc) + 0.5); }
+    g.bits.assign(c->bitRow.begin(), c->bitRow.end());
+    g.evalueThr = c->par.evalue;
+    g.version = ++c->gateSerial;
+    c->gateValid = true;
 }
 
 static int finishAlign(sp_ctx *c, const sp::AlignHost &ah, const std::vector<uint32_t> *order,
@@ -337,15 +348,28 @@ static int finishAlign(sp_ctx *c, const sp::AlignHost &ah, const std::vector<uin
     return SP_OK;
 }
 
+// records assembled on the device went straight into the caller's buffers; otherwise (a pair needed the retry path)
+// assemble on the host from the downloaded pieces
+static int finishDirectOrHost(sp_ctx *c, const sp::AlignDirect &direct, sp_alignment *res, char *cigars, uint64_t cigarCap, uint64_t *cigarUsed) {
+    sp::KernelTimes kt = c->gpu.times();
+    c->stats["ms_sw_forward"] = kt.swForward; c->stats["ms_sw_reverse"] = kt.swReverse; c->stats["ms_traceback"] = kt.traceback; c->stats["ms_assemble"] = kt.assemble;
+    if (direct.overflow) { if (cigarUsed) *cigarUsed = direct.cigarUsed; g_err = "sp_ctx_align: cigar buffer too small"; return SP_ERR_OVERFLOW; }
+    if (direct.done) { if (cigarUsed) *cigarUsed = direct.cigarUsed; return SP_OK; }
+    return finishAlign(c, c->alnHost, nullptr, res, cigars, cigarCap, cigarUsed);
+}
+
 int sp_ctx_align(sp_ctx *c, const uint32_t *qidx, const uint32_t *tidx, uint64_t n, sp_alignment *res, char *cigars, uint64_t cigarCap, uint64_t *cigarUsed) {
     if (!c || c->targets.n == 0) { g_err = "sp_ctx_align: no target set"; return SP_ERR_STATE; }
     std::string err;
     if (!ensureEvaluers(c, true, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
     std::vector<sp::SwPair> pairs(n);
     for (uint64_t i = 0; i < n; i++) { pairs[i].query = qidx[i]; pairs[i].target = tidx[i]; }
-    sp::GateTable gate; buildGate(c, gate);
-    if (!c->gpu.align(pairs.data(), (size_t) n, c->par.gap_open, c->par.gap_extend, gate, c->alnHost, err)) { g_err = err; return SP_ERR_DEVICE; }
-    return finishAlign(c, c->alnHost, nullptr, res, cigars, cigarCap, cigarUsed);
+    buildGate(c);
+    static_assert(sizeof(sp::AlnRec) == sizeof(sp_alignment) && offsetof(sp::AlnRec, evalue) == offsetof(sp_alignment, evalue) &&
+                  offsetof(sp::AlnRec, cigarOffset) == offsetof(sp_alignment, cigar_offset) && offsetof(sp::AlnRec, passed) == offsetof(sp_alignment, passed), "AlnRec mirrors sp_alignment");
+    sp::AlignDirect direct; direct.records = res; direct.cigars = cigars; direct.cigarCap = cigarCap;
+    if (!c->gpu.align(pairs.data(), (size_t) n, c->par.gap_open, c->par.gap_extend, c->gate, c->alnHost, &direct, err)) { g_err = err; return SP_ERR_DEVICE; }
+    return finishDirectOrHost(c, direct, res, cigars, cigarCap, cigarUsed);
 }
 
 /* align every hit of the last sp_ctx_prefilter(): results[i] belongs to hit i of sp_ctx_get_hits_compact() */
@@ -355,11 +379,12 @@ int sp_ctx_align_hits(sp_ctx *c, sp_alignment *res, char *cigars, uint64_t cigar
     if (!ensureEvaluers(c, true, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
     const bool dbg = getenv("SP_DEBUG") != nullptr;
     double t0 = nowMs();
-    sp::GateTable gate; buildGate(c, gate);
+    buildGate(c);
     double t1 = nowMs();
-    if (!c->gpu.align(nullptr, 0, c->par.gap_open, c->par.gap_extend, gate, c->alnHost, err)) { g_err = err; return SP_ERR_DEVICE; }
+    sp::AlignDirect direct; direct.records = res; direct.cigars = cigars; direct.cigarCap = cigarCap;
+    if (!c->gpu.align(nullptr, 0, c->par.gap_open, c->par.gap_extend, c->gate, c->alnHost, &direct, err)) { g_err = err; return SP_ERR_DEVICE; }
     double t2 = nowMs();
-    int rc = finishAlign(c, c->alnHost, nullptr, res, cigars, cigarCap, cigarUsed);
+    int rc = finishDirectOrHost(c, direct, res, cigars, cigarCap, cigarUsed);
     if (dbg) fprintf(stderr, "[sp] align_hits: gate %.3f  gpu.align %.3f  finish %.3f ms\n", t1 - t0, t2 - t1, nowMs() - t2);
     return rc;
 }
@@ -388,6 +413,8 @@ double sp_ctx_stat(const sp_ctx *c, const char *name) {
 }
 
 void *sp_ctx_stream(const sp_ctx *c) { return c->gpu.stream(); }
+void *sp_host_alloc(uint64_t bytes) { return sp::pinnedAlloc((size_t) bytes); }
+void sp_host_free(void *p) { sp::pinnedFree(p); }
 int sp_ctx_sync(sp_ctx *c) { c->gpu.sync(); return SP_OK; }
 int sp_ctx_diag_stream_read(sp_ctx *c, uint64_t bytes, int laneBytes, double *ms) {
     std::string err; double t = 0;

@@ -23,7 +23,14 @@ struct SwFull {
     int32_t status;               // 0 ok
 };
 // E-value gate as a lookup table filled by the host with the exact double-precision test: pass[slotOf[qLen] * stride + min(score, stride-1)]
-struct GateTable { uint32_t stride = 0; std::vector<uint16_t> slotOf; std::vector<uint8_t> pass; };
+// evalue[slot * stride + score] and bits[score] are the statistics the result records carry (doubles computed by the host's libm);
+// version changes whenever the content does, so that the device copy is refreshed only then
+struct GateTable { uint32_t stride = 0; std::vector<uint16_t> slotOf; std::vector<uint8_t> pass; std::vector<double> evalue; std::vector<int32_t> bits;
+                   double evalueThr = 0; uint64_t version = 0; };
+// device-assembled result record: layout of sp_alignment (include/spacepharer_amd.h), checked by a static_assert in sp_api.cpp
+struct AlnRec { uint32_t dbKey; int32_t bitScore, rawScore; float seqId; double evalue; int32_t qStart, qEnd; uint32_t qLen; int32_t dbStart, dbEnd; uint32_t dbLen, alnLen, cigarOffset; int32_t passed; };
+// where align() may put finished records directly (host memory of the caller, ideally page-locked: sp_host_alloc)
+struct AlignDirect { void *records = nullptr; char *cigars = nullptr; uint64_t cigarCap = 0; uint64_t cigarUsed = 0; bool done = false; bool overflow = false; };
 struct DiagRescore { int32_t score, startPos, endPos, diagonalLen, diagonal; uint32_t distToDiagonal; };
 
 // page-locked host memory for device<->host copies (pageable std::vector memory costs a staging copy per transfer)
@@ -57,7 +64,7 @@ struct PrefilterCounters {       // the K, M, D, H terms of the roofline formula
 };
 
 struct KernelTimes {             // HIP-event time of the last prefilter()/align() call, milliseconds
-    float prep = 0, match = 0, score = 0, select = 0, swForward = 0, swReverse = 0, traceback = 0;
+    float prep = 0, match = 0, score = 0, select = 0, swForward = 0, swReverse = 0, traceback = 0, assemble = 0;
 };
 
 class Gpu {
@@ -98,7 +105,9 @@ public:
 
     // device-driven align: forward pass, E-value gate (table), 16-bit redo, reverse pass, banded traceback without host
     // round trips.  hostPairs == nullptr aligns every hit of the last prefilter(), in the order of downloadHits().
-    bool align(const SwPair *hostPairs, size_t n, int gapOpen, int gapExtend, const GateTable &gate, AlignHost &out, std::string &err);
+    // direct != nullptr: result records and backtraces are assembled on the device and copied straight into the caller's
+    // buffers (direct->done); when a pair needs the host-driven retry path, `out` is filled instead (direct->done stays false)
+    bool align(const SwPair *hostPairs, size_t n, int gapOpen, int gapExtend, const GateTable &gate, AlignHost &out, AlignDirect *direct, std::string &err);
     uint32_t maxQueryLen() const;
 
     // rescorediagonal: ungapped score on one diagonal of the UNMASKED residues, align matrix, no composition bias

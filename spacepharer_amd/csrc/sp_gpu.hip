@@ -1054,18 +1054,20 @@ struct SwDev {
     DevBuf<uint16_t> diag; DevBuf<DiagRescore> resc;
     DevBuf<uint32_t> passList, redoList, counters; DevBuf<unsigned long long> cursors; DevBuf<uint8_t> gatePass; DevBuf<uint16_t> gateSlot;
     size_t preparedFor = (size_t) -1; const void *preparedPtr = nullptr;
+    DevBuf<double> evalTab; DevBuf<int32_t> bitTab; uint64_t gateVersion = 0;
+    DevBuf<uint32_t> cigLen, cigOff; DevBuf<AlnRec> rec; DevBuf<char> cig;
 };
 
 struct Gpu::Impl {
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[10] = {};
     int numCU = 256;
     // tables
     DevBuf<uint32_t> ext3; DevBuf<uint16_t> ext3cnt; int cntMin = 0; DevBuf<short> seedSub; DevBuf<double> seedBack; DevBuf<signed char> ungSub; DevBuf<signed char> alnSub;
     DevBuf<short> alnSub16; DevBuf<double> alnBack;
     int ungMinAbs = 0, alnMinAbs = 0;
     // targets
-    DevBuf<uint2> probe; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff;
+    DevBuf<uint2> probe; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff; DevBuf<uint32_t> tkeys;
     size_t nTargets = 0; size_t indexEntries = 0;
     // queries
     DevBuf<uint8_t> qres; DevBuf<uint32_t> qoff; DevBuf<float> biasf; DevBuf<short> qthr; DevBuf<signed char> qcorr; DevBuf<int> qbias; DevBuf<int> qself;
@@ -1228,6 +1230,7 @@ bool Gpu::uploadTargets(const TargetSet &ts, const KmerIndex &idx, std::string &
     if (!upload(d.tplain, ts.plain.data(), ts.plain.size(), d.stream, err)) return false;
     if (!upload(d.tascii, ts.ascii.data(), ts.ascii.size(), d.stream, err)) return false;
     if (!upload(d.toff, ts.offsets.data(), ts.offsets.size(), d.stream, err)) return false;
+    if (!upload(d.tkeys, ts.keys.data(), ts.keys.size(), d.stream, err)) return false;
     HIP_OK(hipStreamSynchronize(d.stream));
     return true;
 }
