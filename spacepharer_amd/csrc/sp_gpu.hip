@@ -659,7 +659,7 @@ struct SelectArgs {
     unsigned long long *counters;   // [4] += hits
 };
 
-__device__ __forceinline__ void selectOne(const SelectArgs &a, const uint32_t qi, uint32_t *hist, uint64_t *keys, uint64_t *scratch, const int lane) {
+__device__ __forceinline__ void selectOne(const SelectArgs &a, const uint32_t qi, const uint32_t obase, uint32_t *hist, uint64_t *keys, uint64_t *scratch, const int lane) {
     const uint32_t D = uni(a.qDiagCnt[qi]);
     if (D == 0) { if (lane == 0) { a.outCount[qi] = 0; a.outBase[qi] = 0; } return; }
     const uint32_t base = uni(a.qDiagBase[qi]);
@@ -752,7 +752,6 @@ __device__ __forceinline__ void selectOne(const SelectArgs &a, const uint32_t qi
     waveSync();
     uint32_t n2 = 1; while (n2 < nOut) n2 <<= 1;
     if (inLds) waveBitonicSort(keys, n2, lane); else waveBitonicSort(K, n2, lane);
-    const uint32_t obase = uni(atomicAdd(a.outCursor, lane == 0 ? nOut : 0u));
     for (uint32_t t = lane; t < nOut; t += 64) {
         const uint64_t k3 = K[t];
         const uint32_t r = (uint32_t) (k3 & 0xFFFF);
@@ -764,21 +763,68 @@ __device__ __forceinline__ void selectOne(const SelectArgs &a, const uint32_t qi
     waveSync();
 }
 
+// Queries with 2..64 double-hit diagonals and fewer diagonals than --max-seqs: everything in registers, one record per
+// lane.  With fewer candidates than maxHits the histogram threshold is minDiagScore and nothing is cut, so the only work
+// is the per-target best and the final (score desc, seqId asc) order -- both by broadcasting one lane at a time.
+__device__ __forceinline__ void selectSmall(const SelectArgs &a, const uint32_t qi, const uint32_t D, const uint32_t obase, const int lane) {
+    const uint32_t base = uni(a.qDiagBase[qi]);
+    const int qL = (int) uni(a.qoff[qi + 1] - a.qoff[qi]);
+    const int bias = (int) uni((uint32_t) a.qbias[qi]);
+    const int maxC = (qL >= 32768) ? 255 : 255 - bias;
+    const int truncAt = 255 - bias;
+    const bool in = (uint32_t) lane < D;
+    DiagRec r{0xFFFFFFFFu, 0, 0}; int ex = 0;
+    if (in) { r = a.diagRec[base + lane]; ex = (int) a.diagScore[base + lane]; }
+    const int c = min(ex, maxC);
+    // per-target best: records arrive sorted by (seqId, stream position); ties -> the earliest
+    bool best = in && c >= a.minDiagScore;
+    for (uint32_t u = 0; u < D; u++) {
+        const uint32_t su = (uint32_t) __builtin_amdgcn_readlane((int) r.seqId, (int) u);
+        const int cu = __builtin_amdgcn_readlane(c, (int) u);
+        if (su == r.seqId && ((u < (uint32_t) lane && cu >= c) || (u > (uint32_t) lane && cu > c))) best = false;
+    }
+    int score = (c >= truncAt) ? ex : c;
+    if (score > 65535) score = 65535;
+    const uint64_t key = ((uint64_t) (65535 - score) << 32) | r.seqId;
+    uint64_t m = __ballot(best);
+    const uint32_t nOut = (uint32_t) __popcll(m);
+    uint32_t rank = 0;
+    while (m) {
+        const int u = __builtin_ctzll(m);
+        m &= m - 1;
+        const uint64_t ku = ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (key >> 32), u) << 32) | (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) key, u);
+        rank += ku < key ? 1u : 0u;
+    }
+    if (best) {
+        GpuHit h; h.seqId = r.seqId; h.score = (uint16_t) score; h.diag = r.diag;
+        a.outHits[(size_t) obase + rank] = h;
+        a.outQuery[(size_t) obase + rank] = qi;
+    }
+    if (lane == 0) { a.outCount[qi] = nOut; a.outBase[qi] = obase; }
+}
+
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_select(SelectArgs a) {
     __shared__ uint64_t s_keys[kWavesPerBlock][kSelCap];
     __shared__ uint32_t s_hist[kWavesPerBlock][256];
     const int lane = laneId();
     const int w = (int) (threadIdx.x >> 6);
     uint64_t *scratch = a.selScratch + (size_t) (blockIdx.x * kWavesPerBlock + w) * kSpillWordsPerWave;
-    // 64 queries per pop: queries with a single double-hit diagonal (the common case for spacer peptides) are
-    // finished lane-parallel; the others are handled one at a time by the whole wave
+    // kSelChunk queries per pop.  Output space is reserved once per chunk (sum of min(D, maxHits) -- an upper bound, the
+    // gaps are closed by k_reorder_hits): single-diagonal queries (the common case for spacer peptides) are finished
+    // lane-parallel, small ones in registers by the whole wave, the rest through LDS.
     for (;;) {
         const uint32_t chunk = popQueue(a.queue, lane);
         if ((uint64_t) chunk * kSelChunk >= a.nq) break;
         const uint32_t qi = chunk * kSelChunk + lane;
-        const uint32_t D = (lane < kSelChunk && qi < a.nq) ? a.qDiagCnt[qi] : 0;
+        const bool mine = lane < kSelChunk && qi < a.nq;
+        const uint32_t D = mine ? a.qDiagCnt[qi] : 0;
+        const uint32_t want = min(D, (uint32_t) a.maxHits);
+        const uint32_t incl = waveInclusiveScan(want, lane);
+        const uint32_t total = lane63(incl);
+        uint32_t cb = 0;
+        if (total) cb = uni(atomicAdd(a.outCursor, lane == 0 ? total : 0u));
+        const uint32_t myBase = cb + incl - want;
         const bool fast = (D == 1) && a.maxHits > 1;
-        bool hit = false; GpuHit h{0, 0, 0};
         if (fast) {
             const uint32_t b = a.qDiagBase[qi];
             const int qL = (int) (a.qoff[qi + 1] - a.qoff[qi]);
@@ -786,24 +832,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_select(SelectArgs a) {
             const int maxC = (qL >= 32768) ? 255 : 255 - bias;
             const int ex = a.diagScore[b];
             const int c = min(ex, maxC);
+            uint32_t cnt = 0;
             if (c >= a.minDiagScore) {
-                hit = true;
                 const DiagRec r = a.diagRec[b];
-                int score = (c >= 255 - bias) ? ex : c;
-                h.seqId = r.seqId; h.score = (uint16_t) (score > 65535 ? 65535 : score); h.diag = r.diag;
+                const int score = (c >= 255 - bias) ? ex : c;
+                GpuHit h; h.seqId = r.seqId; h.score = (uint16_t) (score > 65535 ? 65535 : score); h.diag = r.diag;
+                a.outHits[myBase] = h; a.outQuery[myBase] = qi;
+                cnt = 1;
             }
-        }
-        const uint64_t hm = __ballot(hit);
-        const uint32_t nh = (uint32_t) __popcll(hm);
-        uint32_t ob = 0;
-        if (nh) ob = uni(atomicAdd(a.outCursor, lane == 0 ? nh : 0u));
-        if (hit) { const uint32_t at = ob + (uint32_t) __popcll(hm & laneMaskLt(lane)); a.outHits[at] = h; a.outQuery[at] = qi; a.outBase[qi] = at; a.outCount[qi] = 1; }
-        else if (lane < kSelChunk && qi < a.nq && (D == 0 || fast)) { a.outCount[qi] = 0; a.outBase[qi] = 0; }
+            a.outBase[qi] = myBase; a.outCount[qi] = cnt;
+        } else if (mine && D == 0) { a.outCount[qi] = 0; a.outBase[qi] = 0; }
         uint64_t slow = __ballot(D > 0 && !fast);
         while (slow) {
             const int bit = __builtin_ctzll(slow);
             slow &= slow - 1;
-            selectOne(a, chunk * kSelChunk + (uint32_t) bit, s_hist[w], s_keys[w], scratch, lane);
+            const uint32_t dq = (uint32_t) __builtin_amdgcn_readlane((int) D, bit);
+            const uint32_t ob = (uint32_t) __builtin_amdgcn_readlane((int) myBase, bit);
+            const int qbias = (int) uni((uint32_t) a.qbias[chunk * kSelChunk + (uint32_t) bit]);
+            if (dq <= 64u && dq < (uint32_t) a.maxHits && a.minDiagScore < 255 - qbias) selectSmall(a, chunk * kSelChunk + (uint32_t) bit, dq, ob, lane);
+            else selectOne(a, chunk * kSelChunk + (uint32_t) bit, ob, s_hist[w], s_keys[w], scratch, lane);
         }
     }
 }
@@ -1307,9 +1354,11 @@ bool Gpu::finishPrefilter(bool matched, std::string &err) {
     unsigned long long c[16]; uint32_t qv[8];
     HIP_OK(hipMemcpyAsync(c, d.counters.p, sizeof(c), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipMemcpyAsync(qv, d.queue.p, sizeof(qv), hipMemcpyDeviceToHost, d.stream));
+    uint32_t totalHits = 0;      // k_scan_counts leaves the number of hits behind the last query's offset
+    HIP_OK(hipMemcpyAsync(&totalHits, d.outOffset.p + nq_, sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipStreamSynchronize(d.stream));
     if (matched) { counters_.kmers = c[0]; counters_.dbMatches = c[1]; counters_.diagResidues = c[3]; counters_.diagonals = c[5]; }
-    counters_.overflowQueries = c[2]; counters_.hits = qv[3];
+    counters_.overflowQueries = c[2]; counters_.hits = totalHits;
     d.nCand = qv[4];
 #ifdef SP_PHASE_TIMERS
     if (matched) {
