@@ -858,21 +858,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_select(SelectArgs a) {
 // query-ordered output: exclusive scan of the per-query hit counts (one block), then move the hits from the staging
 // array (allocation order of k_select) to their final place; everything downstream (download, align) is sequential
 __global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t *count, uint32_t n, uint32_t *offset /* n+1 */) {
-    __shared__ uint32_t s_part[1024];
-    const uint32_t per = (n + 1023) / 1024, from = min(n, threadIdx.x * per), to = min(n, from + per);
-    uint32_t sum = 0;
-    for (uint32_t i = from; i < to; i++) sum += count[i];
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        const uint32_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+    // one block; tiles of 1024 counts read coalesced, DPP scan per wave, the 16 wave totals through LDS, carry in a register
+    __shared__ uint32_t s_wave[16];
+    const int lane = laneId(), wv = (int) (threadIdx.x >> 6);
+    uint32_t carry = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += 1024) {
+        const uint32_t i = t0 + threadIdx.x;
+        const uint32_t v = i < n ? count[i] : 0u;
+        const uint32_t incl = waveInclusiveScan(v, lane);
+        if (lane == 63) s_wave[wv] = incl;
         __syncthreads();
-        s_part[threadIdx.x] += v;
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { const uint32_t x = s_wave[w]; all += x; if (w < wv) before += x; }
+        if (i < n) offset[i] = carry + before + incl - v;
+        carry += all;
         __syncthreads();
     }
-    uint32_t run = s_part[threadIdx.x] - sum;
-    for (uint32_t i = from; i < to; i++) { offset[i] = run; run += count[i]; }
-    if (threadIdx.x == 1023) offset[n] = s_part[1023];
+    if (threadIdx.x == 0) offset[n] = carry;
 }
 
 __global__ void k_reorder_hits(const GpuHit *staging, const uint32_t *base, const uint32_t *count, const uint32_t *offset, uint32_t nq, GpuHit *out, uint32_t *outQuery) {
