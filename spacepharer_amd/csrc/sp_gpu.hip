@@ -199,7 +199,10 @@ struct MatchArgs {
     const uint32_t *ext3;           // 8000 x 8000 packed (score+32768)<<16 | index
     const uint16_t *ext3cnt;        // 8000 x kCntW: [row][c - cntMin] = number of partners with score >= c
     int cntMin;
-    const uint2 *probe;             // per 32 k-mer slots: {occupancy bits, number of occupied slots before this word}
+    // rank-compressed slot table.  k-mer = a + 8000 b: the 8000 slots of one b form a "row" of 125 words of 64 slots.
+    const uint64_t *pbits;          // occupancy bits, one u64 per 64 slots (8 MB): all a miss needs
+    const uint16_t *prank;          // occupied slots of the row before this word (2 MB)
+    const uint32_t *prow;           // occupied slots before the row (8000 entries)
     const uint64_t *slots;          // per OCCUPIED slot (rank order): the entry itself (seqId | pos << 32) when the list has one
                                     // entry, else bit 63 | len << 32 | offset into ientries
     const uint64_t *ientries;       // seqId | pos << 32, lists concatenated in k-mer order
@@ -406,18 +409,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                         }
                     }
                     SP_T(3);
-                    uint2 prR[kSuper / 64];
+                    uint64_t prR[kSuper / 64];
 #pragma unroll
-                    for (int r = 0; r < kSuper / 64; r++) prR[r] = (kmerR[r] != 0xFFFFFFFFu) ? a.probe[kmerR[r] >> 5] : make_uint2(0u, 0u);
+                    for (int r = 0; r < kSuper / 64; r++) prR[r] = (kmerR[r] != 0xFFFFFFFFu) ? a.pbits[kmerR[r] >> 6] : 0ull;
                     uint32_t nOcc = 0;
 #pragma unroll
                     for (int r = 0; r < kSuper / 64; r++) {
-                        const uint32_t bit = kmerR[r] & 31u;
-                        const bool occ = kmerR[r] != 0xFFFFFFFFu && ((prR[r].x >> bit) & 1u);
+                        const uint32_t bit = kmerR[r] & 63u;
+                        const bool occ = kmerR[r] != 0xFFFFFFFFu && ((prR[r] >> bit) & 1ull);
                         const uint64_t m = __ballot(occ);
                         if (occ) {
                             const uint32_t at = nOcc + (uint32_t) __popcll(m & laneMaskLt(lane));
-                            occList[at] = prR[r].y + (uint32_t) __popc(prR[r].x & ((1u << bit) - 1u));
+                            // k-mer id (< 2^26) | occupied slots of its word below it: the rest of the rank is looked up in phase 2
+                            occList[at] = kmerR[r] | ((uint32_t) __popcll(prR[r] & ((1ull << bit) - 1ull)) << 26);
                             if (kOrd) occOrd[at] = (uint16_t) (r * 64 + lane);
                         }
                         nOcc += (uint32_t) __popcll(m);
@@ -430,9 +434,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                         for (int r = 0; r < 4; r++) {
                             const uint32_t at = ob + 64u * r + lane;
                             if (at < nOcc) {
-                                slotR[r] = a.slots[occList[at]]; lenR[r] = (slotR[r] >> 63) ? ((uint32_t) (slotR[r] >> 32) & 0x7FFFFFFFu) : 1u;
+                                const uint32_t e = occList[at], km = e & 0x3FFFFFFu;
+                                slotR[r] = (uint64_t) (a.prow[km / 8000u] + (uint32_t) a.prank[km >> 6] + (e >> 26));      // rank of the slot
                                 if (kOrd) ordR[r] = qK0 + kBase + s0 + occOrd[at];
                             }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const uint32_t at = ob + 64u * r + lane;
+                            if (at < nOcc) { slotR[r] = a.slots[(uint32_t) slotR[r]]; lenR[r] = (slotR[r] >> 63) ? ((uint32_t) (slotR[r] >> 32) & 0x7FFFFFFFu) : 1u; }
                         }
                         uint32_t lenMulti = 0, run = M;
 #pragma unroll
@@ -481,16 +491,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
             // Cheap exact pre-filter before the sort: a target hit only once in this query can only be recorded when its
             // 8-bit diagonal is 0 (previous := 0).  Count hits per hashed target in LDS, keep hits whose bucket saw >= 2
             // hits or whose diag8 == 0; bucket collisions merely let a few extra hits through to the exact automaton.
-            uint32_t *hcnt = aStart;                                   // 256 counters; the tile arrays are free now
-            for (uint32_t t = lane; t < 256; t += 64) hcnt[t] = 0;
+            uint32_t *hcnt = occList;                                  // kSuper counters; the enumeration arrays are free now
+            for (uint32_t t = lane * 4; t < (uint32_t) kSuper; t += 256) *reinterpret_cast<uint4 *>(hcnt + t) = make_uint4(0u, 0u, 0u, 0u);
             waveSync();
-            for (uint32_t t = lane; t < M; t += 64) atomicAdd(&hcnt[((uint32_t) (keys[t] >> 32) * 2654435761u) >> 24], 1u);
+            constexpr int kHashShift = 32 - 10;                        // 1024 buckets (kSuper == 1024)
+            static_assert(kSuper == 1024, "hash pre-filter uses kSuper counters");
+            for (uint32_t t = lane; t < M; t += 64) atomicAdd(&hcnt[((uint32_t) (keys[t] >> 32) * 2654435761u) >> kHashShift], 1u);
             waveSync();
             uint32_t wr = 0;
             for (uint32_t base = 0; base < M; base += 64) {
                 const uint32_t t = base + lane;
                 const uint64_t k = t < M ? keys[t] : 0ull;
-                const bool keep = t < M && (hcnt[((uint32_t) (k >> 32) * 2654435761u) >> 24] >= 2u || (k & 0xFF) == 0);
+                const bool keep = t < M && (hcnt[((uint32_t) (k >> 32) * 2654435761u) >> kHashShift] >= 2u || (k & 0xFF) == 0);
                 const uint64_t m = __ballot(keep);
                 if (keep) keys[wr + (uint32_t) __popcll(m & laneMaskLt(lane))] = k;
                 wr += (uint32_t) __popcll(m);
@@ -498,7 +510,56 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
             waveSync();
             M = wr;
         }
-        if (M > 0) {
+        // reserve room for D diagonal records: kDiagChunk at a time per wave (one atomic per query on a single word would
+        // serialise); unused slots of a chunk stay marked invalid (diagQuery == ~0)
+        auto reserve = [&](uint32_t need) {
+            if (dChunkUsed + need > dChunkCap) {
+                dChunkCap = need > kDiagChunk ? need : kDiagChunk;
+                dChunkBase = uni(atomicAdd(a.diagCursor, lane == 0 ? dChunkCap : 0u));
+                dChunkUsed = 0;
+            }
+            dbase = dChunkBase + dChunkUsed;
+            dChunkUsed += need;
+            diagTotal += need;
+            if ((uint64_t) dChunkBase + dChunkCap > a.diagCap) { overflow = true; D = 0; }
+        };
+        if (M > 0 && M <= 64u && !spilled) {
+            // The usual case after the pre-filter: everything in registers, one hit per lane.  Sort by counting (the keys are
+            // distinct), move each key to the lane of its rank, then the automaton is a compare with the left neighbour plus
+            // "diag8 of the previous recorded hit of the same target", found with two ballot masks.
+            const bool in = (uint32_t) lane < M;
+            const uint64_t key = in ? keys[lane] : ~0ull;
+            uint32_t rank = 0;
+            for (uint32_t u = 0; u < M; u++) {
+                const uint64_t ku = ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (key >> 32), (int) u) << 32) | (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) key, (int) u);
+                rank += ku < key ? 1u : 0u;
+            }
+            // ds_permute: lane t sends its key to lane rank(t) (lanes >= M keep ~0 by sending to themselves)
+            const int dst = (int) ((in ? rank : (uint32_t) lane) << 2);
+            const uint32_t sLo = (uint32_t) __builtin_amdgcn_ds_permute(dst, (int) (uint32_t) key), sHi = (uint32_t) __builtin_amdgcn_ds_permute(dst, (int) (key >> 32));
+            const uint32_t id = sHi, d8 = sLo & 0xFFu;
+            const uint32_t idPrev = (uint32_t) waveShiftUp1((int) id), d8Prev = (uint32_t) waveShiftUp1((int) d8);
+            const bool head = in && (lane == 0 || idPrev != id);
+            const bool rec = in && (d8 == (head ? 0u : d8Prev));
+            const uint64_t recMask = __ballot(rec), headMask = __ballot(head);
+            const uint64_t upTo = laneMaskLt(lane) | (1ull << lane);
+            const int myHead = 63 - __builtin_clzll((headMask & upTo) | 1ull);
+            const uint64_t prior = recMask & laneMaskLt(lane) & ~laneMaskLt(myHead);
+            const int lastRecLane = prior ? 63 - __builtin_clzll(prior) : lane;
+            const uint32_t lastD = (uint32_t) __shfl((int) d8, lastRecLane);
+            const bool kept = rec && (prior == 0ull || lastD != d8);
+            SP_T(6);
+            const uint64_t keptMask = __ballot(kept);
+            D = (uint32_t) __popcll(keptMask);
+            if (D > 0) reserve(D);
+            if (D > 0 && kept) {
+                const uint32_t at = dbase + (uint32_t) __popcll(keptMask & laneMaskLt(lane));
+                DiagRec r; r.seqId = id; r.diag = (uint16_t) (sLo & 0xFFFF); r.idx = (uint16_t) ((sLo >> 16) & 0xFFFF);
+                a.diagRec[at] = r;
+                a.diagQuery[at] = qi;
+                if (kOrd) a.diagOrd[at] = r.idx < (uint32_t) kHitCap ? ordL[r.idx] : spillOrd[r.idx];
+            }
+        } else if (M > 0) {
             const bool inLds = !spilled;
             uint32_t n = 1; while (n < M) n <<= 1;
             uint64_t *K = keys; uint32_t *B = bitsL;
@@ -516,19 +577,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
             uint32_t cnt = 0;
             for (uint32_t t = lane; t < (M + 31) / 32; t += 64) cnt += __popc(B[t]);
             D = waveSum(cnt);
-            if (D > 0) {
-                // diagonal records are reserved kDiagChunk at a time per wave (one atomic per query on a single word
-                // would serialise); unused slots of a chunk stay marked invalid (diagQuery == ~0)
-                if (dChunkUsed + D > dChunkCap) {
-                    dChunkCap = D > kDiagChunk ? D : kDiagChunk;
-                    dChunkBase = uni(atomicAdd(a.diagCursor, lane == 0 ? dChunkCap : 0u));
-                    dChunkUsed = 0;
-                }
-                dbase = dChunkBase + dChunkUsed;
-                dChunkUsed += D;
-                diagTotal += D;
-                if ((uint64_t) dChunkBase + dChunkCap > a.diagCap) { overflow = true; D = 0; }
-            }
+            if (D > 0) reserve(D);
             if (D > 0) {
                 uint32_t outPos = dbase;
                 for (uint32_t base = 0; base < M; base += 64) {
@@ -1117,7 +1166,7 @@ struct Gpu::Impl {
     DevBuf<short> alnSub16; DevBuf<double> alnBack;
     int ungMinAbs = 0, alnMinAbs = 0;
     // targets
-    DevBuf<uint2> probe; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff; DevBuf<uint32_t> tkeys;
+    DevBuf<uint64_t> pbits; DevBuf<uint16_t> prank; DevBuf<uint32_t> prow; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff; DevBuf<uint32_t> tkeys;
     size_t nTargets = 0; size_t indexEntries = 0;
     // queries
     DevBuf<uint8_t> qres; DevBuf<uint32_t> qoff; DevBuf<float> biasf; DevBuf<short> qthr; DevBuf<signed char> qcorr; DevBuf<int> qbias; DevBuf<int> qself;
@@ -1250,28 +1299,32 @@ bool Gpu::uploadTargets(const TargetSet &ts, const KmerIndex &idx, std::string &
     Impl &d = *d_;
     d.nTargets = ts.n; d.indexEntries = idx.entries.size();
     {
-        // rank-compressed slot table: one 8-byte probe word per 32 k-mer slots (occupancy bits + rank of the word's first
-        // occupied slot) and one 8-byte word per occupied slot.  A lookup is probe -> slot; the entry array is only touched
-        // for slots with more than one entry.  16 MB + 8 B x occupied slots instead of the 256 MB offsets table.
-        const size_t words = (kTableSize + 31) / 32;
-        std::vector<uint2> probe(words, make_uint2(0u, 0u));
+        // rank-compressed slot table: occupancy bits (u64 per 64 k-mer slots) + the pieces of the rank (per row of 8000
+        // slots = one value of the second 3-mer, per word inside the row) + one 8-byte word per occupied slot.  A lookup is
+        // bits -> [rank pieces] -> slot; the entry array is only touched for slots with more than one entry.  10 MB + 8 B x
+        // occupied slots instead of the 256 MB offsets table, and a miss (86 % at phage scale) costs one 8-byte read.
+        static_assert(kTableSize % 8000 == 0 && 8000 % 64 == 0, "rows of 8000 slots are whole words");
+        const size_t words = kTableSize / 64;
+        std::vector<uint64_t> bits(words, 0); std::vector<uint16_t> rank(words, 0); std::vector<uint32_t> row(kTableSize / 8000, 0);
         std::vector<uint64_t> slots;
         if (idx.offsets.size() == (size_t) kTableSize + 1) {
             slots.reserve(idx.entries.size());
+            uint32_t rowStart = 0;
             for (size_t w = 0; w < words; w++) {
-                uint32_t bits = 0;
-                probe[w].y = (uint32_t) slots.size();
-                const uint32_t k1 = (uint32_t) std::min<size_t>(kTableSize, (w + 1) * 32);
-                for (uint32_t k = (uint32_t) (w * 32); k < k1; k++) {
+                if (w % 125 == 0) { rowStart = (uint32_t) slots.size(); row[w / 125] = rowStart; }
+                rank[w] = (uint16_t) (slots.size() - rowStart);
+                uint64_t b = 0;
+                for (uint32_t k = (uint32_t) (w * 64), k1 = k + 64; k < k1; k++) {
                     const uint32_t o = idx.offsets[k], len = idx.offsets[k + 1] - o;
                     if (len == 0) continue;
-                    bits |= 1u << (k & 31);
+                    b |= 1ull << (k & 63);
                     slots.push_back(len == 1 ? idx.entries[o] : ((1ull << 63) | ((uint64_t) (len & 0x7FFFFFFFu) << 32) | o));
                 }
-                probe[w].x = bits;
+                bits[w] = b;
             }
         }
-        if (!upload(d.probe, probe.data(), probe.size(), d.stream, err)) return false;
+        if (!upload(d.pbits, bits.data(), bits.size(), d.stream, err) || !upload(d.prank, rank.data(), rank.size(), d.stream, err) ||
+            !upload(d.prow, row.data(), row.size(), d.stream, err)) return false;
         if (!upload(d.slots, slots.data(), slots.size(), d.stream, err)) return false;
         HIP_OK(hipStreamSynchronize(d.stream));
     }
@@ -1305,7 +1358,7 @@ bool Gpu::uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std:
 // k_prep, k_match, k_score for every resident query; leaves the scored double-hit diagonals in HBM (events 0..3)
 bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     Impl &d = *d_;
-    if (!d.ext3.p || !d.probe.p) { err = "tables/targets not resident"; return false; }
+    if (!d.ext3.p || !d.pbits.p) { err = "tables/targets not resident"; return false; }
     // persistent match grid: as many blocks per CU as the LDS footprint of the chosen hit-buffer size admits.
     // Expected hits per query ~ (similar k-mers per query) x (index entries per k-mer slot); keep 4x headroom.
     int hitCap = ((double) d.indexEntries / (double) kTableSize * 1300.0 * 2.5 < 512.0) ? 512 : 2048;
@@ -1335,7 +1388,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     hipLaunchKernelGGL(k_prep, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, pa);
     SP_DBG_SYNC("k_prep");
     HIP_OK(hipEventRecord(d.ev[1], d.stream));
-    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.probe.p, d.slots.p, d.ientries.p, d.spill.p, d.queue.p,
+    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.pbits.p, d.prank.p, d.prow.p, d.slots.p, d.ientries.p, d.spill.p, d.queue.p,
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr};
     if (hitCap == 512) { if (withOrd) hipLaunchKernelGGL((k_match<512, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
