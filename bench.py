@@ -53,6 +53,47 @@ def u64p(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint64))
 
 
+def cpu_baseline_reference(tres, toff, qres, qoff, n_sample, procs):
+    """The REAL reference classes (oracle/_ref/ref_harness --bench: QueryMatcher::matchQuery + Matcher::getSWResult, AVX2,
+    compiled from /root/reference by oracle/Makefile) on `procs` host cores: one single-threaded process per core, each
+    searching its own slice of the sample against the full target set.  Only the search loops are timed (index build,
+    similar-k-mer tables and the ALP fit are set-up, as for the GPU number); rate = sample / slowest process."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import matrix_text
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    n_t, tl, ql = len(toff) - 1, int(toff[1]), int(qoff[1])
+    per = (n_sample + procs - 1) // procs
+    with tempfile.TemporaryDirectory() as d:
+        m80, m40, tf = (os.path.join(d, x) for x in ("VTML80.out", "VTML40.out", "t.txt"))
+        open(m80, "w").write(matrix_text("VTML80"))
+        open(m40, "w").write(matrix_text("VTML40"))
+        with open(tf, "wb") as f:
+            f.write(b"\n".join(tres[i * tl:(i + 1) * tl].tobytes() for i in range(n_t)) + b"\n")
+        jobs = []
+        for p in range(procs):
+            lo, hi = p * per, min(n_sample, (p + 1) * per)
+            if lo >= hi:
+                break
+            qf, of = os.path.join(d, "q%d.txt" % p), os.path.join(d, "o%d.json" % p)
+            with open(qf, "wb") as f:
+                f.write(b"\n".join(qres[i * ql:(i + 1) * ql].tobytes() for i in range(lo, hi)) + b"\n")
+            jobs.append((subprocess.Popen([harness, m80, m40, tf, qf, of, "--bench"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL), of))
+        res = []
+        for pr, of in jobs:
+            if pr.wait() != 0:
+                raise RuntimeError("ref_harness failed")
+            res.append(json.load(open(of))["bench"])
+    slowest = max(r["prefilter_s"] + r["align_s"] for r in res)
+    return {"value": (n_sample / 6.0) / slowest, "unit": "spacer-queries/s", "cores": len(res), "kind": "reference",
+            "pairs": sum(r["pairs"] for r in res),
+            "sample": "%d of the workload's peptides (%d SW alignments) split over %d single-threaded processes of oracle/_ref/ref_harness "
+                      "(reference QueryMatcher + Matcher classes, AVX2, g++ -O3); search loops only, slowest process %.2f s "
+                      "(prefilter %.2f s + align %.2f s)" % (n_sample, sum(r["pairs"] for r in res), len(res), slowest,
+                                                            max(r["prefilter_s"] for r in res), max(r["align_s"] for r in res))}
+
+
 def cpu_baseline(tres, toff, qres, qoff, n_sample):
     """The oracle (scalar C port of the reference algorithm, one thread) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -105,7 +146,8 @@ def main():
     ap.add_argument("--targets", type=int, default=50000)
     ap.add_argument("--target-len", type=int, default=200)
     ap.add_argument("--stage", default="full", choices=["full", "prefilter"])
-    ap.add_argument("--cpu-sample", type=int, default=3000, help="peptides for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=3000, help="peptides per core for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-cores", type=int, default=8, help="host cores for the reference CPU baseline (one process each)")
     ap.add_argument("--shard", default="queries", choices=["queries", "targets"],
                     help="N>1 decomposition: query partition with replicated index (default) or target shards + RCCL all-gather")
     args = ap.parse_args()
@@ -218,7 +260,20 @@ def main():
                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes},
     }
     if args.cpu_sample > 0:
-        out["cpu_baseline"] = cpu_baseline(tres, toff, qres, qoff, min(args.cpu_sample, nq))
+        # the reference itself when its harness travelled with the repo (oracle/_ref, built by __graft_entry__.build()), else
+        # the scalar port; either way a bounded sample
+        cores = max(1, min(args.cpu_cores, os.cpu_count() or 1))
+        if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_harness")):
+            try:
+                n_s = nq if args.cpu_sample >= 3000 else min(args.cpu_sample * cores, nq)
+                out["cpu_baseline"] = cpu_baseline_reference(tres, toff, qres, qoff, n_s, cores)
+                if n_s == nq and not sharded and world == 1:     # whole workload: the reference must align exactly the pairs the GPU aligned
+                    out["cpu_baseline"]["pairs_equal_gpu"] = bool(out["cpu_baseline"].pop("pairs") == pairs)
+            except Exception as e:      # noqa: BLE001 -- fall back to the port, say why
+                out["cpu_baseline"] = cpu_baseline(tres, toff, qres, qoff, min(args.cpu_sample, nq))
+                out["cpu_baseline"]["sample"] += " (reference harness unavailable: %s)" % e
+        else:
+            out["cpu_baseline"] = cpu_baseline(tres, toff, qres, qoff, min(args.cpu_sample, nq))
     C.CDLL(None).fflush(None)      # library chatter buffered in C stdio (RCCL prints its path) goes out BEFORE the result line
     print(json.dumps(out), flush=True)
 
