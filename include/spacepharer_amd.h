@@ -155,6 +155,10 @@ double sp_ctx_stat(const sp_ctx *c, const char *name);
 int sp_ctx_sync(sp_ctx *c);
 /* raw HIP stream the context launches on (hipStream_t), for callers that time with their own events */
 void *sp_ctx_stream(const sp_ctx *c);
+/* test hooks: digest of the index built on the device ((k-mer, seqId, pos) triples in table order, FNV-1a as in
+   sp_host_index_digest) and the masked target residues as letters (out: target_residues bytes) */
+int sp_ctx_index_digest(sp_ctx *c, uint64_t *entries, uint64_t *digest);
+int sp_ctx_get_masked(sp_ctx *c, char *out);
 /* page-locked host memory for result buffers (hits, alignment records, cigars): device-to-host copies into such memory
    run at full PCIe rate; ordinary memory works too, only slower.  Needs an initialised device (sp_init). */
 void *sp_host_alloc(uint64_t bytes);

@@ -94,6 +94,8 @@ def load_library():
     L.sp_ctx_sync.argtypes = [vp]
     L.sp_ctx_stream.restype = vp
     L.sp_ctx_stream.argtypes = [vp]
+    L.sp_ctx_index_digest.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.sp_ctx_get_masked.argtypes = [vp, C.c_char_p]
     L.sp_host_alloc.restype = vp
     L.sp_host_alloc.argtypes = [C.c_uint64]
     L.sp_host_free.argtypes = [vp]
@@ -229,6 +231,18 @@ class SearchContext:
         out = np.zeros((max(1, n), C.sizeof(Candidate)), dtype=np.uint8)
         _check(self.L.sp_ctx_get_candidates(self.ctx, out.ctypes.data))
         return out[:n]
+
+    def index_digest(self):
+        """(entries, FNV-1a digest) of the device-built index, comparable with the reference's IndexTable dump"""
+        n, h = C.c_uint64(), C.c_uint64()
+        _check(self.L.sp_ctx_index_digest(self.ctx, C.byref(n), C.byref(h)))
+        return int(n.value), int(h.value)
+
+    def masked_targets(self):
+        """masked target residues (letters, concatenated) as the device holds them"""
+        buf = C.create_string_buffer(int(self.stat("target_residues")) + 1)
+        _check(self.L.sp_ctx_get_masked(self.ctx, buf))
+        return buf.raw[:int(self.stat("target_residues"))].decode()
 
     def candidates_into(self, ptr):
         """copy this shard's candidates to `ptr` (host or device address with room for num_candidates * 16 bytes)"""

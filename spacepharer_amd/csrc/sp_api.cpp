@@ -60,6 +60,8 @@ struct sp_ctx {
     sp::PinVec<sp::GpuHit> hitStage; sp::PinVec<uint32_t> hitOffStage;
 };
 
+static uint64_t fnv1a(const void *p, size_t n, uint64_t h);
+
 extern "C" {
 
 const char *sp_last_error(void) { return g_err.c_str(); }
@@ -146,14 +148,19 @@ static int setTargets(sp_ctx *c, const char *residues, const uint64_t *offsets, 
         c->tablesUp = true;
     }
     double t1 = nowMs();
-    sp::prepareTargets(c->seed, residues, offsets, keys, (size_t) n, c->par.mask != 0 && !noIndex, c->threads, c->targets, (size_t) from, (size_t) to);
-    if (noIndex) { c->index.offsets.assign(2, 0); c->index.entries.clear(); }
-    else sp::buildIndex(c->seed, c->targets, c->kmerThr, c->threads, c->index, (size_t) from, (size_t) to);
-    c->indexEntries = c->index.entries.size();
-    double t2 = nowMs();
-    if (!c->gpu.uploadTargets(c->targets, c->index, err)) { g_err = err; return SP_ERR_DEVICE; }
-    c->index = sp::KmerIndex();     // HBM holds the index now
-    double t3 = nowMs();
+    // the host keeps the target directory only; residue classes, tantan masking and the k-mer index are made on the device
+    sp::TargetSet &ts = c->targets;
+    ts = sp::TargetSet();
+    ts.n = (size_t) n;
+    ts.offsets.assign(offsets, offsets + n + 1);
+    ts.keys.resize((size_t) n);
+    for (size_t i = 0; i < (size_t) n; i++) { ts.keys[i] = keys ? keys[i] : (uint32_t) i; ts.maxLen = std::max<unsigned>(ts.maxLen, (unsigned) (offsets[i + 1] - offsets[i])); }
+    sp::Gpu::TargetBuild tb;
+    if (!c->gpu.buildTargets(residues, ts, c->seed, c->kmerThr, c->par.mask != 0 && !noIndex, !noIndex, (size_t) from, (size_t) to, tb, err)) { g_err = err; return SP_ERR_DEVICE; }
+    ts.maskedCount = tb.maskedResidues;
+    c->indexEntries = tb.indexEntries;
+    double t2 = nowMs(), t3 = t2;
+    c->stats["ms_mask_gpu"] = tb.msMask; c->stats["ms_index_gpu"] = tb.msIndex; c->stats["index_slots"] = (double) tb.indexSlots;
     c->binSize = c->par.bin_size ? c->par.bin_size : sp::binSizeFor((size_t) n, sp::hostL2CacheSize());
     c->stats["ms_ext_table"] = t1 - t0;
     c->stats["ms_index_build"] = t2 - t1;
@@ -413,6 +420,24 @@ double sp_ctx_stat(const sp_ctx *c, const char *name) {
 }
 
 void *sp_ctx_stream(const sp_ctx *c) { return c->gpu.stream(); }
+/* test hooks for the device-built target store: FNV-1a over the (k-mer, seqId, pos) triples of the resident index in table
+   order (the digest tests/golden holds for the reference's IndexTable) and the masked sequences as letters */
+int sp_ctx_index_digest(sp_ctx *c, uint64_t *entries, uint64_t *digest) {
+    std::vector<uint32_t> km; std::vector<uint64_t> en; std::string err;
+    if (!c->gpu.downloadIndex(km, en, err)) { g_err = err; return SP_ERR_DEVICE; }
+    uint64_t h = 0;
+    for (size_t i = 0; i < km.size(); i++) { const uint32_t rec[3] = {km[i], (uint32_t) en[i], (uint32_t) (en[i] >> 32)}; h = fnv1a(rec, sizeof(rec), h); }
+    if (km.empty()) h = 1469598103934665603ULL;
+    *entries = km.size(); *digest = h;
+    return SP_OK;
+}
+int sp_ctx_get_masked(sp_ctx *c, char *out) {
+    std::vector<uint8_t> m; std::string err;
+    if (!c->gpu.downloadMasked(m, err)) { g_err = err; return SP_ERR_DEVICE; }
+    for (size_t i = 0; i < m.size(); i++) out[i] = c->seed.num2aa[m[i]];
+    return SP_OK;
+}
+
 void *sp_host_alloc(uint64_t bytes) { return sp::pinnedAlloc((size_t) bytes); }
 void sp_host_free(void *p) { sp::pinnedFree(p); }
 int sp_ctx_sync(sp_ctx *c) { c->gpu.sync(); return SP_OK; }

@@ -77,6 +77,14 @@ public:
 
     bool uploadTables(const std::vector<uint32_t> &ext3, const SubMat &seed, const SubMat &ungapped, const SubMat &aln, std::string &err);
     bool uploadTargets(const TargetSet &ts, const KmerIndex &idx, std::string &err);
+    // the product path: residues -> classes, tantan masking and the k-mer index of targets [from, to) built on the device
+    // (sp_gpu_index.inc).  ts carries n / offsets / keys; plain, masked and ascii stay empty on the host.
+    struct TargetBuild { uint64_t maskedResidues = 0, indexEntries = 0, indexSlots = 0; float msMask = 0, msIndex = 0; };
+    bool buildTargets(const char *ascii, const TargetSet &ts, const SubMat &seed, int kmerThr, bool mask, bool index, size_t from, size_t to,
+                      TargetBuild &out, std::string &err);
+    // test hook: (k-mer, seqId, pos) triples of the resident index in table order, and the masked residue classes
+    bool downloadIndex(std::vector<uint32_t> &kmers, std::vector<uint64_t> &entries, std::string &err);
+    bool downloadMasked(std::vector<uint8_t> &masked, std::string &err);
     // queries: numeric residues (seed-matrix numbering) concatenated; off has nq+1 entries
     bool uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std::string &err);
     size_t numQueries() const { return nq_; }

@@ -4,6 +4,7 @@
 // Integer scan/lookup work bounded by random HBM gathers -- no MFMA.  Design notes are in DESIGN.md; the
 // reference semantics each kernel reproduces are cited next to it (paths under lib/mmseqs/src/).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstdio>
@@ -1125,6 +1126,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_select_merged(MergeArgs
 }
 
 #include "sp_gpu_sw.inc"
+#include "sp_gpu_index.inc"
 
 // ---------------------------------------------------------------------------------------------------------------
 // device context
@@ -1168,6 +1170,9 @@ struct Gpu::Impl {
     // targets
     DevBuf<uint64_t> pbits; DevBuf<uint16_t> prank; DevBuf<uint32_t> prow; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff; DevBuf<uint32_t> tkeys;
     size_t nTargets = 0; size_t indexEntries = 0;
+    // index construction scratch (kept for the next target set)
+    DevBuf<uint32_t> ixKeys, ixKeys2, ixKeep, ixPos, ixKmer, ixHead, ixSlotOf, ixHeadPos, ixCnt, ixBefore; DevBuf<uint64_t> ixVals, ixVals2;
+    DevBuf<unsigned char> ixTemp; DevBuf<float> ttProbs; DevBuf<double> ttScale, ttLr; DevBuf<unsigned long long> ixCounters;
     // queries
     DevBuf<uint8_t> qres; DevBuf<uint32_t> qoff; DevBuf<float> biasf; DevBuf<short> qthr; DevBuf<signed char> qcorr; DevBuf<int> qbias; DevBuf<int> qself;
     size_t qTotal = 0; uint32_t maxQLen = 0;
@@ -1520,6 +1525,122 @@ bool Gpu::mergeCandidates(const Candidate *src, size_t n, bool onDevice, size_t 
     SP_DBG_SYNC("k_select_merged");
     HIP_OK(hipEventRecord(d.ev[4], d.stream));
     return finishPrefilter(false, err);
+}
+
+bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &seed, int kmerThr, bool mask, bool index, size_t from, size_t to,
+                       TargetBuild &out, std::string &err) {
+    Impl &d = *d_;
+    const size_t n = ts.n;
+    to = std::min(to, n); from = std::min(from, to);
+    const uint64_t R = ts.offsets[n];
+    d.nTargets = n; d.indexEntries = 0;
+    out = TargetBuild();
+    if (!upload(d.tascii, ascii, (size_t) R, d.stream, err) || !upload(d.toff, ts.offsets.data(), n + 1, d.stream, err) ||
+        !upload(d.tkeys, ts.keys.data(), n, d.stream, err)) return false;
+    if (!d.tplain.ensure((size_t) R + 1, err) || !d.tmasked.ensure((size_t) R + 1, err) || !d.ixCounters.ensure(4, err)) return false;
+    HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_aa2num), seed.aa2num, 256, 0, hipMemcpyHostToDevice, d.stream));
+    HIP_OK(hipMemsetAsync(d.ixCounters.p, 0, 4 * sizeof(unsigned long long), d.stream));
+    HIP_OK(hipEventRecord(d.ev[0], d.stream));
+    if (R) { MapArgs ma{d.tascii.p, R, d.tplain.p, d.tmasked.p}; hipLaunchKernelGGL(k_map_residues, dim3((unsigned) std::min<uint64_t>((R + 255) / 256, 65536)), dim3(256), 0, d.stream, ma); }
+    if (mask && to > from) {
+        TantanModel tm; tantanModel(seed, tm);
+        if (!upload(d.ttLr, &tm.lr[0][0], (size_t) kAlph * kAlph, d.stream, err)) return false;
+        if (!d.ttProbs.ensure((size_t) R + 1, err) || !d.ttScale.ensure((size_t) (R / 16 + n + 2), err)) return false;
+        TantanArgs ta{};
+        ta.masked = d.tmasked.p; ta.toff = d.toff.p; ta.from = (uint32_t) from; ta.to = (uint32_t) to; ta.lr = d.ttLr.p;
+        for (int i = 0; i < 50; i++) ta.b2f[i] = tm.b2f[i];
+        ta.b2b = tm.b2b; ta.f2b = tm.f2b; ta.f2f0 = tm.f2f0; ta.probs = d.ttProbs.p; ta.scale = d.ttScale.p; ta.maskedCount = d.ixCounters.p;
+        hipLaunchKernelGGL(k_tantan, dim3((unsigned) ((to - from + 63) / 64)), dim3(64), 0, d.stream, ta);
+    }
+    HIP_OK(hipEventRecord(d.ev[1], d.stream));
+    const size_t words = kTableSize / 64;
+    if (!d.pbits.ensure(words, err) || !d.prank.ensure(words, err) || !d.prow.ensure(kTableSize / 8000, err) || !d.slots.ensure(1, err) || !d.ientries.ensure(1, err)) return false;
+    HIP_OK(hipMemsetAsync(d.pbits.p, 0, words * sizeof(uint64_t), d.stream));
+    HIP_OK(hipMemsetAsync(d.prank.p, 0, words * sizeof(uint16_t), d.stream));
+    HIP_OK(hipMemsetAsync(d.prow.p, 0, (kTableSize / 8000) * sizeof(uint32_t), d.stream));
+    const uint64_t base = ts.offsets[from], Rs = ts.offsets[to] - base;
+    if (index && Rs > 0) {
+        if (Rs >= (1ull << 31)) { err = "index construction: more than 2^31 residues in one shard"; return false; }
+        const uint32_t nItems = (uint32_t) Rs;
+        if (!d.ixKeys.ensure(nItems, err) || !d.ixKeys2.ensure(nItems, err) || !d.ixVals.ensure(nItems, err) || !d.ixVals2.ensure(nItems, err)) return false;
+        ExtractArgs ea{};
+        ea.masked = d.tmasked.p; ea.toff = d.toff.p; ea.from = (uint32_t) from; ea.to = (uint32_t) to; ea.base = base;
+        for (int x = 0; x < kAlph; x++) ea.self[x] = (signed char) seed.sub[x][x];      // getScoreLookup, IndexBuilder.cpp:8-19
+        ea.kmerThr = kmerThr; ea.keys = d.ixKeys.p; ea.vals = d.ixVals.p; ea.counters = d.ixCounters.p;
+        hipLaunchKernelGGL(k_idx_extract, dim3((unsigned) (to - from)), dim3(64), 0, d.stream, ea);
+        // stable LSD radix sort on the 27 key bits: every list comes out in (seqId, pos) order, invalid windows last
+        size_t tempBytes = 0;
+        HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, d.ixKeys.p, d.ixKeys2.p, d.ixVals.p, d.ixVals2.p, (int) nItems, 0, 27, d.stream));
+        size_t scanBytes = 0;
+        HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, d.ixKeys.p, d.ixKeys.p, (int) std::max<size_t>(nItems, words), d.stream));
+        if (!d.ixTemp.ensure(std::max(tempBytes, scanBytes) + 256, err)) return false;
+        tempBytes = d.ixTemp.n;
+        HIP_OK(hipcub::DeviceRadixSort::SortPairs(d.ixTemp.p, tempBytes, d.ixKeys.p, d.ixKeys2.p, d.ixVals.p, d.ixVals2.p, (int) nItems, 0, 27, d.stream));
+        unsigned long long ctr[4];
+        HIP_OK(hipMemcpyAsync(ctr, d.ixCounters.p, sizeof(ctr), hipMemcpyDeviceToHost, d.stream));
+        HIP_OK(hipStreamSynchronize(d.stream));
+        const uint32_t nValid = (uint32_t) ctr[1];
+        if (nValid) {
+            const unsigned gv = (nValid + 255) / 256;
+            if (!d.ixKeep.ensure(nValid + 1, err) || !d.ixPos.ensure(nValid + 1, err)) return false;
+            hipLaunchKernelGGL(k_idx_flags, dim3(gv), dim3(256), 0, d.stream, d.ixKeys2.p, d.ixVals2.p, nValid, d.ixKeep.p);
+            size_t sb = d.ixTemp.n;
+            HIP_OK(hipcub::DeviceScan::ExclusiveSum(d.ixTemp.p, sb, d.ixKeep.p, d.ixPos.p, (int) nValid, d.stream));
+            uint32_t lastPos = 0, lastKeep = 0;
+            HIP_OK(hipMemcpyAsync(&lastPos, d.ixPos.p + (nValid - 1), 4, hipMemcpyDeviceToHost, d.stream));
+            HIP_OK(hipMemcpyAsync(&lastKeep, d.ixKeep.p + (nValid - 1), 4, hipMemcpyDeviceToHost, d.stream));
+            HIP_OK(hipStreamSynchronize(d.stream));
+            const uint32_t E = lastPos + lastKeep;
+            if (!d.ientries.ensure(E + 1, err) || !d.ixKmer.ensure(E + 1, err) || !d.ixHead.ensure(E + 1, err) || !d.ixSlotOf.ensure(E + 1, err)) return false;
+            hipLaunchKernelGGL(k_idx_compact, dim3(gv), dim3(256), 0, d.stream, d.ixKeys2.p, d.ixVals2.p, d.ixKeep.p, d.ixPos.p, nValid, d.ixKmer.p, d.ientries.p);
+            const unsigned ge = (E + 255) / 256;
+            hipLaunchKernelGGL(k_idx_heads, dim3(ge), dim3(256), 0, d.stream, d.ixKmer.p, E, d.ixHead.p);
+            sb = d.ixTemp.n;
+            HIP_OK(hipcub::DeviceScan::ExclusiveSum(d.ixTemp.p, sb, d.ixHead.p, d.ixSlotOf.p, (int) E, d.stream));
+            uint32_t lastSlot = 0, lastHead = 0;
+            HIP_OK(hipMemcpyAsync(&lastSlot, d.ixSlotOf.p + (E - 1), 4, hipMemcpyDeviceToHost, d.stream));
+            HIP_OK(hipMemcpyAsync(&lastHead, d.ixHead.p + (E - 1), 4, hipMemcpyDeviceToHost, d.stream));
+            HIP_OK(hipStreamSynchronize(d.stream));
+            const uint32_t nSlots = lastSlot + lastHead;
+            if (!d.ixHeadPos.ensure(nSlots + 1, err) || !d.slots.ensure(nSlots + 1, err) || !d.ixCnt.ensure(words, err) || !d.ixBefore.ensure(words + 1, err)) return false;
+            hipLaunchKernelGGL(k_idx_slots1, dim3(ge), dim3(256), 0, d.stream, d.ixKmer.p, d.ixHead.p, d.ixSlotOf.p, E, d.ixHeadPos.p, (unsigned long long *) d.pbits.p);
+            hipLaunchKernelGGL(k_idx_slots2, dim3((nSlots + 255) / 256), dim3(256), 0, d.stream, d.ixHeadPos.p, nSlots, E, d.ientries.p, d.slots.p);
+            hipLaunchKernelGGL(k_idx_popc, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, (const unsigned long long *) d.pbits.p, (uint32_t) words, d.ixCnt.p);
+            sb = d.ixTemp.n;
+            HIP_OK(hipcub::DeviceScan::ExclusiveSum(d.ixTemp.p, sb, d.ixCnt.p, d.ixBefore.p, (int) words, d.stream));
+            hipLaunchKernelGGL(k_idx_ranks, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, d.ixBefore.p, (uint32_t) words, d.prank.p, d.prow.p);
+            HIP_OK(hipGetLastError());
+            d.indexEntries = E; out.indexEntries = E; out.indexSlots = nSlots;
+        }
+    }
+    HIP_OK(hipEventRecord(d.ev[2], d.stream));
+    unsigned long long ctr[4];
+    HIP_OK(hipMemcpyAsync(ctr, d.ixCounters.p, sizeof(ctr), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipStreamSynchronize(d.stream));
+    HIP_OK(hipGetLastError());
+    out.maskedResidues = ctr[0];
+    (void) hipEventElapsedTime(&out.msMask, d.ev[0], d.ev[1]);
+    (void) hipEventElapsedTime(&out.msIndex, d.ev[1], d.ev[2]);
+    return true;
+}
+
+bool Gpu::downloadIndex(std::vector<uint32_t> &kmers, std::vector<uint64_t> &entries, std::string &err) {
+    Impl &d = *d_;
+    kmers.resize(d.indexEntries); entries.resize(d.indexEntries);
+    if (d.indexEntries == 0) return true;
+    if (!d.ixKmer.p) { err = "downloadIndex: the resident index was not built on the device"; return false; }
+    HIP_OK(hipMemcpy(kmers.data(), d.ixKmer.p, d.indexEntries * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(entries.data(), d.ientries.p, d.indexEntries * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return true;
+}
+
+bool Gpu::downloadMasked(std::vector<uint8_t> &masked, std::string &err) {
+    Impl &d = *d_;
+    size_t R = 0;
+    { uint64_t last = 0; if (d.nTargets) HIP_OK(hipMemcpy(&last, d.toff.p + d.nTargets, sizeof(uint64_t), hipMemcpyDeviceToHost)); R = (size_t) last; }
+    masked.resize(R);
+    if (R) HIP_OK(hipMemcpy(masked.data(), d.tmasked.p, R, hipMemcpyDeviceToHost));
+    return true;
 }
 
 void *pinnedAlloc(size_t bytes) {

@@ -23,6 +23,12 @@ def test_prefilter_matches_reference_golden(name):
     assert int(ctx.stat("index_entries")) == r["index"]["entries"]
     assert int(ctx.stat("masked_residues")) == r["maskedResidues"]
     assert int(ctx.stat("kmer_thr")) == r["kmerThr"]
+    # the target store is built on the device (tantan masking, index construction): masked sequences and the digest over
+    # the (k-mer, seqId, pos) triples in table order must be the reference's (tantan::maskSequences, IndexTable)
+    assert ctx.masked_targets() == "".join(r["masked"])
+    n_entries, digest = ctx.index_digest()
+    assert n_entries == r["index"]["entries"] and "%016x" % digest == r["index"]["digest"]
+    assert int(ctx.stat("index_slots")) == r["index"]["nonEmpty"]
     ctx.set_queries(g["queries"])
     ctx.prefilter()
     got = ctx.hits()
