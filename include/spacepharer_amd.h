@@ -158,6 +158,7 @@ void *sp_ctx_stream(const sp_ctx *c);
 /* test hooks: digest of the index built on the device ((k-mer, seqId, pos) triples in table order, FNV-1a as in
    sp_host_index_digest) and the masked target residues as letters (out: target_residues bytes) */
 int sp_ctx_index_digest(sp_ctx *c, uint64_t *entries, uint64_t *digest);
+int sp_ctx_ext3_digest(sp_ctx *c, uint64_t *digest);     /* the similar-3-mer table in HBM, hashed like sp_host_ext3_digest */
 int sp_ctx_get_masked(sp_ctx *c, char *out);
 /* page-locked host memory for result buffers (hits, alignment records, cigars): device-to-host copies into such memory
    run at full PCIe rate; ordinary memory works too, only slower.  Needs an initialised device (sp_init). */

@@ -96,6 +96,7 @@ def load_library():
     L.sp_ctx_stream.argtypes = [vp]
     L.sp_ctx_index_digest.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.sp_ctx_get_masked.argtypes = [vp, C.c_char_p]
+    L.sp_ctx_ext3_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.sp_host_alloc.restype = vp
     L.sp_host_alloc.argtypes = [C.c_uint64]
     L.sp_host_free.argtypes = [vp]
@@ -237,6 +238,11 @@ class SearchContext:
         n, h = C.c_uint64(), C.c_uint64()
         _check(self.L.sp_ctx_index_digest(self.ctx, C.byref(n), C.byref(h)))
         return int(n.value), int(h.value)
+
+    def ext3_digest(self):
+        h = C.c_uint64()
+        _check(self.L.sp_ctx_ext3_digest(self.ctx, C.byref(h)))
+        return int(h.value)
 
     def masked_targets(self):
         """masked target residues (letters, concatenated) as the device holds them"""

@@ -61,6 +61,16 @@ struct sp_ctx {
 };
 
 static uint64_t fnv1a(const void *p, size_t n, uint64_t h);
+// digest of a packed similar-3-mer table over the byte streams the reference holds (short score[8000], uint index[8000] per row)
+static uint64_t ext3Digest(const std::vector<uint32_t> &packed, int16_t *scoreHead64, uint32_t *indexHead64, uint32_t row) {
+    uint64_t h = 0; std::vector<int16_t> sc(8000); std::vector<uint32_t> ix(8000);
+    for (size_t r = 0; r < 8000; r++) {
+        for (size_t z = 0; z < 8000; z++) { sc[z] = (int16_t) ((int) (packed[r * 8000 + z] >> 16) - 32768); ix[z] = packed[r * 8000 + z] & 0xFFFF; }
+        h = fnv1a(sc.data(), 16000, h); h = fnv1a(ix.data(), 32000, h);
+        if (scoreHead64 && r == row) for (int z = 0; z < 64; z++) { scoreHead64[z] = sc[z]; indexHead64[z] = ix[z]; }
+    }
+    return h;
+}
 
 extern "C" {
 
@@ -142,9 +152,7 @@ static int setTargets(sp_ctx *c, const char *residues, const uint64_t *offsets, 
     std::string err;
     double t0 = nowMs();
     if (!c->tablesUp) {
-        std::vector<uint32_t> ext3;
-        sp::buildExt3(c->seed, ext3, c->threads);
-        if (!c->gpu.uploadTables(ext3, c->seed, c->ungapped, c->aln, err)) { g_err = err; return SP_ERR_DEVICE; }
+        if (!c->gpu.uploadTables(c->seed, c->ungapped, c->aln, err)) { g_err = err; return SP_ERR_DEVICE; }
         c->tablesUp = true;
     }
     double t1 = nowMs();
@@ -431,6 +439,12 @@ int sp_ctx_index_digest(sp_ctx *c, uint64_t *entries, uint64_t *digest) {
     *entries = km.size(); *digest = h;
     return SP_OK;
 }
+int sp_ctx_ext3_digest(sp_ctx *c, uint64_t *digest) {
+    std::vector<uint32_t> packed; std::string err;
+    if (!c->gpu.downloadExt3(packed, err)) { g_err = err; return SP_ERR_DEVICE; }
+    *digest = ext3Digest(packed, nullptr, nullptr, 0);
+    return SP_OK;
+}
 int sp_ctx_get_masked(sp_ctx *c, char *out) {
     std::vector<uint8_t> m; std::string err;
     if (!c->gpu.downloadMasked(m, err)) { g_err = err; return SP_ERR_DEVICE; }
@@ -467,13 +481,7 @@ int sp_host_ext3_digest(const char *seedSpec, uint64_t *digest, int16_t *scoreHe
     sp::SubMat m; std::string err;
     if (!m.load(seedSpec, (double) 8.0f, (double) -0.2f, err)) { g_err = err; return SP_ERR_ARG; }
     std::vector<uint32_t> packed; sp::buildExt3(m, packed, (int) std::max(1u, std::thread::hardware_concurrency()));
-    uint64_t h = 0; std::vector<int16_t> sc(8000); std::vector<uint32_t> ix(8000);
-    for (size_t r = 0; r < 8000; r++) {
-        for (size_t z = 0; z < 8000; z++) { sc[z] = (int16_t) ((int) (packed[r * 8000 + z] >> 16) - 32768); ix[z] = packed[r * 8000 + z] & 0xFFFF; }
-        h = fnv1a(sc.data(), 16000, h); h = fnv1a(ix.data(), 32000, h);
-        if (r == row) for (int z = 0; z < 64; z++) { scoreHead64[z] = sc[z]; indexHead64[z] = ix[z]; }
-    }
-    *digest = h;
+    *digest = ext3Digest(packed, scoreHead64, indexHead64, row);
     return SP_OK;
 }
 

@@ -75,7 +75,9 @@ public:
     int deviceCount() const;
     const std::string &deviceName() const { return name_; }
 
-    bool uploadTables(const std::vector<uint32_t> &ext3, const SubMat &seed, const SubMat &ungapped, const SubMat &aln, std::string &err);
+    // matrices + the similar-3-mer table (built on the device)
+    bool uploadTables(const SubMat &seed, const SubMat &ungapped, const SubMat &aln, std::string &err);
+    bool downloadExt3(std::vector<uint32_t> &packed, std::string &err);     // test hook
     bool uploadTargets(const TargetSet &ts, const KmerIndex &idx, std::string &err);
     // the product path: residues -> classes, tantan masking and the k-mer index of targets [from, to) built on the device
     // (sp_gpu_index.inc).  ts carries n / offsets / keys; plain, masked and ascii stay empty on the host.

@@ -1261,22 +1261,31 @@ static bool upload(DevBuf<T> &b, const T *src, size_t n, hipStream_t s, std::str
     return true;
 }
 
-bool Gpu::uploadTables(const std::vector<uint32_t> &ext3, const SubMat &seed, const SubMat &ung, const SubMat &aln, std::string &err) {
+bool Gpu::uploadTables(const SubMat &seed, const SubMat &ung, const SubMat &aln, std::string &err) {
     Impl &d = *d_;
-    if (!upload(d.ext3, ext3.data(), ext3.size(), d.stream, err)) return false;
-    {   // count table: for every row and every cutoff c in [cntMin, cntMin + kCntW): how many partners score >= c
-        int lo = 1 << 20, hi = -(1 << 20);
-        for (size_t r = 0; r < 8000; r++) { lo = std::min(lo, extScoreHost(ext3[r * 8000 + 7999])); hi = std::max(hi, extScoreHost(ext3[r * 8000])); }
-        if (hi - lo + 2 > kCntW) { err = "seed matrix 3-mer score range " + std::to_string(hi - lo) + " exceeds the count-table width"; return false; }
+    {   // similar-3-mer table + count table, built on the device (sp_gpu_index.inc)
+        const size_t N2 = (size_t) 8000 * 8000;
+        int lo1 = 1 << 20, hi1 = -(1 << 20);
+        Ext3Args ea{};
+        for (int i = 0; i < 20; i++) for (int j = 0; j < 20; j++) { ea.sub[i * 20 + j] = seed.sub[i][j]; lo1 = std::min<int>(lo1, seed.sub[i][j]); hi1 = std::max<int>(hi1, seed.sub[i][j]); }
+        const int lo = 3 * lo1, hi = 3 * hi1;           // the three positions are independent: extremes of the sum
+        if (hi - lo + 2 > kCntW || hi - lo >= 1024) { err = "seed matrix 3-mer score range " + std::to_string(hi - lo) + " exceeds the count-table width"; return false; }
         d.cntMin = lo;
-        std::vector<uint16_t> cnt((size_t) 8000 * kCntW);
-        for (size_t r = 0; r < 8000; r++) {
-            const uint32_t *row = ext3.data() + r * 8000; uint16_t *out = cnt.data() + r * kCntW;
-            size_t p = 0;      // entries are sorted by score descending: walk cutoffs from high to low
-            for (int x = kCntW - 1; x >= 0; x--) { const int c = lo + x; while (p < 8000 && extScoreHost(row[p]) >= c) p++; out[x] = (uint16_t) p; }
-        }
-        if (!upload(d.ext3cnt, cnt.data(), cnt.size(), d.stream, err)) return false;
+        DevBuf<uint32_t> k1, k2, v1, v2; DevBuf<unsigned char> tmp;
+        if (!d.ext3.ensure(N2, err) || !d.ext3cnt.ensure((size_t) 8000 * kCntW, err) || !k1.ensure(N2, err) || !k2.ensure(N2, err) || !v1.ensure(N2, err) || !v2.ensure(N2, err)) return false;
+        ea.hi = hi; ea.keys = k1.p; ea.vals = v1.p;
+        hipLaunchKernelGGL(k_ext3_fill, dim3((unsigned) (N2 / 256)), dim3(256), 0, d.stream, ea);
+        size_t tempBytes = 0;
+        HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, k1.p, k2.p, v1.p, v2.p, (int) N2, 0, 23, d.stream));
+        if (!tmp.ensure(tempBytes + 256, err)) return false;
+        tempBytes = tmp.n;
+        HIP_OK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tempBytes, k1.p, k2.p, v1.p, v2.p, (int) N2, 0, 23, d.stream));
+        hipLaunchKernelGGL(k_ext3_pack, dim3((unsigned) (N2 / 256)), dim3(256), 0, d.stream, k2.p, v2.p, hi, d.ext3.p);
+        hipLaunchKernelGGL(k_ext3_count, dim3(8000), dim3(kCntW), 0, d.stream, d.ext3.p, lo, d.ext3cnt.p);
+        HIP_OK(hipGetLastError());
         HIP_OK(hipStreamSynchronize(d.stream));
+        for (DevBuf<uint32_t> *b : {&k1, &k2, &v1, &v2}) { (void) hipFree(b->p); b->p = nullptr; }
+        (void) hipFree(tmp.p); tmp.p = nullptr;
     }
     short s16[kAlph * kAlph]; signed char u8[kAlph * kAlph], a8[kAlph * kAlph]; short a16[kAlph * kAlph];
     int mn = 0, mnAln = 0;
@@ -1631,6 +1640,14 @@ bool Gpu::downloadIndex(std::vector<uint32_t> &kmers, std::vector<uint64_t> &ent
     if (!d.ixKmer.p) { err = "downloadIndex: the resident index was not built on the device"; return false; }
     HIP_OK(hipMemcpy(kmers.data(), d.ixKmer.p, d.indexEntries * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(entries.data(), d.ientries.p, d.indexEntries * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return true;
+}
+
+bool Gpu::downloadExt3(std::vector<uint32_t> &packed, std::string &err) {
+    Impl &d = *d_;
+    if (!d.ext3.p) { err = "downloadExt3: tables not resident"; return false; }
+    packed.resize((size_t) 8000 * 8000);
+    HIP_OK(hipMemcpy(packed.data(), d.ext3.p, packed.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return true;
 }
 

@@ -29,6 +29,8 @@ def test_prefilter_matches_reference_golden(name):
     n_entries, digest = ctx.index_digest()
     assert n_entries == r["index"]["entries"] and "%016x" % digest == r["index"]["digest"]
     assert int(ctx.stat("index_slots")) == r["index"]["nonEmpty"]
+    if name == "small":      # the similar-3-mer table is sorted on the device: same bytes as ExtendedSubstitutionMatrix::calcScoreMatrix
+        assert "%016x" % ctx.ext3_digest() == r["ext3"]["digest"]
     ctx.set_queries(g["queries"])
     ctx.prefilter()
     got = ctx.hits()
