@@ -18,6 +18,7 @@
 #include <sstream>
 #include <string>
 #include <sys/stat.h>
+#include <thread>
 #include <vector>
 
 #include "../../include/spacepharer_amd.h"
@@ -37,15 +38,28 @@ struct Db {
     int type() const { return dbtype & 0x7FFFFFFF; }
 
     bool load(const std::string &path, std::string &err) {
-        std::ifstream idx(path + ".index");
-        if (!idx.good()) { err = "cannot open " + path + ".index"; return false; }
-        std::string line;
-        while (std::getline(idx, line)) {
-            if (line.empty()) continue;
-            DbEntry e; unsigned long long k, o, l;
-            if (sscanf(line.c_str(), "%llu\t%llu\t%llu", &k, &o, &l) != 3) { err = "malformed index line in " + path + ".index"; return false; }
-            e.key = (uint32_t) k; e.offset = o; e.length = l;
-            entries.push_back(e);
+        {   // key \t offset \t length \n  -- parsed by hand: result DBs of 10^5 spacers have 6 x 10^5 lines per index
+            std::ifstream idx(path + ".index", std::ios::binary);
+            if (!idx.good()) { err = "cannot open " + path + ".index"; return false; }
+            idx.seekg(0, std::ios::end); const size_t sz = (size_t) idx.tellg(); idx.seekg(0);
+            std::vector<char> text(sz + 1, '\n');
+            idx.read(text.data(), (std::streamsize) sz);
+            const char *p = text.data(), *end = p + sz;
+            entries.reserve(sz / 12 + 1);
+            while (p < end) {
+                if (*p == '\n' || *p == '\r') { p++; continue; }
+                unsigned long long v[3];
+                for (int f = 0; f < 3; f++) {
+                    if (*p < '0' || *p > '9') { err = "malformed index line in " + path + ".index"; return false; }
+                    unsigned long long x = 0;
+                    while (*p >= '0' && *p <= '9') x = x * 10 + (unsigned long long) (*p++ - '0');
+                    v[f] = x;
+                    if (f < 2) { if (*p != '\t') { err = "malformed index line in " + path + ".index"; return false; } p++; }
+                }
+                while (p < end && *p != '\n') p++;
+                DbEntry e; e.key = (uint32_t) v[0]; e.offset = v[1]; e.length = v[2];
+                entries.push_back(e);
+            }
         }
         std::vector<std::string> files;
         struct stat st;
@@ -79,11 +93,26 @@ struct DbWriter {
         data.push_back('\0');
         entries.push_back(e);
     }
+    // a block of consecutive entries formatted elsewhere (payloads concatenated, each followed by its NUL)
+    void addBlock(const std::vector<uint32_t> &keys, const std::vector<uint64_t> &lengths, const std::string &block) {
+        uint64_t at = data.size();
+        data.insert(data.end(), block.begin(), block.end());
+        for (size_t i = 0; i < keys.size(); i++) { DbEntry e; e.key = keys[i]; e.offset = at; e.length = lengths[i]; entries.push_back(e); at += lengths[i]; }
+    }
     bool close(std::string &err) {
         { std::ofstream o(path, std::ios::binary); if (!o.good()) { err = "cannot write " + path; return false; } o.write(data.data(), (std::streamsize) data.size()); }
         std::sort(entries.begin(), entries.end(), [](const DbEntry &a, const DbEntry &b) { return a.key < b.key; });   // DBWriter.cpp:645-660
-        { std::ofstream o(path + ".index"); if (!o.good()) { err = "cannot write " + path + ".index"; return false; }
-          for (const DbEntry &e : entries) o << e.key << '\t' << e.offset << '\t' << e.length << '\n'; }
+        { std::ofstream o(path + ".index", std::ios::binary); if (!o.good()) { err = "cannot write " + path + ".index"; return false; }
+          std::string text; text.reserve(entries.size() * 24);
+          char buf[72];
+          for (const DbEntry &e : entries) {
+              char *q = buf + sizeof(buf); *--q = '\n';
+              uint64_t v = e.length; do { *--q = (char) ('0' + v % 10); v /= 10; } while (v); *--q = '\t';
+              v = e.offset; do { *--q = (char) ('0' + v % 10); v /= 10; } while (v); *--q = '\t';
+              v = e.key; do { *--q = (char) ('0' + v % 10); v /= 10; } while (v);
+              text.append(q, buf + sizeof(buf) - q);
+          }
+          o.write(text.data(), (std::streamsize) text.size()); }
         // .dbtype is written LAST so that a crashed step is re-run by the workflow scripts (DBWriter.cpp:243)
         { std::ofstream o(path + ".dbtype", std::ios::binary); int32_t v = dbtype; o.write((const char *) &v, 4); if (!o.good()) { err = "cannot write " + path + ".dbtype"; return false; } }
         return true;
@@ -158,6 +187,33 @@ static const std::set<std::string> kRescoreFlags = {
 
 static char *u32toa(uint32_t v, char *p) { char t[12]; int n = 0; do { t[n++] = (char) ('0' + v % 10); v /= 10; } while (v); while (n) *p++ = t[--n]; return p; }
 static char *i32toa(int32_t v, char *p) { if (v < 0) { *p++ = '-'; return u32toa((uint32_t) (-(int64_t) v), p); } return u32toa((uint32_t) v, p); }
+
+// DB key -> position: keys are usually dense (0 .. n-1), so a flat table; a sorted list otherwise
+struct KeyMap {
+    std::vector<uint32_t> lut; std::vector<std::pair<uint32_t, uint32_t>> sorted; bool dense = false;
+    void build(const std::vector<uint32_t> &keys) {
+        uint32_t mx = 0; for (uint32_t k : keys) mx = std::max(mx, k);
+        dense = !keys.empty() && (uint64_t) mx < 4ull * keys.size() + 1024;
+        if (dense) { lut.assign((size_t) mx + 1, 0xFFFFFFFFu); for (size_t i = 0; i < keys.size(); i++) lut[keys[i]] = (uint32_t) i; }
+        else { sorted.resize(keys.size()); for (size_t i = 0; i < keys.size(); i++) sorted[i] = {keys[i], (uint32_t) i}; std::sort(sorted.begin(), sorted.end()); }
+    }
+    bool find(uint32_t key, uint32_t &pos) const {
+        if (dense) { if (key >= lut.size() || lut[key] == 0xFFFFFFFFu) return false; pos = lut[key]; return true; }
+        auto it = std::lower_bound(sorted.begin(), sorted.end(), std::make_pair(key, 0u));
+        if (it == sorted.end() || it->first != key) return false;
+        pos = it->second; return true;
+    }
+};
+
+template <typename F>
+static void parallelChunks(size_t n, int threads, F f) {      // f(chunkIndex, from, to), chunks in order
+    const size_t T = (size_t) std::max(1, std::min<int>(threads, (int) std::min<size_t>(n / 2048 + 1, 64)));
+    if (T == 1) { f(0, 0, n); return; }
+    std::vector<std::thread> pool; const size_t per = (n + T - 1) / T;
+    for (size_t t = 0; t < T; t++) pool.emplace_back(f, t, std::min(n, t * per), std::min(n, (t + 1) * per));
+    for (auto &th : pool) th.join();
+}
+static size_t numChunks(size_t n, int threads) { return (size_t) std::max(1, std::min<int>(threads, (int) std::min<size_t>(n / 2048 + 1, 64))); }
 
 struct Ctx {
     sp_ctx *c = nullptr;
@@ -242,26 +298,23 @@ int runPrefilterModule(int argc, const char **argv) {
 // ---------------------------------------------------------------------------------------------------------------
 struct Triples { std::vector<uint32_t> q, t; std::vector<int16_t> d; std::vector<uint64_t> perQuery; /* offsets per result entry */ std::vector<uint32_t> entryQuery; std::vector<uint32_t> entryKey; };
 
-static bool collectTriples(const Db &res, const std::map<uint32_t, uint32_t> &qIndex, const std::map<uint32_t, uint32_t> &tIndex, Triples &tr, std::string &err) {
+static bool collectTriples(const Db &res, const KeyMap &qIndex, const KeyMap &tIndex, Triples &tr, std::string &err) {
     tr.perQuery.assign(1, 0);
+    tr.q.reserve(res.data.size() / 12); tr.t.reserve(res.data.size() / 12); tr.d.reserve(res.data.size() / 12);
     for (size_t i = 0; i < res.entries.size(); i++) {
         const uint32_t key = res.entries[i].key;
         const char *p = res.ptr(i);
         uint32_t qi = 0xFFFFFFFFu;
-        if (*p != '\0') {
-            auto it = qIndex.find(key);
-            if (it == qIndex.end()) { err = "query " + std::to_string(key) + " of the result DB is not in the query DB"; return false; }
-            qi = it->second;
-        }
+        if (*p != '\0' && !qIndex.find(key, qi)) { err = "query " + std::to_string(key) + " of the result DB is not in the query DB"; return false; }
         while (*p != '\0') {
             char *e; unsigned long tk = strtoul(p, &e, 10);
             long score = 0, diag = 0; int cols = 1;
             if (*e == '\t') { score = strtol(e + 1, &e, 10); cols++; }
             if (*e == '\t') { diag = strtol(e + 1, &e, 10); cols++; }
             (void) score;
-            auto it = tIndex.find((uint32_t) tk);
-            if (it == tIndex.end()) { err = "target " + std::to_string(tk) + " of the result DB is not in the target DB"; return false; }
-            tr.q.push_back(qi); tr.t.push_back(it->second); tr.d.push_back(cols == 3 ? (int16_t) diag : 0);
+            uint32_t ti = 0;
+            if (!tIndex.find((uint32_t) tk, ti)) { err = "target " + std::to_string(tk) + " of the result DB is not in the target DB"; return false; }
+            tr.q.push_back(qi); tr.t.push_back(ti); tr.d.push_back(cols == 3 ? (int16_t) diag : 0);
             while (*e != '\n' && *e != '\0') e++;
             p = (*e == '\n') ? e + 1 : e;
         }
@@ -334,9 +387,7 @@ int runAlignModule(int argc, const char **argv) {
     Ctx ctx; Db qdb, tdb, rdb; std::vector<uint32_t> qkeys, tkeys; std::vector<char> qres; std::vector<uint64_t> qoff;
     if (!openSearch(f, "align", true, ctx, qdb, tdb, qkeys, tkeys, qres, qoff, err)) return fail("align: " + err);
     if (!rdb.load(f.positional[2], err)) return fail("align: " + err);
-    std::map<uint32_t, uint32_t> qIndex, tIndex;
-    for (size_t i = 0; i < qkeys.size(); i++) qIndex[qkeys[i]] = (uint32_t) i;
-    for (size_t i = 0; i < tkeys.size(); i++) tIndex[tkeys[i]] = (uint32_t) i;
+    KeyMap qIndex, tIndex; qIndex.build(qkeys); tIndex.build(tkeys);
     Triples tr;
     if (!collectTriples(rdb, qIndex, tIndex, tr, err)) return fail("align: " + err);
     const double minSeqId = f.real("--min-seq-id", 0.0); const long minAlnLen = f.num("--min-aln-len", 0);
@@ -347,20 +398,30 @@ int runAlignModule(int argc, const char **argv) {
     if (rc == SP_ERR_OVERFLOW && used > cig.size()) { cig.resize(used + 16); rc = sp_ctx_align(ctx.c, tr.q.data(), tr.t.data(), tr.q.size(), res.data(), cig.data(), cig.size(), &used); }
     if (rc != SP_OK) return fail(std::string("align: ") + sp_last_error());
     DbWriter w; w.path = f.positional[3]; w.dbtype = 5;       // DBTYPE_ALIGNMENT_RES
-    std::string payload;
-    for (size_t e = 0; e + 1 < tr.perQuery.size(); e++) {
+    // entries are formatted by --threads workers over contiguous ranges and appended in order
+    const size_t nEntries = tr.perQuery.size() - 1;
+    const int threads = (int) f.num("--threads", 0) > 0 ? (int) f.num("--threads", 0) : (int) std::max(1u, std::thread::hardware_concurrency());
+    const size_t nChunks = numChunks(nEntries, threads);
+    std::vector<std::string> blocks(nChunks); std::vector<std::vector<uint32_t>> bKeys(nChunks); std::vector<std::vector<uint64_t>> bLens(nChunks);
+    parallelChunks(nEntries, threads, [&](size_t ci, size_t from, size_t to) {
+        std::string &block = blocks[ci];
         std::vector<std::pair<sp_alignment, const char *>> ok;
-        long passed = 0, rejected = 0;
-        for (uint64_t i = tr.perQuery[e]; i < tr.perQuery[e + 1] && passed < maxAccept && rejected < maxRejected; i++) {
-            const sp_alignment &r = res[i];
-            const bool good = r.passed && r.seq_id >= minSeqId && (long) r.aln_len >= minAlnLen;    // Alignment::checkCriteria, Alignment.cpp:555-574
-            if (good) { ok.push_back({r, cig.data() + r.cigar_offset}); passed++; rejected = 0; } else rejected++;
+        for (size_t e = from; e < to; e++) {
+            ok.clear();
+            long passed = 0, rejected = 0;
+            for (uint64_t i = tr.perQuery[e]; i < tr.perQuery[e + 1] && passed < maxAccept && rejected < maxRejected; i++) {
+                const sp_alignment &r = res[i];
+                const bool good = r.passed && r.seq_id >= minSeqId && (long) r.aln_len >= minAlnLen;    // Alignment::checkCriteria, Alignment.cpp:555-574
+                if (good) { ok.push_back({r, cig.data() + r.cigar_offset}); passed++; rejected = 0; } else rejected++;
+            }
+            std::sort(ok.begin(), ok.end(), [](const std::pair<sp_alignment, const char *> &a, const std::pair<sp_alignment, const char *> &b) { return alnLess(a.first, b.first); });
+            const size_t before = block.size();
+            for (auto &x : ok) appendAlnLine(block, x.first, x.second, true);
+            block.push_back('\0');
+            bKeys[ci].push_back(tr.entryKey[e]); bLens[ci].push_back(block.size() - before);
         }
-        std::sort(ok.begin(), ok.end(), [](const std::pair<sp_alignment, const char *> &a, const std::pair<sp_alignment, const char *> &b) { return alnLess(a.first, b.first); });
-        payload.clear();
-        for (auto &x : ok) appendAlnLine(payload, x.first, x.second, true);
-        w.add(tr.entryKey[e], payload);
-    }
+    });
+    for (size_t ci = 0; ci < nChunks; ci++) w.addBlock(bKeys[ci], bLens[ci], blocks[ci]);
     if (!w.close(err)) return fail("align: " + err);
     return 0;
 }
@@ -380,9 +441,7 @@ int runRescoreDiagonalModule(int argc, const char **argv) {
     Ctx ctx; Db qdb, tdb, rdb; std::vector<uint32_t> qkeys, tkeys; std::vector<char> qres; std::vector<uint64_t> qoff;
     if (!openSearch(f, "rescorediagonal", false, ctx, qdb, tdb, qkeys, tkeys, qres, qoff, err)) return fail("rescorediagonal: " + err);
     if (!rdb.load(f.positional[2], err)) return fail("rescorediagonal: " + err);
-    std::map<uint32_t, uint32_t> qIndex, tIndex;
-    for (size_t i = 0; i < qkeys.size(); i++) qIndex[qkeys[i]] = (uint32_t) i;
-    for (size_t i = 0; i < tkeys.size(); i++) tIndex[tkeys[i]] = (uint32_t) i;
+    KeyMap qIndex, tIndex; qIndex.build(qkeys); tIndex.build(tkeys);
     Triples tr;
     if (!collectTriples(rdb, qIndex, tIndex, tr, err)) return fail("rescorediagonal: " + err);
     std::vector<sp_rescore> res(std::max<size_t>(1, tr.q.size()));
