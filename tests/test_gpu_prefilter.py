@@ -62,3 +62,33 @@ def test_prefilter_matches_oracle_on_fresh_inputs():
     assert nhits > 100
     ctx.close()
     o.close()
+
+
+def test_degenerate_targets_and_queries_against_oracle():
+    """the device-side target preparation and the search on empty / shorter-than-a-window / all-X / repeat-rich targets"""
+    from golden.make_golden import make_case
+    from oracle_lib import Oracle
+    import spacepharer_amd as sa
+    T, Q = make_case(seed=808, n_targets=400, n_queries=200, tmin=20, tmax=120, qmin=8, qmax=12, families=2)
+    odd = ["", "A", "ACDEFGH", "ACDEFGHI", "XXXXXXXXXXXXXXXX", "ACACACACACACACACACACACACACACACACACACAC", "KKKKKKKKKKKKKKKKKKKKKKKKKKKK",
+           "MKVLAAGIXXXXXXXXGGSTRRW", "W" * 70, "ACDEFGHIKLMNPQRSTVWY" * 40]
+    T = odd[:5] + T[:200] + odd[5:] + T[200:] + [""]
+    Q = Q + ["ACDEFGHIK", "ACACACACAC", "KKKKKKKKKK", "WWWWWWWWWW", "ACDEFGHIKLMNPQRSTVWY"]
+    o = Oracle(sens=5.7, max_seqs=300)
+    o.set_targets(T)
+    ctx = sa.SearchContext()
+    ctx.set_targets(T)
+    from oracle_lib import lib
+    assert int(ctx.stat("index_entries")) == lib().spo_index_entries(o.ctx)
+    assert ctx.masked_targets() == "".join(o.masked())           # tantan on the device == the checker's, residue by residue
+    ctx.set_queries(Q)
+    ctx.prefilter()
+    got = ctx.hits()
+    total = 0
+    for i, q in enumerate(Q):
+        exp = o.prefilter_list(q)
+        assert [list(h) for h in got[i]] == exp, (i, q)
+        total += len(exp)
+    assert total > 50
+    ctx.close()
+    o.close()
