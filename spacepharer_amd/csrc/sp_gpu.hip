@@ -1028,14 +1028,56 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_select_merged(MergeArgs
     uint32_t *hist = s_hist[w];
     uint64_t *scratchK = a.scratch + (size_t) (blockIdx.x * kWavesPerBlock + w) * kMergeScratchWords;
     uint32_t *scratchI = (uint32_t *) (scratchK + 65536);
-    for (;;) {
-        const uint32_t qi = popQueue(a.queue, lane);
-        if (qi >= a.nq) break;
+    // kSelChunk queries per pop, output space reserved once per chunk (like k_select); queries whose union holds fewer
+    // candidates than --max-seqs (and at most 64) need no histogram and no cut: one candidate per lane, final order only
+    for (uint32_t chunk = 0, qc = 0, qcEnd = 0, myBase = 0, myD = 0;;) {
+        if (qc == qcEnd) {
+            chunk = popQueue(a.queue, lane);
+            if ((uint64_t) chunk * kSelChunk >= a.nq) break;
+            qc = chunk * kSelChunk; qcEnd = min(a.nq, qc + (uint32_t) kSelChunk);
+            const uint32_t ql = qc + (uint32_t) lane;
+            myD = (lane < kSelChunk && ql < a.nq) ? a.candOffset[ql + 1] - a.candOffset[ql] : 0u;
+            const uint32_t want = min(myD, (uint32_t) a.maxHits);
+            const uint32_t incl = waveInclusiveScan(want, lane);
+            const uint32_t total = lane63(incl);
+            uint32_t cb = 0;
+            if (total) cb = uni(atomicAdd(a.outCursor, lane == 0 ? total : 0u));
+            myBase = cb + incl - want;
+        }
+        const uint32_t qi = qc++;
+        const int slot = (int) (qi - chunk * kSelChunk);
+        uint32_t D = (uint32_t) __builtin_amdgcn_readlane((int) myD, slot);
+        const uint32_t obase = (uint32_t) __builtin_amdgcn_readlane((int) myBase, slot);
         const uint32_t c0 = uni(a.candOffset[qi]);
-        uint32_t D = uni(a.candOffset[qi + 1]) - c0;
         if (D > 65535u) { if (lane == 0) atomicAdd(&a.counters[2], 1ull); D = 0; }
         if (D == 0) { if (lane == 0) { a.outCount[qi] = 0; a.outBase[qi] = 0; } continue; }
         const Candidate *cand = a.cand + c0;
+        if (D <= 64u && D < (uint32_t) a.maxHits) {
+            const int bias0 = (int) uni((uint32_t) a.qbias[qi]);
+            const int qL0 = (int) uni(a.qoff[qi + 1] - a.qoff[qi]);
+            if (a.minDiagScore < 255 - bias0) {
+                const int maxC0 = (qL0 >= 32768) ? 255 : 255 - bias0;
+                const bool in = (uint32_t) lane < D;
+                Candidate c{0, 0xFFFFFFFFu, 0, 0, 0};
+                if (in) c = cand[lane];
+                const int v = min((int) c.exact, maxC0);
+                int score = (v >= 255 - bias0) ? (int) c.exact : v;
+                if (score > 65535) score = 65535;
+                const uint64_t key = ((uint64_t) (65535 - score) << 32) | c.seqId;
+                uint32_t rank = 0;
+                for (uint32_t u = 0; u < D; u++) {
+                    const uint64_t ku = ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (key >> 32), (int) u) << 32) | (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) key, (int) u);
+                    rank += ku < key ? 1u : 0u;
+                }
+                if (in) {
+                    GpuHit h; h.seqId = c.seqId; h.score = (uint16_t) score; h.diag = c.diag;
+                    a.outHits[(size_t) obase + rank] = h;
+                    a.outQuery[(size_t) obase + rank] = qi;
+                }
+                if (lane == 0) { a.outCount[qi] = D; a.outBase[qi] = obase; }
+                continue;
+            }
+        }
         const int qL = (int) uni(a.qoff[qi + 1] - a.qoff[qi]);
         const int bias = (int) uni((uint32_t) a.qbias[qi]);
         const int maxC = (qL >= 32768) ? 255 : 255 - bias;
@@ -1112,7 +1154,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_select_merged(MergeArgs
         }
         waveSync();
         if (keyLds) waveBitonicSort(s_keys[w], n2, lane); else waveBitonicSort(scratchK, n2, lane);
-        const uint32_t obase = uni(atomicAdd(a.outCursor, lane == 0 ? nOut : 0u));
         for (uint32_t t = lane; t < nOut; t += 64) {
             const uint64_t k3 = K[t];
             const Candidate c = cand[I[(uint32_t) (k3 & 0xFFFF)]];
