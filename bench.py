@@ -259,7 +259,7 @@ def main():
                      "frac": achieved / 8000.0, "traffic": traffic,
                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes},
     }
-    if args.cpu_sample > 0:
+    if args.cpu_sample > 0 and world == 1:      # rank 0 at N = 1 only
         # the reference itself when its harness travelled with the repo (oracle/_ref, built by __graft_entry__.build()), else
         # the scalar port; either way a bounded sample
         cores = max(1, min(args.cpu_cores, os.cpu_count() or 1))

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for v in "SP_HITCAP=512" "SP_HITCAP=256"; do echo "== $v"; env $v SP_DEBUG=1 timeout 300 python bench.py --steps 3 --warmup 1 --cpu-sample 0 --stage prefilter 2>&1 | grep "hitCap" | tail -1; env $v timeout 300 python bench.py --steps 20 --warmup 2 --cpu-sample 0 --stage prefilter 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['kernels_ms_per_step']['match'], d['counters_per_step']['hits'])"; done
+timeout 300 python tools/exp_order.py 2>&1 | tail -6
