@@ -42,7 +42,6 @@ struct sp_ctx {
     sp::SubMat seed, ungapped, aln;
     sp::Gpu gpu;
     sp::TargetSet targets;
-    sp::KmerIndex index;         // host copy is dropped after upload
     uint64_t indexEntries = 0;
     int kmerThr = 0;
     unsigned binSize = 2;

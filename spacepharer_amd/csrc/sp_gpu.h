@@ -78,7 +78,6 @@ public:
     // matrices + the similar-3-mer table (built on the device)
     bool uploadTables(const SubMat &seed, const SubMat &ungapped, const SubMat &aln, std::string &err);
     bool downloadExt3(std::vector<uint32_t> &packed, std::string &err);     // test hook
-    bool uploadTargets(const TargetSet &ts, const KmerIndex &idx, std::string &err);
     // the product path: residues -> classes, tantan masking and the k-mer index of targets [from, to) built on the device
     // (sp_gpu_index.inc).  ts carries n / offsets / keys; plain, masked and ascii stay empty on the host.
     struct TargetBuild { uint64_t maskedResidues = 0, indexEntries = 0, indexSlots = 0; float msMask = 0, msIndex = 0; };

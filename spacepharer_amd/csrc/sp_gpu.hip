@@ -1350,49 +1350,6 @@ bool Gpu::uploadTables(const SubMat &seed, const SubMat &ung, const SubMat &aln,
     return true;
 }
 
-bool Gpu::uploadTargets(const TargetSet &ts, const KmerIndex &idx, std::string &err) {
-    Impl &d = *d_;
-    d.nTargets = ts.n; d.indexEntries = idx.entries.size();
-    {
-        // rank-compressed slot table: occupancy bits (u64 per 64 k-mer slots) + the pieces of the rank (per row of 8000
-        // slots = one value of the second 3-mer, per word inside the row) + one 8-byte word per occupied slot.  A lookup is
-        // bits -> [rank pieces] -> slot; the entry array is only touched for slots with more than one entry.  10 MB + 8 B x
-        // occupied slots instead of the 256 MB offsets table, and a miss (86 % at phage scale) costs one 8-byte read.
-        static_assert(kTableSize % 8000 == 0 && 8000 % 64 == 0, "rows of 8000 slots are whole words");
-        const size_t words = kTableSize / 64;
-        std::vector<uint64_t> bits(words, 0); std::vector<uint16_t> rank(words, 0); std::vector<uint32_t> row(kTableSize / 8000, 0);
-        std::vector<uint64_t> slots;
-        if (idx.offsets.size() == (size_t) kTableSize + 1) {
-            slots.reserve(idx.entries.size());
-            uint32_t rowStart = 0;
-            for (size_t w = 0; w < words; w++) {
-                if (w % 125 == 0) { rowStart = (uint32_t) slots.size(); row[w / 125] = rowStart; }
-                rank[w] = (uint16_t) (slots.size() - rowStart);
-                uint64_t b = 0;
-                for (uint32_t k = (uint32_t) (w * 64), k1 = k + 64; k < k1; k++) {
-                    const uint32_t o = idx.offsets[k], len = idx.offsets[k + 1] - o;
-                    if (len == 0) continue;
-                    b |= 1ull << (k & 63);
-                    slots.push_back(len == 1 ? idx.entries[o] : ((1ull << 63) | ((uint64_t) (len & 0x7FFFFFFFu) << 32) | o));
-                }
-                bits[w] = b;
-            }
-        }
-        if (!upload(d.pbits, bits.data(), bits.size(), d.stream, err) || !upload(d.prank, rank.data(), rank.size(), d.stream, err) ||
-            !upload(d.prow, row.data(), row.size(), d.stream, err)) return false;
-        if (!upload(d.slots, slots.data(), slots.size(), d.stream, err)) return false;
-        HIP_OK(hipStreamSynchronize(d.stream));
-    }
-    if (!upload(d.ientries, idx.entries.data(), idx.entries.size(), d.stream, err)) return false;
-    if (!upload(d.tmasked, ts.masked.data(), ts.masked.size(), d.stream, err)) return false;
-    if (!upload(d.tplain, ts.plain.data(), ts.plain.size(), d.stream, err)) return false;
-    if (!upload(d.tascii, ts.ascii.data(), ts.ascii.size(), d.stream, err)) return false;
-    if (!upload(d.toff, ts.offsets.data(), ts.offsets.size(), d.stream, err)) return false;
-    if (!upload(d.tkeys, ts.keys.data(), ts.keys.size(), d.stream, err)) return false;
-    HIP_OK(hipStreamSynchronize(d.stream));
-    return true;
-}
-
 bool Gpu::uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std::string &err) {
     Impl &d = *d_;
     nq_ = nq;
