@@ -104,6 +104,13 @@ __device__ void waveBitonicSort(uint64_t *keys, uint32_t n, int lane) {
 }
 
 
+// Slot numbering of the device index.  The reference numbers a k-mer  first3mer + 8000 * second3mer  (Indexer); the similar
+// k-mers of a window are enumerated first-3-mer-major, so neighbouring lanes of a probe share the FIRST 3-mer and walk
+// through similar SECOND 3-mers.  Numbering slots  second3mer + 8000 * first3mer  puts those probes into one 1000-byte row
+// of occupancy bits (a handful of 128-byte lines per load instruction instead of 64 different ones).
+__host__ __device__ __forceinline__ uint32_t slotOfKmer(uint32_t first3, uint32_t second3) { return second3 + 8000u * first3; }
+__host__ __device__ __forceinline__ uint32_t kmerOfSlot(uint32_t slot) { return slot / 8000u + 8000u * (slot % 8000u); }
+
 __device__ __forceinline__ int extScore(uint32_t packed) { return (int) (packed >> 16) - 32768; }
 __device__ __forceinline__ uint32_t extIndex(uint32_t packed) { return packed & 0xFFFFu; }
 
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                             if (k < tileK) {
                                 const uint32_t bb = k - aStart[ai];
                                 const uint32_t bi = (bb < (uint32_t) kBTile) ? bIdx[bb] : extIndex(rowB[bb]);
-                                kmerR[r] = aIdx[ai] + 8000u * bi;
+                                kmerR[r] = slotOfKmer(aIdx[ai], bi);
                             }
                         }
                     }
@@ -1636,8 +1643,14 @@ bool Gpu::downloadIndex(std::vector<uint32_t> &kmers, std::vector<uint64_t> &ent
     kmers.resize(d.indexEntries); entries.resize(d.indexEntries);
     if (d.indexEntries == 0) return true;
     if (!d.ixKmer.p) { err = "downloadIndex: the resident index was not built on the device"; return false; }
-    HIP_OK(hipMemcpy(kmers.data(), d.ixKmer.p, d.indexEntries * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(entries.data(), d.ientries.p, d.indexEntries * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> slot(d.indexEntries); std::vector<uint64_t> ent(d.indexEntries);
+    HIP_OK(hipMemcpy(slot.data(), d.ixKmer.p, d.indexEntries * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(ent.data(), d.ientries.p, d.indexEntries * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    // back to the reference's table order: k-mer ascending, lists untouched (a stable counting sort by k-mer id)
+    std::vector<uint32_t> start((size_t) kTableSize + 1, 0);
+    for (uint32_t s2 : slot) start[(size_t) kmerOfSlot(s2) + 1]++;
+    for (size_t k = 0; k < kTableSize; k++) start[k + 1] += start[k];
+    for (size_t i = 0; i < slot.size(); i++) { const uint32_t km = kmerOfSlot(slot[i]); const uint32_t at = start[km]++; kmers[at] = km; entries[at] = ent[i]; }
     return true;
 }
 
