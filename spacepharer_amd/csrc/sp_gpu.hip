@@ -915,7 +915,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_select(SelectArgs a) {
 // query-ordered output: exclusive scan of the per-query hit counts (one block), then move the hits from the staging
 // array (allocation order of k_select) to their final place; everything downstream (download, align) is sequential
 __global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t *count, uint32_t n, uint32_t *offset /* n+1 */) {
-    // one block; tiles of 1024 counts read coalesced, DPP scan per wave, the 16 wave totals through LDS, carry in a register
+    // one block (small inputs): tiles of 1024 counts read coalesced, DPP scan per wave, the 16 wave totals through LDS
     __shared__ uint32_t s_wave[16];
     const int lane = laneId(), wv = (int) (threadIdx.x >> 6);
     uint32_t carry = 0;
@@ -1231,6 +1231,18 @@ struct Gpu::Impl {
     DevBuf<GpuHit> outHits; DevBuf<GpuHit> outStage; DevBuf<uint32_t> outQuery; DevBuf<uint32_t> outCount; DevBuf<uint32_t> outBase; DevBuf<uint32_t> outOffset;
     uint32_t matchBlocks = 0;
     size_t diagCap = 0;
+    DevBuf<unsigned char> scanTemp;
+    // exclusive scan of n counts into n + 1 offsets (offset[n] = total); count must have n + 1 readable entries.
+    // Small inputs: one block (k_scan_counts); larger ones: rocPRIM's decoupled look-back scan.
+    bool scanCounts(const uint32_t *count, uint32_t n, uint32_t *offset, std::string &err) {
+        if (n <= 4096) { hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, stream, count, n, offset); return true; }
+        size_t bytes = 0;
+        if (hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, count, offset, (int) (n + 1), stream) != hipSuccess) { err = "scan: temp size query failed"; return false; }
+        if (!scanTemp.ensure(bytes + 256, err)) return false;
+        bytes = scanTemp.n;
+        if (hipcub::DeviceScan::ExclusiveSum(scanTemp.p, bytes, count, offset, (int) (n + 1), stream) != hipSuccess) { err = "scan failed"; return false; }
+        return true;
+    }
     // target-sharded search
     DevBuf<uint32_t> diagOrd; DevBuf<uint32_t> spillOrd; DevBuf<Candidate> cand; DevBuf<Candidate> candUnion; DevBuf<Candidate> candByQuery;
     DevBuf<uint32_t> candCnt; DevBuf<uint32_t> candFill; DevBuf<uint32_t> candOffset; DevBuf<uint64_t> mergeScratch;
@@ -1466,7 +1478,7 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.queue.p + 2,
                   binSize - 1, maxHits, minDiagScore, d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.queue.p + 3, d.counters.p};
     hipLaunchKernelGGL(k_select, dim3(d.matchBlocks), dim3(64 * kWavesPerBlock), 0, d.stream, se);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d.stream, d.outCount.p, (uint32_t) nq_, d.outOffset.p);
+    if (!d.scanCounts(d.outCount.p, (uint32_t) nq_, d.outOffset.p, err)) return false;
     hipLaunchKernelGGL(k_reorder_hits, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.outStage.p, d.outBase.p, d.outCount.p, d.outOffset.p, (uint32_t) nq_, d.outHits.p, d.outQuery.p);
     SP_DBG_SYNC("k_select");
     HIP_OK(hipEventRecord(d.ev[4], d.stream));
@@ -1529,12 +1541,12 @@ bool Gpu::mergeCandidates(const Candidate *src, size_t n, bool onDevice, size_t 
     HIP_OK(hipMemsetAsync(d.candFill.p, 0, (nq_ + 1) * sizeof(uint32_t), d.stream));
     HIP_OK(hipEventRecord(d.ev[3], d.stream));
     if (n) hipLaunchKernelGGL(k_cand_count, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, u, (uint32_t) n, (uint32_t) qFrom, (uint32_t) qTo, d.candCnt.p);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d.stream, d.candCnt.p, (uint32_t) nq_, d.candOffset.p);
+    if (!d.scanCounts(d.candCnt.p, (uint32_t) nq_, d.candOffset.p, err)) return false;
     if (n) hipLaunchKernelGGL(k_cand_scatter, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, u, (uint32_t) n, (uint32_t) qFrom, (uint32_t) qTo, d.candOffset.p, d.candFill.p, d.candByQuery.p);
     MergeArgs me{(uint32_t) nq_, d.candByQuery.p, d.candOffset.p, d.qbias.p, d.qself.p, d.qoff.p, d.mergeScratch.p, d.queue.p + 2, binSize - 1, maxHits, minDiagScore,
                  d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.queue.p + 3, d.counters.p};
     hipLaunchKernelGGL(k_select_merged, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, me);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, d.stream, d.outCount.p, (uint32_t) nq_, d.outOffset.p);
+    if (!d.scanCounts(d.outCount.p, (uint32_t) nq_, d.outOffset.p, err)) return false;
     hipLaunchKernelGGL(k_reorder_hits, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.outStage.p, d.outBase.p, d.outCount.p, d.outOffset.p, (uint32_t) nq_, d.outHits.p, d.outQuery.p);
     SP_DBG_SYNC("k_select_merged");
     HIP_OK(hipEventRecord(d.ev[4], d.stream));
