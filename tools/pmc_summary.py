@@ -14,7 +14,7 @@ GIB = 1 << 30
 
 
 def short(name):
-    for k in ("k_match", "k_prep", "k_score", "k_select", "k_scan_counts", "k_reorder_hits", "k_sw_byte1", "k_sw_byte", "k_sw_word",
+    for k in ("k_match", "k_prep", "k_score", "k_select", "k_scan_counts", "k_reorder_hits", "k_sw_byte1p", "k_sw_byte1", "k_sw_byte", "k_sw_word", "k_aln_assemble", "k_aln_lens", "k_tantan", "k_candidates", "k_select_merged",
               "k_sw_prep", "k_sw_gate", "k_pairs_from_hits", "k_sw_trace", "k_rescore"):
         if k in name:
             return k
