@@ -710,9 +710,9 @@ struct SelectArgs {
     const int *qbias; const int *qself; const uint32_t *qoff;
     uint8_t *diagFlag;              // scratch, one byte per diagonal
     uint64_t *selScratch;           // per-wave HBM key scratch (65536 keys) for oversized candidate lists
-    uint32_t *queue;                // work counter (persistent waves)
+    const uint32_t *wantOff;        // exclusive scan of min(qDiagCnt, maxHits): start of each query's range in the staging buffer
     uint32_t binMask; int maxHits; int minDiagScore;
-    GpuHit *outHits; uint32_t *outQuery; uint32_t *outCount; uint32_t *outBase; uint32_t *outCursor;   // compact output: each query owns [outBase, outBase+outCount)
+    GpuHit *outHits; uint32_t *outQuery; uint32_t *outCount; uint32_t *outBase;   // compact output: each query owns [outBase, outBase+outCount)
     unsigned long long *counters;   // [4] += hits
 };
 
@@ -869,18 +869,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_select(SelectArgs a) {
     // kSelChunk queries per pop.  Output space is reserved once per chunk (sum of min(D, maxHits) -- an upper bound, the
     // gaps are closed by k_reorder_hits): single-diagonal queries (the common case for spacer peptides) are finished
     // lane-parallel, small ones in registers by the whole wave, the rest through LDS.
-    for (;;) {
-        const uint32_t chunk = popQueue(a.queue, lane);
-        if ((uint64_t) chunk * kSelChunk >= a.nq) break;
+    // No atomics: chunks are dealt round-robin to the waves (the work per chunk is even) and every query's output range is
+    // known beforehand (wantOff = exclusive scan of min(D, maxHits)); two contended counters cost more than the kernel's work.
+    const uint32_t nWaves = gridDim.x * kWavesPerBlock;
+    for (uint32_t chunk = blockIdx.x * kWavesPerBlock + w; (uint64_t) chunk * kSelChunk < a.nq; chunk += nWaves) {
         const uint32_t qi = chunk * kSelChunk + lane;
         const bool mine = lane < kSelChunk && qi < a.nq;
         const uint32_t D = mine ? a.qDiagCnt[qi] : 0;
-        const uint32_t want = min(D, (uint32_t) a.maxHits);
-        const uint32_t incl = waveInclusiveScan(want, lane);
-        const uint32_t total = lane63(incl);
-        uint32_t cb = 0;
-        if (total) cb = uni(atomicAdd(a.outCursor, lane == 0 ? total : 0u));
-        const uint32_t myBase = cb + incl - want;
+        const uint32_t myBase = mine ? a.wantOff[qi] : 0;
         const bool fast = (D == 1) && a.maxHits > 1;
         if (fast) {
             const uint32_t b = a.qDiagBase[qi];
@@ -910,6 +906,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_select(SelectArgs a) {
             else selectOne(a, chunk * kSelChunk + (uint32_t) bit, ob, s_hist[w], s_keys[w], scratch, lane);
         }
     }
+}
+
+__global__ void k_select_want(const uint32_t *qDiagCnt, uint32_t nq, uint32_t maxHits, uint32_t *want) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) want[q] = min(qDiagCnt[q], maxHits);
 }
 
 // query-ordered output: exclusive scan of the per-query hit counts (one block), then move the hits from the staging
@@ -1231,7 +1232,7 @@ struct Gpu::Impl {
     DevBuf<GpuHit> outHits; DevBuf<GpuHit> outStage; DevBuf<uint32_t> outQuery; DevBuf<uint32_t> outCount; DevBuf<uint32_t> outBase; DevBuf<uint32_t> outOffset;
     uint32_t matchBlocks = 0;
     size_t diagCap = 0;
-    DevBuf<unsigned char> scanTemp;
+    DevBuf<unsigned char> scanTemp; DevBuf<uint32_t> selWant, selWantOff;
     // exclusive scan of n counts into n + 1 offsets (offset[n] = total); count must have n + 1 readable entries.
     // Small inputs: one block (k_scan_counts); larger ones: rocPRIM's decoupled look-back scan.
     bool scanCounts(const uint32_t *count, uint32_t n, uint32_t *offset, std::string &err) {
@@ -1475,8 +1476,11 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     if (!d.outHits.ensure(nq_ * (size_t) maxHits, err) || !d.outStage.ensure(nq_ * (size_t) maxHits, err) || !d.outQuery.ensure(nq_ * (size_t) maxHits, err)) return false;
     if (!matchAndScore(kmerThr, false, err)) return false;
     const bool dbg = getenv("SP_DEBUG") != nullptr;
-    SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.queue.p + 2,
-                  binSize - 1, maxHits, minDiagScore, d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.queue.p + 3, d.counters.p};
+    if (!d.selWant.ensure(nq_ + 1, err) || !d.selWantOff.ensure(nq_ + 2, err)) return false;
+    hipLaunchKernelGGL(k_select_want, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.qDiagCnt.p, (uint32_t) nq_, (uint32_t) maxHits, d.selWant.p);
+    if (!d.scanCounts(d.selWant.p, (uint32_t) nq_, d.selWantOff.p, err)) return false;
+    SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.selWantOff.p,
+                  binSize - 1, maxHits, minDiagScore, d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.counters.p};
     hipLaunchKernelGGL(k_select, dim3(d.matchBlocks), dim3(64 * kWavesPerBlock), 0, d.stream, se);
     if (!d.scanCounts(d.outCount.p, (uint32_t) nq_, d.outOffset.p, err)) return false;
     hipLaunchKernelGGL(k_reorder_hits, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.outStage.p, d.outBase.p, d.outCount.p, d.outOffset.p, (uint32_t) nq_, d.outHits.p, d.outQuery.p);
