@@ -298,8 +298,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     SP_T_DECL
 
     // one atomic pops kQueryChunk queries: a single counter word serialises at ~12 ns per atomic (60 000 pops = 0.7 ms)
+    // hybrid work distribution: the first kStaticShare of the queries are dealt round-robin (no atomics), the rest are
+    // popped kQueryChunk at a time to even out the tail
+    const uint32_t nWavesTot = gridDim.x * kWavesPerBlock;
+    const uint32_t staticEnd = (uint32_t) ((uint64_t) a.nq * 3 / 4 / (nWavesTot * kQueryChunk)) * (nWavesTot * kQueryChunk);
+    uint32_t sNext = waveGlobal * kQueryChunk;
     for (uint32_t qc = 0, qcEnd = 0;;) {
-        if (qc == qcEnd) { qc = popQueue(a.queue, lane) * kQueryChunk; qcEnd = qc + kQueryChunk; if (qc >= a.nq) break; }
+        if (qc == qcEnd) {
+            if (sNext < staticEnd) { qc = sNext; sNext += nWavesTot * kQueryChunk; }
+            else qc = staticEnd + popQueue(a.queue, lane) * kQueryChunk;
+            qcEnd = qc + kQueryChunk;
+            if (qc >= a.nq) break;
+        }
         const uint32_t qi = qc++;
         if (qi >= a.nq) break;
         const uint32_t qo = uni(a.qoff[qi]);
