@@ -288,10 +288,13 @@ class SearchContext:
     def hits_compact(self):
         """(Hit array of all hits grouped by query, uint64 offsets[n_queries+1])"""
         total = int(self.L.sp_ctx_num_hits(self.ctx))
-        hits = (Hit * max(1, total))()
-        offs = (C.c_uint64 * (self.n_queries + 1))()
-        _check(self.L.sp_ctx_get_hits_compact(self.ctx, hits, offs))
-        return hits, offs, total
+        if getattr(self, "_hit_cap", 0) < total or getattr(self, "_hit_nq", -1) != self.n_queries:      # buffers are reused from call to call
+            self._hit_cap = total + total // 4 + 16
+            self._hit_nq = self.n_queries
+            self._hits = (Hit * self._hit_cap)()
+            self._hit_offs = (C.c_uint64 * (self.n_queries + 1))()
+        _check(self.L.sp_ctx_get_hits_compact(self.ctx, self._hits, self._hit_offs))
+        return self._hits, self._hit_offs, total
 
     def hits(self):
         hits, offs, _ = self.hits_compact()

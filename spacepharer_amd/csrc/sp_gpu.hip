@@ -1243,6 +1243,7 @@ struct Gpu::Impl {
     uint32_t matchBlocks = 0;
     size_t diagCap = 0;
     DevBuf<unsigned char> scanTemp; DevBuf<uint32_t> selWant, selWantOff;
+    unsigned long long *mailbox = nullptr;       // page-locked landing area for counters
     // exclusive scan of n counts into n + 1 offsets (offset[n] = total); count must have n + 1 readable entries.
     // Small inputs: one block (k_scan_counts); larger ones: rocPRIM's decoupled look-back scan.
     bool scanCounts(const uint32_t *count, uint32_t n, uint32_t *offset, std::string &err) {
@@ -1267,6 +1268,7 @@ Gpu::~Gpu() {
     if (d_) {
         if (d_->stream) (void) hipStreamDestroy(d_->stream);
         for (hipEvent_t e : d_->ev) if (e) (void) hipEventDestroy(e);
+        if (d_->mailbox) pinnedFree(d_->mailbox);
         delete d_;
     }
 }
@@ -1449,10 +1451,13 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
 // counters + HIP-event times after the selection kernels were queued (event 4 recorded)
 bool Gpu::finishPrefilter(bool matched, std::string &err) {
     Impl &d = *d_;
-    unsigned long long c[16]; uint32_t qv[8];
-    HIP_OK(hipMemcpyAsync(c, d.counters.p, sizeof(c), hipMemcpyDeviceToHost, d.stream));
-    HIP_OK(hipMemcpyAsync(qv, d.queue.p, sizeof(qv), hipMemcpyDeviceToHost, d.stream));
-    uint32_t totalHits = 0;      // k_scan_counts leaves the number of hits behind the last query's offset
+    // small results land in one page-locked mailbox (copies into pageable memory are staged one by one)
+    if (!d.mailbox) d.mailbox = static_cast<unsigned long long *>(pinnedAlloc(64 * sizeof(unsigned long long)));
+    unsigned long long *c = d.mailbox; uint32_t *qv = reinterpret_cast<uint32_t *>(d.mailbox + 16); uint32_t &totalHits = *reinterpret_cast<uint32_t *>(d.mailbox + 24);
+    totalHits = 0;
+    HIP_OK(hipMemcpyAsync(c, d.counters.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipMemcpyAsync(qv, d.queue.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    // the scan leaves the number of hits behind the last query's offset
     HIP_OK(hipMemcpyAsync(&totalHits, d.outOffset.p + nq_, sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipStreamSynchronize(d.stream));
     if (matched) { counters_.kmers = c[0]; counters_.dbMatches = c[1]; counters_.diagResidues = c[3]; counters_.diagonals = c[5]; }
