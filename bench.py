@@ -2,8 +2,10 @@
 """bench.py -- spacer-queries/s through prefilter+align on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
 A "step" is one pass of the hot path over one resident batch of synthetic spacer peptides:
-    k_prep -> k_match -> k_score -> k_select -> hit download -> SW forward -> E-value gate -> SW reverse + traceback
-with the target index / residues / similar-k-mer tables and the query batch already resident in HBM.
+    k_prep -> k_match -> k_score -> k_select -> SW forward -> E-value gate -> SW reverse + traceback -> record assembly
+with the target index / residues / similar-k-mer tables and the query batch already resident in HBM; both results (the
+prefilter hit list and the alignment records + backtraces) are delivered to host memory inside the step -- the hit list
+travels on a copy stream while the align kernels run.
 
 Workload (BASELINE.json configs[2], SURVEY.md section 8d "synthetic proxy"): 10 000 synthetic 30-nt spacers =
 60 000 peptides of 10 aa (even index: window of a target with one substitution, odd: background i.i.d.) against
@@ -198,10 +200,11 @@ def main():
             sharded_prefilter(ctx, q_from, q_to, device=gpu_dev)   # own shard -> RCCL all-gather -> selection on the union
         else:
             ctx.prefilter()
-        hits, offs, npairs = ctx.hits_compact()           # prefilter result DB content (hit_t triples per query)
+        npairs = ctx.num_hits()
         if args.stage == "full" and npairs:
             ctx.align_hits_raw()                          # alignment result DB content (result_t + backtraces per hit)
-        return npairs
+        ctx.hits_compact()                                # prefilter result DB content (hit_t triples per query); its copy to
+        return npairs                                     # the host started when the prefilter finished and overlapped align
 
     def barrier():
         if dist is not None:

@@ -278,6 +278,9 @@ class SearchContext:
     def prefilter(self):
         _check(self.L.sp_ctx_prefilter(self.ctx))
 
+    def num_hits(self):
+        return int(self.L.sp_ctx_num_hits(self.ctx))
+
     def hits_raw(self):
         ms = self.L.sp_ctx_max_seqs(self.ctx)
         hits = (Hit * (max(1, self.n_queries * ms)))()

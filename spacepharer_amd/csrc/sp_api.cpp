@@ -56,7 +56,6 @@ struct sp_ctx {
     bool tablesUp = false;
     sp::GateTable gate; bool gateValid = false; uint64_t gateSerial = 0;    // E-value tables of the resident query batch / target set
     sp::AlignHost alnHost;                                 // pinned staging, reused; declared last = released before the device context
-    sp::PinVec<sp::GpuHit> hitStage; sp::PinVec<uint32_t> hitOffStage;
 };
 
 static uint64_t fnv1a(const void *p, size_t n, uint64_t h);
@@ -250,17 +249,18 @@ int sp_ctx_merge_candidates(sp_ctx *c, const sp_candidate *cands, uint64_t n, in
 uint64_t sp_ctx_num_hits(const sp_ctx *c) { return (uint64_t) c->gpu.counters().hits; }
 
 int sp_ctx_get_hits_compact(sp_ctx *c, sp_hit *hits, uint64_t *offsets) {
-    sp::PinVec<sp::GpuHit> &h = c->hitStage; sp::PinVec<uint32_t> &off = c->hitOffStage; std::string err;
-    if (!c->gpu.downloadHits(h, off, err)) { g_err = err; return SP_ERR_DEVICE; }
-    for (size_t q = 0; q < off.size(); q++) offsets[q] = off[q];
-    for (size_t i = 0; i < h.size(); i++) { hits[i].seq_id = h[i].seqId; hits[i].score = h[i].score; hits[i].diagonal = (int16_t) h[i].diag; hits[i].pad = 0; }
+    const sp::GpuHit *h = nullptr; const uint32_t *off = nullptr; size_t n = 0; std::string err;
+    if (!c->gpu.hostHits(h, off, n, err)) { g_err = err; return SP_ERR_DEVICE; }
+    const size_t nq = c->gpu.numQueries();
+    for (size_t q = 0; q <= nq; q++) offsets[q] = off[q];
+    for (size_t i = 0; i < n; i++) { hits[i].seq_id = h[i].seqId; hits[i].score = h[i].score; hits[i].diagonal = (int16_t) h[i].diag; hits[i].pad = 0; }
     return SP_OK;
 }
 
 int sp_ctx_get_hits(sp_ctx *c, sp_hit *hits, uint32_t *counts) {
-    sp::PinVec<sp::GpuHit> &h = c->hitStage; sp::PinVec<uint32_t> &off = c->hitOffStage; std::string err;
-    if (!c->gpu.downloadHits(h, off, err)) { g_err = err; return SP_ERR_DEVICE; }
-    const size_t nq = off.size() - 1; const int mh = c->gpu.maxHits();
+    const sp::GpuHit *h = nullptr; const uint32_t *off = nullptr; size_t n = 0; std::string err;
+    if (!c->gpu.hostHits(h, off, n, err)) { g_err = err; return SP_ERR_DEVICE; }
+    const size_t nq = c->gpu.numQueries(); const int mh = c->gpu.maxHits();
     for (size_t q = 0; q < nq; q++) {
         counts[q] = (uint32_t) (off[q + 1] - off[q]);
         for (uint64_t i = off[q]; i < off[q + 1]; i++) {

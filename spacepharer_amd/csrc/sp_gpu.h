@@ -100,7 +100,7 @@ public:
     bool downloadCandidates(Candidate *out, std::string &err);
     bool mergeCandidates(const Candidate *src, size_t n, bool onDevice, size_t qFrom, size_t qTo, unsigned binSize, int maxHits, int minDiagScore, std::string &err);
     // hits grouped by query (query order); offsets has nq+1 entries
-    bool downloadHits(PinVec<GpuHit> &hits, PinVec<uint32_t> &offsets, std::string &err);
+    bool hostHits(const GpuHit *&hits, const uint32_t *&offsets, size_t &n, std::string &err);
     PrefilterCounters counters() const { return counters_; }
     KernelTimes times() const { return times_; }
     int maxHits() const { return maxHits_; }
@@ -129,6 +129,7 @@ public:
     void *stream() const { return stream_; }
 
 private:
+    bool prefetchHits(std::string &err);
     bool matchAndScore(int kmerThr, bool withOrd, std::string &err);
     bool finishPrefilter(bool matched, std::string &err);
     struct Impl;

@@ -1244,6 +1244,10 @@ struct Gpu::Impl {
     size_t diagCap = 0;
     DevBuf<unsigned char> scanTemp; DevBuf<uint32_t> selWant, selWantOff;
     unsigned long long *mailbox = nullptr;       // page-locked landing area for counters
+    // the hit list starts travelling to the host on its own stream as soon as a prefilter pass is complete, so that the copy
+    // overlaps whatever the caller queues next (typically the align kernels)
+    hipStream_t copyStream = nullptr; hipEvent_t hitsOnHost = nullptr;
+    PinVec<GpuHit> hitStage; PinVec<uint32_t> hitOffStage; bool hitsInFlight = false;
     // exclusive scan of n counts into n + 1 offsets (offset[n] = total); count must have n + 1 readable entries.
     // Small inputs: one block (k_scan_counts); larger ones: rocPRIM's decoupled look-back scan.
     bool scanCounts(const uint32_t *count, uint32_t n, uint32_t *offset, std::string &err) {
@@ -1269,6 +1273,9 @@ Gpu::~Gpu() {
         if (d_->stream) (void) hipStreamDestroy(d_->stream);
         for (hipEvent_t e : d_->ev) if (e) (void) hipEventDestroy(e);
         if (d_->mailbox) pinnedFree(d_->mailbox);
+        if (d_->copyStream) { (void) hipStreamSynchronize(d_->copyStream); (void) hipStreamDestroy(d_->copyStream); }
+        if (d_->hitsOnHost) (void) hipEventDestroy(d_->hitsOnHost);
+        d_->hitStage = PinVec<GpuHit>(); d_->hitOffStage = PinVec<uint32_t>();
         delete d_;
     }
 }
@@ -1285,6 +1292,8 @@ bool Gpu::init(int device, std::string &err) {
     name_ = prop.name;
     d_->numCU = prop.multiProcessorCount;
     HIP_OK(hipStreamCreateWithFlags(&d_->stream, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&d_->copyStream, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&d_->hitsOnHost, hipEventDisableTiming));
     for (hipEvent_t &e : d_->ev) HIP_OK(hipEventCreate(&e));
     stream_ = d_->stream;
     return true;
@@ -1462,6 +1471,7 @@ bool Gpu::finishPrefilter(bool matched, std::string &err) {
     HIP_OK(hipStreamSynchronize(d.stream));
     if (matched) { counters_.kmers = c[0]; counters_.dbMatches = c[1]; counters_.diagResidues = c[3]; counters_.diagonals = c[5]; }
     counters_.overflowQueries = c[2]; counters_.hits = totalHits;
+    d.hitsInFlight = false;
     d.nCand = qv[4];
 #ifdef SP_PHASE_TIMERS
     if (matched) {
@@ -1501,7 +1511,7 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     hipLaunchKernelGGL(k_reorder_hits, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.outStage.p, d.outBase.p, d.outCount.p, d.outOffset.p, (uint32_t) nq_, d.outHits.p, d.outQuery.p);
     SP_DBG_SYNC("k_select");
     HIP_OK(hipEventRecord(d.ev[4], d.stream));
-    return finishPrefilter(true, err);
+    return finishPrefilter(true, err) && prefetchHits(err);
 }
 
 // sharded search, step 1: this shard's candidates (per query and target the best double-hit diagonal with score >= min)
@@ -1569,7 +1579,7 @@ bool Gpu::mergeCandidates(const Candidate *src, size_t n, bool onDevice, size_t 
     hipLaunchKernelGGL(k_reorder_hits, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.outStage.p, d.outBase.p, d.outCount.p, d.outOffset.p, (uint32_t) nq_, d.outHits.p, d.outQuery.p);
     SP_DBG_SYNC("k_select_merged");
     HIP_OK(hipEventRecord(d.ev[4], d.stream));
-    return finishPrefilter(false, err);
+    return finishPrefilter(false, err) && prefetchHits(err);
 }
 
 bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &seed, int kmerThr, bool mask, bool index, size_t from, size_t to,
@@ -1709,15 +1719,27 @@ void *pinnedAlloc(size_t bytes) {
 }
 void pinnedFree(void *p) { if (p) (void) hipHostFree(p); }
 
-bool Gpu::downloadHits(PinVec<GpuHit> &hits, PinVec<uint32_t> &offsets, std::string &err) {
+// start copying the (final) hit list of the pass that just completed; called with the main stream idle
+bool Gpu::prefetchHits(std::string &err) {
     Impl &d = *d_;
-    offsets.resize(nq_ + 1);
-    offsets[0] = 0;
-    hits.resize((size_t) counters_.hits);
-    if (nq_ == 0) return true;
-    HIP_OK(hipMemcpyAsync(offsets.data(), d.outOffset.p, (nq_ + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
-    if (!hits.empty()) HIP_OK(hipMemcpyAsync(hits.data(), d.outHits.p, hits.size() * sizeof(GpuHit), hipMemcpyDeviceToHost, d.stream));
-    HIP_OK(hipStreamSynchronize(d.stream));
+    if (d.hitsInFlight) (void) hipEventSynchronize(d.hitsOnHost);      // the staging buffers are about to be rewritten
+    d.hitOffStage.resize(nq_ + 1);
+    d.hitStage.resize((size_t) counters_.hits);
+    if (nq_ == 0) { d.hitsInFlight = false; return true; }
+    HIP_OK(hipMemcpyAsync(d.hitOffStage.data(), d.outOffset.p, (nq_ + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, d.copyStream));
+    if (!d.hitStage.empty()) HIP_OK(hipMemcpyAsync(d.hitStage.data(), d.outHits.p, d.hitStage.size() * sizeof(GpuHit), hipMemcpyDeviceToHost, d.copyStream));
+    HIP_OK(hipEventRecord(d.hitsOnHost, d.copyStream));
+    d.hitsInFlight = true;
+    return true;
+}
+
+// hits of the last pass grouped by query: offsets[nq + 1]; the pointers stay valid until the next pass
+bool Gpu::hostHits(const GpuHit *&hits, const uint32_t *&offsets, size_t &n, std::string &err) {
+    Impl &d = *d_;
+    if (!d.hitsInFlight && !prefetchHits(err)) return false;
+    if (d.hitsInFlight) HIP_OK(hipEventSynchronize(d.hitsOnHost));
+    if (d.hitOffStage.empty()) d.hitOffStage.assign(1, 0);
+    hits = d.hitStage.data(); offsets = d.hitOffStage.data(); n = d.hitStage.size();
     return true;
 }
 
