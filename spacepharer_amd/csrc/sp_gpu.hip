@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     __shared__ uint16_t s_cntB[kWavesPerBlock][kCntW];
     __shared__ uint32_t s_bits[kWavesPerBlock][kHitCap / 32];
     __shared__ uint32_t s_occ[kWavesPerBlock][kSuper];
-    __shared__ uint32_t s_stamp[kWavesPerBlock][64];
+    __shared__ unsigned long long s_hflag[kWavesPerBlock][kSuper / 64];
 
     const int lane = laneId();
     const int w = (int) (threadIdx.x >> 6);
@@ -284,11 +284,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     uint16_t *cntB = s_cntB[w];
     uint32_t *bitsL = s_bits[w];
     uint32_t *occList = s_occ[w];
-    uint32_t *stamp = s_stamp[w];
+    unsigned long long *hflag = s_hflag[w];
     uint16_t *occOrd = s_occOrd[w];
     uint32_t *ordL = s_ordL[w];
-    stamp[lane] = 0;
-    uint32_t stampId = 0;
     const uint32_t waveGlobal = blockIdx.x * kWavesPerBlock + w;
     uint64_t *spillKeys = a.spill + (size_t) waveGlobal * kSpillWordsPerWave;
     uint32_t *spillBits = (uint32_t *) (spillKeys + 65536);
@@ -369,7 +367,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
             bool lastTile = false;
             for (uint32_t a0 = 0; a0 < 8000u && !lastTile; a0 += kATile) {
                 uint32_t tileK = 0, nATile = kATile;
-                uint32_t vA[kATile / 64];
+                uint32_t vA[kATile / 64], nbR[kATile / 64], aStR[kATile / 64];
+#pragma unroll
+                for (int j = 0; j < kATile / 64; j++) { nbR[j] = 0; aStR[j] = 0; }
 #pragma unroll
                 for (int j = 0; j < kATile / 64; j++) { const uint32_t ai = a0 + j * 64 + lane; vA[j] = a0 == 0 ? vA0[j] : (ai < 8000u ? rowA[ai] : 0u); }
 #pragma unroll
@@ -381,6 +381,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                     uint32_t nb = 0;
                     if (ok) { int at = (short) (thr - s) - a.cntMin; at = at < 0 ? 0 : (at >= kCntW ? kCntW - 1 : at); nb = cntB[at]; }
                     const uint32_t incl = waveInclusiveScan(nb, lane);
+                    nbR[j] = nb; aStR[j] = tileK + incl - nb;
                     aStart[j * 64 + lane] = tileK + incl - nb;
                     aIdx[j * 64 + lane] = (uint16_t) extIndex(v);
                     tileK += lane63(incl);
@@ -391,11 +392,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                 waveSync();
                 if (kBase + tileK > kMaxKmerResult - 1) { tileK = kMaxKmerResult - 1 - kBase; lastTile = true; }
                 SP_T(2);
-                // Flattened (a, b) enumeration, 64 similar k-mers per round.  Lane L owns k = k0 + L and needs the largest a
-                // with aStart[a] <= k.  The a's are consecutive and every a contributes >= 1 k-mer, so the a's that START
-                // inside this round are aCur+1 .. aCur+63 at most: lane j looks at candidate aCur+1+j, the start positions
-                // are OR-reduced into a 64-bit mask and a popcount below the own position gives the offset -- no search.
-                uint32_t aCur = 0;
+                // Flattened (a, b) enumeration, 64 similar k-mers per round.  Lane L owns position k = k0 + L of the list and
+                // needs the largest a with aStart[a] <= k.  Every a contributes >= 1 k-mer, so a(k) = (number of list starts at
+                // positions <= k) - 1: the lanes that own the a's set one bit per start in a 1024-bit map in LDS, each round
+                // broadcasts its 64-bit word of the map through a register lane, and a popcount gives the a -- no search and no
+                // LDS round trip per round.
                 // Enumeration in super-rounds of 1024 similar k-mers so that memory round trips are paid per 1024, not per 64:
                 //   phase 1: map the 16 x 64 flattened positions to k-mer ids (registers), fetch their probe words with 16
                 //            independent loads, compact the ranks of the occupied slots (14 % for a phage-scale index) into LDS
@@ -403,6 +404,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                 //   phase 2: 256 occupied slots at a time: 4 independent slot-word loads per lane; one-entry lists are
                 //            finished by that load, longer lists walk the entry array
                 for (uint32_t s0 = 0; s0 < tileK; s0 += kSuper) {
+                    if (lane < kSuper / 64) hflag[lane] = 0ull;
+                    waveSync();
+                    uint32_t aBefore = 0;
+#pragma unroll
+                    for (int j = 0; j < kATile / 64; j++) {
+                        const uint32_t pos = aStR[j] - s0;
+                        if (nbR[j] > 0 && pos < (uint32_t) kSuper) atomicOr(&hflag[pos >> 6], 1ull << (pos & 63u));
+                        aBefore += (uint32_t) __popcll(__ballot(nbR[j] > 0 && aStR[j] < s0));
+                    }
+                    waveSync();
+                    const unsigned long long myW = lane < kSuper / 64 ? hflag[lane] : 0ull;
+                    uint32_t carry = 0;
                     uint32_t kmerR[kSuper / 64];
 #pragma unroll
                     for (int r = 0; r < kSuper / 64; r++) {
@@ -410,15 +423,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                         kmerR[r] = 0xFFFFFFFFu;
                         if (kr0 < tileK) {
                             const uint32_t k = kr0 + lane;
-                            // which of the 64 positions of this round start a new a?  candidates aCur+1+lane stamp their start
-                            // position in LDS, every lane then reads the stamp of its own position, a ballot gives the mask
-                            const uint32_t cand = aCur + 1u + (uint32_t) lane;
-                            stampId++;
-                            if (cand < nATile) { const uint32_t st = aStart[cand]; if (st - kr0 < 64u) stamp[st - kr0] = stampId; }
-                            waveSync();
-                            const unsigned long long startBit = __ballot(stamp[lane] == stampId);
-                            const uint32_t ai = aCur + (uint32_t) __popcll(startBit & (~0ull >> (63 - lane)));
-                            aCur = aCur + (uint32_t) __popcll(startBit);            // a of the last position of this round
+                            const unsigned long long word = ((unsigned long long) (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (myW >> 32), r) << 32) |
+                                                            (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) myW, r);
+                            const uint32_t ai = aBefore + carry + (uint32_t) __popcll(word & (~0ull >> (63 - lane))) - 1u;
+                            carry += (uint32_t) __popcll(word);
                             if (k < tileK) {
                                 const uint32_t bb = k - aStart[ai];
                                 const uint32_t bi = (bb < (uint32_t) kBTile) ? bIdx[bb] : extIndex(rowB[bb]);
