@@ -1420,6 +1420,7 @@ bool Gpu::uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std:
 bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     Impl &d = *d_;
     if (!d.ext3.p || !d.pbits.p) { err = "tables/targets not resident"; return false; }
+    if (d.hitsInFlight) { (void) hipEventSynchronize(d.hitsOnHost); d.hitsInFlight = false; }     // the previous pass's hit list is still being copied
     // persistent match grid: as many blocks per CU as the LDS footprint of the chosen hit-buffer size admits.
     // Expected hits per query ~ (similar k-mers per query) x (index entries per k-mer slot); keep 4x headroom.
     int hitCap = ((double) d.indexEntries / (double) kTableSize * 1300.0 * 2.5 < 512.0) ? 512 : 2048;
@@ -1558,6 +1559,7 @@ bool Gpu::mergeCandidates(const Candidate *src, size_t n, bool onDevice, size_t 
     Impl &d = *d_;
     if (nq_ == 0) return true;
     if (!d.qbias.p || !d.queue.p) { err = "mergeCandidates: run prefilterCandidates() on this query batch first"; return false; }
+    if (d.hitsInFlight) { (void) hipEventSynchronize(d.hitsOnHost); d.hitsInFlight = false; }
     if (n >= (1ull << 32)) { err = "mergeCandidates: more than 2^32 candidates"; return false; }
     qTo = std::min(qTo, nq_); qFrom = std::min(qFrom, qTo);
     maxHits_ = maxHits;
