@@ -133,10 +133,15 @@ def pmc_traffic(kernel):
     if not files:
         return None, None
     try:
-        k = json.load(open(files[-1]))["kernels"][kernel]
+        doc = json.load(open(files[-1]))
+        k = doc["kernels"][kernel]
+        pmc_traffic.measured_stream = doc.get("streaming_read_of_1GiB")
         return k["fetch_bytes_corrected"] + k.get("write_bytes_raw", 0.0), "profiles/" + os.path.basename(files[-1])
     except (KeyError, ValueError):
         return None, None
+
+
+pmc_traffic.measured_stream = None
 
 
 def main():
@@ -260,7 +265,8 @@ def main():
         "counters_per_step": {"similar_kmers": K, "index_entries_fetched": M, "diagonals_scored": D, "diag_residues": R, "hits": H},
         "roofline": {"bound": "hbm", "kernel": "k_match", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": traffic,
-                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes},
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
+                     "measured_streaming_read_GBps": pmc_traffic.measured_stream},
     }
     if args.cpu_sample > 0 and world == 1:      # rank 0 at N = 1 only
         # the reference itself when its harness travelled with the repo (oracle/_ref, built by __graft_entry__.build()), else

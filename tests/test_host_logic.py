@@ -104,3 +104,21 @@ def test_host_evalues(lib):
         assert lib.sp_host_evalue(b"VTML40.out", -1, -1, r["aaDbSize"], float(s), float(ql), C.byref(e), C.byref(b)) == 0
         assert (e.value, b.value) == (evg, bitsg)
     assert lib.sp_host_evalue(b"VTML40.out", 11, 1, 1000, 10.0, 10.0, C.byref(e), C.byref(b)) != 0   # untabulated combination: loud failure
+
+
+def test_bench_reads_the_committed_counter_summary():
+    """bench.py takes roofline.traffic from the newest profiles/rNN_pmc_traffic.json: the file must parse and carry the
+    calibration the DESIGN describes (FETCH_SIZE counts half of a streaming read on gfx950)"""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    traffic, src = bench.pmc_traffic("k_match")
+    assert traffic and src.startswith("profiles/r")
+    doc = json.load(open(os.path.join(ROOT, src)))
+    cal = doc["calibration_factor_known_over_counted"]
+    assert 1.9 < cal["4B_per_lane"] < 2.1 and 1.9 < cal["16B_per_lane"] < 2.1
+    k = doc["kernels"]["k_match"]
+    assert abs(traffic - (k["fetch_bytes_corrected"] + k["write_bytes_raw"])) < 1.0
+    assert 0.5e9 < traffic < 20e9

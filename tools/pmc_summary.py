@@ -48,9 +48,13 @@ def main():
     for width, name in ((4, "k_diag_read<4B>"), (16, "k_diag_read<16B>")):
         if name in res and "FETCH_SIZE" in res[name]:
             calib["%dB_per_lane" % width] = GIB / (res[name]["FETCH_SIZE"] * 1024.0)
+    stream = {}
+    for width, name in ((4, "k_diag_read<4B>"), (16, "k_diag_read<16B>")):
+        if name in res and res[name].get("mean_us_under_pmc"):
+            stream["%dB_per_lane_GBps" % width] = GIB / (res[name]["mean_us_under_pmc"] * 1e-6) / 1e9
     f4 = calib.get("4B_per_lane", 1.0)
     summary = {"source": paths, "unit_note": "FETCH_SIZE/WRITE_SIZE in KiB as printed by rocprofv3; *_bytes fields are bytes per launch",
-               "calibration_factor_known_over_counted": calib, "kernels": res}
+               "calibration_factor_known_over_counted": calib, "streaming_read_of_1GiB": stream, "kernels": res}
     for k in res:
         if "FETCH_SIZE" in res[k] and not k.startswith("k_diag"):
             res[k]["fetch_bytes_raw"] = res[k]["FETCH_SIZE"] * 1024.0
