@@ -117,3 +117,49 @@ def test_align_hits_equals_align_pairs():
         if b.aln_len:
             assert C.string_at(C.addressof(cig) + b.cigar_offset).decode() == c1
     ctx.close()
+
+
+def test_packed_sw_kernel_byte_overflow_and_ragged_groups():
+    """the 4-alignments-per-wave kernel on awkward material: W/C-rich 20-32 aa queries whose perfect matches overflow the
+    8-bit pass (score + bias >= 255 -> 16-bit redo, mixed byte/word lists in the reverse pass), queries of very different
+    lengths side by side in one wave, targets shorter than a 32-column chunk, and a pair count that is not a multiple of 4"""
+    import random
+    from oracle_lib import Alp, Oracle
+    import spacepharer_amd as sa
+    g = load_golden("spacer")["ref"]
+    rnd = random.Random(4242)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    T, Q = [], []
+    for i in range(60):                       # heavy queries + targets that contain them (exact, or with an insertion / deletion)
+        L = rnd.choice([20, 24, 28, 32])
+        q = "".join(rnd.choice("WWWCCYFHM" if rnd.random() < 0.8 else aa) for _ in range(L))
+        Q.append(q)
+        left, right = ("".join(rnd.choice(aa) for _ in range(rnd.randint(0, 40))) for _ in range(2))
+        T.append(left + q + right)
+        T.append(left + q[:L // 2] + rnd.choice(aa) + q[L // 2:] + right)
+        T.append(q[2:L - 3])                  # shorter than the query
+    for i in range(45):                       # short ordinary queries in between
+        q = "".join(rnd.choice(aa) for _ in range(rnd.randint(9, 12)))
+        Q.insert(rnd.randrange(len(Q)), q)
+        T.append("".join(rnd.choice(aa) for _ in range(rnd.randint(5, 31))) + q + "".join(rnd.choice(aa) for _ in range(rnd.randint(0, 9))))
+    o = Oracle()
+    o.set_targets(T)
+    o.set_alp(Alp.from_ref(g["alpGapped"]), Alp.from_ref(g["alpGapless"]))
+    ctx = sa.SearchContext()
+    ctx.set_targets(T)
+    ctx.set_queries(Q)
+    pairs = [(qi, ti) for qi in range(len(Q)) for ti in range(len(T)) if rnd.random() < 0.08]
+    pairs += [(qi, ti) for qi, q in enumerate(Q) for ti, t in enumerate(T) if q in t]
+    if len(pairs) % 4 == 0:
+        pairs.append((0, 0))
+    got = ctx.align(pairs)
+    word = 0
+    for (qi, ti), (res, cig) in zip(pairs, got):
+        e = o.align(Q[qi], ti)
+        assert (res.raw_score, res.bit_score, res.q_end, res.db_end, res.passed) == (e.rawScore, e.score, e.qEndPos, e.dbEndPos, e.passed), (qi, ti)
+        if e.passed:
+            assert (res.q_start, res.db_start, res.aln_len, res.evalue, cig) == (e.qStartPos, e.dbStartPos, e.alnLength, e.eval, e.backtrace.decode()), (qi, ti)
+        word += e.rawScore >= 240
+    assert word >= 8             # the 16-bit redo path really ran
+    ctx.close()
+    o.close()
