@@ -35,10 +35,14 @@ BG = np.array([0.0819, 0.0169, 0.0453, 0.0616, 0.0465, 0.0745, 0.0217, 0.0549, 0
 BG = BG / BG.sum()
 
 
-def make_workload(n_spacers, n_targets, target_len, seed):
+def make_workload(n_spacers, n_targets, target_len, seed, query_seed=None):
+    """targets from `seed`; queries (half of them planted from THOSE targets) from `query_seed` (None: continue the target
+    stream, the single-GPU workload) -- so every rank of a multi-GPU run searches its own spacers against the same phages"""
     rng = np.random.default_rng(seed)
     tres = AA[rng.choice(20, size=n_targets * target_len, p=BG)]
     toff = np.arange(n_targets + 1, dtype=np.uint64) * np.uint64(target_len)
+    if query_seed is not None:
+        rng = np.random.default_rng(query_seed)
     nq, ql = 6 * n_spacers, 10
     q = AA[rng.choice(20, size=nq * ql, p=BG)].reshape(nq, ql)
     tid = rng.integers(0, n_targets, size=nq)
@@ -180,9 +184,8 @@ def main():
     if sharded:
         tres, toff, qres, qoff = make_workload(args.spacers, args.targets, args.target_len, 12345)
     else:
-        tres, toff, qres, qoff = make_workload(args.spacers, args.targets, args.target_len, 12345 + 7919 * rank)
-        if rank != 0:   # same target set on every rank, different spacers
-            tres, toff, _, _ = make_workload(1, args.targets, args.target_len, 12345)
+        # same target set on every rank; rank r > 0 searches its own spacers (planted from the common targets)
+        tres, toff, qres, qoff = make_workload(args.spacers, args.targets, args.target_len, 12345, None if rank == 0 else 12345 + 7919 * rank)
     ctx = sa.SearchContext(device_mask=1 << local_rank)
     nq = len(qoff) - 1
     q_from, q_to = 0, nq
