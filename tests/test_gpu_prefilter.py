@@ -92,3 +92,27 @@ def test_degenerate_targets_and_queries_against_oracle():
     assert total > 50
     ctx.close()
     o.close()
+
+
+def test_empty_batches_and_no_hit_batches():
+    """zero queries, queries that hit nothing, an align call without hits: nothing to do must not be an error"""
+    import spacepharer_amd as sa
+    from golden.make_golden import make_case
+    T, Q = make_case(seed=5150, n_targets=100, n_queries=10, tmin=30, tmax=80, qmin=9, qmax=12)
+    ctx = sa.SearchContext()
+    ctx.set_targets(T)
+    ctx.set_queries([])
+    ctx.prefilter()
+    assert ctx.hits() == [] and ctx.num_hits() == 0
+    ctx.set_queries(["WWWWWWWWWW", "CCCCCCCCCC", "", "AC"])
+    ctx.prefilter()
+    assert ctx.hits() == [[], [], [], []]
+    aln, cig, n = ctx.align_hits_raw()
+    assert n == 0
+    assert ctx.align([]) == []
+    ctx.set_queries(Q)              # and the context still works afterwards
+    ctx.prefilter()
+    assert ctx.num_hits() > 0
+    aln, cig, n = ctx.align_hits_raw()
+    assert n == ctx.num_hits()
+    ctx.close()
