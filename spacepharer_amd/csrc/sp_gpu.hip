@@ -510,10 +510,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
         }
         matchesTotal += M;
         if (M > (uint32_t) kSpillCap) { overflow = true; M = 0; }
-        const bool spilled = M > (uint32_t) kHitCap;
-
         uint32_t D = 0, dbase = 0;
-        if (M > 0 && M <= (uint32_t) kHitCap) {
+        if (M > 0) {
             // Cheap exact pre-filter before the sort: a target hit only once in this query can only be recorded when its
             // 8-bit diagonal is 0 (previous := 0).  Count hits per hashed target in LDS, keep hits whose bucket saw >= 2
             // hits or whose diag8 == 0; bucket collisions merely let a few extra hits through to the exact automaton.
@@ -522,20 +520,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
             waveSync();
             constexpr int kHashShift = 32 - 10;                        // 1024 buckets (kSuper == 1024)
             static_assert(kSuper == 1024, "hash pre-filter uses kSuper counters");
-            for (uint32_t t = lane; t < M; t += 64) atomicAdd(&hcnt[((uint32_t) (keys[t] >> 32) * 2654435761u) >> kHashShift], 1u);
+            // (hits beyond the LDS buffer live in the per-wave HBM scratch; the survivors usually fit LDS again)
+            auto keyAt = [&](uint32_t t) -> uint64_t { return t < (uint32_t) kHitCap ? keys[t] : spillKeys[t]; };
+            for (uint32_t t = lane; t < M; t += 64) atomicAdd(&hcnt[((uint32_t) (keyAt(t) >> 32) * 2654435761u) >> kHashShift], 1u);
             waveSync();
             uint32_t wr = 0;
             for (uint32_t base = 0; base < M; base += 64) {
                 const uint32_t t = base + lane;
-                const uint64_t k = t < M ? keys[t] : 0ull;
+                const uint64_t k = t < M ? keyAt(t) : 0ull;
                 const bool keep = t < M && (hcnt[((uint32_t) (k >> 32) * 2654435761u) >> kHashShift] >= 2u || (k & 0xFF) == 0);
                 const uint64_t m = __ballot(keep);
-                if (keep) keys[wr + (uint32_t) __popcll(m & laneMaskLt(lane))] = k;
+                if (keep) { const uint32_t at = wr + (uint32_t) __popcll(m & laneMaskLt(lane)); if (at < (uint32_t) kHitCap) keys[at] = k; else spillKeys[at] = k; }
                 wr += (uint32_t) __popcll(m);
             }
             waveSync();
             M = wr;
         }
+        const bool spilled = M > (uint32_t) kHitCap;
         // reserve room for D diagonal records: kDiagChunk at a time per wave (one atomic per query on a single word would
         // serialise); unused slots of a chunk stay marked invalid (diagQuery == ~0)
         auto reserve = [&](uint32_t need) {
