@@ -222,6 +222,7 @@ struct MatchArgs {
     // target-sharded search only (kOrd): ordinal of the similar k-mer that produced the recording hit, counted over the
     // query's whole k-mer enumeration -- identical on every shard, so (ordinal, seqId) orders records globally
     uint32_t *diagOrd; uint32_t *spillOrd;
+    uint32_t staticEighths, dynChunk;   // work distribution: share of the queries dealt round-robin, queries per atomic pop for the rest
 };
 
 // phase timers (build with -DSP_PHASE_TIMERS): shader-clock ticks per phase, summed over waves into counters[8 + phase]
@@ -296,16 +297,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     SP_T_DECL
 
     // one atomic pops kQueryChunk queries: a single counter word serialises at ~12 ns per atomic (60 000 pops = 0.7 ms)
-    // hybrid work distribution: the first kStaticShare of the queries are dealt round-robin (no atomics), the rest are
-    // popped kQueryChunk at a time to even out the tail
+    // hybrid work distribution: the first staticEighths / 8 of the queries are dealt round-robin (no atomics), the rest are
+    // popped dynChunk at a time to even out the tail (half / 4 measured best on the spacer workload: SP_MATCH_STATIC, SP_MATCH_DCHUNK)
     const uint32_t nWavesTot = gridDim.x * kWavesPerBlock;
-    const uint32_t staticEnd = (uint32_t) ((uint64_t) a.nq * 3 / 4 / (nWavesTot * kQueryChunk)) * (nWavesTot * kQueryChunk);
+    const uint32_t staticEnd = (uint32_t) ((uint64_t) a.nq * a.staticEighths / 8 / (nWavesTot * kQueryChunk)) * (nWavesTot * kQueryChunk);
     uint32_t sNext = waveGlobal * kQueryChunk;
     for (uint32_t qc = 0, qcEnd = 0;;) {
         if (qc == qcEnd) {
-            if (sNext < staticEnd) { qc = sNext; sNext += nWavesTot * kQueryChunk; }
-            else qc = staticEnd + popQueue(a.queue, lane) * kQueryChunk;
-            qcEnd = qc + kQueryChunk;
+            if (sNext < staticEnd) { qc = sNext; sNext += nWavesTot * kQueryChunk; qcEnd = qc + kQueryChunk; }
+            else { qc = staticEnd + popQueue(a.queue, lane) * a.dynChunk; qcEnd = qc + a.dynChunk; }
             if (qc >= a.nq) break;
         }
         const uint32_t qi = qc++;
@@ -1453,7 +1453,8 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     HIP_OK(hipEventRecord(d.ev[1], d.stream));
     MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.pbits.p, d.prank.p, d.prow.p, d.slots.p, d.ientries.p, d.spill.p, d.queue.p,
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
-                 withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr};
+                 withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
+                 (uint32_t) (getenv("SP_MATCH_STATIC") ? atoi(getenv("SP_MATCH_STATIC")) : 4), (uint32_t) (getenv("SP_MATCH_DCHUNK") ? std::max(1, atoi(getenv("SP_MATCH_DCHUNK"))) : 4)};
     if (hitCap == 512) { if (withOrd) hipLaunchKernelGGL((k_match<512, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
                          else hipLaunchKernelGGL((k_match<512, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma); }
     else { if (withOrd) hipLaunchKernelGGL((k_match<2048, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
