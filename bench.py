@@ -4,8 +4,9 @@
 A "step" is one pass of the hot path over one resident batch of synthetic spacer peptides:
     k_prep -> k_match -> k_score -> k_select -> SW forward -> E-value gate -> SW reverse + traceback -> record assembly
 with the target index / residues / similar-k-mer tables and the query batch already resident in HBM; both results (the
-prefilter hit list and the alignment records + backtraces) are delivered to host memory inside the step -- the hit list
-travels on a copy stream while the align kernels run.
+prefilter hit list and the alignment records + backtraces) are delivered to host memory -- the hit list travels on a copy
+stream while the align kernels run, the alignment records while the NEXT step's prefilter runs (sp_ctx_align_hits_begin /
+_end); the last step's records are collected before the closing barrier, so all K steps complete inside the timed region.
 
 Workload (BASELINE.json configs[2], SURVEY.md section 8d "synthetic proxy"): 10 000 synthetic 30-nt spacers =
 60 000 peptides of 10 aa (even index: window of a target with one substitution, odd: background i.i.d.) against
@@ -210,11 +211,13 @@ def main():
             ctx.prefilter()
         npairs = ctx.num_hits()
         if args.stage == "full" and npairs:
-            ctx.align_hits_raw()                          # alignment result DB content (result_t + backtraces per hit)
+            ctx.align_hits_begin()                        # alignment result DB content (result_t + backtraces per hit): returns when
+                                                          # the kernels are done, the 5 MB travel while the next pass's prefilter runs
         ctx.hits_compact()                                # prefilter result DB content (hit_t triples per query); its copy to
         return npairs                                     # the host started when the prefilter finished and overlapped align
 
     def barrier():
+        ctx.align_hits_end()                              # the last pass's alignment records are in host memory
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()

@@ -123,6 +123,11 @@ int sp_ctx_align(sp_ctx *c, const uint32_t *query_idx, const uint32_t *target_id
 /* align every hit of the last sp_ctx_prefilter() without a host round trip in between; results[i] belongs to hit i of
    sp_ctx_get_hits_compact() (n = sp_ctx_num_hits()) */
 int sp_ctx_align_hits(sp_ctx *c, sp_alignment *results, char *cigars, uint64_t cigar_cap, uint64_t *cigar_used);
+/* sp_ctx_align_hits() in two halves: _begin returns when the kernels are done and the results are travelling to `results` /
+   `cigars` (page-locked buffers from sp_host_alloc(); do not touch them), _end waits for them.  In between the caller may
+   run the next sp_ctx_prefilter(): the copy overlaps it. */
+int sp_ctx_align_hits_begin(sp_ctx *c, sp_alignment *results, char *cigars, uint64_t cigar_cap, uint64_t *cigar_used);
+int sp_ctx_align_hits_end(sp_ctx *c);
 /* rescorediagonal core: mode 1 = substitution score, 2 = score + start/end */
 int sp_ctx_rescore(sp_ctx *c, const uint32_t *query_idx, const uint32_t *target_idx, const int16_t *diagonal, uint64_t n,
                    int mode, sp_rescore *results);

@@ -79,6 +79,8 @@ def load_library():
     L.sp_ctx_align.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(Alignment), C.c_char_p,
                                C.c_uint64, C.POINTER(C.c_uint64)]
     L.sp_ctx_align_hits.argtypes = [vp, C.POINTER(Alignment), C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.sp_ctx_align_hits_begin.argtypes = [vp, C.POINTER(Alignment), C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.sp_ctx_align_hits_end.argtypes = [vp]
     L.sp_ctx_rescore.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int16), C.c_uint64, C.c_int,
                                  C.POINTER(Rescore)]
     L.sp_ctx_set_targets_shard.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint64, C.c_uint64, C.c_uint64]
@@ -364,6 +366,25 @@ class SearchContext:
                 continue
             _check(rc)
             return self._aln, self._cig, n
+
+    def align_hits_begin(self):
+        """like align_hits_raw(), but returns while the results are still on their way; align_hits_end() collects them"""
+        n = int(self.L.sp_ctx_num_hits(self.ctx))
+        self._result_buffers(n)
+        used = C.c_uint64()
+        while True:
+            rc = self.L.sp_ctx_align_hits_begin(self.ctx, self._aln, C.cast(self._cig, C.c_char_p), self._cig_cap, C.byref(used))
+            if rc == -5 and used.value > self._cig_cap:
+                _check(self.L.sp_ctx_align_hits_end(self.ctx))
+                self._cig_cap = int(used.value) * 2
+                self._new_pinned_results()
+                continue
+            _check(rc)
+            return n
+
+    def align_hits_end(self):
+        _check(self.L.sp_ctx_align_hits_end(self.ctx))
+        return self._aln, self._cig
 
     def rescore(self, triples, mode):
         n = len(triples)

@@ -403,6 +403,23 @@ int sp_ctx_align_hits(sp_ctx *c, sp_alignment *res, char *cigars, uint64_t cigar
     return rc;
 }
 
+/* split form of sp_ctx_align_hits(): _begin returns when the device work is done and the results are on their way to
+   `res` / `cigars` (leave both alone), _end waits for them.  Between the two the caller may queue the next prefilter pass. */
+int sp_ctx_align_hits_begin(sp_ctx *c, sp_alignment *res, char *cigars, uint64_t cigarCap, uint64_t *cigarUsed) {
+    if (!c || c->targets.n == 0) { g_err = "sp_ctx_align_hits_begin: no target set"; return SP_ERR_STATE; }
+    std::string err;
+    if (!ensureEvaluers(c, true, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
+    buildGate(c);
+    sp::AlignDirect direct; direct.records = res; direct.cigars = cigars; direct.cigarCap = cigarCap; direct.async = true;
+    if (!c->gpu.align(nullptr, 0, c->par.gap_open, c->par.gap_extend, c->gate, c->alnHost, &direct, err)) { g_err = err; return SP_ERR_DEVICE; }
+    return finishDirectOrHost(c, direct, res, cigars, cigarCap, cigarUsed);
+}
+int sp_ctx_align_hits_end(sp_ctx *c) {
+    std::string err;
+    if (!c->gpu.waitAlignCopy(err)) { g_err = err; return SP_ERR_DEVICE; }
+    return SP_OK;
+}
+
 int sp_ctx_rescore(sp_ctx *c, const uint32_t *qidx, const uint32_t *tidx, const int16_t *diag, uint64_t n, int mode, sp_rescore *res) {
     if (!c || c->targets.n == 0) { g_err = "sp_ctx_rescore: no target set"; return SP_ERR_STATE; }
     std::string err;

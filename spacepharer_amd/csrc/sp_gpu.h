@@ -30,7 +30,8 @@ struct GateTable { uint32_t stride = 0; std::vector<uint16_t> slotOf; std::vecto
 // device-assembled result record: layout of sp_alignment (include/spacepharer_amd.h), checked by a static_assert in sp_api.cpp
 struct AlnRec { uint32_t dbKey; int32_t bitScore, rawScore; float seqId; double evalue; int32_t qStart, qEnd; uint32_t qLen; int32_t dbStart, dbEnd; uint32_t dbLen, alnLen, cigarOffset; int32_t passed; };
 // where align() may put finished records directly (host memory of the caller, ideally page-locked: sp_host_alloc)
-struct AlignDirect { void *records = nullptr; char *cigars = nullptr; uint64_t cigarCap = 0; uint64_t cigarUsed = 0; bool done = false; bool overflow = false; };
+// async: return as soon as the copies are queued; the caller collects them with Gpu::waitAlignCopy()
+struct AlignDirect { void *records = nullptr; char *cigars = nullptr; uint64_t cigarCap = 0; uint64_t cigarUsed = 0; bool done = false; bool overflow = false; bool async = false; };
 struct DiagRescore { int32_t score, startPos, endPos, diagonalLen, diagonal; uint32_t distToDiagonal; };
 
 // page-locked host memory for device<->host copies (pageable std::vector memory costs a staging copy per transfer)
@@ -117,6 +118,7 @@ public:
     // direct != nullptr: result records and backtraces are assembled on the device and copied straight into the caller's
     // buffers (direct->done); when a pair needs the host-driven retry path, `out` is filled instead (direct->done stays false)
     bool align(const SwPair *hostPairs, size_t n, int gapOpen, int gapExtend, const GateTable &gate, AlignHost &out, AlignDirect *direct, std::string &err);
+    bool waitAlignCopy(std::string &err);
     uint32_t maxQueryLen() const;
 
     // rescorediagonal: ungapped score on one diagonal of the UNMASKED residues, align matrix, no composition bias

@@ -1255,7 +1255,7 @@ struct Gpu::Impl {
     unsigned long long *mailbox = nullptr;       // page-locked landing area for counters
     // the hit list starts travelling to the host on its own stream as soon as a prefilter pass is complete, so that the copy
     // overlaps whatever the caller queues next (typically the align kernels)
-    hipStream_t copyStream = nullptr; hipEvent_t hitsOnHost = nullptr;
+    hipStream_t copyStream = nullptr; hipEvent_t hitsOnHost = nullptr, alnOnHost = nullptr; bool alnInFlight = false;
     PinVec<GpuHit> hitStage; PinVec<uint32_t> hitOffStage; bool hitsInFlight = false;
     // exclusive scan of n counts into n + 1 offsets (offset[n] = total); count must have n + 1 readable entries.
     // Small inputs: one block (k_scan_counts); larger ones: rocPRIM's decoupled look-back scan.
@@ -1284,6 +1284,7 @@ Gpu::~Gpu() {
         if (d_->mailbox) pinnedFree(d_->mailbox);
         if (d_->copyStream) { (void) hipStreamSynchronize(d_->copyStream); (void) hipStreamDestroy(d_->copyStream); }
         if (d_->hitsOnHost) (void) hipEventDestroy(d_->hitsOnHost);
+        if (d_->alnOnHost) (void) hipEventDestroy(d_->alnOnHost);
         d_->hitStage = PinVec<GpuHit>(); d_->hitOffStage = PinVec<uint32_t>();
         delete d_;
     }
@@ -1303,6 +1304,7 @@ bool Gpu::init(int device, std::string &err) {
     HIP_OK(hipStreamCreateWithFlags(&d_->stream, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&d_->copyStream, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&d_->hitsOnHost, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&d_->alnOnHost, hipEventDisableTiming));
     for (hipEvent_t &e : d_->ev) HIP_OK(hipEventCreate(&e));
     stream_ = d_->stream;
     return true;
@@ -1730,6 +1732,12 @@ void *pinnedAlloc(size_t bytes) {
     return p;
 }
 void pinnedFree(void *p) { if (p) (void) hipHostFree(p); }
+
+bool Gpu::waitAlignCopy(std::string &err) {
+    Impl &d = *d_;
+    if (d.alnInFlight) { HIP_OK(hipEventSynchronize(d.alnOnHost)); d.alnInFlight = false; }
+    return true;
+}
 
 // start copying the (final) hit list of the pass that just completed; called with the main stream idle
 bool Gpu::prefetchHits(std::string &err) {

@@ -163,3 +163,26 @@ def test_packed_sw_kernel_byte_overflow_and_ragged_groups():
     assert word >= 8             # the 16-bit redo path really ran
     ctx.close()
     o.close()
+
+
+def test_align_hits_begin_end_equals_blocking_call():
+    """the split call (results still travelling when _begin returns; the next prefilter may be queued meanwhile) delivers
+    the same bytes as the blocking one"""
+    import ctypes as C
+    import spacepharer_amd as sa
+    g = load_golden("spacer")
+    ctx = sa.SearchContext(sensitivity=g["ref"]["sens"], max_seqs=g["ref"]["maxSeqs"])
+    ctx.set_targets(g["targets"])
+    ctx.set_queries(g["queries"])
+    ctx.prefilter()
+    aln, cig, n = ctx.align_hits_raw()
+    ref_rec = C.string_at(C.addressof(aln), n * C.sizeof(sa._lib.Alignment))
+    ref_cig = bytes(cig[:4096])
+    C.memset(C.addressof(aln), 0xEE, n * C.sizeof(sa._lib.Alignment))
+    assert ctx.align_hits_begin() == n
+    ctx.prefilter()                                   # queued while the records are on their way
+    aln2, cig2 = ctx.align_hits_end()
+    assert C.string_at(C.addressof(aln2), n * C.sizeof(sa._lib.Alignment)) == ref_rec
+    assert bytes(cig2[:4096]) == ref_cig
+    assert n > 50
+    ctx.close()
