@@ -384,7 +384,7 @@ class SearchContext:
 
     def align_hits_end(self):
         _check(self.L.sp_ctx_align_hits_end(self.ctx))
-        return self._aln, self._cig
+        return getattr(self, "_aln", None), getattr(self, "_cig", None)
 
     def rescore(self, triples, mode):
         n = len(triples)

@@ -1424,12 +1424,11 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     Impl &d = *d_;
     if (!d.ext3.p || !d.pbits.p) { err = "tables/targets not resident"; return false; }
     if (d.hitsInFlight) { (void) hipEventSynchronize(d.hitsOnHost); d.hitsInFlight = false; }     // the previous pass's hit list is still being copied
-    // persistent match grid: as many blocks per CU as the LDS footprint of the chosen hit-buffer size admits.
-    // Expected hits per query ~ (similar k-mers per query) x (index entries per k-mer slot); keep 4x headroom.
-    int hitCap = ((double) d.indexEntries / (double) kTableSize * 1300.0 * 2.5 < 512.0) ? 512 : 2048;
-    if (const char *e = getenv("SP_HITCAP")) hitCap = atoi(e) <= 512 ? 512 : 2048;
-    const void *fn = hitCap == 512 ? (withOrd ? (const void *) k_match<512, true> : (const void *) k_match<512, false>)
-                                   : (withOrd ? (const void *) k_match<2048, true> : (const void *) k_match<2048, false>);
+    // persistent match grid: as many blocks per CU as the LDS footprint admits.  512 hits per query live in LDS; more go to
+    // the per-wave HBM scratch and come back through the pre-filter (faster than a larger LDS buffer even for dense indices:
+    // 45 vs 51 ms at 2 x 10^8 residues, because three blocks per CU stay resident instead of one).
+    constexpr int hitCap = 512;
+    const void *fn = withOrd ? (const void *) k_match<512, true> : (const void *) k_match<512, false>;
     int perCU = 2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, fn, 64 * kWavesPerBlock, 0) != hipSuccess || perCU < 1) perCU = 2;
     if (const char *e = getenv("SP_MATCH_PERCU")) perCU = std::max(1, atoi(e));
@@ -1457,10 +1456,8 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
                  (uint32_t) (getenv("SP_MATCH_STATIC") ? atoi(getenv("SP_MATCH_STATIC")) : 4), (uint32_t) (getenv("SP_MATCH_DCHUNK") ? std::max(1, atoi(getenv("SP_MATCH_DCHUNK"))) : 4)};
-    if (hitCap == 512) { if (withOrd) hipLaunchKernelGGL((k_match<512, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
-                         else hipLaunchKernelGGL((k_match<512, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma); }
-    else { if (withOrd) hipLaunchKernelGGL((k_match<2048, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
-           else hipLaunchKernelGGL((k_match<2048, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma); }
+    if (withOrd) hipLaunchKernelGGL((k_match<512, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+    else hipLaunchKernelGGL((k_match<512, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     SP_DBG_SYNC("k_match");
     HIP_OK(hipEventRecord(d.ev[2], d.stream));
     ScoreArgs sa{d.diagRec.p, d.diagQuery.p, d.queue.p + 1, (uint32_t) diagCap, d.qres.p, d.qoff.p, d.qcorr.p, d.tmasked.p, d.toff.p, d.ungSub.p, d.diagScore.p, d.counters.p};
