@@ -489,12 +489,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; r++) if (lenR[r] == 1u && !(slotR[r] >> 63)) emit(slotR[r], hR[r], ordR[r]);
                         if (__ballot(lenMulti != 0u)) {
-                            for (uint32_t e = 0; e < lenMulti; e++) {
-                                uint64_t ent[4] = {0, 0, 0, 0};
+                            // four list positions per step: 16 independent entry loads in flight instead of 4 (dense indices have
+                            // lists of 3 on average and the longest of 256 decides the trip count)
+                            for (uint32_t e0 = 0; e0 < lenMulti; e0 += 4) {
+                                uint64_t ent[4][4];
 #pragma unroll
-                                for (int r = 0; r < 4; r++) if ((slotR[r] >> 63) && e < lenR[r]) ent[r] = a.ientries[(uint32_t) slotR[r] + e];
+                                for (int u = 0; u < 4; u++)
 #pragma unroll
-                                for (int r = 0; r < 4; r++) if ((slotR[r] >> 63) && e < lenR[r]) emit(ent[r], hR[r] + e, ordR[r]);
+                                    for (int r = 0; r < 4; r++) ent[u][r] = ((slotR[r] >> 63) && e0 + u < lenR[r]) ? a.ientries[(uint32_t) slotR[r] + e0 + u] : 0ull;
+#pragma unroll
+                                for (int u = 0; u < 4; u++)
+#pragma unroll
+                                    for (int r = 0; r < 4; r++) if ((slotR[r] >> 63) && e0 + u < lenR[r]) emit(ent[u][r], hR[r] + e0 + u, ordR[r]);
                             }
                         }
                         M = run;
