@@ -258,7 +258,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
-        "dtype": "u8/i16 (integer k-mer lookup, u8/i16 Smith-Waterman)", "data": "synthetic",
+        "dtype": "u8/i16", "data": "synthetic",
         "config": {"workload": "%d synthetic 30-nt spacers (= %d peptides of 10 aa) vs %d synthetic phage ORFs x %d aa "
                                "(%.1e residues), 1xMI355X per rank, %s" % (args.spacers, nq, args.targets, args.target_len,
                                                                          args.targets * args.target_len,
