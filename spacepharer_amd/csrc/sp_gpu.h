@@ -106,12 +106,8 @@ public:
     KernelTimes times() const { return times_; }
     int maxHits() const { return maxHits_; }
 
-    // Smith-Waterman (align module): forward pass for all pairs, then reverse pass + banded traceback for
-    // the pairs whose flag is set (the host applies the E-value gate in between)
-    bool swForward(const SwPair *pairs, size_t n, int gapOpen, int gapExtend, std::vector<SwForward> &out, std::string &err);
-    bool swFinish(const uint8_t *passMask, std::vector<SwFull> &out, std::vector<char> &backtraces, std::string &err);
+    // retry path of align(): banded traceback with host-computed scratch offsets for the flagged pairs
     bool traceHostDriven(const uint8_t *passMask, std::vector<SwFull> &out, std::vector<char> &backtraces, std::string &err);
-    bool reverseAndTrace(const uint8_t *passMask, bool runReverse, std::vector<SwFull> &out, std::vector<char> &backtraces, std::string &err);
 
     // device-driven align: forward pass, E-value gate (table), 16-bit redo, reverse pass, banded traceback without host
     // round trips.  hostPairs == nullptr aligns every hit of the last prefilter(), in the order of downloadHits().
