@@ -367,6 +367,7 @@ static int finishAlign(sp_ctx *c, const sp::AlignHost &ah, const std::vector<uin
 static int finishDirectOrHost(sp_ctx *c, const sp::AlignDirect &direct, sp_alignment *res, char *cigars, uint64_t cigarCap, uint64_t *cigarUsed) {
     sp::KernelTimes kt = c->gpu.times();
     c->stats["ms_sw_forward"] = kt.swForward; c->stats["ms_sw_reverse"] = kt.swReverse; c->stats["ms_traceback"] = kt.traceback; c->stats["ms_assemble"] = kt.assemble;
+    c->stats["align_retries"] = (double) c->gpu.alignRetries();
     if (direct.overflow) { if (cigarUsed) *cigarUsed = direct.cigarUsed; g_err = "sp_ctx_align: cigar buffer too small"; return SP_ERR_OVERFLOW; }
     if (direct.done) { if (cigarUsed) *cigarUsed = direct.cigarUsed; return SP_OK; }
     return finishAlign(c, c->alnHost, nullptr, res, cigars, cigarCap, cigarUsed);

@@ -116,6 +116,7 @@ public:
     bool align(const SwPair *hostPairs, size_t n, int gapOpen, int gapExtend, const GateTable &gate, AlignHost &out, AlignDirect *direct, std::string &err);
     bool waitAlignCopy(std::string &err);
     uint32_t maxQueryLen() const;
+    size_t alignRetries() const { return alignRetries_; }      // pairs of the last align() that went through the host-driven traceback
 
     // rescorediagonal: ungapped score on one diagonal of the UNMASKED residues, align matrix, no composition bias
     bool rescoreDiagonals(const SwPair *pairs, const uint16_t *diags, size_t n, int mode, std::vector<DiagRescore> &out, std::string &err);
@@ -136,6 +137,7 @@ private:
     std::string name_;
     size_t nq_ = 0;
     int maxHits_ = 0;
+    size_t alignRetries_ = 0;
     PrefilterCounters counters_{};
     KernelTimes times_{};
 };

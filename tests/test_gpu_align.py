@@ -24,6 +24,8 @@ def test_align_matches_reference_golden(name):
             exp.append(raw)
     assert pairs
     got = ctx.align(pairs)
+    if name == "longq":      # a long gapped alignment outgrows its share of the traceback pool: the host-driven retry ran
+        assert ctx.stat("align_retries") >= 1
     gapped = word = 0
     for (res, cig), raw in zip(got, exp):
         dbKey, bits, qs, qe, ts, te, alnLen, ev, ok, bt = raw
