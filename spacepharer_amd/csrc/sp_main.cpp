@@ -3,6 +3,7 @@
 // spacepharer binary, and the unmodified workflow scripts (lib/mmseqs/data/workflow/blastp.sh:33,41,48) land
 // in the MI355X implementation.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/spacepharer_amd.h"
@@ -10,7 +11,10 @@
 int main(int argc, const char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: %s <prefilter|align|rescorediagonal> <args>\n", argv[0]); return 1; }
     int rc;
-    if (sp_init(0) != SP_OK) { fprintf(stderr, "%s\n", sp_last_error()); return 1; }
+    // SP_GPUS=N: the module forks one worker per GPU; this process must not touch the HIP runtime before the fork
+    const char *gpus = getenv("SP_GPUS");
+    const bool fanOut = gpus && atoi(gpus) > 1;
+    if (!fanOut && sp_init(0) != SP_OK) { fprintf(stderr, "%s\n", sp_last_error()); return 1; }
     if (!strcmp(argv[1], "prefilter")) rc = sp_prefilter_run(argc - 2, argv + 2);
     else if (!strcmp(argv[1], "align")) rc = sp_align_run(argc - 2, argv + 2);
     else if (!strcmp(argv[1], "rescorediagonal")) rc = sp_rescorediagonal_run(argc - 2, argv + 2);

@@ -18,6 +18,8 @@
 #include <sstream>
 #include <string>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -84,8 +86,34 @@ struct Db {
     const char *ptr(size_t i) const { return data.data() + entries[i].offset; }
 };
 
+// One module call can be spread over the GPUs of a node (SP_GPUS=N): the parent forks N children BEFORE anything touches
+// the HIP runtime, child r takes slice r of the entries (DBReader::decomposeDomainByAminoAcid arithmetic) on GPU r and writes
+// the data file <out>.<r> -- the split-data-file form MMseqs2 DBs have anyway (DBWriter.cpp:117-123) -- plus a private index;
+// the parent merges the indexes into <out>.index (offsets shifted by the sizes of the preceding parts) and writes .dbtype last.
+struct Part { int rank = 0, count = 1; };
+static Part currentPart() {
+    Part p;
+    if (const char *e = getenv("SP_PART")) { int r = 0, n = 1; if (sscanf(e, "%d/%d", &r, &n) == 2 && n >= 1 && r >= 0 && r < n) { p.rank = r; p.count = n; } }
+    return p;
+}
+// contiguous slice of `lengths.size()` entries for this part, balanced by data size (commons/DBReader.cpp:1171-1213)
+static void partRange(const std::vector<uint64_t> &lengths, const Part &p, size_t &from, size_t &to) {
+    const size_t n = lengths.size();
+    from = 0; to = n;
+    if (p.count <= 1) return;
+    uint64_t total = 0; for (uint64_t l : lengths) total += l;
+    if (n <= (size_t) p.count) { from = std::min<size_t>(n, (size_t) p.rank); to = std::min<size_t>(n, from + 1); return; }
+    const uint64_t chunk = (total + (uint64_t) p.count - 1) / (uint64_t) p.count;
+    std::vector<size_t> per((size_t) p.count, 0);
+    size_t cur = 0; uint64_t acc = 0;
+    for (uint64_t l : lengths) { if (acc >= chunk && cur + 1 < (size_t) p.count) { acc = 0; cur++; } acc += l; per[cur]++; }
+    for (int r = 0; r < p.rank; r++) from += per[(size_t) r];
+    to = from + per[(size_t) p.rank];
+}
+
 struct DbWriter {
     std::string path; int dbtype;
+    Part part = currentPart();
     std::vector<char> data; std::vector<DbEntry> entries;
     void add(uint32_t key, const std::string &payload) {
         DbEntry e; e.key = key; e.offset = data.size(); e.length = payload.size() + 1;
@@ -100,9 +128,12 @@ struct DbWriter {
         for (size_t i = 0; i < keys.size(); i++) { DbEntry e; e.key = keys[i]; e.offset = at; e.length = lengths[i]; entries.push_back(e); at += lengths[i]; }
     }
     bool close(std::string &err) {
-        { std::ofstream o(path, std::ios::binary); if (!o.good()) { err = "cannot write " + path; return false; } o.write(data.data(), (std::streamsize) data.size()); }
+        const std::string dataPath = part.count > 1 ? path + "." + std::to_string(part.rank) : path;
+        const std::string indexPath = part.count > 1 ? dataPath + ".idxpart" : path + ".index";
+        const std::string typePath = part.count > 1 ? dataPath + ".typepart" : path + ".dbtype";
+        { std::ofstream o(dataPath, std::ios::binary); if (!o.good()) { err = "cannot write " + dataPath; return false; } o.write(data.data(), (std::streamsize) data.size()); }
         std::sort(entries.begin(), entries.end(), [](const DbEntry &a, const DbEntry &b) { return a.key < b.key; });   // DBWriter.cpp:645-660
-        { std::ofstream o(path + ".index", std::ios::binary); if (!o.good()) { err = "cannot write " + path + ".index"; return false; }
+        { std::ofstream o(indexPath, std::ios::binary); if (!o.good()) { err = "cannot write " + indexPath; return false; }
           std::string text; text.reserve(entries.size() * 24);
           char buf[72];
           for (const DbEntry &e : entries) {
@@ -114,7 +145,7 @@ struct DbWriter {
           }
           o.write(text.data(), (std::streamsize) text.size()); }
         // .dbtype is written LAST so that a crashed step is re-run by the workflow scripts (DBWriter.cpp:243)
-        { std::ofstream o(path + ".dbtype", std::ios::binary); int32_t v = dbtype; o.write((const char *) &v, 4); if (!o.good()) { err = "cannot write " + path + ".dbtype"; return false; } }
+        { std::ofstream o(typePath, std::ios::binary); int32_t v = dbtype; o.write((const char *) &v, 4); if (!o.good()) { err = "cannot write " + typePath; return false; } }
         return true;
     }
 };
@@ -240,6 +271,46 @@ static void flatten(const Db &db, std::vector<char> &res, std::vector<uint64_t> 
 
 static int fail(const std::string &e) { setLastError(e); fprintf(stderr, "%s\n", e.c_str()); return 1; }
 
+// SP_GPUS=N and not yet a child: fork one child per GPU, wait, merge.  Returns -1 when the call is not to be fanned out.
+static int fanOut(const char *module, int (*fn)(int, const char **), int argc, const char **argv, const std::string &out) {
+    const char *e = getenv("SP_GPUS");
+    const int n = e ? atoi(e) : 1;
+    if (n <= 1 || getenv("SP_PART")) return -1;
+    std::vector<pid_t> kids;
+    for (int r = 0; r < n; r++) {
+        const pid_t pid = fork();
+        if (pid < 0) return fail(std::string(module) + ": fork failed");
+        if (pid == 0) {
+            const std::string part = std::to_string(r) + "/" + std::to_string(n), rank = std::to_string(r);
+            setenv("SP_PART", part.c_str(), 1);
+            setenv("LOCAL_RANK", rank.c_str(), 1);          // device = LOCAL_RANK mod visible devices (sp_init)
+            _exit(fn(argc, argv));
+        }
+        kids.push_back(pid);
+    }
+    bool ok = true;
+    for (pid_t k : kids) { int st = 0; if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) ok = false; }
+    if (!ok) return fail(std::string(module) + ": a per-GPU worker failed");
+    // merge: parts are data files <out>.0 .. <out>.N-1 read back to back, so part r's offsets shift by the sizes before it
+    std::vector<DbEntry> all; uint64_t shift = 0; int32_t dbtype = -1;
+    for (int r = 0; r < n; r++) {
+        const std::string dp = out + "." + std::to_string(r);
+        std::ifstream ix(dp + ".idxpart");
+        if (!ix.good()) return fail(std::string(module) + ": missing " + dp + ".idxpart");
+        unsigned long long k, o, l;
+        while (ix >> k >> o >> l) { DbEntry en; en.key = (uint32_t) k; en.offset = o + shift; en.length = l; all.push_back(en); }
+        struct stat st; if (stat(dp.c_str(), &st) != 0) return fail(std::string(module) + ": missing " + dp);
+        shift += (uint64_t) st.st_size;
+        std::ifstream tp(dp + ".typepart", std::ios::binary); int32_t v = -1; tp.read((char *) &v, 4); if (r == 0) dbtype = v;
+        remove((dp + ".idxpart").c_str()); remove((dp + ".typepart").c_str());
+    }
+    std::sort(all.begin(), all.end(), [](const DbEntry &a, const DbEntry &b) { return a.key < b.key; });
+    { std::ofstream o(out + ".index", std::ios::binary); if (!o.good()) return fail(std::string(module) + ": cannot write " + out + ".index");
+      for (const DbEntry &en : all) o << en.key << '\t' << en.offset << '\t' << en.length << '\n'; }
+    { std::ofstream o(out + ".dbtype", std::ios::binary); o.write((const char *) &dbtype, 4); if (!o.good()) return fail(std::string(module) + ": cannot write " + out + ".dbtype"); }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // prefilter <queryDB> <targetDB> <outDB>
 // ---------------------------------------------------------------------------------------------------------------
@@ -251,6 +322,7 @@ int runPrefilterModule(int argc, const char **argv) {
         !requireValue(f, "--spaced-kmer-pattern", {"11011101", ""}, err) || !requireValue(f, "--mask-lower-case", {"0"}, err) || !requireValue(f, "--compressed", {"0"}, err) ||
         !requireValue(f, "--add-self-matches", {"0"}, err) || !requireValue(f, "--split", {"0", "1"}, err) || !requireValue(f, "-c", {"0", "0.0", "0.000"}, err))
         return fail("prefilter: " + err);
+    { const int rc = fanOut("prefilter", runPrefilterModule, argc, argv, f.positional[2]); if (rc >= 0) return rc; }
     Db qdb, tdb;
     if (!loadSeqDb(f.positional[0], qdb, err) || !loadSeqDb(f.positional[1], tdb, err)) return fail("prefilter: " + err);
     sp_search_params p; sp_default_params(&p);
@@ -269,9 +341,11 @@ int runPrefilterModule(int argc, const char **argv) {
     if (sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) return fail(std::string("prefilter: ") + sp_last_error());
     flatten(qdb, qres, qoff, qkeys);
     DbWriter w; w.path = f.positional[2]; w.dbtype = 7;      // DBTYPE_PREFILTER_RES
-    const size_t nq = qkeys.size(), batch = 1u << 20;
+    const size_t batch = 1u << 20;
+    size_t qFrom = 0, nq = qkeys.size();
+    { std::vector<uint64_t> lens(qkeys.size()); for (size_t i = 0; i < lens.size(); i++) lens[i] = qoff[i + 1] - qoff[i] + 2; partRange(lens, w.part, qFrom, nq); }   // this GPU's queries
     std::string payload; char buf[64];
-    for (size_t b0 = 0; b0 < nq; b0 += batch) {
+    for (size_t b0 = qFrom; b0 < nq; b0 += batch) {
         const size_t b1 = std::min(nq, b0 + batch);
         std::vector<uint64_t> off(qoff.begin() + b0, qoff.begin() + b1 + 1);
         for (uint64_t &o : off) o -= qoff[b0];
@@ -301,7 +375,9 @@ struct Triples { std::vector<uint32_t> q, t; std::vector<int16_t> d; std::vector
 static bool collectTriples(const Db &res, const KeyMap &qIndex, const KeyMap &tIndex, Triples &tr, std::string &err) {
     tr.perQuery.assign(1, 0);
     tr.q.reserve(res.data.size() / 12); tr.t.reserve(res.data.size() / 12); tr.d.reserve(res.data.size() / 12);
-    for (size_t i = 0; i < res.entries.size(); i++) {
+    size_t eFrom = 0, eTo = res.entries.size();
+    { std::vector<uint64_t> lens(res.entries.size()); for (size_t i = 0; i < lens.size(); i++) lens[i] = res.entries[i].length; partRange(lens, currentPart(), eFrom, eTo); }   // this GPU's entries
+    for (size_t i = eFrom; i < eTo; i++) {
         const uint32_t key = res.entries[i].key;
         const char *p = res.ptr(i);
         uint32_t qi = 0xFFFFFFFFu;
@@ -384,6 +460,7 @@ int runAlignModule(int argc, const char **argv) {
         !requireValue(f, "-c", {"0", "0.0", "0.000"}, err) || !requireValue(f, "--seq-id-mode", {"0"}, err))
         return fail("align: " + err);
     if (f.num("-a", 0) != 1) return fail("align: only -a 1 (backtrace => score, coverage and sequence identity) is implemented, which is what predictmatch passes");
+    { const int rc = fanOut("align", runAlignModule, argc, argv, f.positional[3]); if (rc >= 0) return rc; }
     Ctx ctx; Db qdb, tdb, rdb; std::vector<uint32_t> qkeys, tkeys; std::vector<char> qres; std::vector<uint64_t> qoff;
     if (!openSearch(f, "align", true, ctx, qdb, tdb, qkeys, tkeys, qres, qoff, err)) return fail("align: " + err);
     if (!rdb.load(f.positional[2], err)) return fail("align: " + err);
@@ -438,6 +515,7 @@ int runRescoreDiagonalModule(int argc, const char **argv) {
         return fail("rescorediagonal: " + err);
     const int mode = (int) f.num("--rescore-mode", 0);
     if (mode != 1 && mode != 2) return fail("rescorediagonal: only --rescore-mode 1 and 2 are implemented");
+    { const int rc = fanOut("rescorediagonal", runRescoreDiagonalModule, argc, argv, f.positional[3]); if (rc >= 0) return rc; }
     Ctx ctx; Db qdb, tdb, rdb; std::vector<uint32_t> qkeys, tkeys; std::vector<char> qres; std::vector<uint64_t> qoff;
     if (!openSearch(f, "rescorediagonal", false, ctx, qdb, tdb, qkeys, tkeys, qres, qoff, err)) return fail("rescorediagonal: " + err);
     if (!rdb.load(f.positional[2], err)) return fail("rescorediagonal: " + err);

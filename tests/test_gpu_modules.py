@@ -41,7 +41,13 @@ def write_seq_db(path, seqs, key0=0, split=False):
 
 
 def read_db(path):
-    data = open(path, "rb").read()
+    if os.path.exists(path):
+        data = open(path, "rb").read()
+    else:                                   # split data files <path>.0, <path>.1, ... read back to back
+        data, i = b"", 0
+        while os.path.exists("%s.%d" % (path, i)):
+            data += open("%s.%d" % (path, i), "rb").read()
+            i += 1
     out = {}
     for line in open(path + ".index"):
         k, o, l = (int(x) for x in line.split("\t"))
@@ -103,3 +109,32 @@ def test_module_fails_without_touching_dbtype_on_error(tmp_path):
     with pytest.raises(sa.SpError):
         sa.module_prefilter([q, t, pref])          # target DB missing
     assert not os.path.exists(pref + ".dbtype")
+
+
+def test_modules_fan_out_over_gpus_with_identical_results(tmp_path):
+    """SP_GPUS=N: the front-end binary forks one worker per GPU (here 3 workers sharing the one GPU of the box), each
+    writes the data file <out>.<rank>, the parent merges the indexes -- the decoded DBs equal the reference's text"""
+    import subprocess
+    g = load_golden("family")
+    r = g["ref"]
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spacepharer_amd", "spacepharer-amd")
+    q, t, pref, aln = (str(tmp_path / x) for x in ("qdb", "tdb", "pref", "aln"))
+    write_seq_db(q, g["queries"])
+    write_seq_db(t, g["targets"])
+    env = dict(os.environ, SP_GPUS="3")
+    p = subprocess.run([exe, "prefilter", q, t, pref] + (PREF_FLAGS % r["maxSeqs"]).split(), env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert all(os.path.exists("%s.%d" % (pref, i)) for i in range(3)) and not os.path.exists(pref)
+    got, dbtype = read_db(pref)
+    assert dbtype == 7 and sorted(got) == list(range(len(g["queries"])))
+    for qq in r["queries"]:
+        assert got[qq["id"]] == qq["pref"], qq["id"]
+    p = subprocess.run([exe, "align", q, t, pref, aln] + ALN_FLAGS.split(), env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got, dbtype = read_db(aln)
+    assert dbtype == 5
+    for a in r["aln"]:
+        assert got[a["id"]] == a["text"], a["id"]
+    keys = [int(l.split("\t")[0]) for l in open(aln + ".index")]
+    assert keys == sorted(keys) and len(keys) == len(g["queries"])
+    assert not [f for f in os.listdir(tmp_path) if f.endswith("part")]       # the private indexes are gone
