@@ -60,11 +60,12 @@ def u64p(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint64))
 
 
-def cpu_baseline_reference(tres, toff, qres, qoff, n_sample, procs):
+def cpu_baseline_reference(tres, toff, qres, qoff, n_sample, procs, reps=5):
     """The REAL reference classes (oracle/_ref/ref_harness --bench: QueryMatcher::matchQuery + Matcher::getSWResult, AVX2,
     compiled from /root/reference by oracle/Makefile) on `procs` host cores: one single-threaded process per core, each
     searching its own slice of the sample against the full target set.  Only the search loops are timed (index build,
-    similar-k-mer tables and the ALP fit are set-up, as for the GPU number); rate = sample / slowest process."""
+    similar-k-mer tables and the ALP fit are set-up, as for the GPU number) and they run `reps` times over the slice so that
+    the sample is a few seconds per core; rate = sample / slowest process's mean time per pass."""
     import subprocess
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -86,7 +87,7 @@ def cpu_baseline_reference(tres, toff, qres, qoff, n_sample, procs):
             qf, of = os.path.join(d, "q%d.txt" % p), os.path.join(d, "o%d.json" % p)
             with open(qf, "wb") as f:
                 f.write(b"\n".join(qres[i * ql:(i + 1) * ql].tobytes() for i in range(lo, hi)) + b"\n")
-            jobs.append((subprocess.Popen([harness, m80, m40, tf, qf, of, "--bench"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL), of))
+            jobs.append((subprocess.Popen([harness, m80, m40, tf, qf, of, "--bench-reps", str(reps)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL), of))
         res = []
         for pr, of in jobs:
             if pr.wait() != 0:
@@ -96,8 +97,8 @@ def cpu_baseline_reference(tres, toff, qres, qoff, n_sample, procs):
     return {"value": (n_sample / 6.0) / slowest, "unit": "spacer-queries/s", "cores": len(res), "kind": "reference",
             "pairs": sum(r["pairs"] for r in res),
             "sample": "%d of the workload's peptides (%d SW alignments) split over %d single-threaded processes of oracle/_ref/ref_harness "
-                      "(reference QueryMatcher + Matcher classes, AVX2, g++ -O3); search loops only, slowest process %.2f s "
-                      "(prefilter %.2f s + align %.2f s)" % (n_sample, sum(r["pairs"] for r in res), len(res), slowest,
+                      "(reference QueryMatcher + Matcher classes, AVX2, g++ -O3); search loops only, %d passes each, slowest process %.2f s per pass "
+                      "(prefilter %.2f s + align %.2f s)" % (n_sample, sum(r["pairs"] for r in res), len(res), reps, slowest,
                                                             max(r["prefilter_s"] for r in res), max(r["align_s"] for r in res))}
 
 
