@@ -198,6 +198,7 @@ constexpr uint32_t kMaxKmerResult = 262144u * 32u;   // KmerGenerator.h:45
 constexpr int kWavesPerBlock = 4;
 constexpr uint32_t kDiagChunk = 64;   // diagonal records reserved per atomic in k_match
 constexpr uint32_t kQueryChunk = 4;
+constexpr int kDeferCap = 128;       // multi-entry index lists per wave whose entries are fetched together (k_match)
 constexpr int kSuper = 1024;         // similar k-mers per enumeration super-round in k_match   // queries per work-queue pop in k_match
 
 struct DiagRec { uint32_t seqId; uint16_t diag; uint16_t idx; };
@@ -208,9 +209,8 @@ struct MatchArgs {
     const uint16_t *ext3cnt;        // 8000 x kCntW: [row][c - cntMin] = number of partners with score >= c
     int cntMin;
     // rank-compressed slot table.  k-mer = a + 8000 b: the 8000 slots of one b form a "row" of 125 words of 64 slots.
-    const uint64_t *pbits;          // occupancy bits, one u64 per 64 slots (8 MB): all a miss needs
-    const uint16_t *prank;          // occupied slots of the row before this word (2 MB)
-    const uint32_t *prow;           // occupied slots before the row (8000 entries)
+    const uint64_t *probe;          // per 32 slots: occupancy bits (low half) | occupied slots before the word (high half) -- 16 MB, one 8-byte load
+                                    // answers "occupied?" and gives the slot's rank
     const uint64_t *slots;          // per OCCUPIED slot (rank order): the entry itself (seqId | pos << 32) when the list has one
                                     // entry, else bit 63 | len << 32 | offset into ientries
     const uint64_t *ientries;       // seqId | pos << 32, lists concatenated in k-mer order
@@ -275,6 +275,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     __shared__ uint32_t s_bits[kWavesPerBlock][kHitCap / 32];
     __shared__ uint32_t s_occ[kWavesPerBlock][kSuper];
     __shared__ unsigned long long s_hflag[kWavesPerBlock][kSuper / 64];
+    __shared__ uint64_t s_defSlot[kWavesPerBlock][kDeferCap];      // multi-entry lists whose walk is deferred (slot word)
+    __shared__ uint32_t s_defMeta[kWavesPerBlock][kDeferCap];      // ... stream position of the list's first hit | window << 16
+    __shared__ uint32_t s_defOrd[kWavesPerBlock][kOrd ? kDeferCap : 1];
 
     const int lane = laneId();
     const int w = (int) (threadIdx.x >> 6);
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     unsigned long long *hflag = s_hflag[w];
     uint16_t *occOrd = s_occOrd[w];
     uint32_t *ordL = s_ordL[w];
+    uint64_t *defSlot = s_defSlot[w]; uint32_t *defMeta = s_defMeta[w]; uint32_t *defOrd = s_defOrd[w];
     const uint32_t waveGlobal = blockIdx.x * kWavesPerBlock + w;
     uint64_t *spillKeys = a.spill + (size_t) waveGlobal * kSpillWordsPerWave;
     uint32_t *spillBits = (uint32_t *) (spillKeys + 65536);
@@ -324,6 +328,42 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
         const int myThr = lane < L ? (int) a.qthr[qo + lane] : -1;
         SP_T(0);
 
+        auto emit = [&](uint64_t ent, uint32_t h, uint32_t ord, int win) {
+            const uint32_t seqId = (uint32_t) ent;
+            const uint32_t diag = (uint32_t) (win - (int) (uint32_t) ((ent >> 32) & 0xFFFF)) & 0xFFFFu;
+            const uint64_t key = ((uint64_t) seqId << 32) | ((uint64_t) (h & 0xFFFFu) << 16) | diag;
+            if (h < (uint32_t) kHitCap) { keys[h] = key; if (kOrd) ordL[h] = ord; }
+            else if (h < (uint32_t) kSpillCap) { spillKeys[h] = key; if (kOrd) spillOrd[h] = ord; }
+        };
+        // Multi-entry lists are rare while the index is sparse (3 % of the occupied slots at phage scale) but walking them
+        // right away costs every batch of slots another dependent memory round trip: their slot words are parked in LDS
+        // (the stream positions of their hits are already assigned -- the slot word holds the length) and the entries of up
+        // to kDeferCap lists are fetched together.
+        uint32_t defN = 0;
+        auto flushDeferred = [&]() {
+            waveSync();
+            uint64_t sw[kDeferCap / 64]; uint32_t mt[kDeferCap / 64], od[kDeferCap / 64], ln[kDeferCap / 64], lenMax = 0;
+#pragma unroll
+            for (int r = 0; r < kDeferCap / 64; r++) {
+                const uint32_t t = 64u * r + lane;
+                sw[r] = 0ull; mt[r] = 0u; od[r] = 0u; ln[r] = 0u;
+                if (t < defN) { sw[r] = defSlot[t]; mt[r] = defMeta[t]; if (kOrd) od[r] = defOrd[t]; ln[r] = (uint32_t) (sw[r] >> 32) & 0x7FFFFFFFu; }
+                lenMax = ln[r] > lenMax ? ln[r] : lenMax;
+            }
+            for (uint32_t e0 = 0; e0 < lenMax; e0 += 4) {
+                uint64_t ent[4][kDeferCap / 64];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int r = 0; r < kDeferCap / 64; r++) ent[u][r] = (e0 + u < ln[r]) ? a.ientries[(uint32_t) sw[r] + e0 + u] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int r = 0; r < kDeferCap / 64; r++) if (e0 + u < ln[r]) emit(ent[u][r], (mt[r] & 0xFFFFu) + e0 + u, od[r], (int) (mt[r] >> 16));
+            }
+            defN = 0;
+            waveSync();
+        };
         for (int i = 0; i < nScan; i++) {
             int thr; uint32_t ia, ib;
             if (i + kSpan <= 64) {
@@ -437,17 +477,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                     SP_T(3);
                     uint64_t prR[kSuper / 64];
 #pragma unroll
-                    for (int r = 0; r < kSuper / 64; r++) prR[r] = (kmerR[r] != 0xFFFFFFFFu) ? a.pbits[kmerR[r] >> 6] : 0ull;
+                    for (int r = 0; r < kSuper / 64; r++) prR[r] = (kmerR[r] != 0xFFFFFFFFu) ? a.probe[kmerR[r] >> 5] : 0ull;
                     uint32_t nOcc = 0;
 #pragma unroll
                     for (int r = 0; r < kSuper / 64; r++) {
-                        const uint32_t bit = kmerR[r] & 63u;
-                        const bool occ = kmerR[r] != 0xFFFFFFFFu && ((prR[r] >> bit) & 1ull);
+                        const uint32_t bit = kmerR[r] & 31u, word = (uint32_t) prR[r];
+                        const bool occ = kmerR[r] != 0xFFFFFFFFu && ((word >> bit) & 1u);
                         const uint64_t m = __ballot(occ);
                         if (occ) {
                             const uint32_t at = nOcc + (uint32_t) __popcll(m & laneMaskLt(lane));
-                            // k-mer id (< 2^26) | occupied slots of its word below it: the rest of the rank is looked up in phase 2
-                            occList[at] = kmerR[r] | ((uint32_t) __popcll(prR[r] & ((1ull << bit) - 1ull)) << 26);
+                            // rank of the slot = occupied slots before its word + occupied slots of the word below it
+                            occList[at] = (uint32_t) (prR[r] >> 32) + (uint32_t) __popc(word & ((1u << bit) - 1u));
                             if (kOrd) occOrd[at] = (uint16_t) (r * 64 + lane);
                         }
                         nOcc += (uint32_t) __popcll(m);
@@ -460,15 +500,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                         for (int r = 0; r < 4; r++) {
                             const uint32_t at = ob + 64u * r + lane;
                             if (at < nOcc) {
-                                const uint32_t e = occList[at], km = e & 0x3FFFFFFu;
-                                slotR[r] = (uint64_t) (a.prow[km / 8000u] + (uint32_t) a.prank[km >> 6] + (e >> 26));      // rank of the slot
+                                slotR[r] = a.slots[occList[at]]; lenR[r] = (slotR[r] >> 63) ? ((uint32_t) (slotR[r] >> 32) & 0x7FFFFFFFu) : 1u;
                                 if (kOrd) ordR[r] = qK0 + kBase + s0 + occOrd[at];
                             }
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const uint32_t at = ob + 64u * r + lane;
-                            if (at < nOcc) { slotR[r] = a.slots[(uint32_t) slotR[r]]; lenR[r] = (slotR[r] >> 63) ? ((uint32_t) (slotR[r] >> 32) & 0x7FFFFFFFu) : 1u; }
                         }
                         uint32_t lenMulti = 0, run = M;
 #pragma unroll
@@ -478,19 +512,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                             run += lane63(incl);
                             if ((slotR[r] >> 63) && lenR[r] > lenMulti) lenMulti = lenR[r];
                         }
-                        auto emit = [&](uint64_t ent, uint32_t h, uint32_t ord) {
-                            const uint32_t seqId = (uint32_t) ent;
-                            const uint32_t diag = (uint32_t) (i - (int) (uint32_t) ((ent >> 32) & 0xFFFF)) & 0xFFFFu;
-                            const uint64_t key = ((uint64_t) seqId << 32) | ((uint64_t) (h & 0xFFFFu) << 16) | diag;
-                            if (h < (uint32_t) kHitCap) { keys[h] = key; if (kOrd) ordL[h] = ord; }
-                            else if (h < (uint32_t) kSpillCap) { spillKeys[h] = key; if (kOrd) spillOrd[h] = ord; }
-                        };
                         // one-entry lists (the rule while the index is sparse) are complete with the slot word
+                        uint32_t nMulti = 0;
 #pragma unroll
-                        for (int r = 0; r < 4; r++) if (lenR[r] == 1u && !(slotR[r] >> 63)) emit(slotR[r], hR[r], ordR[r]);
-                        if (__ballot(lenMulti != 0u)) {
-                            // four list positions per step: 16 independent entry loads in flight instead of 4 (dense indices have
-                            // lists of 3 on average and the longest of 256 decides the trip count)
+                        for (int r = 0; r < 4; r++) {
+                            if (lenR[r] == 1u && !(slotR[r] >> 63)) emit(slotR[r], hR[r], ordR[r], i);
+                            nMulti += (uint32_t) __popcll(__ballot((slotR[r] >> 63) != 0ull));
+                        }
+                        if (nMulti > (uint32_t) kDeferCap / 4 || defN + nMulti > (uint32_t) kDeferCap) {
+                            // dense index (or the parking area is full): most lists are long, the batch amortises the walk by itself.  Four list positions per
+                            // step: 16 independent entry loads in flight (lists of 3 on average, the longest of 256 decides the
+                            // trip count)
                             for (uint32_t e0 = 0; e0 < lenMulti; e0 += 4) {
                                 uint64_t ent[4][4];
 #pragma unroll
@@ -500,7 +532,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
 #pragma unroll
                                 for (int u = 0; u < 4; u++)
 #pragma unroll
-                                    for (int r = 0; r < 4; r++) if ((slotR[r] >> 63) && e0 + u < lenR[r]) emit(ent[u][r], hR[r] + e0 + u, ordR[r]);
+                                    for (int r = 0; r < 4; r++) if ((slotR[r] >> 63) && e0 + u < lenR[r]) emit(ent[u][r], hR[r] + e0 + u, ordR[r], i);
+                            }
+                        } else if (nMulti > 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const bool multi = (slotR[r] >> 63) != 0ull && hR[r] < (uint32_t) kSpillCap;
+                                const uint64_t m = __ballot(multi);
+                                if (multi) {
+                                    const uint32_t at = defN + (uint32_t) __popcll(m & laneMaskLt(lane));
+                                    defSlot[at] = slotR[r]; defMeta[at] = hR[r] | ((uint32_t) i << 16); if (kOrd) defOrd[at] = ordR[r];
+                                }
+                                defN += (uint32_t) __popcll(m);
                             }
                         }
                         M = run;
@@ -514,6 +557,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
             kmersTotal += kBase;
             qK0 += kBase;
         }
+        if (defN) flushDeferred();
         matchesTotal += M;
         if (M > (uint32_t) kSpillCap) { overflow = true; M = 0; }
         uint32_t D = 0, dbase = 0;
@@ -1247,7 +1291,7 @@ struct Gpu::Impl {
     DevBuf<short> alnSub16; DevBuf<double> alnBack;
     int ungMinAbs = 0, alnMinAbs = 0;
     // targets
-    DevBuf<uint64_t> pbits; DevBuf<uint16_t> prank; DevBuf<uint32_t> prow; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff; DevBuf<uint32_t> tkeys;
+    DevBuf<uint32_t> pbits; DevBuf<uint64_t> probe; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff; DevBuf<uint32_t> tkeys;
     size_t nTargets = 0; size_t indexEntries = 0;
     // index construction scratch (kept for the next target set)
     DevBuf<uint32_t> ixKeys, ixKeys2, ixKeep, ixPos, ixKmer, ixHead, ixSlotOf, ixHeadPos, ixCnt, ixBefore; DevBuf<uint64_t> ixVals, ixVals2;
@@ -1433,7 +1477,7 @@ bool Gpu::uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std:
 // k_prep, k_match, k_score for every resident query; leaves the scored double-hit diagonals in HBM (events 0..3)
 bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     Impl &d = *d_;
-    if (!d.ext3.p || !d.pbits.p) { err = "tables/targets not resident"; return false; }
+    if (!d.ext3.p || !d.probe.p) { err = "tables/targets not resident"; return false; }
     if (d.hitsInFlight) { (void) hipEventSynchronize(d.hitsOnHost); d.hitsInFlight = false; }     // the previous pass's hit list is still being copied
     // persistent match grid: as many blocks per CU as the LDS footprint admits.  512 hits per query live in LDS; more go to
     // the per-wave HBM scratch and come back through the pre-filter (faster than a larger LDS buffer even for dense indices:
@@ -1463,7 +1507,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     hipLaunchKernelGGL(k_prep, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, pa);
     SP_DBG_SYNC("k_prep");
     HIP_OK(hipEventRecord(d.ev[1], d.stream));
-    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.pbits.p, d.prank.p, d.prow.p, d.slots.p, d.ientries.p, d.spill.p, d.queue.p,
+    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.probe.p, d.slots.p, d.ientries.p, d.spill.p, d.queue.p,
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
                  (uint32_t) (getenv("SP_MATCH_STATIC") ? atoi(getenv("SP_MATCH_STATIC")) : 4), (uint32_t) (getenv("SP_MATCH_DCHUNK") ? std::max(1, atoi(getenv("SP_MATCH_DCHUNK"))) : 4)};
@@ -1630,11 +1674,10 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
         hipLaunchKernelGGL(k_tantan, dim3((unsigned) ((to - from + 63) / 64)), dim3(64), 0, d.stream, ta);
     }
     HIP_OK(hipEventRecord(d.ev[1], d.stream));
-    const size_t words = kTableSize / 64;
-    if (!d.pbits.ensure(words, err) || !d.prank.ensure(words, err) || !d.prow.ensure(kTableSize / 8000, err) || !d.slots.ensure(1, err) || !d.ientries.ensure(1, err)) return false;
-    HIP_OK(hipMemsetAsync(d.pbits.p, 0, words * sizeof(uint64_t), d.stream));
-    HIP_OK(hipMemsetAsync(d.prank.p, 0, words * sizeof(uint16_t), d.stream));
-    HIP_OK(hipMemsetAsync(d.prow.p, 0, (kTableSize / 8000) * sizeof(uint32_t), d.stream));
+    const size_t words = kTableSize / 32;
+    if (!d.pbits.ensure(words, err) || !d.probe.ensure(words, err) || !d.slots.ensure(1, err) || !d.ientries.ensure(1, err)) return false;
+    HIP_OK(hipMemsetAsync(d.pbits.p, 0, words * sizeof(uint32_t), d.stream));
+    HIP_OK(hipMemsetAsync(d.probe.p, 0, words * sizeof(uint64_t), d.stream));
     const uint64_t base = ts.offsets[from], Rs = ts.offsets[to] - base;
     if (index && Rs > 0) {
         if (Rs >= (1ull << 31)) { err = "index construction: more than 2^31 residues in one shard"; return false; }
@@ -1680,12 +1723,12 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
             HIP_OK(hipStreamSynchronize(d.stream));
             const uint32_t nSlots = lastSlot + lastHead;
             if (!d.ixHeadPos.ensure(nSlots + 1, err) || !d.slots.ensure(nSlots + 1, err) || !d.ixCnt.ensure(words, err) || !d.ixBefore.ensure(words + 1, err)) return false;
-            hipLaunchKernelGGL(k_idx_slots1, dim3(ge), dim3(256), 0, d.stream, d.ixKmer.p, d.ixHead.p, d.ixSlotOf.p, E, d.ixHeadPos.p, (unsigned long long *) d.pbits.p);
+            hipLaunchKernelGGL(k_idx_slots1, dim3(ge), dim3(256), 0, d.stream, d.ixKmer.p, d.ixHead.p, d.ixSlotOf.p, E, d.ixHeadPos.p, d.pbits.p);
             hipLaunchKernelGGL(k_idx_slots2, dim3((nSlots + 255) / 256), dim3(256), 0, d.stream, d.ixHeadPos.p, nSlots, E, d.ientries.p, d.slots.p);
-            hipLaunchKernelGGL(k_idx_popc, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, (const unsigned long long *) d.pbits.p, (uint32_t) words, d.ixCnt.p);
+            hipLaunchKernelGGL(k_idx_popc, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, d.pbits.p, (uint32_t) words, d.ixCnt.p);
             sb = d.ixTemp.n;
             HIP_OK(hipcub::DeviceScan::ExclusiveSum(d.ixTemp.p, sb, d.ixCnt.p, d.ixBefore.p, (int) words, d.stream));
-            hipLaunchKernelGGL(k_idx_ranks, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, d.ixBefore.p, (uint32_t) words, d.prank.p, d.prow.p);
+            hipLaunchKernelGGL(k_idx_probe, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, d.pbits.p, d.ixBefore.p, (uint32_t) words, d.probe.p);
             HIP_OK(hipGetLastError());
             d.indexEntries = E; out.indexEntries = E; out.indexSlots = nSlots;
         }
