@@ -121,10 +121,12 @@ def test_align_hits_equals_align_pairs():
     ctx.close()
 
 
-def test_packed_sw_kernel_byte_overflow_and_ragged_groups():
-    """the 4-alignments-per-wave kernel on awkward material: W/C-rich 20-32 aa queries whose perfect matches overflow the
-    8-bit pass (score + bias >= 255 -> 16-bit redo, mixed byte/word lists in the reverse pass), queries of very different
-    lengths side by side in one wave, targets shorter than a 32-column chunk, and a pair count that is not a multiple of 4"""
+@pytest.mark.parametrize("heavy_lengths,min_word", [((20, 24, 28, 32), 8), ((13, 14, 15, 16), 0)])
+def test_packed_sw_kernel_byte_overflow_and_ragged_groups(heavy_lengths, min_word):
+    """the packed kernels (4 alignments per wave for queries up to 32 aa, 8 per wave when no query is longer than 16) on
+    awkward material: W/C-rich queries whose perfect matches overflow the 8-bit pass when they are long enough
+    (score + bias >= 255 -> 16-bit redo, mixed byte/word lists in the reverse pass), queries of very different lengths
+    side by side in one wave, targets shorter than a column chunk, and a pair count that is not a multiple of 8"""
     import random
     from oracle_lib import Alp, Oracle
     import spacepharer_amd as sa
@@ -133,7 +135,7 @@ def test_packed_sw_kernel_byte_overflow_and_ragged_groups():
     aa = "ACDEFGHIKLMNPQRSTVWY"
     T, Q = [], []
     for i in range(60):                       # heavy queries + targets that contain them (exact, or with an insertion / deletion)
-        L = rnd.choice([20, 24, 28, 32])
+        L = rnd.choice(heavy_lengths)
         q = "".join(rnd.choice("WWWCCYFHM" if rnd.random() < 0.8 else aa) for _ in range(L))
         Q.append(q)
         left, right = ("".join(rnd.choice(aa) for _ in range(rnd.randint(0, 40))) for _ in range(2))
@@ -152,7 +154,7 @@ def test_packed_sw_kernel_byte_overflow_and_ragged_groups():
     ctx.set_queries(Q)
     pairs = [(qi, ti) for qi in range(len(Q)) for ti in range(len(T)) if rnd.random() < 0.08]
     pairs += [(qi, ti) for qi, q in enumerate(Q) for ti, t in enumerate(T) if q in t]
-    if len(pairs) % 4 == 0:
+    while len(pairs) % 8 != 5:
         pairs.append((0, 0))
     got = ctx.align(pairs)
     word = 0
@@ -162,7 +164,7 @@ def test_packed_sw_kernel_byte_overflow_and_ragged_groups():
         if e.passed:
             assert (res.q_start, res.db_start, res.aln_len, res.evalue, cig) == (e.qStartPos, e.dbStartPos, e.alnLength, e.eval, e.backtrace.decode()), (qi, ti)
         word += e.rawScore >= 240
-    assert word >= 8             # the 16-bit redo path really ran
+    assert word >= min_word      # the 16-bit redo path really ran (long queries)
     ctx.close()
     o.close()
 
