@@ -214,8 +214,8 @@ def main():
         if args.stage == "full" and npairs:
             ctx.align_hits_begin()                        # alignment result DB content (result_t + backtraces per hit): returns when
                                                           # the kernels are done, the 5 MB travel while the next pass's prefilter runs
-        ctx.hits_compact()                                # prefilter result DB content (hit_t triples per query); its copy to
-        return npairs                                     # the host started when the prefilter finished and overlapped align
+        ctx.hits_view()                                   # prefilter result DB content (hit_t triples per query) in host memory: its
+        return npairs                                     # copy started when the prefilter finished and overlapped align
 
     def barrier():
         ctx.align_hits_end()                              # the last pass's alignment records are in host memory

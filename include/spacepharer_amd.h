@@ -115,6 +115,10 @@ int sp_ctx_max_seqs(const sp_ctx *c);
 /* compact form: total = sp_ctx_num_hits(); hits[total] grouped by query in query order, offsets[n_queries + 1] */
 uint64_t sp_ctx_num_hits(const sp_ctx *c);
 int sp_ctx_get_hits_compact(sp_ctx *c, sp_hit *hits, uint64_t *offsets);
+/* the same list without a copy: the page-locked buffers the device delivered it to (hits[*n] grouped by query,
+   offsets[n_queries + 1]); the pointers stay valid until the next prefilter / merge call on this context */
+typedef struct { uint32_t seq_id; uint16_t score; int16_t diagonal; } sp_hit_packed;   /* 8 bytes */
+int sp_ctx_hits_view(sp_ctx *c, const sp_hit_packed **hits, const uint32_t **offsets, uint64_t *n);
 
 /* align (query index, target index) pairs of the resident batch.  results[n]; cigars: caller buffer of cigar_cap
    bytes, *cigar_used returns the bytes needed/used (SP_ERR_OVERFLOW if cigar_cap is too small). */

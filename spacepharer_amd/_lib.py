@@ -30,6 +30,11 @@ class Hit(C.Structure):
     _fields_ = [("seq_id", C.c_uint32), ("score", C.c_int32), ("diagonal", C.c_int16), ("pad", C.c_int16)]
 
 
+class HitPacked(C.Structure):
+    """sp_hit_packed: the 8-byte hit record as the device delivers it"""
+    _fields_ = [("seq_id", C.c_uint32), ("score", C.c_uint16), ("diagonal", C.c_int16)]
+
+
 class Alignment(C.Structure):
     _fields_ = [("db_key", C.c_uint32), ("bit_score", C.c_int32), ("raw_score", C.c_int32), ("seq_id", C.c_float),
                 ("evalue", C.c_double), ("q_start", C.c_int32), ("q_end", C.c_int32), ("q_len", C.c_uint32),
@@ -76,6 +81,7 @@ def load_library():
     L.sp_ctx_num_hits.restype = C.c_uint64
     L.sp_ctx_num_hits.argtypes = [vp]
     L.sp_ctx_get_hits_compact.argtypes = [vp, C.POINTER(Hit), C.POINTER(C.c_uint64)]
+    L.sp_ctx_hits_view.argtypes = [vp, C.POINTER(C.POINTER(HitPacked)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint64)]
     L.sp_ctx_align.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(Alignment), C.c_char_p,
                                C.c_uint64, C.POINTER(C.c_uint64)]
     L.sp_ctx_align_hits.argtypes = [vp, C.POINTER(Alignment), C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -300,6 +306,13 @@ class SearchContext:
             self._hit_offs = (C.c_uint64 * (self.n_queries + 1))()
         _check(self.L.sp_ctx_get_hits_compact(self.ctx, self._hits, self._hit_offs))
         return self._hits, self._hit_offs, total
+
+    def hits_view(self):
+        """(HitPacked array, uint32 offsets[n_queries+1], total) -- the library's page-locked delivery buffers, no copy;
+        valid until the next prefilter()"""
+        hp, op, n = C.POINTER(HitPacked)(), C.POINTER(C.c_uint32)(), C.c_uint64()
+        _check(self.L.sp_ctx_hits_view(self.ctx, C.byref(hp), C.byref(op), C.byref(n)))
+        return hp, op, int(n.value)
 
     def hits(self):
         hits, offs, _ = self.hits_compact()

@@ -257,6 +257,14 @@ int sp_ctx_get_hits_compact(sp_ctx *c, sp_hit *hits, uint64_t *offsets) {
     return SP_OK;
 }
 
+int sp_ctx_hits_view(sp_ctx *c, const sp_hit_packed **hits, const uint32_t **offsets, uint64_t *n) {
+    static_assert(sizeof(sp_hit_packed) == sizeof(sp::GpuHit), "sp_hit_packed is the device hit record");
+    const sp::GpuHit *h = nullptr; const uint32_t *off = nullptr; size_t cnt = 0; std::string err;
+    if (!c->gpu.hostHits(h, off, cnt, err)) { g_err = err; return SP_ERR_DEVICE; }
+    *hits = reinterpret_cast<const sp_hit_packed *>(h); *offsets = off; *n = cnt;
+    return SP_OK;
+}
+
 int sp_ctx_get_hits(sp_ctx *c, sp_hit *hits, uint32_t *counts) {
     const sp::GpuHit *h = nullptr; const uint32_t *off = nullptr; size_t n = 0; std::string err;
     if (!c->gpu.hostHits(h, off, n, err)) { g_err = err; return SP_ERR_DEVICE; }

@@ -30,6 +30,18 @@ def full():
     ctx.close()
 
 
+def test_hits_view_is_the_compact_list_without_a_copy(full):
+    """sp_ctx_hits_view(): the page-locked delivery buffers hold exactly what sp_ctx_get_hits_compact() copies out"""
+    ctx, h, off, n = full["ctx"], full["h"], full["off"], full["n"]
+    hp, op, cnt = ctx.hits_view()
+    assert cnt == n
+    v = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_uint16)), shape=(max(1, n), 4))[:n]
+    seq = v[:, 0].astype(np.int64) | (v[:, 1].astype(np.int64) << 16)
+    assert np.array_equal(seq, h[:, 0]) and np.array_equal(v[:, 2].astype(np.int64), h[:, 1])
+    assert np.array_equal(v[:, 3].astype(np.int16), ((h[:, 2] << 16) >> 16).astype(np.int16))
+    assert np.array_equal(np.ctypeslib.as_array(op, shape=(len(off),)).astype(np.int64), off)
+
+
 def test_counters_and_shapes(full):
     ctx, h, off, nq, n = full["ctx"], full["h"], full["off"], full["nq"], full["n"]
     assert off[0] == 0 and off[-1] == n and np.all(np.diff(off) >= 0) and np.all(np.diff(off) <= 300)
