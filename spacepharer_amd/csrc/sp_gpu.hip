@@ -178,6 +178,182 @@ __global__ void k_prep(PrepArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_weigh: how many similar k-mers will a query generate?  The cost of a query in k_match is proportional to that
+// number and very skewed (median 350, mean 870, one in a thousand above 11 000 for spacer peptides): a heavy query
+// popped late keeps one wave busy long after the others have finished.  Per window the count is exact and cheap from
+// the count tables: sum over the score values s of row A that reach the cut-off of  #a(score == s) * #b(score >= thr - s).
+// Queries above `heavyThr` are listed; k_match starts with them (one per wave, spread over the CUs).  Only the ORDER
+// of the work depends on this, never a result.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kCntW = 320;         // width of a row of the count table: cutoffs cntMin .. cntMin + 319
+struct WeighArgs {
+    const uint8_t *qres; const uint32_t *qoff; uint32_t nq; const short *qthr;
+    const uint32_t *ext3; const uint16_t *ext3cnt; int cntMin; uint32_t heavyThr;
+    uint32_t *heavyList; uint8_t *heavyFlag; uint32_t *heavyCount;
+};
+__global__ __launch_bounds__(256) void k_weigh(WeighArgs a) {
+    // 8 lanes per query share the score values of a window (the loads of one lane would be a long dependent chain); a block
+    // walks a contiguous range of queries and appends its heavy ones with ONE atomic (atomics on one word serialise)
+    __shared__ uint32_t s_list[1024]; __shared__ uint32_t s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t per = (a.nq + gridDim.x - 1) / gridDim.x, qFrom = blockIdx.x * per, qTo = min(a.nq, qFrom + per);
+    const int sub = (int) (threadIdx.x & 7u);
+    for (uint32_t q0 = qFrom; q0 < qTo; q0 += 32) {
+        const uint32_t qi = q0 + (threadIdx.x >> 3);
+        uint32_t K = 0;
+        if (qi < qTo) {
+            const uint32_t o = a.qoff[qi];
+            const int L = (int) (a.qoff[qi + 1] - o);
+            const uint8_t *q = a.qres + o;
+            for (int i = 0; i < L - 8; i++) {
+                const int thr = a.qthr[o + i];
+                if (thr < 0) continue;
+                const uint32_t ia = q[i] + 20u * q[i + 1] + 400u * q[i + 3], ib = q[i + 4] + 20u * q[i + 5] + 400u * q[i + 7];
+                const int sA0 = extScore(a.ext3[(size_t) ia * 8000u]), sB0 = extScore(a.ext3[(size_t) ib * 8000u]);
+                const uint16_t *cA = a.ext3cnt + (size_t) ia * kCntW, *cB = a.ext3cnt + (size_t) ib * kCntW;
+                auto at = [&](const uint16_t *row, int c) -> uint32_t { int x = c - a.cntMin; x = x < 0 ? 0 : (x > kCntW - 1 ? kCntW - 1 : x); return row[x]; };
+                const int lo = thr - sB0 > a.cntMin ? thr - sB0 : a.cntMin;
+                for (int base = lo; base <= sA0; base += 64) {        // 64 score values per trip: 24 independent loads per lane
+                    uint32_t nGe[8], nGt[8], nB[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int sc = base + sub + 8 * j; const bool ok = sc <= sA0;
+                        nGe[j] = ok ? at(cA, sc) : 0u;
+                        nGt[j] = ok && sc + 1 - a.cntMin <= kCntW - 1 ? at(cA, sc + 1) : 0u;
+                        nB[j] = ok ? at(cB, thr - sc) : 0u;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) K += (nGe[j] - nGt[j]) * nB[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) K += (uint32_t) __shfl_xor((int) K, d, 8);
+        const bool heavy = qi < qTo && sub == 0 && K >= a.heavyThr;
+        if (qi < qTo && sub == 0) a.heavyFlag[qi] = heavy ? 1 : 0;
+        if (heavy) { const uint32_t at = atomicAdd(&s_n, 1u); if (at < 1024u) s_list[at] = qi; else { a.heavyFlag[qi] = 0; } }   // (a full list: the query keeps its normal place)
+    }
+    __syncthreads();
+    const uint32_t n = min(s_n, 1024u);
+    if (threadIdx.x == 0 && n) s_base = atomicAdd(a.heavyCount, n);
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < n; x += blockDim.x) a.heavyList[s_base + x] = s_list[x];
+}
+
+// k_prep + k_weigh in one launch for batches whose queries have at most 64 residues (every spacer batch): 8 lanes per query,
+// residues / bias values / thresholds staged in LDS, so the chains of dependent global round trips of the one-lane-per-query
+// kernels (store bias -> load it back per window, threshold -> table heads -> count rows) shrink to three.  Same
+// arithmetic, in the same order, as k_prep; same counts as k_weigh.
+struct Prep8Args { PrepArgs p; WeighArgs w; };
+__global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
+    const PrepArgs &a = a8.p; const WeighArgs &wa = a8.w;
+    __shared__ short s_seed[kAlph * kAlph]; __shared__ double s_back[kAlph]; __shared__ signed char s_ung[kAlph * kAlph];
+    __shared__ uint8_t s_q[32][64]; __shared__ float s_b[32][64]; __shared__ short s_t[32][64]; __shared__ signed char s_c[32][64];
+    __shared__ uint32_t s_top[32][64];
+    __shared__ uint32_t s_list[1024]; __shared__ uint32_t s_n, s_base;
+    for (int x = threadIdx.x; x < kAlph * kAlph; x += blockDim.x) { s_seed[x] = a.seedSub[x]; s_ung[x] = a.ungSub[x]; }
+    if (threadIdx.x < kAlph) s_back[threadIdx.x] = a.seedBack[threadIdx.x];
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t per = (a.nq + gridDim.x - 1) / gridDim.x, qFrom = blockIdx.x * per, qTo = min(a.nq, qFrom + per);
+    const int sub = (int) (threadIdx.x & 7u), slot = (int) (threadIdx.x >> 3);
+    for (uint32_t q0 = qFrom; q0 < qTo; q0 += 32) {
+        const uint32_t qi = q0 + (uint32_t) slot;
+        const bool have = qi < qTo;
+        const uint32_t o = have ? a.qoff[qi] : 0u;
+        const int L = have ? (int) (a.qoff[qi + 1] - o) : 0;
+        for (int i = sub; i < L; i += 8) s_q[slot][i] = a.qres[o + i];
+        __syncthreads();
+        // local amino-acid bias (SubstitutionMatrix::calcLocalAaBiasCorrection, SubstitutionMatrix.cpp:85-114)
+        int aaBias = 0;
+        for (int i = sub; i < L; i += 8) {
+            const int minPos = max(0, i - 20), maxPos = min(L, i + 20);
+            const short *row = s_seed + s_q[slot][i] * kAlph;
+            int sum = 0;
+            for (int j = minPos; j < maxPos; j++) sum += row[s_q[slot][j]];
+            sum -= row[s_q[slot][i]];
+            float d = (float) sum;
+            d = (float) ((double) d / (-1.0 * (double) (float) (maxPos - minPos)));
+            for (int x = 0; x < kAlph; x++) d = (float) ((double) d + s_back[x] * (double) (float) row[x]);
+            a.biasf[o + i] = d; s_b[slot][i] = d;
+            float c = d;
+            c = (float) ((c < 0.0) ? (double) (c / 4) - 0.5 : (double) (c / 4) + 0.5);
+            const signed char cc = (signed char) c;
+            a.qcorr[o + i] = cc; s_c[slot][i] = cc;
+            aaBias = (cc < aaBias) ? cc : aaBias;
+        }
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) { const int ob = __shfl_xor(aaBias, d, 8); aaBias = ob < aaBias ? ob : aaBias; }
+        if (have && sub == 0) a.qbias[qi] = a.ungMinAbs + abs(aaBias > 0 ? 0 : aaBias);
+        __syncthreads();
+        // k-mer thresholds per window (QueryMatcher.cpp:205-219)
+        for (int i = sub; i < L; i += 8) {
+            short t = -1;
+            if (i + kSpan <= L) {
+                float bc = 0; bool hasX = false;
+                const int pp[6] = {0, 1, 3, 4, 5, 7};
+#pragma unroll
+                for (int p = 0; p < 6; p++) { bc += s_b[slot][i + pp[p]]; hasX |= (s_q[slot][i + pp[p]] == kX); }
+                if (!hasX) {
+                    const short b = (short) ((bc < 0.0) ? (double) bc - 0.5 : (double) bc + 0.5);
+                    int v = a.kmerThr - b; if (v < 0) v = 0;
+                    t = (short) v;
+                }
+            }
+            a.qthr[o + i] = t; s_t[slot][i] = t;
+        }
+        // self score on diagonal 0 (QueryMatcher::rescoreHits, prefiltering/QueryMatcher.cpp:489-494)
+        if (have && sub == 0) {
+            int mx = 0, sc = 0;
+            for (int i = 0; i < L; i++) { sc += s_ung[s_q[slot][i] * kAlph + s_q[slot][i]] + s_c[slot][i]; sc = sc < 0 ? 0 : sc; mx = sc > mx ? sc : mx; }
+            a.qself[qi] = mx;
+        }
+        __syncthreads();
+        // similar k-mers the query will generate (see k_weigh); the best scores of all windows' rows are fetched together
+        for (int i = sub; i < L - 8; i += 8) {
+            const uint8_t *q = s_q[slot];
+            const uint32_t ia = q[i] + 20u * q[i + 1] + 400u * q[i + 3], ib = q[i + 4] + 20u * q[i + 5] + 400u * q[i + 7];
+            s_top[slot][i] = s_t[slot][i] < 0 ? 0u : (wa.ext3[(size_t) ia * 8000u] >> 16) | (wa.ext3[(size_t) ib * 8000u] & 0xFFFF0000u);
+        }
+        __syncthreads();
+        uint32_t K = 0;
+        for (int i = 0; i < L - 8; i++) {
+            const int thr = s_t[slot][i];
+            if (thr < 0) continue;
+            const uint8_t *q = s_q[slot];
+            const uint32_t ia = q[i] + 20u * q[i + 1] + 400u * q[i + 3], ib = q[i + 4] + 20u * q[i + 5] + 400u * q[i + 7];
+            const int sA0 = (int) (s_top[slot][i] & 0xFFFFu) - 32768, sB0 = (int) (s_top[slot][i] >> 16) - 32768;
+            const uint16_t *cA = wa.ext3cnt + (size_t) ia * kCntW, *cB = wa.ext3cnt + (size_t) ib * kCntW;
+            auto at = [&](const uint16_t *row, int c) -> uint32_t { int x = c - wa.cntMin; x = x < 0 ? 0 : (x > kCntW - 1 ? kCntW - 1 : x); return row[x]; };
+            const int lo = thr - sB0 > wa.cntMin ? thr - sB0 : wa.cntMin;
+            for (int base = lo; base <= sA0; base += 32) {
+                uint32_t nGe[4], nGt[4], nB[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int sc = base + sub + 8 * j; const bool ok = sc <= sA0;
+                    nGe[j] = ok ? at(cA, sc) : 0u;
+                    nGt[j] = ok && sc + 1 - wa.cntMin <= kCntW - 1 ? at(cA, sc + 1) : 0u;
+                    nB[j] = ok ? at(cB, thr - sc) : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) K += (nGe[j] - nGt[j]) * nB[j];
+            }
+        }
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) K += (uint32_t) __shfl_xor((int) K, d, 8);
+        const bool heavy = have && sub == 0 && K >= wa.heavyThr;
+        if (have && sub == 0) wa.heavyFlag[qi] = heavy ? 1 : 0;
+        if (heavy) { const uint32_t at = atomicAdd(&s_n, 1u); if (at < 1024u) s_list[at] = qi; else wa.heavyFlag[qi] = 0; }
+        __syncthreads();
+    }
+    const uint32_t n = min(s_n, 1024u);
+    if (threadIdx.x == 0 && n) s_base = atomicAdd(wa.heavyCount, n);
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < n; x += blockDim.x) wa.heavyList[s_base + x] = s_list[x];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // K_match: one wavefront per query (persistent waves pulling queries from an atomic counter)
 //   similar k-mer lists        KmerGenerator::generateKmerList / calculateArrayProduct, KmerGenerator.cpp:107-216
 //   index lookup + hit stream  QueryMatcher::match, QueryMatcher.cpp:188-307
@@ -193,7 +369,6 @@ __global__ void k_prep(PrepArgs a) {
 constexpr int kSpillCap = 65535;     // hits per query in the per-wave HBM scratch (16-bit stream index)
 constexpr int kATile = 256;
 constexpr int kBTile = 512;
-constexpr int kCntW = 320;         // width of a row of the count table: cutoffs cntMin .. cntMin + 319
 constexpr uint32_t kMaxKmerResult = 262144u * 32u;   // KmerGenerator.h:45
 constexpr int kWavesPerBlock = 4;
 constexpr uint32_t kDiagChunk = 64;   // diagonal records reserved per atomic in k_match
@@ -223,6 +398,7 @@ struct MatchArgs {
     // query's whole k-mer enumeration -- identical on every shard, so (ordinal, seqId) orders records globally
     uint32_t *diagOrd; uint32_t *spillOrd;
     uint32_t staticEighths, dynChunk;   // work distribution: share of the queries dealt round-robin, queries per atomic pop for the rest
+    const uint32_t *heavyList; const uint8_t *heavyFlag; const uint32_t *heavyCount;   // k_weigh: queries to start with
 };
 
 // phase timers (build with -DSP_PHASE_TIMERS): shader-clock ticks per phase, summed over waves into counters[8 + phase]
@@ -306,14 +482,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     const uint32_t nWavesTot = gridDim.x * kWavesPerBlock;
     const uint32_t staticEnd = (uint32_t) ((uint64_t) a.nq * a.staticEighths / 8 / (nWavesTot * kQueryChunk)) * (nWavesTot * kQueryChunk);
     uint32_t sNext = waveGlobal * kQueryChunk;
+    // the heavy queries first: the j-th of them goes to wave j / #blocks of block j % #blocks (one per block -- one per SIMD of
+    // a CU -- before any block gets a second one); everybody skips them later
+    const uint32_t nHeavy = uni(*a.heavyCount);
+    uint32_t hNext = (uint32_t) w * gridDim.x + blockIdx.x;
     for (uint32_t qc = 0, qcEnd = 0;;) {
-        if (qc == qcEnd) {
-            if (sNext < staticEnd) { qc = sNext; sNext += nWavesTot * kQueryChunk; qcEnd = qc + kQueryChunk; }
-            else { qc = staticEnd + popQueue(a.queue, lane) * a.dynChunk; qcEnd = qc + a.dynChunk; }
-            if (qc >= a.nq) break;
+        uint32_t qi;
+        if (hNext < nHeavy) { qi = uni(a.heavyList[hNext]); hNext += nWavesTot; }
+        else {
+            if (qc == qcEnd) {
+                if (sNext < staticEnd) { qc = sNext; sNext += nWavesTot * kQueryChunk; qcEnd = qc + kQueryChunk; }
+                else { qc = staticEnd + popQueue(a.queue, lane) * a.dynChunk; qcEnd = qc + a.dynChunk; }
+                if (qc >= a.nq) break;
+            }
+            qi = qc++;
+            if (qi >= a.nq) break;
+            if (uni((uint32_t) a.heavyFlag[qi])) continue;
         }
-        const uint32_t qi = qc++;
-        if (qi >= a.nq) break;
         const uint32_t qo = uni(a.qoff[qi]);
         const int L = (int) (uni(a.qoff[qi + 1]) - qo);
         const uint8_t *q = a.qres + qo;
@@ -1301,7 +1486,7 @@ struct Gpu::Impl {
     size_t qTotal = 0; uint32_t maxQLen = 0;
     std::vector<uint32_t> hQoff;
     // match / select
-    DevBuf<uint64_t> spill; DevBuf<uint32_t> queue; DevBuf<DiagRec> diagRec; DevBuf<uint32_t> diagQuery; DevBuf<uint16_t> diagScore; DevBuf<uint8_t> diagFlag;
+    DevBuf<uint64_t> spill; DevBuf<uint32_t> heavyList; DevBuf<uint8_t> heavyFlag; DevBuf<uint32_t> queue; DevBuf<DiagRec> diagRec; DevBuf<uint32_t> diagQuery; DevBuf<uint16_t> diagScore; DevBuf<uint8_t> diagFlag;
     DevBuf<uint32_t> qDiagBase; DevBuf<uint32_t> qDiagCnt; DevBuf<unsigned long long> counters;
     DevBuf<GpuHit> outHits; DevBuf<GpuHit> outStage; DevBuf<uint32_t> outQuery; DevBuf<uint32_t> outCount; DevBuf<uint32_t> outBase; DevBuf<uint32_t> outOffset;
     uint32_t matchBlocks = 0;
@@ -1502,7 +1687,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     const uint32_t blocks = (uint32_t) std::min<size_t>((nq_ + kWavesPerBlock - 1) / kWavesPerBlock, (size_t) d.numCU * perCU);
     d.matchBlocks = blocks;
     if (!d.spill.ensure((size_t) blocks * kWavesPerBlock * kSpillWordsPerWave, err)) return false;
-    if (!d.queue.ensure(8, err) || !d.counters.ensure(16, err)) return false;
+    if (!d.queue.ensure(8, err) || !d.counters.ensure(16, err) || !d.heavyList.ensure(nq_ + 1, err) || !d.heavyFlag.ensure(nq_ + 1, err)) return false;
     // diagonal buffer: generous, HBM is plentiful (64 M records = 512 MB + side arrays)
     const size_t diagCap = std::max<size_t>((size_t) 1 << 22, std::min<size_t>((size_t) 1 << 26, nq_ * 64));
     d.diagCap = diagCap;
@@ -1514,13 +1699,26 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
 
     HIP_OK(hipEventRecord(d.ev[0], d.stream));
     PrepArgs pa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.seedSub.p, d.seedBack.p, d.ungSub.p, kmerThr, d.ungMinAbs, d.biasf.p, d.qthr.p, d.qcorr.p, d.qbias.p, d.qself.p};
-    hipLaunchKernelGGL(k_prep, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, pa);
-    SP_DBG_SYNC("k_prep");
+    // SP_MATCH_HEAVY: similar k-mers from which a query counts as heavy and is started first (0 = none)
+    const uint32_t heavyThr = getenv("SP_MATCH_HEAVY") ? (uint32_t) atoi(getenv("SP_MATCH_HEAVY")) : 4000u;
+    WeighArgs wa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, heavyThr ? heavyThr : 0xFFFFFFFFu, d.heavyList.p, d.heavyFlag.p, d.queue.p + 5};
+    const unsigned weighBlocks = (unsigned) std::min<size_t>((nq_ + 31) / 32, (size_t) d.numCU * 8);
+    if (d.maxQLen <= 64 && !getenv("SP_PREP_SPLIT")) {
+        Prep8Args p8{pa, wa};
+        hipLaunchKernelGGL(k_prep8, dim3(weighBlocks), dim3(256), 0, d.stream, p8);
+        SP_DBG_SYNC("k_prep8");
+    } else {
+        hipLaunchKernelGGL(k_prep, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, pa);
+        SP_DBG_SYNC("k_prep");
+        hipLaunchKernelGGL(k_weigh, dim3(weighBlocks), dim3(256), 0, d.stream, wa);
+        SP_DBG_SYNC("k_weigh");
+    }
     HIP_OK(hipEventRecord(d.ev[1], d.stream));
     MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.probe.p, d.slots.p, d.ientries.p, d.spill.p, d.queue.p,
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
-                 (uint32_t) (getenv("SP_MATCH_STATIC") ? atoi(getenv("SP_MATCH_STATIC")) : 4), (uint32_t) (getenv("SP_MATCH_DCHUNK") ? std::max(1, atoi(getenv("SP_MATCH_DCHUNK"))) : 4)};
+                 (uint32_t) (getenv("SP_MATCH_STATIC") ? atoi(getenv("SP_MATCH_STATIC")) : 4), (uint32_t) (getenv("SP_MATCH_DCHUNK") ? std::max(1, atoi(getenv("SP_MATCH_DCHUNK"))) : 4),
+                 d.heavyList.p, d.heavyFlag.p, d.queue.p + 5};
     if (withOrd) hipLaunchKernelGGL((k_match<512, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     else hipLaunchKernelGGL((k_match<512, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     SP_DBG_SYNC("k_match");
