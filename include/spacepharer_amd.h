@@ -162,6 +162,9 @@ int sp_ctx_merge_candidates(sp_ctx *c, const sp_candidate *candidates, uint64_t 
 double sp_ctx_stat(const sp_ctx *c, const char *name);
 /* wait for everything queued on the context's stream */
 int sp_ctx_sync(sp_ctx *c);
+/* HIP-event timing inside the pipeline (sp_ctx_stat "ms_*"): 0 = none, 1 = the k-mer matching kernel only (default; every
+   event record between two kernels costs ~6 us of idle GPU), 2 = every stage.  Stages that are not timed report NaN. */
+int sp_ctx_set_timing(sp_ctx *c, int level);
 /* raw HIP stream the context launches on (hipStream_t), for callers that time with their own events */
 void *sp_ctx_stream(const sp_ctx *c);
 /* test hooks: digest of the index built on the device ((k-mer, seqId, pos) triples in table order, FNV-1a as in

@@ -100,6 +100,7 @@ def load_library():
     L.sp_ctx_stat.restype = C.c_double
     L.sp_ctx_stat.argtypes = [vp, C.c_char_p]
     L.sp_ctx_sync.argtypes = [vp]
+    L.sp_ctx_set_timing.argtypes = [vp, C.c_int]
     L.sp_ctx_stream.restype = vp
     L.sp_ctx_stream.argtypes = [vp]
     L.sp_ctx_index_digest.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -343,6 +344,10 @@ class SearchContext:
 
     def sync(self):
         _check(self.L.sp_ctx_sync(self.ctx))
+
+    def set_timing(self, level):
+        """0: no HIP events inside the pipeline, 1: around the matching kernel only (default), 2: every stage"""
+        _check(self.L.sp_ctx_set_timing(self.ctx, level))
 
     def diag_stream_read(self, nbytes, lane_bytes):
         """profiling aid: milliseconds of one streaming read of nbytes (FETCH_SIZE calibration)"""

@@ -125,6 +125,7 @@ public:
     bool diagStreamRead(uint64_t bytes, int laneBytes, double &ms, std::string &err);
 
     void sync();
+    void setTiming(int level);     // 0 none, 1 k_match only (default), 2 every stage
     void *stream() const { return stream_; }
 
 private:

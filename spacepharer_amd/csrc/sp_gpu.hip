@@ -1493,6 +1493,7 @@ struct Gpu::Impl {
     size_t diagCap = 0;
     DevBuf<unsigned char> scanTemp; DevBuf<uint32_t> selWant, selWantOff;
     unsigned long long *mailbox = nullptr;       // page-locked landing area for counters
+    int timing = 1;                              // 0: no HIP events in the pipeline, 1: around k_match only (each record costs ~6 us of idle GPU), 2: every stage
     // the hit list starts travelling to the host on its own stream as soon as a prefilter pass is complete, so that the copy
     // overlaps whatever the caller queues next (typically the align kernels)
     hipStream_t copyStream = nullptr; hipEvent_t hitsOnHost = nullptr, alnOnHost = nullptr; bool alnInFlight = false;
@@ -1537,6 +1538,22 @@ static hipError_t spinSync(hipStream_t s) {
         const hipError_t e = hipStreamQuery(s);
         if (e != hipErrorNotReady) return e;
         __builtin_ia32_pause();
+    }
+}
+
+// stage timing: an event record between two kernels opens a ~6 us bubble, so only the roofline kernel is bracketed by default
+#define SP_EV(i, level) do { if (d.timing >= (level)) HIP_OK(hipEventRecord(d.ev[i], d.stream)); } while (0)
+static float evMs(int timing, int level, hipEvent_t a, hipEvent_t b) {
+    float t = 0; if (timing < level || hipEventElapsedTime(&t, a, b) != hipSuccess) return __builtin_nanf(""); return t;
+}
+void Gpu::setTiming(int level) { d_->timing = level < 0 ? 0 : (level > 2 ? 2 : level); }
+
+// several small fills in one launch (each hipMemsetAsync is a kernel of its own plus a gap)
+struct FillArgs { void *p[4]; unsigned long long bytes[4]; uint32_t value[4]; };
+__global__ void k_fill(FillArgs a) {
+    for (int r = 0; r < 4; r++) {
+        uint32_t *w = static_cast<uint32_t *>(a.p[r]); const unsigned long long n = a.bytes[r] / 4;
+        for (unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long) gridDim.x * blockDim.x) w[i] = a.value[r];
     }
 }
 
@@ -1693,11 +1710,9 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     d.diagCap = diagCap;
     if (!d.diagRec.ensure(diagCap, err) || !d.diagQuery.ensure(diagCap, err) || !d.diagScore.ensure(diagCap, err) || !d.diagFlag.ensure(diagCap, err)) return false;
     if (withOrd && (!d.diagOrd.ensure(diagCap, err) || !d.spillOrd.ensure((size_t) blocks * kWavesPerBlock * 65536, err))) return false;
-    HIP_OK(hipMemsetAsync(d.queue.p, 0, 8 * sizeof(uint32_t), d.stream));
-    HIP_OK(hipMemsetAsync(d.counters.p, 0, 16 * sizeof(unsigned long long), d.stream));
-    HIP_OK(hipMemsetAsync(d.diagQuery.p, 0xFF, diagCap * sizeof(uint32_t), d.stream));
-
-    HIP_OK(hipEventRecord(d.ev[0], d.stream));
+    {   FillArgs fa{{d.queue.p, d.counters.p, d.diagQuery.p, nullptr}, {8 * sizeof(uint32_t), 16 * sizeof(unsigned long long), diagCap * sizeof(uint32_t), 0}, {0u, 0u, 0xFFFFFFFFu, 0u}};
+        hipLaunchKernelGGL(k_fill, dim3((unsigned) d.numCU * 4), dim3(256), 0, d.stream, fa); }
+    SP_EV(0, 2);
     PrepArgs pa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.seedSub.p, d.seedBack.p, d.ungSub.p, kmerThr, d.ungMinAbs, d.biasf.p, d.qthr.p, d.qcorr.p, d.qbias.p, d.qself.p};
     // SP_MATCH_HEAVY: similar k-mers from which a query counts as heavy and is started first (0 = none)
     const uint32_t heavyThr = getenv("SP_MATCH_HEAVY") ? (uint32_t) atoi(getenv("SP_MATCH_HEAVY")) : 4000u;
@@ -1713,7 +1728,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
         hipLaunchKernelGGL(k_weigh, dim3(weighBlocks), dim3(256), 0, d.stream, wa);
         SP_DBG_SYNC("k_weigh");
     }
-    HIP_OK(hipEventRecord(d.ev[1], d.stream));
+    SP_EV(1, 1);
     MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.probe.p, d.slots.p, d.ientries.p, d.spill.p, d.queue.p,
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
@@ -1722,11 +1737,11 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     if (withOrd) hipLaunchKernelGGL((k_match<512, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     else hipLaunchKernelGGL((k_match<512, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     SP_DBG_SYNC("k_match");
-    HIP_OK(hipEventRecord(d.ev[2], d.stream));
+    SP_EV(2, 1);
     ScoreArgs sa{d.diagRec.p, d.diagQuery.p, d.queue.p + 1, (uint32_t) diagCap, d.qres.p, d.qoff.p, d.qcorr.p, d.tmasked.p, d.toff.p, d.ungSub.p, d.diagScore.p, d.counters.p};
     hipLaunchKernelGGL(k_score, dim3((unsigned) d.numCU * 8), dim3(256), 0, d.stream, sa);
     SP_DBG_SYNC("k_score");
-    HIP_OK(hipEventRecord(d.ev[3], d.stream));
+    SP_EV(3, 2);
     return true;
 }
 
@@ -1755,11 +1770,11 @@ bool Gpu::finishPrefilter(bool matched, std::string &err) {
     }
 #endif
     if (matched) {
-        (void) hipEventElapsedTime(&times_.prep, d.ev[0], d.ev[1]);
-        (void) hipEventElapsedTime(&times_.match, d.ev[1], d.ev[2]);
-        (void) hipEventElapsedTime(&times_.score, d.ev[2], d.ev[3]);
+        times_.prep = evMs(d.timing, 2, d.ev[0], d.ev[1]);
+        times_.match = evMs(d.timing, 1, d.ev[1], d.ev[2]);
+        times_.score = evMs(d.timing, 2, d.ev[2], d.ev[3]);
     }
-    (void) hipEventElapsedTime(&times_.select, d.ev[3], d.ev[4]);
+    times_.select = evMs(d.timing, 2, d.ev[3], d.ev[4]);
     if (counters_.overflowQueries) {
         err = std::to_string(counters_.overflowQueries) + " queries produced more index hits, diagonals or candidates than the device buffers hold";
         return false;
@@ -1783,7 +1798,7 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     if (!d.scanCounts(d.outCount.p, (uint32_t) nq_, d.outOffset.p, err)) return false;
     hipLaunchKernelGGL(k_reorder_hits, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.outStage.p, d.outBase.p, d.outCount.p, d.outOffset.p, (uint32_t) nq_, d.outHits.p, d.outQuery.p);
     SP_DBG_SYNC("k_select");
-    HIP_OK(hipEventRecord(d.ev[4], d.stream));
+    SP_EV(4, 2);
     return finishPrefilter(true, err) && prefetchHits(err);
 }
 
@@ -1799,7 +1814,7 @@ bool Gpu::prefilterCandidates(int kmerThr, int minDiagScore, std::string &err) {
                 d.cand.p, d.queue.p + 4, (uint32_t) d.diagCap};
     hipLaunchKernelGGL(k_candidates, dim3((unsigned) d.numCU * 8), dim3(256), 0, d.stream, ca);
     SP_DBG_SYNC("k_candidates");
-    HIP_OK(hipEventRecord(d.ev[4], d.stream));
+    SP_EV(4, 2);
     if (!finishPrefilter(true, err)) return false;
     counters_.hits = 0;
     return true;
@@ -1842,7 +1857,7 @@ bool Gpu::mergeCandidates(const Candidate *src, size_t n, bool onDevice, size_t 
     HIP_OK(hipMemsetAsync(d.counters.p + 2, 0, sizeof(unsigned long long), d.stream));
     HIP_OK(hipMemsetAsync(d.candCnt.p, 0, (nq_ + 1) * sizeof(uint32_t), d.stream));
     HIP_OK(hipMemsetAsync(d.candFill.p, 0, (nq_ + 1) * sizeof(uint32_t), d.stream));
-    HIP_OK(hipEventRecord(d.ev[3], d.stream));
+    SP_EV(3, 2);
     if (n) hipLaunchKernelGGL(k_cand_count, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, u, (uint32_t) n, (uint32_t) qFrom, (uint32_t) qTo, d.candCnt.p);
     if (!d.scanCounts(d.candCnt.p, (uint32_t) nq_, d.candOffset.p, err)) return false;
     if (n) hipLaunchKernelGGL(k_cand_scatter, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, u, (uint32_t) n, (uint32_t) qFrom, (uint32_t) qTo, d.candOffset.p, d.candFill.p, d.candByQuery.p);
@@ -1852,7 +1867,7 @@ bool Gpu::mergeCandidates(const Candidate *src, size_t n, bool onDevice, size_t 
     if (!d.scanCounts(d.outCount.p, (uint32_t) nq_, d.outOffset.p, err)) return false;
     hipLaunchKernelGGL(k_reorder_hits, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.outStage.p, d.outBase.p, d.outCount.p, d.outOffset.p, (uint32_t) nq_, d.outHits.p, d.outQuery.p);
     SP_DBG_SYNC("k_select_merged");
-    HIP_OK(hipEventRecord(d.ev[4], d.stream));
+    SP_EV(4, 2);
     return finishPrefilter(false, err) && prefetchHits(err);
 }
 

@@ -14,6 +14,7 @@ ctx = sa.SearchContext()
 ctx.set_targets_raw(tres.tobytes(), bench.u64p(toff), len(toff) - 1)
 nq = len(qoff) - 1
 ctx.set_queries_raw(qres.tobytes(), bench.u64p(qoff), nq)
+ctx.set_timing(2)
 rng = np.random.default_rng(1)
 for n in (256, 2048, 8192, 16384, 32768, 57344, 65536, 73465, 114688, 131072, 262144):
     qi = rng.integers(0, nq, size=n).astype(np.uint32)

@@ -7,6 +7,7 @@ ctx = sa.SearchContext()
 ctx.set_targets_raw(tres.tobytes(), bench.u64p(toff), len(toff) - 1)
 nq = len(qoff) - 1
 ctx.set_queries_raw(qres.tobytes(), bench.u64p(qoff), nq)
+ctx.set_timing(2)
 acc = [0.0] * 4
 N = 30
 for it in range(N + 5):
