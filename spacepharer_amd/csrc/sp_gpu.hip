@@ -311,14 +311,15 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
         }
         __syncthreads();
         // similar k-mers the query will generate (see k_weigh); the best scores of all windows' rows are fetched together
-        for (int i = sub; i < L - 8; i += 8) {
+        const bool weigh = wa.heavyThr != 0xFFFFFFFFu;        // off for large batches (see matchAndScore)
+        for (int i = sub; i < (weigh ? L - 8 : 0); i += 8) {
             const uint8_t *q = s_q[slot];
             const uint32_t ia = q[i] + 20u * q[i + 1] + 400u * q[i + 3], ib = q[i + 4] + 20u * q[i + 5] + 400u * q[i + 7];
             s_top[slot][i] = s_t[slot][i] < 0 ? 0u : (wa.ext3[(size_t) ia * 8000u] >> 16) | (wa.ext3[(size_t) ib * 8000u] & 0xFFFF0000u);
         }
         __syncthreads();
         uint32_t K = 0;
-        for (int i = 0; i < L - 8; i++) {
+        for (int i = 0; i < (weigh ? L - 8 : 0); i++) {
             const int thr = s_t[slot][i];
             if (thr < 0) continue;
             const uint8_t *q = s_q[slot];
@@ -1715,7 +1716,9 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     SP_EV(0, 2);
     PrepArgs pa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.seedSub.p, d.seedBack.p, d.ungSub.p, kmerThr, d.ungMinAbs, d.biasf.p, d.qthr.p, d.qcorr.p, d.qbias.p, d.qself.p};
     // SP_MATCH_HEAVY: similar k-mers from which a query counts as heavy and is started first (0 = none)
-    const uint32_t heavyThr = getenv("SP_MATCH_HEAVY") ? (uint32_t) atoi(getenv("SP_MATCH_HEAVY")) : 4000u;
+    // (worth its 30 us per 60 000 queries only while a wave gets few queries: with more than ~30 per wave the heavy ones no
+    // longer decide when the kernel ends)
+    const uint32_t heavyThr = getenv("SP_MATCH_HEAVY") ? (uint32_t) atoi(getenv("SP_MATCH_HEAVY")) : (nq_ <= (size_t) blocks * kWavesPerBlock * 32 ? 4000u : 0u);
     WeighArgs wa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, heavyThr ? heavyThr : 0xFFFFFFFFu, d.heavyList.p, d.heavyFlag.p, d.queue.p + 5};
     const unsigned weighBlocks = (unsigned) std::min<size_t>((nq_ + 31) / 32, (size_t) d.numCU * 8);
     if (d.maxQLen <= 64 && !getenv("SP_PREP_SPLIT")) {
@@ -1725,7 +1728,8 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     } else {
         hipLaunchKernelGGL(k_prep, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, pa);
         SP_DBG_SYNC("k_prep");
-        hipLaunchKernelGGL(k_weigh, dim3(weighBlocks), dim3(256), 0, d.stream, wa);
+        if (heavyThr) hipLaunchKernelGGL(k_weigh, dim3(weighBlocks), dim3(256), 0, d.stream, wa);
+        else HIP_OK(hipMemsetAsync(d.heavyFlag.p, 0, nq_, d.stream));
         SP_DBG_SYNC("k_weigh");
     }
     SP_EV(1, 1);
