@@ -400,6 +400,8 @@ struct MatchArgs {
     uint32_t *diagOrd; uint32_t *spillOrd;
     uint32_t staticEighths, dynChunk;   // work distribution: share of the queries dealt round-robin, queries per atomic pop for the rest
     const uint32_t *heavyList; const uint8_t *heavyFlag; const uint32_t *heavyCount;   // k_weigh: queries to start with
+    unsigned long long *wavePartial;   // [wave][4]: similar k-mers, index entries, diagonals of this wave (summed by k_score: 9 000 atomics on
+                                       // one cache line at the end of the kernel, when all waves finish together, cost tens of microseconds)
 };
 
 // phase timers (build with -DSP_PHASE_TIMERS): shader-clock ticks per phase, summed over waves into counters[8 + phase]
@@ -873,7 +875,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
         SP_T(7);
     }
     SP_T_FLUSH(a.counters);
-    if (lane == 0) { atomicAdd(&a.counters[0], kmersTotal); atomicAdd(&a.counters[1], matchesTotal); atomicAdd(&a.counters[5], diagTotal); }
+    if (lane == 0) { unsigned long long *wp = a.wavePartial + (size_t) waveGlobal * 4; wp[0] = kmersTotal; wp[1] = matchesTotal; wp[2] = diagTotal; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -889,6 +891,7 @@ struct ScoreArgs {
     const signed char *ungSub;
     uint16_t *diagScore;
     unsigned long long *counters;   // [3] += residues read
+    const unsigned long long *wavePartial; uint32_t nWaves;      // k_match's per-wave counters, folded into counters[0], [1], [5] here
 };
 
 __device__ __forceinline__ int diagRun(const signed char *sub, const uint8_t *q, const signed char *corr, const uint8_t *db, uint32_t len) {
@@ -919,6 +922,16 @@ __global__ void k_score(ScoreArgs a) {
     __shared__ signed char s_sub[kAlph * kAlph];
     for (int t = threadIdx.x; t < kAlph * kAlph; t += blockDim.x) s_sub[t] = a.ungSub[t];
     __syncthreads();
+    if (blockIdx.x == gridDim.x - 1) {          // (the last block has the fewest diagonals to score)
+        __shared__ unsigned long long s_part[3];
+        if (threadIdx.x < 3) s_part[threadIdx.x] = 0;
+        __syncthreads();
+        unsigned long long p0 = 0, p1 = 0, p2 = 0;
+        for (uint32_t wv = threadIdx.x; wv < a.nWaves; wv += blockDim.x) { const unsigned long long *wp = a.wavePartial + (size_t) wv * 4; p0 += wp[0]; p1 += wp[1]; p2 += wp[2]; }
+        atomicAdd(&s_part[0], p0); atomicAdd(&s_part[1], p1); atomicAdd(&s_part[2], p2);
+        __syncthreads();
+        if (threadIdx.x == 0) { a.counters[0] += s_part[0]; a.counters[1] += s_part[1]; a.counters[5] += s_part[2]; }
+    }
     uint32_t nDiag = *a.diagCursor; if (nDiag > a.diagCap) nDiag = a.diagCap;
     uint32_t read = 0;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nDiag; r += gridDim.x * blockDim.x) {
@@ -948,8 +961,14 @@ __global__ void k_score(ScoreArgs a) {
         }
         a.diagScore[r] = (uint16_t) (mx > 65535 ? 65535 : mx);
     }
+    // one atomic per block (thousands of them on one word serialise at ~12 ns each)
+    __shared__ uint32_t s_read;
+    if (threadIdx.x == 0) s_read = 0;
+    __syncthreads();
     read = waveSum(read);
-    if (laneId() == 0 && read) atomicAdd(&a.counters[3], (unsigned long long) read);
+    if (laneId() == 0 && read) atomicAdd(&s_read, read);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_read) atomicAdd(&a.counters[3], (unsigned long long) s_read);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1487,7 +1506,7 @@ struct Gpu::Impl {
     size_t qTotal = 0; uint32_t maxQLen = 0;
     std::vector<uint32_t> hQoff;
     // match / select
-    DevBuf<uint64_t> spill; DevBuf<uint32_t> heavyList; DevBuf<uint8_t> heavyFlag; DevBuf<uint32_t> queue; DevBuf<DiagRec> diagRec; DevBuf<uint32_t> diagQuery; DevBuf<uint16_t> diagScore; DevBuf<uint8_t> diagFlag;
+    DevBuf<uint64_t> spill; DevBuf<uint32_t> heavyList; DevBuf<uint8_t> heavyFlag; DevBuf<unsigned long long> wavePartial; DevBuf<uint32_t> queue; DevBuf<DiagRec> diagRec; DevBuf<uint32_t> diagQuery; DevBuf<uint16_t> diagScore; DevBuf<uint8_t> diagFlag;
     DevBuf<uint32_t> qDiagBase; DevBuf<uint32_t> qDiagCnt; DevBuf<unsigned long long> counters;
     DevBuf<GpuHit> outHits; DevBuf<GpuHit> outStage; DevBuf<uint32_t> outQuery; DevBuf<uint32_t> outCount; DevBuf<uint32_t> outBase; DevBuf<uint32_t> outOffset;
     uint32_t matchBlocks = 0;
@@ -1705,7 +1724,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     const uint32_t blocks = (uint32_t) std::min<size_t>((nq_ + kWavesPerBlock - 1) / kWavesPerBlock, (size_t) d.numCU * perCU);
     d.matchBlocks = blocks;
     if (!d.spill.ensure((size_t) blocks * kWavesPerBlock * kSpillWordsPerWave, err)) return false;
-    if (!d.queue.ensure(8, err) || !d.counters.ensure(16, err) || !d.heavyList.ensure(nq_ + 1, err) || !d.heavyFlag.ensure(nq_ + 1, err)) return false;
+    if (!d.queue.ensure(8, err) || !d.counters.ensure(16, err) || !d.heavyList.ensure(nq_ + 1, err) || !d.heavyFlag.ensure(nq_ + 1, err) || !d.wavePartial.ensure((size_t) blocks * kWavesPerBlock * 4, err)) return false;
     // diagonal buffer: generous, HBM is plentiful (64 M records = 512 MB + side arrays)
     const size_t diagCap = std::max<size_t>((size_t) 1 << 22, std::min<size_t>((size_t) 1 << 26, nq_ * 64));
     d.diagCap = diagCap;
@@ -1737,12 +1756,12 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
                  (uint32_t) (getenv("SP_MATCH_STATIC") ? atoi(getenv("SP_MATCH_STATIC")) : 4), (uint32_t) (getenv("SP_MATCH_DCHUNK") ? std::max(1, atoi(getenv("SP_MATCH_DCHUNK"))) : 4),
-                 d.heavyList.p, d.heavyFlag.p, d.queue.p + 5};
+                 d.heavyList.p, d.heavyFlag.p, d.queue.p + 5, d.wavePartial.p};
     if (withOrd) hipLaunchKernelGGL((k_match<512, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     else hipLaunchKernelGGL((k_match<512, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     SP_DBG_SYNC("k_match");
     SP_EV(2, 1);
-    ScoreArgs sa{d.diagRec.p, d.diagQuery.p, d.queue.p + 1, (uint32_t) diagCap, d.qres.p, d.qoff.p, d.qcorr.p, d.tmasked.p, d.toff.p, d.ungSub.p, d.diagScore.p, d.counters.p};
+    ScoreArgs sa{d.diagRec.p, d.diagQuery.p, d.queue.p + 1, (uint32_t) diagCap, d.qres.p, d.qoff.p, d.qcorr.p, d.tmasked.p, d.toff.p, d.ungSub.p, d.diagScore.p, d.counters.p, d.wavePartial.p, blocks * (uint32_t) kWavesPerBlock};
     hipLaunchKernelGGL(k_score, dim3((unsigned) d.numCU * 8), dim3(256), 0, d.stream, sa);
     SP_DBG_SYNC("k_score");
     SP_EV(3, 2);
