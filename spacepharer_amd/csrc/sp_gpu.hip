@@ -1577,6 +1577,16 @@ __global__ void k_fill(FillArgs a) {
     }
 }
 
+// small results for the host: one kernel stores them straight into the page-locked mailbox (each hipMemcpyAsync of a few
+// bytes is a copy kernel of its own)
+struct PublishArgs { const void *src[3]; uint32_t words[3]; uint32_t at[3]; uint32_t *mailbox; };
+__global__ void k_publish(PublishArgs a) {
+    for (int r = 0; r < 3; r++) {
+        const uint32_t *s = static_cast<const uint32_t *>(a.src[r]);
+        for (uint32_t i = threadIdx.x; i < a.words[r]; i += blockDim.x) a.mailbox[a.at[r] + i] = s[i];
+    }
+}
+
 int Gpu::deviceCount() const { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
 bool Gpu::init(int device, std::string &err) {
@@ -1775,10 +1785,10 @@ bool Gpu::finishPrefilter(bool matched, std::string &err) {
     if (!d.mailbox) d.mailbox = static_cast<unsigned long long *>(pinnedAlloc(64 * sizeof(unsigned long long)));
     unsigned long long *c = d.mailbox; uint32_t *qv = reinterpret_cast<uint32_t *>(d.mailbox + 16); uint32_t &totalHits = *reinterpret_cast<uint32_t *>(d.mailbox + 24);
     totalHits = 0;
-    HIP_OK(hipMemcpyAsync(c, d.counters.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.stream));
-    HIP_OK(hipMemcpyAsync(qv, d.queue.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
-    // the scan leaves the number of hits behind the last query's offset
-    HIP_OK(hipMemcpyAsync(&totalHits, d.outOffset.p + nq_, sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    {   // counters -> mailbox words 0..31, queue -> 32..39, the number of hits (the scan leaves it behind the last query's offset) -> 48
+        PublishArgs pa{{d.counters.p, d.queue.p, d.outOffset.p + nq_}, {32, 8, 1}, {0, 32, 48}, reinterpret_cast<uint32_t *>(d.mailbox)};
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, d.stream, pa);
+    }
     HIP_OK(spinSync(d.stream));
     if (matched) { counters_.kmers = c[0]; counters_.dbMatches = c[1]; counters_.diagResidues = c[3]; counters_.diagonals = c[5]; }
     counters_.overflowQueries = c[2]; counters_.hits = totalHits;
