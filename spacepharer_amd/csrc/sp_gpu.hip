@@ -186,6 +186,9 @@ __global__ void k_prep(PrepArgs a) {
 // of the work depends on this, never a result.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kCntW = 320;         // width of a row of the count table: cutoffs cntMin .. cntMin + 319
+constexpr int kHeavyLists = 16;    // the heavy queries are collected in 16 lists with counters on separate cache lines (a block appends with one
+                                   // atomic, and a thousand blocks finishing together on ONE counter would queue up for ~12 ns each)
+constexpr int kHeavyStride = 32;   // words between two counters
 struct WeighArgs {
     const uint8_t *qres; const uint32_t *qoff; uint32_t nq; const short *qthr;
     const uint32_t *ext3; const uint16_t *ext3cnt; int cntMin; uint32_t heavyThr;
@@ -236,9 +239,10 @@ __global__ __launch_bounds__(256) void k_weigh(WeighArgs a) {
     }
     __syncthreads();
     const uint32_t n = min(s_n, 1024u);
-    if (threadIdx.x == 0 && n) s_base = atomicAdd(a.heavyCount, n);
+    const uint32_t hl = blockIdx.x % kHeavyLists;
+    if (threadIdx.x == 0 && n) s_base = atomicAdd(a.heavyCount + hl * kHeavyStride, n);
     __syncthreads();
-    for (uint32_t x = threadIdx.x; x < n; x += blockDim.x) a.heavyList[s_base + x] = s_list[x];
+    for (uint32_t x = threadIdx.x; x < n; x += blockDim.x) a.heavyList[(size_t) hl * a.nq + s_base + x] = s_list[x];
 }
 
 // k_prep + k_weigh in one launch for batches whose queries have at most 64 residues (every spacer batch): 8 lanes per query,
@@ -349,9 +353,10 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
         __syncthreads();
     }
     const uint32_t n = min(s_n, 1024u);
-    if (threadIdx.x == 0 && n) s_base = atomicAdd(wa.heavyCount, n);
+    const uint32_t hl = blockIdx.x % kHeavyLists;
+    if (threadIdx.x == 0 && n) s_base = atomicAdd(wa.heavyCount + hl * kHeavyStride, n);
     __syncthreads();
-    for (uint32_t x = threadIdx.x; x < n; x += blockDim.x) wa.heavyList[s_base + x] = s_list[x];
+    for (uint32_t x = threadIdx.x; x < n; x += blockDim.x) wa.heavyList[(size_t) hl * a.nq + s_base + x] = s_list[x];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -487,11 +492,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     uint32_t sNext = waveGlobal * kQueryChunk;
     // the heavy queries first: the j-th of them goes to wave j / #blocks of block j % #blocks (one per block -- one per SIMD of
     // a CU -- before any block gets a second one); everybody skips them later
-    const uint32_t nHeavy = uni(*a.heavyCount);
-    uint32_t hNext = (uint32_t) w * gridDim.x + blockIdx.x;
+    // (16 lists: block b serves list b % 16; within a list the entries go to wave 0 of each of its blocks first, then wave 1 ...)
+    const uint32_t myList = blockIdx.x % (uint32_t) kHeavyLists;
+    const uint32_t listBlocks = (gridDim.x - myList + (uint32_t) kHeavyLists - 1u) / (uint32_t) kHeavyLists;
+    const uint32_t nHeavy = uni(a.heavyCount[myList * kHeavyStride]);
+    const uint32_t *heavyList = a.heavyList + (size_t) myList * a.nq;
+    uint32_t hNext = (uint32_t) w * listBlocks + blockIdx.x / (uint32_t) kHeavyLists;
     for (uint32_t qc = 0, qcEnd = 0;;) {
         uint32_t qi;
-        if (hNext < nHeavy) { qi = uni(a.heavyList[hNext]); hNext += nWavesTot; }
+        if (hNext < nHeavy) { qi = uni(heavyList[hNext]); hNext += listBlocks * kWavesPerBlock; }
         else {
             if (qc == qcEnd) {
                 if (sNext < staticEnd) { qc = sNext; sNext += nWavesTot * kQueryChunk; qcEnd = qc + kQueryChunk; }
@@ -1506,7 +1515,7 @@ struct Gpu::Impl {
     size_t qTotal = 0; uint32_t maxQLen = 0;
     std::vector<uint32_t> hQoff;
     // match / select
-    DevBuf<uint64_t> spill; DevBuf<uint32_t> heavyList; DevBuf<uint8_t> heavyFlag; DevBuf<unsigned long long> wavePartial; DevBuf<uint32_t> queue; DevBuf<DiagRec> diagRec; DevBuf<uint32_t> diagQuery; DevBuf<uint16_t> diagScore; DevBuf<uint8_t> diagFlag;
+    DevBuf<uint64_t> spill; DevBuf<uint32_t> heavyList; DevBuf<uint32_t> heavyCnt; DevBuf<uint8_t> heavyFlag; DevBuf<unsigned long long> wavePartial; DevBuf<uint32_t> queue; DevBuf<DiagRec> diagRec; DevBuf<uint32_t> diagQuery; DevBuf<uint16_t> diagScore; DevBuf<uint8_t> diagFlag;
     DevBuf<uint32_t> qDiagBase; DevBuf<uint32_t> qDiagCnt; DevBuf<unsigned long long> counters;
     DevBuf<GpuHit> outHits; DevBuf<GpuHit> outStage; DevBuf<uint32_t> outQuery; DevBuf<uint32_t> outCount; DevBuf<uint32_t> outBase; DevBuf<uint32_t> outOffset;
     uint32_t matchBlocks = 0;
@@ -1734,13 +1743,13 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     const uint32_t blocks = (uint32_t) std::min<size_t>((nq_ + kWavesPerBlock - 1) / kWavesPerBlock, (size_t) d.numCU * perCU);
     d.matchBlocks = blocks;
     if (!d.spill.ensure((size_t) blocks * kWavesPerBlock * kSpillWordsPerWave, err)) return false;
-    if (!d.queue.ensure(8, err) || !d.counters.ensure(16, err) || !d.heavyList.ensure(nq_ + 1, err) || !d.heavyFlag.ensure(nq_ + 1, err) || !d.wavePartial.ensure((size_t) blocks * kWavesPerBlock * 4, err)) return false;
+    if (!d.queue.ensure(8, err) || !d.counters.ensure(16, err) || !d.heavyList.ensure((size_t) kHeavyLists * nq_ + 1, err) || !d.heavyCnt.ensure(kHeavyLists * kHeavyStride, err) || !d.heavyFlag.ensure(nq_ + 1, err) || !d.wavePartial.ensure((size_t) blocks * kWavesPerBlock * 4, err)) return false;
     // diagonal buffer: generous, HBM is plentiful (64 M records = 512 MB + side arrays)
     const size_t diagCap = std::max<size_t>((size_t) 1 << 22, std::min<size_t>((size_t) 1 << 26, nq_ * 64));
     d.diagCap = diagCap;
     if (!d.diagRec.ensure(diagCap, err) || !d.diagQuery.ensure(diagCap, err) || !d.diagScore.ensure(diagCap, err) || !d.diagFlag.ensure(diagCap, err)) return false;
     if (withOrd && (!d.diagOrd.ensure(diagCap, err) || !d.spillOrd.ensure((size_t) blocks * kWavesPerBlock * 65536, err))) return false;
-    {   FillArgs fa{{d.queue.p, d.counters.p, d.diagQuery.p, nullptr}, {8 * sizeof(uint32_t), 16 * sizeof(unsigned long long), diagCap * sizeof(uint32_t), 0}, {0u, 0u, 0xFFFFFFFFu, 0u}};
+    {   FillArgs fa{{d.queue.p, d.counters.p, d.diagQuery.p, d.heavyCnt.p}, {8 * sizeof(uint32_t), 16 * sizeof(unsigned long long), diagCap * sizeof(uint32_t), kHeavyLists * kHeavyStride * sizeof(uint32_t)}, {0u, 0u, 0xFFFFFFFFu, 0u}};
         hipLaunchKernelGGL(k_fill, dim3((unsigned) d.numCU * 4), dim3(256), 0, d.stream, fa); }
     SP_EV(0, 2);
     PrepArgs pa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.seedSub.p, d.seedBack.p, d.ungSub.p, kmerThr, d.ungMinAbs, d.biasf.p, d.qthr.p, d.qcorr.p, d.qbias.p, d.qself.p};
@@ -1748,7 +1757,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     // (worth its 30 us per 60 000 queries only while a wave gets few queries: with more than ~30 per wave the heavy ones no
     // longer decide when the kernel ends)
     const uint32_t heavyThr = getenv("SP_MATCH_HEAVY") ? (uint32_t) atoi(getenv("SP_MATCH_HEAVY")) : (nq_ <= (size_t) blocks * kWavesPerBlock * 32 ? 4000u : 0u);
-    WeighArgs wa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, heavyThr ? heavyThr : 0xFFFFFFFFu, d.heavyList.p, d.heavyFlag.p, d.queue.p + 5};
+    WeighArgs wa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, heavyThr ? heavyThr : 0xFFFFFFFFu, d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p};
     const unsigned weighBlocks = (unsigned) std::min<size_t>((nq_ + 31) / 32, (size_t) d.numCU * 8);
     if (d.maxQLen <= 64 && !getenv("SP_PREP_SPLIT")) {
         Prep8Args p8{pa, wa};
@@ -1766,7 +1775,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
                  (uint32_t) (getenv("SP_MATCH_STATIC") ? atoi(getenv("SP_MATCH_STATIC")) : 4), (uint32_t) (getenv("SP_MATCH_DCHUNK") ? std::max(1, atoi(getenv("SP_MATCH_DCHUNK"))) : 4),
-                 d.heavyList.p, d.heavyFlag.p, d.queue.p + 5, d.wavePartial.p};
+                 d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p, d.wavePartial.p};
     if (withOrd) hipLaunchKernelGGL((k_match<512, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     else hipLaunchKernelGGL((k_match<512, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     SP_DBG_SYNC("k_match");
