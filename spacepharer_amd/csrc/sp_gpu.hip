@@ -1841,7 +1841,7 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     hipLaunchKernelGGL(k_reorder_hits, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.outStage.p, d.outBase.p, d.outCount.p, d.outOffset.p, (uint32_t) nq_, d.outHits.p, d.outQuery.p);
     SP_DBG_SYNC("k_select");
     SP_EV(4, 2);
-    return finishPrefilter(true, err) && prefetchHits(err);
+    return finishPrefilter(true, err);      // the hit list travels when somebody asks for it (hostHits) or underneath the align kernels (align)
 }
 
 // sharded search, step 1: this shard's candidates (per query and target the best double-hit diagonal with score >= min)
@@ -1910,7 +1910,7 @@ bool Gpu::mergeCandidates(const Candidate *src, size_t n, bool onDevice, size_t 
     hipLaunchKernelGGL(k_reorder_hits, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.outStage.p, d.outBase.p, d.outCount.p, d.outOffset.p, (uint32_t) nq_, d.outHits.p, d.outQuery.p);
     SP_DBG_SYNC("k_select_merged");
     SP_EV(4, 2);
-    return finishPrefilter(false, err) && prefetchHits(err);
+    return finishPrefilter(false, err);
 }
 
 bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &seed, int kmerThr, bool mask, bool index, size_t from, size_t to,
