@@ -482,6 +482,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
     uint32_t *spillOrd = kOrd ? a.spillOrd + (size_t) waveGlobal * 65536 : nullptr;
     unsigned long long kmersTotal = 0, matchesTotal = 0, diagTotal = 0;
     uint32_t dChunkBase = 0, dChunkUsed = 0, dChunkCap = 0;
+    // slots of a reservation chunk that got no record are marked invalid when the wave leaves the chunk (instead of a
+    // 16 MB fill of the whole array before every pass)
+    auto markUnused = [&]() {
+        for (uint32_t t = dChunkUsed + lane; t < dChunkCap; t += 64) if ((uint64_t) dChunkBase + t < a.diagCap) a.diagQuery[dChunkBase + t] = 0xFFFFFFFFu;
+    };
     SP_T_DECL
 
     // one atomic pops kQueryChunk queries: a single counter word serialises at ~12 ns per atomic (60 000 pops = 0.7 ms)
@@ -793,14 +798,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
         // serialise); unused slots of a chunk stay marked invalid (diagQuery == ~0)
         auto reserve = [&](uint32_t need) {
             if (dChunkUsed + need > dChunkCap) {
+                markUnused();
                 dChunkCap = need > kDiagChunk ? need : kDiagChunk;
                 dChunkBase = uni(atomicAdd(a.diagCursor, lane == 0 ? dChunkCap : 0u));
                 dChunkUsed = 0;
             }
-            dbase = dChunkBase + dChunkUsed;
-            dChunkUsed += need;
-            diagTotal += need;
-            if ((uint64_t) dChunkBase + dChunkCap > a.diagCap) { overflow = true; D = 0; }
+            if ((uint64_t) dChunkBase + dChunkCap > a.diagCap) { overflow = true; D = 0; dbase = 0; }      // (the chunk stays unused)
+            else { dbase = dChunkBase + dChunkUsed; dChunkUsed += need; diagTotal += need; }
         };
         if (M > 0 && M <= 64u && !spilled) {
             // The usual case after the pre-filter: everything in registers, one hit per lane.  Sort by counting (the keys are
@@ -884,6 +888,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
         SP_T(7);
     }
     SP_T_FLUSH(a.counters);
+    markUnused();
     if (lane == 0) { unsigned long long *wp = a.wavePartial + (size_t) waveGlobal * 4; wp[0] = kmersTotal; wp[1] = matchesTotal; wp[2] = diagTotal; }
 }
 
@@ -1749,8 +1754,8 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     d.diagCap = diagCap;
     if (!d.diagRec.ensure(diagCap, err) || !d.diagQuery.ensure(diagCap, err) || !d.diagScore.ensure(diagCap, err) || !d.diagFlag.ensure(diagCap, err)) return false;
     if (withOrd && (!d.diagOrd.ensure(diagCap, err) || !d.spillOrd.ensure((size_t) blocks * kWavesPerBlock * 65536, err))) return false;
-    {   FillArgs fa{{d.queue.p, d.counters.p, d.diagQuery.p, d.heavyCnt.p}, {8 * sizeof(uint32_t), 16 * sizeof(unsigned long long), diagCap * sizeof(uint32_t), kHeavyLists * kHeavyStride * sizeof(uint32_t)}, {0u, 0u, 0xFFFFFFFFu, 0u}};
-        hipLaunchKernelGGL(k_fill, dim3((unsigned) d.numCU * 4), dim3(256), 0, d.stream, fa); }
+    {   FillArgs fa{{d.queue.p, d.counters.p, d.heavyCnt.p, nullptr}, {8 * sizeof(uint32_t), 16 * sizeof(unsigned long long), kHeavyLists * kHeavyStride * sizeof(uint32_t), 0}, {0u, 0u, 0u, 0u}};
+        hipLaunchKernelGGL(k_fill, dim3(1), dim3(256), 0, d.stream, fa); }
     SP_EV(0, 2);
     PrepArgs pa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.seedSub.p, d.seedBack.p, d.ungSub.p, kmerThr, d.ungMinAbs, d.biasf.p, d.qthr.p, d.qcorr.p, d.qbias.p, d.qself.p};
     // SP_MATCH_HEAVY: similar k-mers from which a query counts as heavy and is started first (0 = none)
