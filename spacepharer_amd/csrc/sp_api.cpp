@@ -53,7 +53,7 @@ struct sp_ctx {
     std::map<uint32_t, std::vector<uint8_t>> gateRows;     // E-value gate rows per query length (for this target set / -e)
     std::map<uint32_t, std::vector<double>> evalRows;      // evalue(score, qLen) per query length
     std::vector<int32_t> bitRow;                           // int(bitScore(score) + 0.5)
-    bool tablesUp = false;
+    bool tablesUp = false, kmerTablesUp = false;
     sp::GateTable gate; bool gateValid = false; uint64_t gateSerial = 0;    // E-value tables of the resident query batch / target set
     sp::AlignHost alnHost;                                 // pinned staging, reused; declared last = released before the device context
 };
@@ -116,11 +116,14 @@ sp_ctx *sp_ctx_create(const sp_search_params *p) {
     c->par.sub_mat = c->subName.c_str();
     c->threads = p->threads > 0 ? p->threads : (int) std::max(1u, std::thread::hardware_concurrency());
     std::string err;
+    const bool laps = getenv("SP_MODULE_TIMES") != nullptr; const double tc0 = nowMs();
     // bit factors / score biases: prefiltering/Prefiltering.cpp:63-67, alignment/Alignment.cpp:157-162
     if (!c->seed.load(c->seedName, (double) 8.0f, (double) -0.2f, err) || !c->ungapped.load(c->subName, (double) 2.0f, (double) -0.2f, err) ||
         !c->aln.load(c->subName, (double) 2.0f, (double) 0.0f, err)) { g_err = err; return nullptr; }
     c->kmerThr = sp::kmerThreshold(p->sensitivity, p->kmer_score, sp::kKmer);
+    const double tc1 = nowMs();
     if (!c->gpu.init(sp::currentDevice(), err)) { g_err = "sp_ctx_create: " + err + " (this library has no CPU path)"; return nullptr; }
+    if (laps) fprintf(stderr, "[sp] sp_ctx_create: matrices %.3f ms, device context %.3f ms\n", tc1 - tc0, nowMs() - tc1);
     c->stats["kmer_thr"] = c->kmerThr;
     return c.release();
 }
@@ -149,9 +152,9 @@ static int setTargets(sp_ctx *c, const char *residues, const uint64_t *offsets, 
     const bool noIndex = (flags & 1) != 0;
     std::string err;
     double t0 = nowMs();
-    if (!c->tablesUp) {
-        if (!c->gpu.uploadTables(c->seed, c->ungapped, c->aln, err)) { g_err = err; return SP_ERR_DEVICE; }
-        c->tablesUp = true;
+    if (!c->tablesUp || (!noIndex && !c->kmerTablesUp)) {      // matrices always; the similar-k-mer tables only for a set that will be searched
+        if (!c->gpu.uploadTables(c->seed, c->ungapped, c->aln, !noIndex, err)) { g_err = err; return SP_ERR_DEVICE; }
+        c->tablesUp = true; c->kmerTablesUp = c->kmerTablesUp || !noIndex;
     }
     double t1 = nowMs();
     // the host keeps the target directory only; residue classes, tantan masking and the k-mer index are made on the device

@@ -77,7 +77,7 @@ public:
     const std::string &deviceName() const { return name_; }
 
     // matrices + the similar-3-mer table (built on the device)
-    bool uploadTables(const SubMat &seed, const SubMat &ungapped, const SubMat &aln, std::string &err);
+    bool uploadTables(const SubMat &seed, const SubMat &ungapped, const SubMat &aln, bool kmerTables, std::string &err);
     bool downloadExt3(std::vector<uint32_t> &packed, std::string &err);     // test hook
     // the product path: residues -> classes, tantan masking and the k-mer index of targets [from, to) built on the device
     // (sp_gpu_index.inc).  ts carries n / offsets / keys; plain, masked and ascii stay empty on the host.

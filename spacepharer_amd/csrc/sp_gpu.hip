@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <string>
 
 #include "sp_gpu.h"
 
@@ -1608,10 +1610,17 @@ bool Gpu::init(int device, std::string &err) {
     HIP_OK(hipGetDeviceCount(&n));
     if (n <= 0) { err = "no HIP device visible"; return false; }
     HIP_OK(hipSetDevice(device % n));
-    hipDeviceProp_t prop;
-    HIP_OK(hipGetDeviceProperties(&prop, device % n));
-    name_ = prop.name;
-    d_->numCU = prop.multiProcessorCount;
+    // (hipGetDeviceProperties takes milliseconds: asked once per process and device)
+    static std::mutex propMutex; static std::map<int, std::pair<std::string, int>> propCache;
+    {   std::lock_guard<std::mutex> lock(propMutex);
+        auto it = propCache.find(device % n);
+        if (it == propCache.end()) {
+            hipDeviceProp_t prop;
+            HIP_OK(hipGetDeviceProperties(&prop, device % n));
+            it = propCache.emplace(device % n, std::make_pair(std::string(prop.name), (int) prop.multiProcessorCount)).first;
+        }
+        name_ = it->second.first; d_->numCU = it->second.second;
+    }
     HIP_OK(hipStreamCreateWithFlags(&d_->stream, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&d_->copyStream, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&d_->hitsOnHost, hipEventDisableTiming));
@@ -1665,9 +1674,9 @@ static bool upload(DevBuf<T> &b, const T *src, size_t n, hipStream_t s, std::str
     return true;
 }
 
-bool Gpu::uploadTables(const SubMat &seed, const SubMat &ung, const SubMat &aln, std::string &err) {
+bool Gpu::uploadTables(const SubMat &seed, const SubMat &ung, const SubMat &aln, bool kmerTables, std::string &err) {
     Impl &d = *d_;
-    {   // similar-3-mer table + count table, built on the device (sp_gpu_index.inc)
+    if (kmerTables && !d.ext3.p) {   // similar-3-mer table + count table, built on the device (sp_gpu_index.inc); not needed to align / rescore
         const size_t N2 = (size_t) 8000 * 8000;
         int lo1 = 1 << 20, hi1 = -(1 << 20);
         Ext3Args ea{};

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -260,9 +261,12 @@ static bool loadSeqDb(const std::string &path, Db &db, std::string &err) {
 
 static void flatten(const Db &db, std::vector<char> &res, std::vector<uint64_t> &off, std::vector<uint32_t> &keys) {
     off.assign(1, 0); keys.clear(); res.clear();
+    off.reserve(db.entries.size() + 1); keys.reserve(db.entries.size()); res.reserve(db.data.size());
     for (size_t i = 0; i < db.entries.size(); i++) {
         const char *p = db.ptr(i); uint64_t L = db.seqLen(i);
-        uint64_t l = 0; while (l < L && p[l] != '\n' && p[l] != '\0') l++;        // Sequence::mapSequence stops at \n / \0
+        uint64_t l = L;                                                            // Sequence::mapSequence stops at \n / \0
+        if (const void *nl = memchr(p, '\n', (size_t) l)) l = (uint64_t) ((const char *) nl - p);
+        if (const void *z = memchr(p, '\0', (size_t) l)) l = (uint64_t) ((const char *) z - p);
         res.insert(res.end(), p, p + l);
         off.push_back(res.size()); keys.push_back(db.entries[i].key);
     }
@@ -311,6 +315,19 @@ static int fanOut(const char *module, int (*fn)(int, const char **), int argc, c
     return 0;
 }
 
+// SP_MODULE_TIMES=1: wall-clock laps of a module run on stderr
+struct Laps {
+    bool on = getenv("SP_MODULE_TIMES") != nullptr; const char *module;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    explicit Laps(const char *m) : module(m) {}
+    void lap(const char *what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sp] %s: %-28s %8.3f ms\n", module, what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // prefilter <queryDB> <targetDB> <outDB>
 // ---------------------------------------------------------------------------------------------------------------
@@ -323,8 +340,10 @@ int runPrefilterModule(int argc, const char **argv) {
         !requireValue(f, "--add-self-matches", {"0"}, err) || !requireValue(f, "--split", {"0", "1"}, err) || !requireValue(f, "-c", {"0", "0.0", "0.000"}, err))
         return fail("prefilter: " + err);
     { const int rc = fanOut("prefilter", runPrefilterModule, argc, argv, f.positional[2]); if (rc >= 0) return rc; }
+    Laps laps("prefilter");
     Db qdb, tdb;
     if (!loadSeqDb(f.positional[0], qdb, err) || !loadSeqDb(f.positional[1], tdb, err)) return fail("prefilter: " + err);
+    laps.lap("read DBs");
     sp_search_params p; sp_default_params(&p);
     std::string seed = aaPart(f.str("--seed-sub-mat", "VTML80.out")), sub = aaPart(f.str("--sub-mat", "VTML40.out"));
     p.seed_sub_mat = seed.c_str(); p.sub_mat = sub.c_str();
@@ -336,9 +355,11 @@ int runPrefilterModule(int argc, const char **argv) {
     p.threads = (int) f.num("--threads", 0);
     Ctx ctx; ctx.c = sp_ctx_create(&p);
     if (!ctx.c) return fail(std::string("prefilter: ") + sp_last_error());
+    laps.lap("context (matrices, tables)");
     std::vector<char> tres, qres; std::vector<uint64_t> toff, qoff; std::vector<uint32_t> tkeys, qkeys;
     flatten(tdb, tres, toff, tkeys);
     if (sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) return fail(std::string("prefilter: ") + sp_last_error());
+    laps.lap("targets -> device, index");
     flatten(qdb, qres, qoff, qkeys);
     DbWriter w; w.path = f.positional[2]; w.dbtype = 7;      // DBTYPE_PREFILTER_RES
     const size_t batch = 1u << 20;
@@ -350,6 +371,7 @@ int runPrefilterModule(int argc, const char **argv) {
         std::vector<uint64_t> off(qoff.begin() + b0, qoff.begin() + b1 + 1);
         for (uint64_t &o : off) o -= qoff[b0];
         if (sp_ctx_set_queries(ctx.c, qres.data() + qoff[b0], off.data(), b1 - b0) != SP_OK || sp_ctx_prefilter(ctx.c) != SP_OK) return fail(std::string("prefilter: ") + sp_last_error());
+        laps.lap("queries -> device, search");
         std::vector<sp_hit> hits(std::max<uint64_t>(1, sp_ctx_num_hits(ctx.c))); std::vector<uint64_t> ho(b1 - b0 + 1);
         if (sp_ctx_get_hits_compact(ctx.c, hits.data(), ho.data()) != SP_OK) return fail(std::string("prefilter: ") + sp_last_error());
         for (size_t q = b0; q < b1; q++) {
@@ -363,7 +385,9 @@ int runPrefilterModule(int argc, const char **argv) {
             w.add(qkeys[q], payload);     // every query key gets an entry, empty ones too
         }
     }
+    laps.lap("format hits");
     if (!w.close(err)) return fail("prefilter: " + err);
+    laps.lap("write DB");
     return 0;
 }
 
@@ -430,7 +454,9 @@ static bool alnLess(const sp_alignment &a, const sp_alignment &b) {      // Matc
 
 static bool openSearch(const Flags &f, const char *module, bool gapped, Ctx &ctx, Db &qdb, Db &tdb, std::vector<uint32_t> &qkeys, std::vector<uint32_t> &tkeys,
                        std::vector<char> &qres, std::vector<uint64_t> &qoff, std::string &err) {
+    Laps laps(module);
     if (!loadSeqDb(f.positional[0], qdb, err) || !loadSeqDb(f.positional[1], tdb, err)) return false;
+    laps.lap("  read sequence DBs");
     sp_search_params p; sp_default_params(&p);
     static std::string sub; sub = aaPart(f.str("--sub-mat", "VTML40.out"));
     p.sub_mat = sub.c_str();
@@ -439,12 +465,15 @@ static bool openSearch(const Flags &f, const char *module, bool gapped, Ctx &ctx
     if (gapped) { p.gap_open = (int) strtol(aaPart(f.str("--gap-open", "11")).c_str(), NULL, 10); p.gap_extend = (int) strtol(aaPart(f.str("--gap-extend", "1")).c_str(), NULL, 10); }
     ctx.c = sp_ctx_create(&p);
     if (!ctx.c) { err = sp_last_error(); return false; }
+    laps.lap("  context");
     std::vector<char> tres; std::vector<uint64_t> toff;
     flatten(tdb, tres, toff, tkeys);
+    laps.lap("  flatten targets");
     if (sp_ctx_set_targets_ex(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size(), 1 /* no k-mer index needed */) != SP_OK) { err = sp_last_error(); return false; }
+    laps.lap("  targets -> device");
     flatten(qdb, qres, qoff, qkeys);
     if (sp_ctx_set_queries(ctx.c, qres.data(), qoff.data(), qkeys.size()) != SP_OK) { err = sp_last_error(); return false; }
-    (void) module;
+    laps.lap("  queries -> device");
     return true;
 }
 
@@ -461,12 +490,15 @@ int runAlignModule(int argc, const char **argv) {
         return fail("align: " + err);
     if (f.num("-a", 0) != 1) return fail("align: only -a 1 (backtrace => score, coverage and sequence identity) is implemented, which is what predictmatch passes");
     { const int rc = fanOut("align", runAlignModule, argc, argv, f.positional[3]); if (rc >= 0) return rc; }
+    Laps laps("align");
     Ctx ctx; Db qdb, tdb, rdb; std::vector<uint32_t> qkeys, tkeys; std::vector<char> qres; std::vector<uint64_t> qoff;
     if (!openSearch(f, "align", true, ctx, qdb, tdb, qkeys, tkeys, qres, qoff, err)) return fail("align: " + err);
+    laps.lap("read DBs, context, device");
     if (!rdb.load(f.positional[2], err)) return fail("align: " + err);
     KeyMap qIndex, tIndex; qIndex.build(qkeys); tIndex.build(tkeys);
     Triples tr;
     if (!collectTriples(rdb, qIndex, tIndex, tr, err)) return fail("align: " + err);
+    laps.lap("read + parse result DB");
     const double minSeqId = f.real("--min-seq-id", 0.0); const long minAlnLen = f.num("--min-aln-len", 0);
     const long maxAccept = f.num("--max-accept", INT_MAX), maxRejected = f.num("--max-rejected", INT_MAX);
     std::vector<sp_alignment> res(std::max<size_t>(1, tr.q.size()));
@@ -474,6 +506,7 @@ int runAlignModule(int argc, const char **argv) {
     int rc = sp_ctx_align(ctx.c, tr.q.data(), tr.t.data(), tr.q.size(), res.data(), cig.data(), cig.size(), &used);
     if (rc == SP_ERR_OVERFLOW && used > cig.size()) { cig.resize(used + 16); rc = sp_ctx_align(ctx.c, tr.q.data(), tr.t.data(), tr.q.size(), res.data(), cig.data(), cig.size(), &used); }
     if (rc != SP_OK) return fail(std::string("align: ") + sp_last_error());
+    laps.lap("align on the device");
     DbWriter w; w.path = f.positional[3]; w.dbtype = 5;       // DBTYPE_ALIGNMENT_RES
     // entries are formatted by --threads workers over contiguous ranges and appended in order
     const size_t nEntries = tr.perQuery.size() - 1;
@@ -499,7 +532,9 @@ int runAlignModule(int argc, const char **argv) {
         }
     });
     for (size_t ci = 0; ci < nChunks; ci++) w.addBlock(bKeys[ci], bLens[ci], blocks[ci]);
+    laps.lap("format records");
     if (!w.close(err)) return fail("align: " + err);
+    laps.lap("write DB");
     return 0;
 }
 
