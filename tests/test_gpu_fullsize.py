@@ -94,6 +94,29 @@ def test_idempotent(full):
     assert n == full["n"] and np.array_equal(h2, h) and np.array_equal(np.ctypeslib.as_array(offs).astype(np.int64), off)
 
 
+def test_work_order_and_timing_level_do_not_change_results(full):
+    """the scheduler's knobs only reorder the work: heavy-query list off / with another threshold, every HIP-event timing level
+    (stages that are not timed report NaN) -- the hit list stays bit-identical"""
+    ctx, h, off = full["ctx"], full["h"], full["off"]
+    def same():
+        ctx.prefilter()
+        hits, offs, n = ctx.hits_compact()
+        h2 = np.ctypeslib.as_array(C.cast(hits, C.POINTER(C.c_int32)), shape=(max(1, n), 3))[:n]
+        return n == full["n"] and np.array_equal(h2, h) and np.array_equal(np.ctypeslib.as_array(offs).astype(np.int64), off)
+    try:
+        for thr in ("0", "1500", "20000"):
+            os.environ["SP_MATCH_HEAVY"] = thr
+            assert same(), thr
+    finally:
+        os.environ.pop("SP_MATCH_HEAVY", None)
+    try:
+        ctx.set_timing(0); assert same(); assert ctx.stat("ms_match") != ctx.stat("ms_match")          # NaN
+        ctx.set_timing(2); assert same(); assert ctx.stat("ms_match") > 0 and ctx.stat("ms_select") > 0
+    finally:
+        ctx.set_timing(1)
+    assert same() and ctx.stat("ms_match") > 0 and ctx.stat("ms_select") != ctx.stat("ms_select")
+
+
 def test_sample_against_oracle_at_full_size(full):
     import gzip
     from oracle_lib import Alp, Oracle
