@@ -685,6 +685,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                     uint32_t nOcc = 0;
 #pragma unroll
                     for (int r = 0; r < kSuper / 64; r++) {
+                        if (s0 + 64u * r >= tileK) break;                          // (uniform: the rounds beyond the list hold nothing)
                         const uint32_t bit = kmerR[r] & 31u, word = (uint32_t) prR[r];
                         const bool occ = kmerR[r] != 0xFFFFFFFFu && ((word >> bit) & 1u);
                         const uint64_t m = __ballot(occ);
@@ -711,6 +712,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                         uint32_t lenMulti = 0, run = M;
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
+                            hR[r] = run;
+                            if (ob + 64u * r >= nOcc) continue;                    // (uniform: no slot in this register)
                             const uint32_t incl = waveInclusiveScan(lenR[r], lane);
                             hR[r] = run + incl - lenR[r];
                             run += lane63(incl);
