@@ -1008,7 +1008,7 @@ struct SelectArgs {
     const int *qbias; const int *qself; const uint32_t *qoff;
     uint8_t *diagFlag;              // scratch, one byte per diagonal
     uint64_t *selScratch;           // per-wave HBM key scratch (65536 keys) for oversized candidate lists
-    const uint32_t *wantOff;        // exclusive scan of min(qDiagCnt, maxHits): start of each query's range in the staging buffer
+    const uint32_t *wantOff;        // start of each query's range in the staging buffer (= qDiagBase: a query selects at most as many hits as it has diagonals)
     uint32_t binMask; int maxHits; int minDiagScore;
     GpuHit *outHits; uint32_t *outQuery; uint32_t *outCount; uint32_t *outBase;   // compact output: each query owns [outBase, outBase+outCount)
     unsigned long long *counters;   // [4] += hits
@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_select(SelectArgs a) {
     // gaps are closed by k_reorder_hits): single-diagonal queries (the common case for spacer peptides) are finished
     // lane-parallel, small ones in registers by the whole wave, the rest through LDS.
     // No atomics: chunks are dealt round-robin to the waves (the work per chunk is even) and every query's output range is
-    // known beforehand (wantOff = exclusive scan of min(D, maxHits)); two contended counters cost more than the kernel's work.
+    // known beforehand (the place of its diagonal records); two contended counters cost more than the kernel's work.
     const uint32_t nWaves = gridDim.x * kWavesPerBlock;
     for (uint32_t chunk = blockIdx.x * kWavesPerBlock + w; (uint64_t) chunk * kSelChunk < a.nq; chunk += nWaves) {
         const uint32_t qi = chunk * kSelChunk + lane;
@@ -1845,13 +1845,12 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     Impl &d = *d_;
     if (nq_ == 0) return true;
     maxHits_ = maxHits;
-    if (!d.outHits.ensure(nq_ * (size_t) maxHits, err) || !d.outStage.ensure(nq_ * (size_t) maxHits, err) || !d.outQuery.ensure(nq_ * (size_t) maxHits, err)) return false;
     if (!matchAndScore(kmerThr, false, err)) return false;
     const bool dbg = getenv("SP_DEBUG") != nullptr;
-    if (!d.selWant.ensure(nq_ + 1, err) || !d.selWantOff.ensure(nq_ + 2, err)) return false;
-    hipLaunchKernelGGL(k_select_want, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.qDiagCnt.p, (uint32_t) nq_, (uint32_t) maxHits, d.selWant.p);
-    if (!d.scanCounts(d.selWant.p, (uint32_t) nq_, d.selWantOff.p, err)) return false;
-    SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.selWantOff.p,
+    // a query's selected hits are staged where its diagonal records sit (they are at most as many): no separate layout pass
+    const size_t stageCap = std::max<size_t>(nq_ * (size_t) maxHits, d.diagCap);
+    if (!d.outHits.ensure(nq_ * (size_t) maxHits, err) || !d.outStage.ensure(stageCap, err) || !d.outQuery.ensure(stageCap, err)) return false;
+    SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.qDiagBase.p,
                   binSize - 1, maxHits, minDiagScore, d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.counters.p};
     hipLaunchKernelGGL(k_select, dim3(d.matchBlocks), dim3(64 * kWavesPerBlock), 0, d.stream, se);
     if (!d.scanCounts(d.outCount.p, (uint32_t) nq_, d.outOffset.p, err)) return false;
