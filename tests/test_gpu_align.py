@@ -121,9 +121,11 @@ def test_align_hits_equals_align_pairs():
     ctx.close()
 
 
-@pytest.mark.parametrize("heavy_lengths,min_word", [((20, 24, 28, 32), 8), ((13, 14, 15, 16), 0)])
-def test_packed_sw_kernel_byte_overflow_and_ragged_groups(heavy_lengths, min_word):
-    """the packed kernels (4 alignments per wave for queries up to 32 aa, 8 per wave when no query is longer than 16) on
+@pytest.mark.parametrize("heavy_lengths,short_range,min_word", [((20, 24, 28, 32), (9, 12), 8), ((13, 14, 15, 16), (9, 12), 0),
+                                                              ((11, 12, 12, 12), (9, 11), 0), ((9, 10, 10, 10), (9, 10), 0)])
+def test_packed_sw_kernel_byte_overflow_and_ragged_groups(heavy_lengths, short_range, min_word):
+    """the packed kernels (4 alignments per wave for queries up to 32 aa, 8 / 10 / 12 per wave when no query is longer than
+    16 / 12 / 10: groups of 10 and 12 lanes straddle the DPP rows) on
     awkward material: W/C-rich queries whose perfect matches overflow the 8-bit pass when they are long enough
     (score + bias >= 255 -> 16-bit redo, mixed byte/word lists in the reverse pass), queries of very different lengths
     side by side in one wave, targets shorter than a column chunk, and a pair count that is not a multiple of 8"""
@@ -143,7 +145,7 @@ def test_packed_sw_kernel_byte_overflow_and_ragged_groups(heavy_lengths, min_wor
         T.append(left + q[:L // 2] + rnd.choice(aa) + q[L // 2:] + right)
         T.append(q[2:L - 3])                  # shorter than the query
     for i in range(45):                       # short ordinary queries in between
-        q = "".join(rnd.choice(aa) for _ in range(rnd.randint(9, 12)))
+        q = "".join(rnd.choice(aa) for _ in range(rnd.randint(*short_range)))
         Q.insert(rnd.randrange(len(Q)), q)
         T.append("".join(rnd.choice(aa) for _ in range(rnd.randint(5, 31))) + q + "".join(rnd.choice(aa) for _ in range(rnd.randint(0, 9))))
     o = Oracle()
