@@ -7,6 +7,9 @@ with the target index / residues / similar-k-mer tables and the query batch alre
 prefilter hit list and the alignment records + backtraces) are delivered to host memory -- the hit list travels on a copy
 stream while the align kernels run, the alignment records while the NEXT step's prefilter runs (sp_ctx_align_hits_begin /
 _end); the last step's records are collected before the closing barrier, so all K steps complete inside the timed region.
+The K steps are dealt to --pipeline (default 2) search contexts per GPU, each with its own HIP streams and host thread: the
+matching kernel is latency-bound (a third of the VALU issue slots), the Smith-Waterman kernel VALU-bound, and two passes in
+flight fill the machine better than one (two whole bench PROCESSES on one GPU reach 1.3x the throughput of one).
 
 Workload (BASELINE.json configs[2], SURVEY.md section 8d "synthetic proxy"): 10 000 synthetic 30-nt spacers =
 60 000 peptides of 10 aa (even index: window of a target with one substitution, odd: background i.i.d.) against
@@ -153,14 +156,17 @@ pmc_traffic.measured_stream = None
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--spacers", type=int, default=10000)
     ap.add_argument("--targets", type=int, default=50000)
     ap.add_argument("--target-len", type=int, default=200)
     ap.add_argument("--stage", default="full", choices=["full", "prefilter"])
     ap.add_argument("--cpu-sample", type=int, default=3000, help="peptides per core for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=8, help="host cores for the reference CPU baseline (one process each)")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="search contexts per GPU, each on its own HIP streams and host thread, taking the steps in turn: the latency-bound "
+                         "matcher of one pass and the VALU-bound aligner of another share the machine (1 = strictly one pass at a time)")
     ap.add_argument("--shard", default="queries", choices=["queries", "targets"],
                     help="N>1 decomposition: query partition with replicated index (default) or target shards + RCCL all-gather")
     args = ap.parse_args()
@@ -204,41 +210,72 @@ def main():
     gpu_dev = None
     if dist is not None:
         gpu_dev = torch.device("cuda", local_rank)
+    # further contexts of the pipeline: same resident targets and queries, own streams (the exchange step of the target-sharded
+    # path is a collective on the process group: one context there)
+    n_pipe = 1 if sharded else max(1, min(args.pipeline, args.steps))
+    ctxs = [ctx]
+    for _ in range(n_pipe - 1):
+        c2 = sa.SearchContext(device_mask=1 << local_rank)
+        c2.set_targets_raw(tres.tobytes(), u64p(toff), len(toff) - 1)
+        c2.set_queries_raw(qres.tobytes(), u64p(qoff), nq)
+        ctxs.append(c2)
 
-    def step():
+    def step(c=ctx):
         if sharded:
-            sharded_prefilter(ctx, q_from, q_to, device=gpu_dev)   # own shard -> RCCL all-gather -> selection on the union
+            sharded_prefilter(c, q_from, q_to, device=gpu_dev)   # own shard -> RCCL all-gather -> selection on the union
         else:
-            ctx.prefilter()
-        npairs = ctx.num_hits()
+            c.prefilter()
+        npairs = c.num_hits()
         if args.stage == "full" and npairs:
-            ctx.align_hits_begin()                        # alignment result DB content (result_t + backtraces per hit): returns when
+            c.align_hits_begin()                          # alignment result DB content (result_t + backtraces per hit): returns when
                                                           # the kernels are done, the 5 MB travel while the next pass's prefilter runs
-        ctx.hits_view()                                   # prefilter result DB content (hit_t triples per query) in host memory: its
-        return npairs                                     # copy started when the prefilter finished and overlapped align
+        c.hits_view()                                     # prefilter result DB content (hit_t triples per query) in host memory: its
+        return npairs                                     # copy started underneath the align kernels
 
     def barrier():
-        ctx.align_hits_end()                              # the last pass's alignment records are in host memory
+        for c in ctxs:
+            c.align_hits_end()                            # the last pass's alignment records are in host memory
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
 
-    for _ in range(args.warmup):
-        step()
+    for c in ctxs:
+        for _ in range(args.warmup):
+            step(c)
     # timed region: HIP events bracket only the dominant kernel (k_match, the roofline figure) -- every event record between
-    # two kernels costs ~6 us of idle GPU, so the per-stage breakdown is taken in a separate short pass after the clock stops
-    ctx.set_timing(1)
-    ms_match_sum = 0.0
+    # two kernels costs ~6 us of idle GPU, so the per-stage breakdown is taken in a separate short pass after the clock stops.
+    # The K steps are dealt to the contexts of the pipeline; each context runs its share on its own host thread (ctypes
+    # releases the GIL for the duration of a call), so up to n_pipe passes are in flight on the GPU at any time.
+    import threading
+    for c in ctxs:
+        c.set_timing(1)
+    share = [args.steps // n_pipe + (1 if i < args.steps % n_pipe else 0) for i in range(n_pipe)]
+    acc = [[0.0, 0] for _ in range(n_pipe)]          # per context: sum of k_match event times, pairs of its last step
+
+    def run(i):
+        c = ctxs[i]
+        for _ in range(share[i]):
+            acc[i][1] = step(c)
+            v = c.stat("ms_match")
+            acc[i][0] += 0.0 if v != v else v
+
     barrier()
     t0 = time.perf_counter()
-    pairs = 0
-    for _ in range(args.steps):
-        pairs = step()
-        v = ctx.stat("ms_match")
-        ms_match_sum += 0.0 if v != v else v
+    if n_pipe == 1:
+        run(0)
+    else:
+        threads = [threading.Thread(target=run, args=(i,)) for i in range(n_pipe)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
     barrier()
     dt = time.perf_counter() - t0
+    ms_match_sum = sum(a[0] for a in acc)
+    pairs = acc[0][1]
+    # per-stage breakdown: one context alone, HIP events around every stage, outside the timed region
     stats = {"ms_match": 0.0, "ms_prep": 0.0, "ms_score": 0.0, "ms_select": 0.0, "ms_sw_forward": 0.0, "ms_sw_reverse": 0.0, "ms_traceback": 0.0}
     ctx.set_timing(2)
     n_breakdown = 3
@@ -279,14 +316,22 @@ def main():
                    "stage": args.stage, "pairs_aligned_per_step": pairs, "sensitivity": 5.7, "max_seqs": 300,
                    "parallelism": ("target shards x%d, RCCL all-gather of candidates, selection + align by query slice" % world) if sharded
                                   else ("query partition x%d, index replicated" % world),
+                   "passes_in_flight_per_gpu": n_pipe,
                    "index_build_s": round(t_index, 3)},
         "kernels_ms_per_step": {k[3:]: round(v / n_breakdown, 4) for k, v in stats.items()},
-        "kernels_ms_source": "HIP events around every stage in %d extra steps AFTER the timed region (the timed steps bracket k_match only: %.4f ms)" % (n_breakdown, ms_match),
+        "kernels_ms_source": "HIP events around every stage in %d extra steps of ONE context AFTER the timed region (the timed steps bracket k_match only: "
+                             "%.4f ms per launch with %d passes in flight)" % (n_breakdown, ms_match, n_pipe),
         "counters_per_step": {"similar_kmers": K, "index_entries_fetched": M, "diagonals_scored": D, "diag_residues": R, "hits": H},
         "roofline": {"bound": "hbm", "kernel": "k_match", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": traffic,
                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
-                     "measured_streaming_read_GBps": pmc_traffic.measured_stream},
+                     "measured_streaming_read_GBps": pmc_traffic.measured_stream,
+                     # the same kernel with the GPU to itself (one context, the breakdown pass after the timed region): its launches in the
+                     # timed region share the machine with the other context's aligner and take longer each, while more work gets done
+                     "exclusive": {"ms_per_launch": round(stats["ms_match"] / n_breakdown, 4),
+                                   "achieved": algo_bytes / (stats["ms_match"] / n_breakdown * 1e-3) / 1e9 if stats["ms_match"] > 0 else 0.0,
+                                   "frac": algo_bytes / (stats["ms_match"] / n_breakdown * 1e-3) / 1e9 / 8000.0 if stats["ms_match"] > 0 else 0.0},
+                     "passes_in_flight": n_pipe},
     }
     if args.cpu_sample > 0 and world == 1:      # rank 0 at N = 1 only
         # the reference itself when its harness travelled with the repo (oracle/_ref, built by __graft_entry__.build()), else

@@ -148,6 +148,7 @@ int sp_ctx_set_targets_shard(sp_ctx *c, const char *residues, const uint64_t *of
 }
 
 static int setTargets(sp_ctx *c, const char *residues, const uint64_t *offsets, const uint32_t *keys, uint64_t n, int flags, uint64_t from, uint64_t to) {
+    if (c) c->gpu.makeCurrent();
     if (!c || !residues || !offsets) { g_err = "sp_ctx_set_targets: null argument"; return SP_ERR_ARG; }
     const bool noIndex = (flags & 1) != 0;
     std::string err;
@@ -184,6 +185,7 @@ static int setTargets(sp_ctx *c, const char *residues, const uint64_t *offsets, 
 }
 
 int sp_ctx_set_queries(sp_ctx *c, const char *residues, const uint64_t *offsets, uint64_t n) {
+    if (c) c->gpu.makeCurrent();
     if (!c || !residues || !offsets) { g_err = "sp_ctx_set_queries: null argument"; return SP_ERR_ARG; }
     if (offsets[n] >= (1ull << 32)) { g_err = "query batch larger than 4 GiB of residues"; return SP_ERR_ARG; }
     c->qres.resize(offsets[n]);
@@ -201,6 +203,7 @@ int sp_ctx_set_queries(sp_ctx *c, const char *residues, const uint64_t *offsets,
 static void prefilterStats(sp_ctx *c);
 
 int sp_ctx_prefilter(sp_ctx *c) {
+    if (c) c->gpu.makeCurrent();
     if (!c || c->targets.n == 0) { g_err = "sp_ctx_prefilter: no target set"; return SP_ERR_STATE; }
     if (c->indexEntries == 0) { g_err = "sp_ctx_prefilter: the target set has no k-mer index (no indexable k-mer, or staged without one)"; return SP_ERR_STATE; }
     std::string err;
@@ -220,6 +223,7 @@ static void prefilterStats(sp_ctx *c) {
 }
 
 int sp_ctx_prefilter_candidates(sp_ctx *c) {
+    if (c) c->gpu.makeCurrent();
     if (!c || c->targets.n == 0) { g_err = "sp_ctx_prefilter_candidates: no target set"; return SP_ERR_STATE; }
     std::string err;
     if (!c->gpu.prefilterCandidates(c->kmerThr, c->par.min_ungapped_score, err)) { g_err = err; return SP_ERR_OVERFLOW; }
@@ -232,6 +236,7 @@ uint64_t sp_ctx_num_candidates(const sp_ctx *c) { return (uint64_t) c->gpu.numCa
 const void *sp_ctx_candidates_device(const sp_ctx *c) { return c->gpu.candidatesDevice(); }
 
 int sp_ctx_get_candidates(sp_ctx *c, sp_candidate *out) {
+    if (c) c->gpu.makeCurrent();
     static_assert(sizeof(sp_candidate) == sizeof(sp::Candidate), "candidate layout");
     std::string err;
     if (!c->gpu.downloadCandidates(reinterpret_cast<sp::Candidate *>(out), err)) { g_err = err; return SP_ERR_DEVICE; }
@@ -239,6 +244,7 @@ int sp_ctx_get_candidates(sp_ctx *c, sp_candidate *out) {
 }
 
 int sp_ctx_merge_candidates(sp_ctx *c, const sp_candidate *cands, uint64_t n, int onDevice, uint64_t qFrom, uint64_t qTo) {
+    if (c) c->gpu.makeCurrent();
     if (!c || c->targets.n == 0) { g_err = "sp_ctx_merge_candidates: no target set"; return SP_ERR_STATE; }
     if (n && !cands) { g_err = "sp_ctx_merge_candidates: null candidate list"; return SP_ERR_ARG; }
     std::string err;
@@ -252,6 +258,7 @@ int sp_ctx_merge_candidates(sp_ctx *c, const sp_candidate *cands, uint64_t n, in
 uint64_t sp_ctx_num_hits(const sp_ctx *c) { return (uint64_t) c->gpu.counters().hits; }
 
 int sp_ctx_get_hits_compact(sp_ctx *c, sp_hit *hits, uint64_t *offsets) {
+    if (c) c->gpu.makeCurrent();
     const sp::GpuHit *h = nullptr; const uint32_t *off = nullptr; size_t n = 0; std::string err;
     if (!c->gpu.hostHits(h, off, n, err)) { g_err = err; return SP_ERR_DEVICE; }
     const size_t nq = c->gpu.numQueries();
@@ -261,6 +268,7 @@ int sp_ctx_get_hits_compact(sp_ctx *c, sp_hit *hits, uint64_t *offsets) {
 }
 
 int sp_ctx_hits_view(sp_ctx *c, const sp_hit_packed **hits, const uint32_t **offsets, uint64_t *n) {
+    if (c) c->gpu.makeCurrent();
     static_assert(sizeof(sp_hit_packed) == sizeof(sp::GpuHit), "sp_hit_packed is the device hit record");
     const sp::GpuHit *h = nullptr; const uint32_t *off = nullptr; size_t cnt = 0; std::string err;
     if (!c->gpu.hostHits(h, off, cnt, err)) { g_err = err; return SP_ERR_DEVICE; }
@@ -269,6 +277,7 @@ int sp_ctx_hits_view(sp_ctx *c, const sp_hit_packed **hits, const uint32_t **off
 }
 
 int sp_ctx_get_hits(sp_ctx *c, sp_hit *hits, uint32_t *counts) {
+    if (c) c->gpu.makeCurrent();
     const sp::GpuHit *h = nullptr; const uint32_t *off = nullptr; size_t n = 0; std::string err;
     if (!c->gpu.hostHits(h, off, n, err)) { g_err = err; return SP_ERR_DEVICE; }
     const size_t nq = c->gpu.numQueries(); const int mh = c->gpu.maxHits();
@@ -385,6 +394,7 @@ static int finishDirectOrHost(sp_ctx *c, const sp::AlignDirect &direct, sp_align
 }
 
 int sp_ctx_align(sp_ctx *c, const uint32_t *qidx, const uint32_t *tidx, uint64_t n, sp_alignment *res, char *cigars, uint64_t cigarCap, uint64_t *cigarUsed) {
+    if (c) c->gpu.makeCurrent();
     if (!c || c->targets.n == 0) { g_err = "sp_ctx_align: no target set"; return SP_ERR_STATE; }
     std::string err;
     if (!ensureEvaluers(c, true, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
@@ -400,6 +410,7 @@ int sp_ctx_align(sp_ctx *c, const uint32_t *qidx, const uint32_t *tidx, uint64_t
 
 /* align every hit of the last sp_ctx_prefilter(): results[i] belongs to hit i of sp_ctx_get_hits_compact() */
 int sp_ctx_align_hits(sp_ctx *c, sp_alignment *res, char *cigars, uint64_t cigarCap, uint64_t *cigarUsed) {
+    if (c) c->gpu.makeCurrent();
     if (!c || c->targets.n == 0) { g_err = "sp_ctx_align_hits: no target set"; return SP_ERR_STATE; }
     std::string err;
     if (!ensureEvaluers(c, true, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
@@ -418,6 +429,7 @@ int sp_ctx_align_hits(sp_ctx *c, sp_alignment *res, char *cigars, uint64_t cigar
 /* split form of sp_ctx_align_hits(): _begin returns when the device work is done and the results are on their way to
    `res` / `cigars` (leave both alone), _end waits for them.  Between the two the caller may queue the next prefilter pass. */
 int sp_ctx_align_hits_begin(sp_ctx *c, sp_alignment *res, char *cigars, uint64_t cigarCap, uint64_t *cigarUsed) {
+    if (c) c->gpu.makeCurrent();
     if (!c || c->targets.n == 0) { g_err = "sp_ctx_align_hits_begin: no target set"; return SP_ERR_STATE; }
     std::string err;
     if (!ensureEvaluers(c, true, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
@@ -427,12 +439,14 @@ int sp_ctx_align_hits_begin(sp_ctx *c, sp_alignment *res, char *cigars, uint64_t
     return finishDirectOrHost(c, direct, res, cigars, cigarCap, cigarUsed);
 }
 int sp_ctx_align_hits_end(sp_ctx *c) {
+    if (c) c->gpu.makeCurrent();
     std::string err;
     if (!c->gpu.waitAlignCopy(err)) { g_err = err; return SP_ERR_DEVICE; }
     return SP_OK;
 }
 
 int sp_ctx_rescore(sp_ctx *c, const uint32_t *qidx, const uint32_t *tidx, const int16_t *diag, uint64_t n, int mode, sp_rescore *res) {
+    if (c) c->gpu.makeCurrent();
     if (!c || c->targets.n == 0) { g_err = "sp_ctx_rescore: no target set"; return SP_ERR_STATE; }
     std::string err;
     if (!ensureEvaluers(c, false, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
@@ -482,7 +496,7 @@ int sp_ctx_get_masked(sp_ctx *c, char *out) {
 
 void *sp_host_alloc(uint64_t bytes) { return sp::pinnedAlloc((size_t) bytes); }
 void sp_host_free(void *p) { sp::pinnedFree(p); }
-int sp_ctx_sync(sp_ctx *c) { c->gpu.sync(); return SP_OK; }
+int sp_ctx_sync(sp_ctx *c) { c->gpu.makeCurrent(); c->gpu.sync(); return SP_OK; }
 int sp_ctx_set_timing(sp_ctx *c, int level) { c->gpu.setTiming(level); return SP_OK; }
 int sp_ctx_diag_stream_read(sp_ctx *c, uint64_t bytes, int laneBytes, double *ms) {
     std::string err; double t = 0;

@@ -125,7 +125,8 @@ public:
     bool diagStreamRead(uint64_t bytes, int laneBytes, double &ms, std::string &err);
 
     void sync();
-    void setTiming(int level);     // 0 none, 1 k_match only (default), 2 every stage
+    void setTiming(int level);
+    void makeCurrent();            // HIP's current device is per host thread: every entry point that may run on another thread calls this     // 0 none, 1 k_match only (default), 2 every stage
     void *stream() const { return stream_; }
 
 private:

@@ -1532,6 +1532,7 @@ struct Gpu::Impl {
     size_t diagCap = 0;
     DevBuf<unsigned char> scanTemp; DevBuf<uint32_t> selWant, selWantOff;
     unsigned long long *mailbox = nullptr;       // page-locked landing area for counters
+    int device = 0;
     int timing = 1;                              // 0: no HIP events in the pipeline, 1: around k_match only (each record costs ~6 us of idle GPU), 2: every stage
     // the hit list starts travelling to the host on its own stream as soon as a prefilter pass is complete, so that the copy
     // overlaps whatever the caller queues next (typically the align kernels)
@@ -1585,6 +1586,7 @@ static hipError_t spinSync(hipStream_t s) {
 static float evMs(int timing, int level, hipEvent_t a, hipEvent_t b) {
     float t = 0; if (timing < level || hipEventElapsedTime(&t, a, b) != hipSuccess) return __builtin_nanf(""); return t;
 }
+void Gpu::makeCurrent() { (void) hipSetDevice(d_->device); }
 void Gpu::setTiming(int level) { d_->timing = level < 0 ? 0 : (level > 2 ? 2 : level); }
 
 // several small fills in one launch (each hipMemsetAsync is a kernel of its own plus a gap)
@@ -1613,6 +1615,7 @@ bool Gpu::init(int device, std::string &err) {
     HIP_OK(hipGetDeviceCount(&n));
     if (n <= 0) { err = "no HIP device visible"; return false; }
     HIP_OK(hipSetDevice(device % n));
+    d_->device = device % n;
     // (hipGetDeviceProperties takes milliseconds: asked once per process and device)
     static std::mutex propMutex; static std::map<int, std::pair<std::string, int>> propCache;
     {   std::lock_guard<std::mutex> lock(propMutex);
