@@ -165,6 +165,9 @@ int sp_ctx_sync(sp_ctx *c);
 /* HIP-event timing inside the pipeline (sp_ctx_stat "ms_*"): 0 = none, 1 = the k-mer matching kernel only (default; every
    event record between two kernels costs ~6 us of idle GPU), 2 = every stage.  Stages that are not timed report NaN. */
 int sp_ctx_set_timing(sp_ctx *c, int level);
+/* tuning knobs (never change a result).  "match_blocks_per_cu": resident blocks of the matching kernel per CU, 0 = as many as
+   fit (3).  Two leave LDS for the aligner of another context on the same GPU -- better when several passes are in flight. */
+int sp_ctx_set_tuning(sp_ctx *c, const char *name, int value);
 /* raw HIP stream the context launches on (hipStream_t), for callers that time with their own events */
 void *sp_ctx_stream(const sp_ctx *c);
 /* test hooks: digest of the index built on the device ((k-mer, seqId, pos) triples in table order, FNV-1a as in

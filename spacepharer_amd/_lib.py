@@ -101,6 +101,7 @@ def load_library():
     L.sp_ctx_stat.argtypes = [vp, C.c_char_p]
     L.sp_ctx_sync.argtypes = [vp]
     L.sp_ctx_set_timing.argtypes = [vp, C.c_int]
+    L.sp_ctx_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
     L.sp_ctx_stream.restype = vp
     L.sp_ctx_stream.argtypes = [vp]
     L.sp_ctx_index_digest.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -344,6 +345,10 @@ class SearchContext:
 
     def sync(self):
         _check(self.L.sp_ctx_sync(self.ctx))
+
+    def set_tuning(self, name, value):
+        """knobs that never change a result, e.g. ("match_blocks_per_cu", 2)"""
+        _check(self.L.sp_ctx_set_tuning(self.ctx, name.encode(), int(value)))
 
     def set_timing(self, level):
         """0: no HIP events inside the pipeline, 1: around the matching kernel only (default), 2: every stage"""

@@ -498,6 +498,10 @@ void *sp_host_alloc(uint64_t bytes) { return sp::pinnedAlloc((size_t) bytes); }
 void sp_host_free(void *p) { sp::pinnedFree(p); }
 int sp_ctx_sync(sp_ctx *c) { c->gpu.makeCurrent(); c->gpu.sync(); return SP_OK; }
 int sp_ctx_set_timing(sp_ctx *c, int level) { c->gpu.setTiming(level); return SP_OK; }
+int sp_ctx_set_tuning(sp_ctx *c, const char *name, int value) {
+    if (c && name && !strcmp(name, "match_blocks_per_cu")) { c->gpu.setMatchBlocksPerCU(value); return SP_OK; }
+    g_err = std::string("sp_ctx_set_tuning: unknown knob '") + (name ? name : "") + "'"; return SP_ERR_ARG;
+}
 int sp_ctx_diag_stream_read(sp_ctx *c, uint64_t bytes, int laneBytes, double *ms) {
     std::string err; double t = 0;
     if (!c->gpu.diagStreamRead(bytes, laneBytes, t, err)) { g_err = err; return SP_ERR_DEVICE; }

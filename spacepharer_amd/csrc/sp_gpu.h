@@ -126,6 +126,7 @@ public:
 
     void sync();
     void setTiming(int level);
+    void setMatchBlocksPerCU(int n);   // 0 = as many as fit
     void makeCurrent();            // HIP's current device is per host thread: every entry point that may run on another thread calls this     // 0 none, 1 k_match only (default), 2 every stage
     void *stream() const { return stream_; }
 

@@ -1533,6 +1533,7 @@ struct Gpu::Impl {
     DevBuf<unsigned char> scanTemp; DevBuf<uint32_t> selWant, selWantOff;
     unsigned long long *mailbox = nullptr;       // page-locked landing area for counters
     int device = 0;
+    int matchPerCU = 0;                          // resident k_match blocks per CU (0 = what the occupancy calculator says)
     int timing = 1;                              // 0: no HIP events in the pipeline, 1: around k_match only (each record costs ~6 us of idle GPU), 2: every stage
     // the hit list starts travelling to the host on its own stream as soon as a prefilter pass is complete, so that the copy
     // overlaps whatever the caller queues next (typically the align kernels)
@@ -1586,6 +1587,7 @@ static hipError_t spinSync(hipStream_t s) {
 static float evMs(int timing, int level, hipEvent_t a, hipEvent_t b) {
     float t = 0; if (timing < level || hipEventElapsedTime(&t, a, b) != hipSuccess) return __builtin_nanf(""); return t;
 }
+void Gpu::setMatchBlocksPerCU(int n) { d_->matchPerCU = n < 0 ? 0 : n; }
 void Gpu::makeCurrent() { (void) hipSetDevice(d_->device); }
 void Gpu::setTiming(int level) { d_->timing = level < 0 ? 0 : (level > 2 ? 2 : level); }
 
@@ -1757,6 +1759,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     const void *fn = withOrd ? (const void *) k_match<512, true> : (const void *) k_match<512, false>;
     int perCU = 2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, fn, 64 * kWavesPerBlock, 0) != hipSuccess || perCU < 1) perCU = 2;
+    if (d.matchPerCU > 0) perCU = std::min(perCU, d.matchPerCU);
     if (const char *e = getenv("SP_MATCH_PERCU")) perCU = std::max(1, atoi(e));
     const bool dbg = getenv("SP_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[sp] k_match hitCap=%d ord=%d blocks/CU=%d\n", hitCap, (int) withOrd, perCU);

@@ -1,8 +1,8 @@
-# GPU box: A/B of k_match scheduling knobs on one box (SP_MATCH_HEAVY / SP_MATCH_STATIC / SP_MATCH_DCHUNK)
+# GPU box: A/B of pipeline depth x k_match blocks per CU on one box
 cd $GRAFT_REPO_ROOT
-for cfg in "4000 4 4" "3000 4 4" "2000 4 4" "6000 4 4" "3000 6 4" "3000 5 4" "3000 4 8" "2500 6 8" "4000 4 4"; do
+for cfg in "2 3" "2 2" "3 3" "3 2" "4 2" "2 3"; do
   set -- $cfg
-  export SP_MATCH_HEAVY=$1 SP_MATCH_STATIC=$2 SP_MATCH_DCHUNK=$3
-  timeout 300 python bench.py --steps 20 --warmup 3 --cpu-sample 0 --stage prefilter 2>&1 | grep '^{' | tail -1 | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print('heavy>=$1 static=$2/8 dchunk=$3', '|', round(d['value']), d['ms_per_step'], d['roofline']['achieved'] and round(1182.99/d['roofline']['achieved'],4))"
+  export SP_MATCH_PERCU=$2
+  timeout 300 python bench.py --steps 120 --warmup 3 --cpu-sample 0 --pipeline $1 2>&1 | grep '^{' | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('pipeline=$1 blocks/CU=$2', '|', round(d['value']), round(d['ms_per_step'],4), round(d['roofline']['frac'],4), d['roofline']['exclusive']['ms_per_launch'])"
 done
