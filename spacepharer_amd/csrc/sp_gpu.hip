@@ -110,8 +110,22 @@ __device__ void waveBitonicSort(uint64_t *keys, uint32_t n, int lane) {
 // k-mers of a window are enumerated first-3-mer-major, so neighbouring lanes of a probe share the FIRST 3-mer and walk
 // through similar SECOND 3-mers.  Numbering slots  second3mer + 8000 * first3mer  puts those probes into one 1000-byte row
 // of occupancy bits (a handful of 128-byte lines per load instruction instead of 64 different ones).
-__host__ __device__ __forceinline__ uint32_t slotOfKmer(uint32_t first3, uint32_t second3) { return second3 + 8000u * first3; }
-__host__ __device__ __forceinline__ uint32_t kmerOfSlot(uint32_t slot) { return slot / 8000u + 8000u * (slot % 8000u); }
+// Inside a row the second 3-mers are numbered with the residues in an order that keeps exchangeable ones next to each other
+// (C | G A S T P | N D E Q | K R H | Y W F | M L I V instead of the alphabet): the similar second 3-mers of a window differ from
+// it in a few positions by such residues, so their slots bunch into fewer 128-byte lines of the probe table -- line traffic is
+// what bounds the search once two passes are in flight.  The renumbering lives in the tables only (the partner indices stored
+// in the similar-3-mer table and the keys of the index construction are already permuted; perm3 / unperm3 are build- and
+// test-time functions), never in the matching kernel.
+__host__ __device__ __forceinline__ uint32_t perm3(uint32_t idx) {       // reference 3-mer number -> permuted number
+    constexpr uint8_t pi[20] = {2, 0, 7, 8, 15, 1, 12, 18, 10, 17, 16, 6, 5, 9, 11, 3, 4, 19, 14, 13};     // A C D E F G H I K L M N P Q R S T V W Y
+    return pi[idx % 20u] + 20u * pi[(idx / 20u) % 20u] + 400u * pi[idx / 400u];
+}
+__host__ __device__ __forceinline__ uint32_t unperm3(uint32_t idx) {
+    constexpr uint8_t inv[20] = {1, 5, 0, 15, 16, 12, 11, 2, 3, 13, 8, 14, 6, 19, 18, 4, 10, 9, 7, 17};
+    return inv[idx % 20u] + 20u * inv[(idx / 20u) % 20u] + 400u * inv[idx / 400u];
+}
+__host__ __device__ __forceinline__ uint32_t slotOfKmer(uint32_t first3p, uint32_t second3p) { return second3p + 8000u * first3p; }      // permuted 3-mer numbers in
+__host__ __device__ __forceinline__ uint32_t kmerOfSlot(uint32_t slot) { return unperm3(slot / 8000u) + 8000u * unperm3(slot % 8000u); }  // reference k-mer id out
 
 __device__ __forceinline__ int extScore(uint32_t packed) { return (int) (packed >> 16) - 32768; }
 __device__ __forceinline__ uint32_t extIndex(uint32_t packed) { return packed & 0xFFFFu; }
@@ -392,8 +406,9 @@ struct MatchArgs {
     const uint16_t *ext3cnt;        // 8000 x kCntW: [row][c - cntMin] = number of partners with score >= c
     int cntMin;
     // rank-compressed slot table.  k-mer = a + 8000 b: the 8000 slots of one b form a "row" of 125 words of 64 slots.
-    const uint64_t *probe;          // per 32 slots: occupancy bits (low half) | occupied slots before the word (high half) -- 16 MB, one 8-byte load
-                                    // answers "occupied?" and gives the slot's rank
+    const uint64_t *pbits;          // occupancy bits, one u64 per 64 slots (8 MB): all a miss needs; a 128-byte line covers 1 024 slots
+    const uint16_t *prank;          // occupied slots of the row before the word (2 MB)
+    const uint32_t *prow;           // occupied slots before the row (8 000 entries)
     const uint64_t *slots;          // per OCCUPIED slot (rank order): the entry itself (seqId | pos << 32) when the list has one
                                     // entry, else bit 63 | len << 32 | offset into ientries
     const uint64_t *ientries;       // seqId | pos << 32, lists concatenated in k-mer order
@@ -681,18 +696,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                     SP_T(3);
                     uint64_t prR[kSuper / 64];
 #pragma unroll
-                    for (int r = 0; r < kSuper / 64; r++) prR[r] = (kmerR[r] != 0xFFFFFFFFu) ? a.probe[kmerR[r] >> 5] : 0ull;
+                    for (int r = 0; r < kSuper / 64; r++) prR[r] = (kmerR[r] != 0xFFFFFFFFu) ? a.pbits[kmerR[r] >> 6] : 0ull;
                     uint32_t nOcc = 0;
 #pragma unroll
                     for (int r = 0; r < kSuper / 64; r++) {
                         if (s0 + 64u * r >= tileK) break;                          // (uniform: the rounds beyond the list hold nothing)
-                        const uint32_t bit = kmerR[r] & 31u, word = (uint32_t) prR[r];
-                        const bool occ = kmerR[r] != 0xFFFFFFFFu && ((word >> bit) & 1u);
+                        const uint32_t bit = kmerR[r] & 63u;
+                        const bool occ = kmerR[r] != 0xFFFFFFFFu && ((prR[r] >> bit) & 1ull);
                         const uint64_t m = __ballot(occ);
                         if (occ) {
                             const uint32_t at = nOcc + (uint32_t) __popcll(m & laneMaskLt(lane));
-                            // rank of the slot = occupied slots before its word + occupied slots of the word below it
-                            occList[at] = (uint32_t) (prR[r] >> 32) + (uint32_t) __popc(word & ((1u << bit) - 1u));
+                            // slot number (< 2^26) | occupied slots of its word below it: the rest of the rank is looked up in phase 2
+                            occList[at] = kmerR[r] | ((uint32_t) __popcll(prR[r] & ((1ull << bit) - 1ull)) << 26);
                             if (kOrd) occOrd[at] = (uint16_t) (r * 64 + lane);
                         }
                         nOcc += (uint32_t) __popcll(m);
@@ -700,14 +715,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                     waveSync();
                     SP_T(4);
                     for (uint32_t ob = 0; ob < nOcc; ob += 256) {
-                        uint64_t slotR[4] = {0, 0, 0, 0}; uint32_t lenR[4] = {0, 0, 0, 0}, hR[4], ordR[4] = {0, 0, 0, 0};
+                        uint64_t slotR[4] = {0, 0, 0, 0}; uint32_t lenR[4] = {0, 0, 0, 0}, hR[4], ordR[4] = {0, 0, 0, 0}, rankR[4] = {0, 0, 0, 0};
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             const uint32_t at = ob + 64u * r + lane;
                             if (at < nOcc) {
-                                slotR[r] = a.slots[occList[at]]; lenR[r] = (slotR[r] >> 63) ? ((uint32_t) (slotR[r] >> 32) & 0x7FFFFFFFu) : 1u;
+                                const uint32_t e = occList[at], km = e & 0x3FFFFFFu;
+                                rankR[r] = a.prow[km / 8000u] + (uint32_t) a.prank[km >> 6] + (e >> 26);      // rank of the slot
                                 if (kOrd) ordR[r] = qK0 + kBase + s0 + occOrd[at];
                             }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            if (ob + 64u * r + lane < nOcc) { slotR[r] = a.slots[rankR[r]]; lenR[r] = (slotR[r] >> 63) ? ((uint32_t) (slotR[r] >> 32) & 0x7FFFFFFFu) : 1u; }
                         }
                         uint32_t lenMulti = 0, run = M;
 #pragma unroll
@@ -1515,7 +1535,7 @@ struct Gpu::Impl {
     DevBuf<short> alnSub16; DevBuf<double> alnBack;
     int ungMinAbs = 0, alnMinAbs = 0;
     // targets
-    DevBuf<uint32_t> pbits; DevBuf<uint64_t> probe; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff; DevBuf<uint32_t> tkeys;
+    DevBuf<uint64_t> pbits; DevBuf<uint16_t> prank; DevBuf<uint32_t> prow; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff; DevBuf<uint32_t> tkeys;
     size_t nTargets = 0; size_t indexEntries = 0;
     // index construction scratch (kept for the next target set)
     DevBuf<uint32_t> ixKeys, ixKeys2, ixKeep, ixPos, ixKmer, ixHead, ixSlotOf, ixHeadPos, ixCnt, ixBefore; DevBuf<uint64_t> ixVals, ixVals2;
@@ -1750,7 +1770,7 @@ bool Gpu::uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std:
 // k_prep, k_match, k_score for every resident query; leaves the scored double-hit diagonals in HBM (events 0..3)
 bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     Impl &d = *d_;
-    if (!d.ext3.p || !d.probe.p) { err = "tables/targets not resident"; return false; }
+    if (!d.ext3.p || !d.pbits.p) { err = "tables/targets not resident"; return false; }
     if (d.hitsInFlight) { (void) hipEventSynchronize(d.hitsOnHost); d.hitsInFlight = false; }     // the previous pass's hit list is still being copied
     // persistent match grid: as many blocks per CU as the LDS footprint admits.  512 hits per query live in LDS; more go to
     // the per-wave HBM scratch and come back through the pre-filter (faster than a larger LDS buffer even for dense indices:
@@ -1794,7 +1814,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
         SP_DBG_SYNC("k_weigh");
     }
     SP_EV(1, 1);
-    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.probe.p, d.slots.p, d.ientries.p, d.spill.p, d.queue.p,
+    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.pbits.p, d.prank.p, d.prow.p, d.slots.p, d.ientries.p, d.spill.p, d.queue.p,
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
                  (uint32_t) (getenv("SP_MATCH_STATIC") ? atoi(getenv("SP_MATCH_STATIC")) : 4), (uint32_t) (getenv("SP_MATCH_DCHUNK") ? std::max(1, atoi(getenv("SP_MATCH_DCHUNK"))) : 4),
@@ -1961,10 +1981,11 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
         hipLaunchKernelGGL(k_tantan, dim3((unsigned) ((to - from + 63) / 64)), dim3(64), 0, d.stream, ta);
     }
     HIP_OK(hipEventRecord(d.ev[1], d.stream));
-    const size_t words = kTableSize / 32;
-    if (!d.pbits.ensure(words, err) || !d.probe.ensure(words, err) || !d.slots.ensure(1, err) || !d.ientries.ensure(1, err)) return false;
-    HIP_OK(hipMemsetAsync(d.pbits.p, 0, words * sizeof(uint32_t), d.stream));
-    HIP_OK(hipMemsetAsync(d.probe.p, 0, words * sizeof(uint64_t), d.stream));
+    const size_t words = kTableSize / 64;
+    if (!d.pbits.ensure(words, err) || !d.prank.ensure(words, err) || !d.prow.ensure(kTableSize / 8000, err) || !d.slots.ensure(1, err) || !d.ientries.ensure(1, err)) return false;
+    HIP_OK(hipMemsetAsync(d.pbits.p, 0, words * sizeof(uint64_t), d.stream));
+    HIP_OK(hipMemsetAsync(d.prank.p, 0, words * sizeof(uint16_t), d.stream));
+    HIP_OK(hipMemsetAsync(d.prow.p, 0, (kTableSize / 8000) * sizeof(uint32_t), d.stream));
     const uint64_t base = ts.offsets[from], Rs = ts.offsets[to] - base;
     if (index && Rs > 0) {
         if (Rs >= (1ull << 31)) { err = "index construction: more than 2^31 residues in one shard"; return false; }
@@ -2010,12 +2031,12 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
             HIP_OK(hipStreamSynchronize(d.stream));
             const uint32_t nSlots = lastSlot + lastHead;
             if (!d.ixHeadPos.ensure(nSlots + 1, err) || !d.slots.ensure(nSlots + 1, err) || !d.ixCnt.ensure(words, err) || !d.ixBefore.ensure(words + 1, err)) return false;
-            hipLaunchKernelGGL(k_idx_slots1, dim3(ge), dim3(256), 0, d.stream, d.ixKmer.p, d.ixHead.p, d.ixSlotOf.p, E, d.ixHeadPos.p, d.pbits.p);
+            hipLaunchKernelGGL(k_idx_slots1, dim3(ge), dim3(256), 0, d.stream, d.ixKmer.p, d.ixHead.p, d.ixSlotOf.p, E, d.ixHeadPos.p, (unsigned long long *) d.pbits.p);
             hipLaunchKernelGGL(k_idx_slots2, dim3((nSlots + 255) / 256), dim3(256), 0, d.stream, d.ixHeadPos.p, nSlots, E, d.ientries.p, d.slots.p);
-            hipLaunchKernelGGL(k_idx_popc, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, d.pbits.p, (uint32_t) words, d.ixCnt.p);
+            hipLaunchKernelGGL(k_idx_popc, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, (const unsigned long long *) d.pbits.p, (uint32_t) words, d.ixCnt.p);
             sb = d.ixTemp.n;
             HIP_OK(hipcub::DeviceScan::ExclusiveSum(d.ixTemp.p, sb, d.ixCnt.p, d.ixBefore.p, (int) words, d.stream));
-            hipLaunchKernelGGL(k_idx_probe, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, d.pbits.p, d.ixBefore.p, (uint32_t) words, d.probe.p);
+            hipLaunchKernelGGL(k_idx_ranks, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, d.ixBefore.p, (uint32_t) words, d.prank.p, d.prow.p);
             HIP_OK(hipGetLastError());
             d.indexEntries = E; out.indexEntries = E; out.indexSlots = nSlots;
         }
@@ -2052,6 +2073,7 @@ bool Gpu::downloadExt3(std::vector<uint32_t> &packed, std::string &err) {
     if (!d.ext3.p) { err = "downloadExt3: tables not resident"; return false; }
     packed.resize((size_t) 8000 * 8000);
     HIP_OK(hipMemcpy(packed.data(), d.ext3.p, packed.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t &v : packed) v = (v & 0xFFFF0000u) | unperm3(v & 0xFFFFu);      // the reference's partner numbers
     return true;
 }
 
