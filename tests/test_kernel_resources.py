@@ -1,0 +1,46 @@
+"""Register / LDS budget of the kernels whose speed hangs on occupancy (cross-compiled for gfx950, no GPU needed).
+
+k_match is latency-bound and runs three waves per SIMD only while it stays at or below 168 VGPRs and 53 KB of LDS per
+block of four waves; it sits at 167.  A change that pushes it over the edge costs a third of the
+occupancy and 15-50 % of the kernel time without failing any parity test -- this test fails instead."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.mark.skipif(not (shutil.which(HIPCC) or os.path.exists(HIPCC)), reason="hipcc not available")
+def test_match_and_sw_kernels_keep_their_occupancy(tmp_path):
+    src = os.path.join(ROOT, "spacepharer_amd", "csrc", "sp_gpu.hip")
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--cuda-device-only", "-c", src,
+                          "-o", str(tmp_path / "sp_gpu.o"), "-Rpass-analysis=kernel-resource-usage"],
+                         cwd=os.path.dirname(src), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    info, name = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            info[name] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+(?:\[[^\]]*\])?): (\d+)", line)
+        if m and name:
+            info[name][m.group(1).strip()] = int(m.group(2))
+
+    def kernel(fragment):
+        hits = [v for k, v in info.items() if fragment in k]
+        assert hits, (fragment, list(info)[:5])
+        return hits[0]
+
+    match = kernel("k_matchILi512ELb0")                       # k_match<512, false>: the unsharded search
+    assert match["Occupancy [waves/SIMD]"] >= 3, match
+    assert match["VGPRs"] <= 168 and match.get("VGPRs Spill", 0) == 0, match
+    assert match["LDS Size [bytes/block]"] * 3 <= 160 * 1024, match
+    for gl in (10, 12, 16, 32):                               # the packed Smith-Waterman kernels: eight waves per SIMD
+        sw = kernel("k_sw_byte1pILi%dE" % gl)
+        assert sw["Occupancy [waves/SIMD]"] >= 8, (gl, sw)
