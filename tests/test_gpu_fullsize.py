@@ -115,6 +115,14 @@ def test_work_order_and_timing_level_do_not_change_results(full):
     finally:
         ctx.set_timing(1)
     assert same() and ctx.stat("ms_match") > 0 and ctx.stat("ms_select") != ctx.stat("ms_select")
+    import spacepharer_amd as sa
+    try:
+        ctx.set_tuning("match_blocks_per_cu", 2); assert same()
+        ctx.set_tuning("match_blocks_per_cu", 1); assert same()
+    finally:
+        ctx.set_tuning("match_blocks_per_cu", 0)
+    with pytest.raises(sa.SpError):
+        ctx.set_tuning("no_such_knob", 1)
 
 
 def test_sample_against_oracle_at_full_size(full):
