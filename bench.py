@@ -3,23 +3,29 @@
 
 A "step" is one pass of the hot path over one resident batch of synthetic spacer peptides:
     k_prep -> k_match -> k_score -> k_select -> SW forward -> E-value gate -> SW reverse + traceback -> record assembly
-with the target index / residues / similar-k-mer tables and the query batch already resident in HBM; both results (the
+with the target index / residues / similar-k-mer tables and the query batches already resident in HBM; both results (the
 prefilter hit list and the alignment records + backtraces) are delivered to host memory -- the hit list travels on a copy
 stream while the align kernels run, the alignment records while the NEXT step's prefilter runs (sp_ctx_align_hits_begin /
 _end); the last step's records are collected before the closing barrier, so all K steps complete inside the timed region.
-The K steps are dealt to --pipeline (default 2) search contexts per GPU, each with its own HIP streams and host thread: the
-matching kernel is latency-bound (a third of the VALU issue slots), the Smith-Waterman kernel VALU-bound, and two passes in
-flight fill the machine better than one (two whole bench PROCESSES on one GPU reach 1.3x the throughput of one).
+Every step delivers into its OWN page-locked buffers; after the clock has stopped every delivered result (hit list,
+offsets, alignment records, backtraces) is digested and must equal the digest of the same batch searched by one context
+alone -- a wrong byte anywhere fails the run.
 
-Workload (BASELINE.json configs[2], SURVEY.md section 8d "synthetic proxy"): 10 000 synthetic 30-nt spacers =
-60 000 peptides of 10 aa (even index: window of a target with one substitution, odd: background i.i.d.) against
-50 000 synthetic phage ORFs x 200 aa = 1e7 residues drawn from the VTML40 background, seed 12345.
-N > 1 (torchrun): every rank holds the full target index and searches its own 10 000 spacers (weak scaling, query
-partition like the reference's default QUERY_DB_SPLIT; no data-path collective) -- value = all spacers / max time.
+N = 1 (BASELINE.json configs[2], SURVEY.md section 8d "synthetic proxy"): 10 000 synthetic 30-nt spacers = 60 000 peptides of
+10 aa (even index: window of a target with one substitution, odd: background i.i.d.) against 50 000 synthetic phage ORFs x
+200 aa = 1e7 residues drawn from the VTML40 background, seed 12345.  The K steps are dealt to --pipeline (default 2) search
+contexts, each with its own HIP streams, host thread and its own DISTINCT query batch (so consecutive steps search different
+spacers): the matching kernel is latency-bound, the Smith-Waterman kernel VALU-bound, two passes in flight fill the machine
+better than one.  The K-step region is repeated --regions times (default 5); `value` is the median region, the spread is
+reported next to it.
 
---shard targets selects the target-sharded path instead (BASELINE.json configs[3]): the SAME 10 000
-spacers on every rank, rank g indexes target range g, the per-shard candidates are all-gathered over RCCL/xGMI and each
-rank finishes (selection on the union + align) its slice of the queries -- strong scaling, value = spacers / max time.
+N > 1 (BASELINE.json configs[3]): 100 000 spacers (600 000 peptides) against the same phages SHARDED BY TARGET RANGE over the
+N GPUs: rank g indexes range g, all ranks match all queries against their shard, the per-shard candidates are all-gathered
+over RCCL/xGMI (HBM -> xGMI -> HBM) and each rank finishes (selection on the union + align) its slice of the queries --
+strong scaling, value = spacers / max time over ranks.  The same run then also measures the query partition (every rank
+holds the full index and searches its own 10 000 spacers, no data-path collective; key "replica", weak scaling).
+`python bench.py --gpus N` starts the N ranks itself (child processes, started before anything touches the GPU); under
+torchrun it uses the ranks it is given.
 """
 import argparse
 import ctypes as C
@@ -27,6 +33,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -41,7 +48,7 @@ BG = BG / BG.sum()
 
 def make_workload(n_spacers, n_targets, target_len, seed, query_seed=None):
     """targets from `seed`; queries (half of them planted from THOSE targets) from `query_seed` (None: continue the target
-    stream, the single-GPU workload) -- so every rank of a multi-GPU run searches its own spacers against the same phages"""
+    stream, the single-GPU workload) -- so every batch / rank searches its own spacers against the same phages"""
     rng = np.random.default_rng(seed)
     tres = AA[rng.choice(20, size=n_targets * target_len, p=BG)]
     toff = np.arange(n_targets + 1, dtype=np.uint64) * np.uint64(target_len)
@@ -63,46 +70,60 @@ def u64p(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint64))
 
 
-def cpu_baseline_reference(tres, toff, qres, qoff, n_sample, procs, reps=5):
+def host_info():
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    avail = None
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable"):
+                avail = int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {"nproc": os.cpu_count() or 1, "usable_cores": usable, "cpu_model": model, "mem_available_bytes": avail}
+
+
+def cpu_baseline_reference(tres, toff, qres, qoff, n_sample, threads, target_s=4.0):
     """The REAL reference classes (oracle/_ref/ref_harness --bench: QueryMatcher::matchQuery + Matcher::getSWResult, AVX2,
-    compiled from /root/reference by oracle/Makefile) on `procs` host cores: one single-threaded process per core, each
-    searching its own slice of the sample against the full target set.  Only the search loops are timed (index build,
-    similar-k-mer tables and the ALP fit are set-up, as for the GPU number) and they run `reps` times over the slice so that
-    the sample is a few seconds per core; rate = sample / slowest process's mean time per pass."""
+    compiled from /root/reference by oracle/Makefile) on `threads` host cores: ONE process whose worker threads share the index
+    table, the sequence store and the similar-k-mer tables and own a QueryMatcher / Matcher each, like the reference's OpenMP
+    regions; thread t searches query slice t.  Only the search loops are timed (index build, similar-k-mer tables and the ALP
+    fit are set-up, as for the GPU number); every thread walks its slice `reps` times so that the timed part lasts a few
+    seconds; rate = sample / wall time per pass.  (Round 1 ran one single-threaded PROCESS per core: with 256 of them, each
+    with its own 1 GB of tables, the cores starve each other -- 0.5 k peptides/s per core instead of 15 k.)"""
     import subprocess
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import matrix_text
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     n_t, tl, ql = len(toff) - 1, int(toff[1]), int(qoff[1])
-    per = (n_sample + procs - 1) // procs
+    per = (n_sample + threads - 1) // threads
+    reps = int(max(3, min(2000, round(target_s / max(1e-3, per * 1.0e-4)))))      # ~0.1 ms per peptide and core
     with tempfile.TemporaryDirectory() as d:
-        m80, m40, tf = (os.path.join(d, x) for x in ("VTML80.out", "VTML40.out", "t.txt"))
+        m80, m40, tf, qf, of = (os.path.join(d, x) for x in ("VTML80.out", "VTML40.out", "t.txt", "q.txt", "o.json"))
         open(m80, "w").write(matrix_text("VTML80"))
         open(m40, "w").write(matrix_text("VTML40"))
         with open(tf, "wb") as f:
             f.write(b"\n".join(tres[i * tl:(i + 1) * tl].tobytes() for i in range(n_t)) + b"\n")
-        jobs = []
-        for p in range(procs):
-            lo, hi = p * per, min(n_sample, (p + 1) * per)
-            if lo >= hi:
-                break
-            qf, of = os.path.join(d, "q%d.txt" % p), os.path.join(d, "o%d.json" % p)
-            with open(qf, "wb") as f:
-                f.write(b"\n".join(qres[i * ql:(i + 1) * ql].tobytes() for i in range(lo, hi)) + b"\n")
-            jobs.append((subprocess.Popen([harness, m80, m40, tf, qf, of, "--bench-reps", str(reps)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL), of))
-        res = []
-        for pr, of in jobs:
-            if pr.wait() != 0:
-                raise RuntimeError("ref_harness failed")
-            res.append(json.load(open(of))["bench"])
-    slowest = max(r["prefilter_s"] + r["align_s"] for r in res)
-    return {"value": (n_sample / 6.0) / slowest, "unit": "spacer-queries/s", "cores": len(res), "kind": "reference",
-            "pairs": sum(r["pairs"] for r in res),
-            "sample": "%d of the workload's peptides (%d SW alignments) split over %d single-threaded processes of oracle/_ref/ref_harness "
-                      "(reference QueryMatcher + Matcher classes, AVX2, g++ -O3); search loops only, %d passes each, slowest process %.2f s per pass "
-                      "(prefilter %.2f s + align %.2f s)" % (n_sample, sum(r["pairs"] for r in res), len(res), reps, slowest,
-                                                            max(r["prefilter_s"] for r in res), max(r["align_s"] for r in res))}
+        with open(qf, "wb") as f:
+            f.write(b"\n".join(qres[i * ql:(i + 1) * ql].tobytes() for i in range(n_sample)) + b"\n")
+        subprocess.run([harness, m80, m40, tf, qf, of, "--bench-reps", str(reps), "--bench-threads", str(threads)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        r = json.load(open(of))["bench"]
+    t_pass = r["prefilter_s"] + r["align_s"]
+    return {"value": (n_sample / 6.0) / t_pass, "unit": "spacer-queries/s", "cores": r["threads"], "kind": "reference", "pairs": r["pairs"],
+            "sample": "%d of the workload's peptides (%d SW alignments) in one process of oracle/_ref/ref_harness (reference QueryMatcher + Matcher classes, AVX2, "
+                      "g++ -O3) with %d worker threads sharing one index; search loops only, %d passes, %.4f s per pass (prefilter %.4f s + align %.4f s)"
+                      % (n_sample, r["pairs"], r["threads"], reps, t_pass, r["prefilter_s"], r["align_s"])}
 
 
 def cpu_baseline(tres, toff, qres, qoff, n_sample):
@@ -130,15 +151,11 @@ def cpu_baseline(tres, toff, qres, qoff, n_sample):
                       "index build excluded" % (n_sample, pairs)}
 
 
-def default_workload(args):
-    return (args.spacers, args.targets, args.target_len) == (10000, 50000, 200)
-
-
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the newest committed counter pass (profiles/rNN_pmc_traffic.json, made by
     tools/gpu_pmc.sh on this same workload: FETCH_SIZE corrected by the calibration reads + WRITE_SIZE); None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
         return None, None
     try:
@@ -153,205 +170,381 @@ def pmc_traffic(kernel):
 pmc_traffic.measured_stream = None
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# result slots: page-locked buffers one step delivers into, and their digest
+# ---------------------------------------------------------------------------------------------------------------------
+REC_BYTES = 64      # sizeof(sp_alignment): 60 bytes of fields + 4 bytes of tail padding (never compared)
+
+
+def record_fields(addr, n):
+    """the 60 field bytes of n sp_alignment records (the 4 bytes of tail padding per record are not part of the result)"""
+    a = np.frombuffer(C.string_at(addr, REC_BYTES * n), dtype=np.uint32).reshape(n, REC_BYTES // 4)
+    return np.ascontiguousarray(a[:, :15]).tobytes()
+
+
+class Slot:
+    def __init__(self, L, nq, cap_hits, full):
+        self.L, self.nq, self.cap = L, nq, cap_hits
+        self.hits = L.sp_host_alloc(8 * cap_hits)
+        self.off = L.sp_host_alloc(4 * (nq + 1))
+        self.rec = L.sp_host_alloc(REC_BYTES * cap_hits) if full else None
+        self.cig_cap = 24 * cap_hits
+        self.cig = L.sp_host_alloc(self.cig_cap) if full else None
+        self.used = C.c_uint64(0)
+        self.n = 0                      # hits (= pairs aligned) of the step that last delivered here
+        self.hits_ptr_ok = True
+        self.into = (self.rec, self.cig, self.cig_cap, self.used) if full else None
+
+    def digest(self, full):
+        """crc32 over everything the step delivered: offsets, hit records, alignment records, backtrace pool"""
+        n = self.n
+        h = zlib.crc32(C.string_at(self.off, 4 * (self.nq + 1)))
+        h = zlib.crc32(C.string_at(self.hits, 8 * n), h)
+        if full and n:
+            h = zlib.crc32(record_fields(self.rec, n), h)
+            h = zlib.crc32(C.string_at(self.cig, int(self.used.value)), h)
+        return h
+
+    def free(self):
+        for p in (self.hits, self.off, self.rec, self.cig):
+            if p:
+                self.L.sp_host_free(p)
+        self.hits = self.off = self.rec = self.cig = None
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (nothing in this process has touched
+    the GPU), rank 0 prints the result line on the inherited stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--spacers", type=int, default=10000)
+    ap.add_argument("--regions", type=int, default=5, help="the K-step timed region is repeated this many times; value = median region")
+    ap.add_argument("--spacers", type=int, default=None, help="default: 10 000 (N = 1, replica mode), 100 000 (target shards at N > 1)")
     ap.add_argument("--targets", type=int, default=50000)
     ap.add_argument("--target-len", type=int, default=200)
     ap.add_argument("--stage", default="full", choices=["full", "prefilter"])
-    ap.add_argument("--cpu-sample", type=int, default=3000, help="peptides per core for the CPU baseline (0 = skip)")
-    ap.add_argument("--cpu-cores", type=int, default=8, help="host cores for the reference CPU baseline (one process each)")
+    ap.add_argument("--cpu-sample", type=int, default=3000, help="0 = skip the CPU baseline; < 3000: that many peptides per core instead of the whole workload")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the reference CPU baseline (one process each); 0 = all usable cores")
     ap.add_argument("--pipeline", type=int, default=2,
-                    help="search contexts per GPU, each on its own HIP streams and host thread, taking the steps in turn: the latency-bound "
-                         "matcher of one pass and the VALU-bound aligner of another share the machine (1 = strictly one pass at a time)")
-    ap.add_argument("--shard", default="queries", choices=["queries", "targets"],
-                    help="N>1 decomposition: query partition with replicated index (default) or target shards + RCCL all-gather")
+                    help="search contexts per GPU, each on its own HIP streams and host thread with its own query batch, taking the steps in turn "
+                         "(1 = strictly one pass at a time)")
+    ap.add_argument("--shard", default=None, choices=["queries", "targets"],
+                    help="decomposition: target shards + RCCL all-gather (default at N > 1) or query partition with replicated index (default at N = 1)")
+    ap.add_argument("--no-replica", action="store_true", help="N > 1: skip the additional query-partition (replica) measurement")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "gloo"], help="transport of the candidate all-gather (gloo: through host memory; tests)")
+    ap.add_argument("--same-gpu", action="store_true", help="all ranks use HIP device 0 (tests of the N > 1 path on a one-GPU box; needs --exchange gloo)")
     args = ap.parse_args()
 
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.same_gpu and args.exchange != "gloo":
+        sys.exit("bench.py: --same-gpu needs --exchange gloo (RCCL refuses two ranks on one device)")
+    if env_world is None and (args.gpus or 1) > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    sharded = args.shard == "targets"
+    world = int(env_world or "1")
+    local_rank = 0 if args.same_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus is not None and args.gpus != world:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (start it without a launcher, or make the two agree)" % (args.gpus, world))
+    mode = args.shard or ("targets" if world > 1 else "queries")
+    sharded = mode == "targets"
+    n_spacers = args.spacers or (100000 if (sharded and world > 1) else 10000)
+    full = args.stage == "full"
+
+    dist = torch = None
+    gpu_dev = None
     if world > 1 or sharded:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if world == 1:      # single-GPU run of the sharded path: a one-rank RCCL group
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=0, world_size=1)
-        else:
-            dist.init_process_group("nccl")
+        if args.exchange == "rccl":
+            torch.cuda.set_device(local_rank)
+            gpu_dev = torch.device("cuda", local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl" if args.exchange == "rccl" else "gloo", rank=rank, world_size=world)
 
     import spacepharer_amd as sa
     from spacepharer_amd.dist import decompose_by_residues, sharded_prefilter
-    if sharded:
-        tres, toff, qres, qoff = make_workload(args.spacers, args.targets, args.target_len, 12345)
-    else:
-        # same target set on every rank; rank r > 0 searches its own spacers (planted from the common targets)
-        tres, toff, qres, qoff = make_workload(args.spacers, args.targets, args.target_len, 12345, None if rank == 0 else 12345 + 7919 * rank)
-    ctx = sa.SearchContext(device_mask=1 << local_rank)
-    nq = len(qoff) - 1
-    q_from, q_to = 0, nq
-    t0 = time.perf_counter()
-    if sharded:
-        t_from, t_cnt = decompose_by_residues(np.diff(toff).astype(np.int64) + 2, rank, world)
-        ctx.set_targets_shard_raw(tres.tobytes(), u64p(toff), len(toff) - 1, t_from, t_from + t_cnt)
-        q_from, q_cnt = decompose_by_residues(np.diff(qoff).astype(np.int64) + 2, rank, world)
-        q_to = q_from + q_cnt
-    else:
-        ctx.set_targets_raw(tres.tobytes(), u64p(toff), len(toff) - 1)
-    t_index = time.perf_counter() - t0
-    ctx.set_queries_raw(qres.tobytes(), u64p(qoff), nq)
-    gpu_dev = None
+    L = sa.load_library()
+
+    def all_max(x):
+        if dist is None or world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=gpu_dev or "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_sum(x):
+        if dist is None or world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=gpu_dev or "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def measure(shard_targets, spacers, steps, regions, warmup, want_breakdown):
+        """one decomposition on this rank: set-up, reference digests, `regions` timed K-step regions with digest checks."""
+        n_pipe = 1 if shard_targets else max(1, min(args.pipeline, steps))
+        # batch b is searched by context b: batch 0 = the single-GPU workload's spacers; further batches / ranks draw their own
+        batches = []
+        for b in range(n_pipe):
+            if shard_targets:
+                qs = None                                         # the SAME spacers on every rank
+            else:
+                qs = None if (rank == 0 and b == 0) else 12345 + 7919 * rank + 104729 * b
+            batches.append(make_workload(spacers, args.targets, args.target_len, 12345, qs))
+        tres, toff = batches[0][0], batches[0][1]
+        nq = len(batches[0][3]) - 1
+        q_from, q_to = 0, nq
+        ctxs = []
+        t0 = time.perf_counter()
+        for b in range(n_pipe):
+            c = sa.SearchContext(device_mask=1 << local_rank)
+            if shard_targets:
+                t_from, t_cnt = decompose_by_residues(np.diff(toff).astype(np.int64) + 2, rank, world)
+                c.set_targets_shard_raw(tres.tobytes(), u64p(toff), len(toff) - 1, t_from, t_from + t_cnt)
+                q_from, q_cnt = decompose_by_residues(np.diff(batches[b][3]).astype(np.int64) + 2, rank, world)
+                q_to = q_from + q_cnt
+            else:
+                c.set_targets_raw(tres.tobytes(), u64p(toff), len(toff) - 1)
+            if b == 0:
+                t_index = time.perf_counter() - t0
+            c.set_queries_raw(batches[b][2].tobytes(), u64p(batches[b][3]), nq)
+            ctxs.append(c)
+        ctx = ctxs[0]
+        xch = {"s": 0.0, "bytes": 0, "n": 0}
+
+        def search(c):
+            if shard_targets:
+                info = sharded_prefilter(c, q_from, q_to, device=gpu_dev)     # own shard -> all-gather -> selection on the union
+                xch["s"] += info["exchange_s"]
+                xch["bytes"] += info["bytes"]
+                xch["n"] += 1
+            else:
+                c.prefilter()
+
+        # sizing pass (also the first warm-up): how many hits does a batch deliver?
+        caps = []
+        for c in ctxs:
+            search(c)
+            caps.append(int(c.num_hits() * 1.05) + 1024)
+        share = [steps // n_pipe + (1 if i < steps % n_pipe else 0) for i in range(n_pipe)]
+        slots = [[Slot(L, nq, caps[i], full) for _ in range(share[i])] for i in range(n_pipe)]
+        ref_slot = [Slot(L, nq, caps[i], full) for i in range(n_pipe)]
+
+        def step(c, slot):
+            c.set_hit_sink(slot.hits, slot.off, slot.cap)
+            search(c)
+            n = slot.n = c.num_hits()
+            if full and n:
+                c.align_hits_begin(into=slot.into)         # alignment result DB content (result_t + backtraces per hit): returns when the
+                                                           # kernels are done, the records travel while the next pass's prefilter runs
+            hp, _, cnt = c.hits_view()                     # prefilter result DB content (hit_t triples per query) in host memory: its copy
+            slot.hits_ptr_ok = (C.cast(hp, C.c_void_p).value == slot.hits) and cnt == n      # started underneath the align kernels
+            return n
+
+        def barrier():
+            for c in ctxs:
+                c.align_hits_end()                         # the last pass's alignment records are in host memory
+            if dist is not None and world > 1:
+                dist.barrier()
+            if gpu_dev is not None:
+                torch.cuda.synchronize()
+            for c in ctxs:
+                c.sync()
+
+        # reference digests: every batch searched by its context ALONE, default tuning, nothing else on the GPU
+        ref = []
+        for i, c in enumerate(ctxs):
+            step(c, ref_slot[i])
+            barrier()
+            assert ref_slot[i].hits_ptr_ok
+            ref.append(ref_slot[i].digest(full))
+        if n_pipe > 1:
+            for c in ctxs:
+                c.set_tuning("match_blocks_per_cu", 2)     # leaves LDS for the other context's aligner on every CU
+        for i, c in enumerate(ctxs):
+            for _ in range(warmup):
+                step(c, slots[i][0])
+        barrier()
+        import threading
+        for c in ctxs:
+            c.set_timing(1)
+        acc = [[0.0, 0] for _ in range(n_pipe)]
+
+        def run(i):
+            c = ctxs[i]
+            for j in range(share[i]):
+                acc[i][1] = step(c, slots[i][j])
+                v = c.stat("ms_match")
+                acc[i][0] += 0.0 if v != v else v
+
+        region_dt, region_match, checked = [], [], 0
+        for _ in range(regions):
+            for a in acc:
+                a[0] = 0.0
+            xch.update(s=0.0, bytes=0, n=0)
+            barrier()
+            t0 = time.perf_counter()
+            if n_pipe == 1:
+                run(0)
+            else:
+                threads = [threading.Thread(target=run, args=(i,)) for i in range(n_pipe)]
+                for th in threads:
+                    th.start()
+                for th in threads:
+                    th.join()
+            barrier()
+            dt = time.perf_counter() - t0
+            region_dt.append(all_max(dt))
+            region_match.append(sum(a[0] for a in acc) / steps)
+            # the clock has stopped: every result this region delivered must be the bytes the context delivered alone
+            for i in range(n_pipe):
+                for j in range(share[i]):
+                    s = slots[i][j]
+                    if not s.hits_ptr_ok or s.digest(full) != ref[i]:
+                        raise RuntimeError("rank %d: result of step %d of context %d differs from the single-context result of the same batch" % (rank, j, i))
+                    checked += 1
+        xch_region = dict(xch)
+        pairs = [acc[i][1] for i in range(n_pipe)]
+        stats = None
+        if want_breakdown:      # per-stage breakdown: one context alone, HIP events around every stage, outside the timed regions
+            stats = {"ms_match": 0.0, "ms_prep": 0.0, "ms_score": 0.0, "ms_select": 0.0, "ms_sw_forward": 0.0, "ms_sw_reverse": 0.0, "ms_traceback": 0.0}
+            ctx.set_timing(2)
+            ctx.set_tuning("match_blocks_per_cu", 0)       # alone on the GPU the matcher wants all the LDS
+            for _ in range(3):
+                step(ctx, ref_slot[0])
+                for k in stats:
+                    v = ctx.stat(k)
+                    stats[k] += 0.0 if v != v else v
+            barrier()
+            stats = {k: v / 3 for k, v in stats.items()}
+            ctx.set_timing(1)
+        counters = {k: ctx.stat(k) for k in ("kmers", "db_matches", "diagonals", "diag_residues", "hits")}
+        out = dict(region_dt=region_dt, region_match=region_match, checked=checked, pairs=pairs, stats=stats, counters=counters, n_pipe=n_pipe, nq=nq,
+                   t_index=t_index, batches=batches, xch=xch_region, q_slice=(q_from, q_to))
+        for grp in slots + [ref_slot]:
+            for s in grp:
+                s.free()
+        for c in ctxs:
+            c.close()
+        return out
+
+    m = measure(sharded, n_spacers, args.steps, args.regions, args.warmup, True)
+    rep = None
+    if world > 1 and sharded and not args.no_replica:
+        rep = measure(False, 10000, max(4, args.steps // 2), max(1, min(3, args.regions)), args.warmup, False)
+    pairs_total = all_sum(float(m["pairs"][0]))      # batch 0 of every rank (sharded: the ranks' query slices add up to the batch)
     if dist is not None:
-        gpu_dev = torch.device("cuda", local_rank)
-    # further contexts of the pipeline: same resident targets and queries, own streams (the exchange step of the target-sharded
-    # path is a collective on the process group: one context there)
-    n_pipe = 1 if sharded else max(1, min(args.pipeline, args.steps))
-    ctxs = [ctx]
-    for _ in range(n_pipe - 1):
-        c2 = sa.SearchContext(device_mask=1 << local_rank)
-        c2.set_targets_raw(tres.tobytes(), u64p(toff), len(toff) - 1)
-        c2.set_queries_raw(qres.tobytes(), u64p(qoff), nq)
-        ctxs.append(c2)
-
-    def step(c=ctx):
-        if sharded:
-            sharded_prefilter(c, q_from, q_to, device=gpu_dev)   # own shard -> RCCL all-gather -> selection on the union
-        else:
-            c.prefilter()
-        npairs = c.num_hits()
-        if args.stage == "full" and npairs:
-            c.align_hits_begin()                          # alignment result DB content (result_t + backtraces per hit): returns when
-                                                          # the kernels are done, the 5 MB travel while the next pass's prefilter runs
-        c.hits_view()                                     # prefilter result DB content (hit_t triples per query) in host memory: its
-        return npairs                                     # copy started underneath the align kernels
-
-    def barrier():
-        for c in ctxs:
-            c.align_hits_end()                            # the last pass's alignment records are in host memory
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-        for c in ctxs:
-            c.sync()
-
-    if n_pipe > 1:
-        for c in ctxs:
-            c.set_tuning("match_blocks_per_cu", 2)      # leaves LDS for the other context's aligner on every CU (14.7 M against 13.6 M)
-    for c in ctxs:
-        for _ in range(args.warmup):
-            step(c)
-    # timed region: HIP events bracket only the dominant kernel (k_match, the roofline figure) -- every event record between
-    # two kernels costs ~6 us of idle GPU, so the per-stage breakdown is taken in a separate short pass after the clock stops.
-    # The K steps are dealt to the contexts of the pipeline; each context runs its share on its own host thread (ctypes
-    # releases the GIL for the duration of a call), so up to n_pipe passes are in flight on the GPU at any time.
-    import threading
-    for c in ctxs:
-        c.set_timing(1)
-    share = [args.steps // n_pipe + (1 if i < args.steps % n_pipe else 0) for i in range(n_pipe)]
-    acc = [[0.0, 0] for _ in range(n_pipe)]          # per context: sum of k_match event times, pairs of its last step
-
-    def run(i):
-        c = ctxs[i]
-        for _ in range(share[i]):
-            acc[i][1] = step(c)
-            v = c.stat("ms_match")
-            acc[i][0] += 0.0 if v != v else v
-
-    barrier()
-    t0 = time.perf_counter()
-    if n_pipe == 1:
-        run(0)
-    else:
-        threads = [threading.Thread(target=run, args=(i,)) for i in range(n_pipe)]
-        for th in threads:
-            th.start()
-        for th in threads:
-            th.join()
-    barrier()
-    dt = time.perf_counter() - t0
-    ms_match_sum = sum(a[0] for a in acc)
-    pairs = acc[0][1]
-    # per-stage breakdown: one context alone, HIP events around every stage, outside the timed region
-    stats = {"ms_match": 0.0, "ms_prep": 0.0, "ms_score": 0.0, "ms_select": 0.0, "ms_sw_forward": 0.0, "ms_sw_reverse": 0.0, "ms_traceback": 0.0}
-    ctx.set_timing(2)
-    ctx.set_tuning("match_blocks_per_cu", 0)           # alone on the GPU the matcher wants all the LDS
-    n_breakdown = 3
-    for _ in range(n_breakdown):
-        step()
-        for k in stats:
-            v = ctx.stat(k)
-            stats[k] += 0.0 if v != v else v
-    barrier()
-    ctx.set_timing(1)
-    if dist is not None:
-        t = torch.tensor([dt, float(pairs)], device="cuda")
-        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
-        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
-        dt, pairs = float(t[0].item()), int(t[1].item())
+        dist.barrier()
         dist.destroy_process_group()
     if rank != 0:
         return
-    K, M, D, R, H = (ctx.stat(k) for k in ("kmers", "db_matches", "diagonals", "diag_residues", "hits"))
-    ms_match = ms_match_sum / args.steps      # HIP events on the context's stream, inside the timed region
+
+    def region_summary(mm, spacers_per_region):
+        dts = sorted(mm["region_dt"])
+        med = dts[len(dts) // 2] if len(dts) % 2 else 0.5 * (dts[len(dts) // 2 - 1] + dts[len(dts) // 2])
+        return med, {"n": len(dts), "spacer_queries_per_s": [round(spacers_per_region / d, 1) for d in mm["region_dt"]],
+                     "min": spacers_per_region / dts[-1], "max": spacers_per_region / dts[0], "median": spacers_per_region / med}
+
+    spacers_per_region = n_spacers * (1 if sharded else world) * args.steps
+    dt, regions = region_summary(m, spacers_per_region)
+    K, M, D, R, H = (m["counters"][k] for k in ("kmers", "db_matches", "diagonals", "diag_residues", "hits"))
+    order = sorted(range(len(m["region_dt"])), key=lambda i: m["region_dt"][i])
+    ms_match = m["region_match"][order[len(order) // 2]]      # HIP events on the context's stream, inside the (median) timed region
     # algorithmic bytes of the dominant kernel (k_match) per launch: 6 B similar-k-mer table entry + 16 B offsets pair
     # per similar k-mer, 6 B per index entry fetched, 7 B per double-hit diagonal written (SURVEY.md section 8d)
     algo_bytes = 22.0 * K + 6.0 * M + 7.0 * D
     achieved = algo_bytes / (ms_match * 1e-3) / 1e9 if ms_match > 0 else 0.0
-    traffic, traffic_src = pmc_traffic("k_match") if default_workload(args) else (None, None)
+    default_wl = (n_spacers, args.targets, args.target_len, world) == (10000, 50000, 200, 1)
+    traffic, traffic_src = pmc_traffic("k_match") if default_wl else (None, None)
+    stats, n_pipe, nq = m["stats"], m["n_pipe"], m["nq"]
     out = {
         "metric": "spacer-queries/sec through prefilter+align; achieved HBM GB/s vs roofline",
-        "value": args.spacers * (1 if sharded else world) * args.steps / dt,
+        "value": spacers_per_region / dt,
         "unit": "spacer-queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
         "dtype": "u8/i16", "data": "synthetic",
         "config": {"workload": "%d synthetic 30-nt spacers (= %d peptides of 10 aa) vs %d synthetic phage ORFs x %d aa "
-                               "(%.1e residues), 1xMI355X per rank, %s" % (args.spacers, nq, args.targets, args.target_len,
-                                                                         args.targets * args.target_len,
-                                                                         "prefilter + ungapped + banded-SW align" if args.stage == "full" else "prefilter only"),
-                   "stage": args.stage, "pairs_aligned_per_step": pairs, "sensitivity": 5.7, "max_seqs": 300,
-                   "parallelism": ("target shards x%d, RCCL all-gather of candidates, selection + align by query slice" % world) if sharded
+                               "(%.1e residues), %s, %s" % (n_spacers, nq, args.targets, args.target_len, args.targets * args.target_len,
+                                                            ("targets sharded over %d x MI355X" % world) if sharded else "1xMI355X per rank",
+                                                            "prefilter + ungapped + banded-SW align" if full else "prefilter only"),
+                   "stage": args.stage, "pairs_aligned_per_step": int(pairs_total), "pairs_aligned_per_step_by_batch_rank0": m["pairs"], "sensitivity": 5.7, "max_seqs": 300,
+                   "parallelism": ("target shards x%d, %s all-gather of candidates, selection + align by query slice" % (world, "RCCL" if args.exchange == "rccl" else "gloo")) if sharded
                                   else ("query partition x%d, index replicated" % world),
-                   "passes_in_flight_per_gpu": n_pipe,
-                   "index_build_s": round(t_index, 3)},
-        "kernels_ms_per_step": {k[3:]: round(v / n_breakdown, 4) for k, v in stats.items()},
-        "kernels_ms_source": "HIP events around every stage in %d extra steps of ONE context AFTER the timed region (the timed steps bracket k_match only: "
-                             "%.4f ms per launch with %d passes in flight)" % (n_breakdown, ms_match, n_pipe),
+                   "passes_in_flight_per_gpu": n_pipe, "distinct_query_batches": n_pipe,
+                   "index_build_s": round(m["t_index"], 3)},
+        "regions": regions,
+        "results_checked": {"steps": m["checked"], "equal_to_single_context_result": True,
+                            "what": "crc32 over offsets + hit records%s of EVERY timed step, compared after the clock stopped with the same batch searched by one context alone"
+                                    % (" + alignment records + backtrace pool" if full else "")},
+        "kernels_ms_per_step": {k[3:]: round(v, 4) for k, v in stats.items()},
+        "kernels_ms_source": "HIP events around every stage in 3 extra steps of ONE context AFTER the timed regions (the timed steps bracket k_match only: "
+                             "%.4f ms per launch with %d passes in flight)" % (ms_match, n_pipe),
         "counters_per_step": {"similar_kmers": K, "index_entries_fetched": M, "diagonals_scored": D, "diag_residues": R, "hits": H},
         "roofline": {"bound": "hbm", "kernel": "k_match", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": traffic,
                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
                      "measured_streaming_read_GBps": pmc_traffic.measured_stream,
-                     # the same kernel with the GPU to itself (one context, the breakdown pass after the timed region): its launches in the
-                     # timed region share the machine with the other context's aligner and take longer each, while more work gets done
-                     "exclusive": {"ms_per_launch": round(stats["ms_match"] / n_breakdown, 4),
-                                   "achieved": algo_bytes / (stats["ms_match"] / n_breakdown * 1e-3) / 1e9 if stats["ms_match"] > 0 else 0.0,
-                                   "frac": algo_bytes / (stats["ms_match"] / n_breakdown * 1e-3) / 1e9 / 8000.0 if stats["ms_match"] > 0 else 0.0},
+                     # the same kernel with the GPU to itself (one context, the breakdown pass after the timed regions): its launches in the
+                     # timed regions share the machine with the other context's aligner and take longer each, while more work gets done
+                     "exclusive": {"ms_per_launch": round(stats["ms_match"], 4),
+                                   "achieved": algo_bytes / (stats["ms_match"] * 1e-3) / 1e9 if stats["ms_match"] > 0 else 0.0,
+                                   "frac": algo_bytes / (stats["ms_match"] * 1e-3) / 1e9 / 8000.0 if stats["ms_match"] > 0 else 0.0},
                      "passes_in_flight": n_pipe},
+        "host": host_info(),
     }
+    if sharded:
+        x = m["xch"]
+        out["exchange"] = {"transport": "RCCL all-gather (HBM -> xGMI -> HBM)" if args.exchange == "rccl" else "gloo all-gather through host memory",
+                           "rccl_ranks": world if args.exchange == "rccl" else 0, "ranks": world,
+                           "allgather_bytes_per_step": x["bytes"] / max(1, x["n"]),
+                           "exchange_ms_per_step": 1e3 * x["s"] / max(1, x["n"]),
+                           "query_slice_of_rank0": list(m["q_slice"])}
+    if rep is not None:
+        rdt, rregions = region_summary(rep, 10000 * world * max(4, args.steps // 2))
+        out["replica"] = {"value": 10000 * world * max(4, args.steps // 2) / rdt, "unit": "spacer-queries/s", "scaling": "weak",
+                          "ms_per_step": rdt / max(4, args.steps // 2) * 1e3, "regions": rregions, "results_checked": rep["checked"],
+                          "parallelism": "query partition x%d: every rank holds the full index and searches its own 10 000 spacers, no data-path collective" % world}
     if args.cpu_sample > 0 and world == 1:      # rank 0 at N = 1 only
         # the reference itself when its harness travelled with the repo (oracle/_ref, built by __graft_entry__.build()), else
         # the scalar port; either way a bounded sample
-        cores = max(1, min(args.cpu_cores, os.cpu_count() or 1))
+        hi = out["host"]
+        cores = args.cpu_cores if args.cpu_cores > 0 else hi["usable_cores"]
+        cores = max(1, min(cores, hi["usable_cores"], 512))
+        tres, toff, qres, qoff = m["batches"][0]
         if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_harness")):
             try:
                 n_s = nq if args.cpu_sample >= 3000 else min(args.cpu_sample * cores, nq)
                 out["cpu_baseline"] = cpu_baseline_reference(tres, toff, qres, qoff, n_s, cores)
-                if n_s == nq and not sharded and world == 1:     # whole workload: the reference must align exactly the pairs the GPU aligned
-                    out["cpu_baseline"]["pairs_equal_gpu"] = bool(out["cpu_baseline"].pop("pairs") == pairs)
+                if n_s == nq and not sharded:     # whole workload: the reference must align exactly the pairs the GPU aligned
+                    out["cpu_baseline"]["pairs_equal_gpu"] = bool(out["cpu_baseline"].pop("pairs") == m["pairs"][0])
             except Exception as e:      # noqa: BLE001 -- fall back to the port, say why
                 out["cpu_baseline"] = cpu_baseline(tres, toff, qres, qoff, min(args.cpu_sample, nq))
                 out["cpu_baseline"]["sample"] += " (reference harness unavailable: %s)" % e
         else:
             out["cpu_baseline"] = cpu_baseline(tres, toff, qres, qoff, min(args.cpu_sample, nq))
+        out["cpu_baseline"]["nproc"] = hi["nproc"]
+        out["cpu_baseline"]["cpu_model"] = hi["cpu_model"]
     C.CDLL(None).fflush(None)      # library chatter buffered in C stdio (RCCL prints its path) goes out BEFORE the result line
     print(json.dumps(out), flush=True)
 

@@ -119,6 +119,11 @@ int sp_ctx_get_hits_compact(sp_ctx *c, sp_hit *hits, uint64_t *offsets);
    offsets[n_queries + 1]); the pointers stay valid until the next prefilter / merge call on this context */
 typedef struct { uint32_t seq_id; uint16_t score; int16_t diagonal; } sp_hit_packed;   /* 8 bytes */
 int sp_ctx_hits_view(sp_ctx *c, const sp_hit_packed **hits, const uint32_t **offsets, uint64_t *n);
+/* deliver the hit lists of the FOLLOWING passes into caller-owned memory (page-locked: sp_host_alloc) instead of the context's
+   own staging buffers: hits[cap_hits], offsets[n_queries + 1].  sp_ctx_hits_view() then returns these pointers; a pass with
+   more than cap_hits hits falls back to the internal buffers (check the pointer).  NULL switches back.  Lets a caller keep
+   the results of several passes (one buffer set per pass) without copying them. */
+int sp_ctx_set_hit_sink(sp_ctx *c, sp_hit_packed *hits, uint32_t *offsets, uint64_t cap_hits);
 
 /* align (query index, target index) pairs of the resident batch.  results[n]; cigars: caller buffer of cigar_cap
    bytes, *cigar_used returns the bytes needed/used (SP_ERR_OVERFLOW if cigar_cap is too small). */

@@ -82,6 +82,7 @@ def load_library():
     L.sp_ctx_num_hits.argtypes = [vp]
     L.sp_ctx_get_hits_compact.argtypes = [vp, C.POINTER(Hit), C.POINTER(C.c_uint64)]
     L.sp_ctx_hits_view.argtypes = [vp, C.POINTER(C.POINTER(HitPacked)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint64)]
+    L.sp_ctx_set_hit_sink.argtypes = [vp, vp, vp, C.c_uint64]
     L.sp_ctx_align.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(Alignment), C.c_char_p,
                                C.c_uint64, C.POINTER(C.c_uint64)]
     L.sp_ctx_align_hits.argtypes = [vp, C.POINTER(Alignment), C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -316,6 +317,10 @@ class SearchContext:
         _check(self.L.sp_ctx_hits_view(self.ctx, C.byref(hp), C.byref(op), C.byref(n)))
         return hp, op, int(n.value)
 
+    def set_hit_sink(self, hits_ptr, offsets_ptr, cap_hits):
+        """deliver the following passes' hit lists to caller-owned page-locked memory (addresses; None switches back)"""
+        _check(self.L.sp_ctx_set_hit_sink(self.ctx, hits_ptr, offsets_ptr, cap_hits))
+
     def hits(self):
         hits, offs, _ = self.hits_compact()
         return [[(hits[i].seq_id, hits[i].score, hits[i].diagonal) for i in range(offs[q], offs[q + 1])]
@@ -390,9 +395,14 @@ class SearchContext:
             _check(rc)
             return self._aln, self._cig, n
 
-    def align_hits_begin(self):
-        """like align_hits_raw(), but returns while the results are still on their way; align_hits_end() collects them"""
+    def align_hits_begin(self, into=None):
+        """like align_hits_raw(), but returns while the results are still on their way; align_hits_end() collects them.
+        into = (records address, cigar address, cigar capacity, ctypes c_uint64 for the cigar bytes used): caller-owned page-locked
+        buffers with room for num_hits() records; no retry when the cigar pool is too small (SpError)"""
         n = int(self.L.sp_ctx_num_hits(self.ctx))
+        if into is not None:
+            _check(self.L.sp_ctx_align_hits_begin(self.ctx, C.cast(into[0], C.POINTER(Alignment)), C.cast(into[1], C.c_char_p), into[2], C.byref(into[3])))
+            return n
         self._result_buffers(n)
         used = C.c_uint64()
         while True:

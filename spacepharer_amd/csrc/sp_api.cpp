@@ -276,6 +276,13 @@ int sp_ctx_hits_view(sp_ctx *c, const sp_hit_packed **hits, const uint32_t **off
     return SP_OK;
 }
 
+int sp_ctx_set_hit_sink(sp_ctx *c, sp_hit_packed *hits, uint32_t *offsets, uint64_t cap_hits) {
+    if (!c) { g_err = "sp_ctx_set_hit_sink: null context"; return SP_ERR_ARG; }
+    c->gpu.makeCurrent();
+    c->gpu.setHitSink(reinterpret_cast<sp::GpuHit *>(hits), offsets, (size_t) cap_hits);
+    return SP_OK;
+}
+
 int sp_ctx_get_hits(sp_ctx *c, sp_hit *hits, uint32_t *counts) {
     if (c) c->gpu.makeCurrent();
     const sp::GpuHit *h = nullptr; const uint32_t *off = nullptr; size_t n = 0; std::string err;

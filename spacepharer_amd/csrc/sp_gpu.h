@@ -102,6 +102,9 @@ public:
     bool mergeCandidates(const Candidate *src, size_t n, bool onDevice, size_t qFrom, size_t qTo, unsigned binSize, int maxHits, int minDiagScore, std::string &err);
     // hits grouped by query (query order); offsets has nq+1 entries
     bool hostHits(const GpuHit *&hits, const uint32_t *&offsets, size_t &n, std::string &err);
+    // deliver the hit lists of the following passes into caller-owned (page-locked) memory: hits[capHits], offsets[nq + 1];
+    // a pass with more hits than capHits falls back to the internal staging buffers.  nullptr switches back.
+    void setHitSink(GpuHit *hits, uint32_t *offsets, size_t capHits);
     PrefilterCounters counters() const { return counters_; }
     KernelTimes times() const { return times_; }
     int maxHits() const { return maxHits_; }

@@ -1559,6 +1559,7 @@ struct Gpu::Impl {
     // overlaps whatever the caller queues next (typically the align kernels)
     hipStream_t copyStream = nullptr; hipEvent_t hitsOnHost = nullptr, alnOnHost = nullptr; bool alnInFlight = false;
     PinVec<GpuHit> hitStage; PinVec<uint32_t> hitOffStage; bool hitsInFlight = false;
+    GpuHit *sinkHits = nullptr; uint32_t *sinkOff = nullptr; size_t sinkCap = 0, sinkN = 0; bool sinkUsed = false;      // caller-owned delivery buffers (setHitSink)
     // exclusive scan of n counts into n + 1 offsets (offset[n] = total); count must have n + 1 readable entries.
     // Small inputs: one block (k_scan_counts); larger ones: rocPRIM's decoupled look-back scan.
     bool scanCounts(const uint32_t *count, uint32_t n, uint32_t *offset, std::string &err) {
@@ -2100,14 +2101,24 @@ bool Gpu::waitAlignCopy(std::string &err) {
 }
 
 // start copying the (final) hit list of the pass that just completed; called with the main stream idle
+void Gpu::setHitSink(GpuHit *hits, uint32_t *offsets, size_t capHits) {
+    Impl &d = *d_;
+    if (d.hitsInFlight) { (void) hipEventSynchronize(d.hitsOnHost); }      // a copy into the previous destination is still running
+    d.sinkHits = hits; d.sinkOff = offsets; d.sinkCap = (hits && offsets) ? capHits : 0;
+}
+
+// start copying the (final) hit list of the pass that just completed; called with the main stream idle
 bool Gpu::prefetchHits(std::string &err) {
     Impl &d = *d_;
     if (d.hitsInFlight) (void) hipEventSynchronize(d.hitsOnHost);      // the staging buffers are about to be rewritten
-    d.hitOffStage.resize(nq_ + 1);
-    d.hitStage.resize((size_t) counters_.hits);
+    const size_t nHits = (size_t) counters_.hits;
+    d.sinkUsed = d.sinkCap >= nHits && d.sinkHits != nullptr;           // the caller's buffers when they are large enough
+    GpuHit *dstHits; uint32_t *dstOff;
+    if (d.sinkUsed) { dstHits = d.sinkHits; dstOff = d.sinkOff; d.sinkN = nHits; }
+    else { d.hitOffStage.resize(nq_ + 1); d.hitStage.resize(nHits); dstHits = d.hitStage.data(); dstOff = d.hitOffStage.data(); }
     if (nq_ == 0) { d.hitsInFlight = false; return true; }
-    HIP_OK(hipMemcpyAsync(d.hitOffStage.data(), d.outOffset.p, (nq_ + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, d.copyStream));
-    if (!d.hitStage.empty()) HIP_OK(hipMemcpyAsync(d.hitStage.data(), d.outHits.p, d.hitStage.size() * sizeof(GpuHit), hipMemcpyDeviceToHost, d.copyStream));
+    HIP_OK(hipMemcpyAsync(dstOff, d.outOffset.p, (nq_ + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, d.copyStream));
+    if (nHits) HIP_OK(hipMemcpyAsync(dstHits, d.outHits.p, nHits * sizeof(GpuHit), hipMemcpyDeviceToHost, d.copyStream));
     HIP_OK(hipEventRecord(d.hitsOnHost, d.copyStream));
     d.hitsInFlight = true;
     return true;
@@ -2118,6 +2129,7 @@ bool Gpu::hostHits(const GpuHit *&hits, const uint32_t *&offsets, size_t &n, std
     Impl &d = *d_;
     if (!d.hitsInFlight && !prefetchHits(err)) return false;
     if (d.hitsInFlight) HIP_OK(hipEventSynchronize(d.hitsOnHost));
+    if (d.sinkUsed) { hits = d.sinkHits; offsets = d.sinkOff; n = d.sinkN; return true; }
     if (d.hitOffStage.empty()) d.hitOffStage.assign(1, 0);
     hits = d.hitStage.data(); offsets = d.hitOffStage.data(); n = d.hitStage.size();
     return true;

@@ -11,7 +11,8 @@
 int main(int argc, const char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: %s <prefilter|align|rescorediagonal> <args>\n", argv[0]); return 1; }
     int rc;
-    // SP_GPUS=N: the module forks one worker per GPU; this process must not touch the HIP runtime before the fork
+    // SP_GPUS=N: the module starts one worker process per GPU (this binary again, with SP_PART set); the parent only merges
+    // the parts and has no use for a device
     const char *gpus = getenv("SP_GPUS");
     const bool fanOut = gpus && atoi(gpus) > 1;
     if (!fanOut && sp_init(0) != SP_OK) { fprintf(stderr, "%s\n", sp_last_error()); return 1; }

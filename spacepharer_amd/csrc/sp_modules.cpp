@@ -18,6 +18,9 @@
 #include <set>
 #include <sstream>
 #include <string>
+#include <dlfcn.h>
+#include <signal.h>
+#include <spawn.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -25,6 +28,8 @@
 #include <vector>
 
 #include "../../include/spacepharer_amd.h"
+
+extern char **environ;
 
 namespace sp {
 
@@ -87,8 +92,7 @@ struct Db {
     const char *ptr(size_t i) const { return data.data() + entries[i].offset; }
 };
 
-// One module call can be spread over the GPUs of a node (SP_GPUS=N): the parent forks N children BEFORE anything touches
-// the HIP runtime, child r takes slice r of the entries (DBReader::decomposeDomainByAminoAcid arithmetic) on GPU r and writes
+// One module call can be spread over the GPUs of a node (SP_GPUS=N): the parent starts N worker processes, worker r takes slice r of the entries (DBReader::decomposeDomainByAminoAcid arithmetic) on GPU r and writes
 // the data file <out>.<r> -- the split-data-file form MMseqs2 DBs have anyway (DBWriter.cpp:117-123) -- plus a private index;
 // the parent merges the indexes into <out>.index (offsets shifted by the sizes of the preceding parts) and writes .dbtype last.
 struct Part { int rank = 0, count = 1; };
@@ -132,6 +136,8 @@ struct DbWriter {
         const std::string dataPath = part.count > 1 ? path + "." + std::to_string(part.rank) : path;
         const std::string indexPath = part.count > 1 ? dataPath + ".idxpart" : path + ".index";
         const std::string typePath = part.count > 1 ? dataPath + ".typepart" : path + ".dbtype";
+        if (part.count <= 1)      // split parts left by an earlier fan-out run would be read in front of / behind this data file
+            for (int i = 0;; i++) { const std::string dp = path + "." + std::to_string(i); struct stat st; if (stat(dp.c_str(), &st) != 0) break; remove(dp.c_str()); }
         { std::ofstream o(dataPath, std::ios::binary); if (!o.good()) { err = "cannot write " + dataPath; return false; } o.write(data.data(), (std::streamsize) data.size()); }
         std::sort(entries.begin(), entries.end(), [](const DbEntry &a, const DbEntry &b) { return a.key < b.key; });   // DBWriter.cpp:645-660
         { std::ofstream o(indexPath, std::ios::binary); if (!o.good()) { err = "cannot write " + indexPath; return false; }
@@ -275,26 +281,61 @@ static void flatten(const Db &db, std::vector<char> &res, std::vector<uint64_t> 
 
 static int fail(const std::string &e) { setLastError(e); fprintf(stderr, "%s\n", e.c_str()); return 1; }
 
-// SP_GPUS=N and not yet a child: fork one child per GPU, wait, merge.  Returns -1 when the call is not to be fanned out.
-static int fanOut(const char *module, int (*fn)(int, const char **), int argc, const char **argv, const std::string &out) {
+// Path of the front-end binary that workers are started from: $SP_WORKER_EXE, else `spacepharer-amd` next to this library.
+static std::string workerExe() {
+    if (const char *e = getenv("SP_WORKER_EXE")) return e;
+    Dl_info info;
+    if (dladdr((const void *) &workerExe, &info) && info.dli_fname) {
+        std::string p = info.dli_fname; const size_t s = p.rfind('/');
+        p = (s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/spacepharer-amd";
+        if (access(p.c_str(), X_OK) == 0) return p;
+    }
+    return "";
+}
+
+static void removeOutputs(const std::string &out, int keepParts) {
+    remove(out.c_str()); remove((out + ".index").c_str()); remove((out + ".dbtype").c_str());
+    for (int i = 0;; i++) {
+        const std::string dp = out + "." + std::to_string(i);
+        struct stat st; const bool have = stat(dp.c_str(), &st) == 0;
+        remove((dp + ".idxpart").c_str()); remove((dp + ".typepart").c_str());
+        if (!have && i >= std::max(keepParts, 64)) break;      // parts of an earlier, wider split (a node has at most a few dozen GPUs)
+        if (have) remove(dp.c_str());
+    }
+}
+
+// SP_GPUS=N and not yet a worker: start one worker PROCESS per GPU, wait, merge.  Returns -1 when the call is not to be fanned
+// out.  Workers are fresh processes of the front-end binary (posix_spawn: fork + exec in one step, the way a shell starts a
+// child) with SP_PART=r/N and LOCAL_RANK=r -- never a bare fork(): the caller may already have initialised the HIP runtime
+// (sp_init / a live sp_ctx), and a forked copy of an initialised runtime is undefined.
+static int fanOut(const char *module, int argc, const char **argv, const std::string &out) {
     const char *e = getenv("SP_GPUS");
     const int n = e ? atoi(e) : 1;
     if (n <= 1 || getenv("SP_PART")) return -1;
+    const std::string exe = workerExe();
+    if (exe.empty()) return fail(std::string(module) + ": SP_GPUS=" + std::to_string(n) + " needs the worker binary (spacepharer-amd next to the library, or $SP_WORKER_EXE)");
+    // leftovers of an earlier (crashed, or differently split) run must not be mixed with this run's parts: readers prefer an
+    // unsplit <out> over <out>.0.., and parts with rank >= N would be appended to the data
+    removeOutputs(out, n);
     std::vector<pid_t> kids;
+    auto reap = [&](bool kill9) { bool ok = true; for (pid_t k : kids) { if (kill9) kill(k, SIGKILL); int st = 0; if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) ok = false; } kids.clear(); return ok; };
     for (int r = 0; r < n; r++) {
-        const pid_t pid = fork();
-        if (pid < 0) return fail(std::string(module) + ": fork failed");
-        if (pid == 0) {
-            const std::string part = std::to_string(r) + "/" + std::to_string(n), rank = std::to_string(r);
-            setenv("SP_PART", part.c_str(), 1);
-            setenv("LOCAL_RANK", rank.c_str(), 1);          // device = LOCAL_RANK mod visible devices (sp_init)
-            _exit(fn(argc, argv));
+        std::vector<std::string> envs;
+        for (char **ev = environ; *ev; ev++) if (strncmp(*ev, "SP_PART=", 8) && strncmp(*ev, "LOCAL_RANK=", 11)) envs.push_back(*ev);
+        envs.push_back("SP_PART=" + std::to_string(r) + "/" + std::to_string(n));
+        envs.push_back("LOCAL_RANK=" + std::to_string(r));          // device = LOCAL_RANK mod visible devices (sp_init)
+        std::vector<char *> envp; for (std::string &s : envs) envp.push_back(&s[0]); envp.push_back(nullptr);
+        std::vector<std::string> args = {exe, module}; for (int i = 0; i < argc; i++) args.push_back(argv[i]);
+        std::vector<char *> av; for (std::string &s : args) av.push_back(&s[0]); av.push_back(nullptr);
+        pid_t pid = 0;
+        if (posix_spawn(&pid, exe.c_str(), nullptr, nullptr, av.data(), envp.data()) != 0) {
+            reap(true);                                             // do not leave started workers writing behind a failed call
+            removeOutputs(out, n);
+            return fail(std::string(module) + ": cannot start worker " + exe);
         }
         kids.push_back(pid);
     }
-    bool ok = true;
-    for (pid_t k : kids) { int st = 0; if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) ok = false; }
-    if (!ok) return fail(std::string(module) + ": a per-GPU worker failed");
+    if (!reap(false)) { removeOutputs(out, n); return fail(std::string(module) + ": a per-GPU worker failed"); }
     // merge: parts are data files <out>.0 .. <out>.N-1 read back to back, so part r's offsets shift by the sizes before it
     std::vector<DbEntry> all; uint64_t shift = 0; int32_t dbtype = -1;
     for (int r = 0; r < n; r++) {
@@ -339,7 +380,7 @@ int runPrefilterModule(int argc, const char **argv) {
         !requireValue(f, "--spaced-kmer-pattern", {"11011101", ""}, err) || !requireValue(f, "--mask-lower-case", {"0"}, err) || !requireValue(f, "--compressed", {"0"}, err) ||
         !requireValue(f, "--add-self-matches", {"0"}, err) || !requireValue(f, "--split", {"0", "1"}, err) || !requireValue(f, "-c", {"0", "0.0", "0.000"}, err))
         return fail("prefilter: " + err);
-    { const int rc = fanOut("prefilter", runPrefilterModule, argc, argv, f.positional[2]); if (rc >= 0) return rc; }
+    { const int rc = fanOut("prefilter", argc, argv, f.positional[2]); if (rc >= 0) return rc; }
     Laps laps("prefilter");
     Db qdb, tdb;
     if (!loadSeqDb(f.positional[0], qdb, err) || !loadSeqDb(f.positional[1], tdb, err)) return fail("prefilter: " + err);
@@ -489,7 +530,7 @@ int runAlignModule(int argc, const char **argv) {
         !requireValue(f, "-c", {"0", "0.0", "0.000"}, err) || !requireValue(f, "--seq-id-mode", {"0"}, err))
         return fail("align: " + err);
     if (f.num("-a", 0) != 1) return fail("align: only -a 1 (backtrace => score, coverage and sequence identity) is implemented, which is what predictmatch passes");
-    { const int rc = fanOut("align", runAlignModule, argc, argv, f.positional[3]); if (rc >= 0) return rc; }
+    { const int rc = fanOut("align", argc, argv, f.positional[3]); if (rc >= 0) return rc; }
     Laps laps("align");
     Ctx ctx; Db qdb, tdb, rdb; std::vector<uint32_t> qkeys, tkeys; std::vector<char> qres; std::vector<uint64_t> qoff;
     if (!openSearch(f, "align", true, ctx, qdb, tdb, qkeys, tkeys, qres, qoff, err)) return fail("align: " + err);
@@ -550,7 +591,7 @@ int runRescoreDiagonalModule(int argc, const char **argv) {
         return fail("rescorediagonal: " + err);
     const int mode = (int) f.num("--rescore-mode", 0);
     if (mode != 1 && mode != 2) return fail("rescorediagonal: only --rescore-mode 1 and 2 are implemented");
-    { const int rc = fanOut("rescorediagonal", runRescoreDiagonalModule, argc, argv, f.positional[3]); if (rc >= 0) return rc; }
+    { const int rc = fanOut("rescorediagonal", argc, argv, f.positional[3]); if (rc >= 0) return rc; }
     Ctx ctx; Db qdb, tdb, rdb; std::vector<uint32_t> qkeys, tkeys; std::vector<char> qres; std::vector<uint64_t> qoff;
     if (!openSearch(f, "rescorediagonal", false, ctx, qdb, tdb, qkeys, tkeys, qres, qoff, err)) return fail("rescorediagonal: " + err);
     if (!rdb.load(f.positional[2], err)) return fail("rescorediagonal: " + err);

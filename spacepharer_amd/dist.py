@@ -120,17 +120,23 @@ def allgather_candidates(local, group=None, device=None):
 def sharded_prefilter(ctx, q_from=0, q_to=None, group=None, device=None):
     """One target-sharded prefilter pass on this rank's context (targets staged with set_targets_shard*): candidates of
     the own shard -> all-gather (RCCL when `device` is the GPU: the payload goes HBM -> xGMI -> HBM) -> selection on the
-    union for queries [q_from, q_to).  Afterwards ctx.hits_compact() / ctx.align_hits_raw() see the merged hits."""
+    union for queries [q_from, q_to).  Afterwards ctx.hits_compact() / ctx.align_hits_raw() see the merged hits.
+    Returns {"union": rows of the gathered list, "bytes": bytes this rank received, "exchange_s": wall time of the exchange
+    step (counts + payload collectives, until the union is in place)}."""
+    import time
     import torch
     n = ctx.prefilter_candidates()
     dev = device if device is not None else torch.device("cpu")
     local = torch.empty((n, CAND_BYTES), dtype=torch.uint8, device=dev)
     if n:
         ctx.candidates_into(local.data_ptr())          # synchronises the context's stream
+    t0 = time.perf_counter()
     union = allgather_candidates(local, group=group, device=dev)
     if dev.type != "cpu":
         torch.cuda.synchronize(dev)                     # the collective ran on torch's stream
+    dt = time.perf_counter() - t0
+    if dev.type != "cpu":
         ctx.merge_candidates_device(union.data_ptr(), union.shape[0], q_from, q_to)
     else:
         ctx.merge_candidates(union.numpy(), q_from, q_to)
-    return int(union.shape[0])
+    return {"union": int(union.shape[0]), "bytes": int(union.shape[0]) * CAND_BYTES, "exchange_s": dt}

@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/examples.json.gz: BASELINE.json configs[0] -- the reference's bundled examples
+(/root/reference/examples: two spacer files vs three phage genomes, the workload of util/run_regression.sh) taken through
+the set-level steps around the search hot path by the REAL reference code (oracle/_ref/ref_sets + oracle/_ref/ref_harness,
+both compiled in place from /root/reference by oracle/Makefile).
+
+Runs only in the build container.  The committed output is pure data: the example sequences (data files of the reference's
+own regression test) and the content of every DB a step produced, keyed by DB key.
+
+Pipeline (reference workflow lines in parentheses):
+  nucleotide DBs (createdb is out of scope: sequences in file order, keys 0..n-1, set = source file)
+  queries : extractorfs --min-length 9 --orf-start-mode 1  -> translatenucs          (data/createsetdb.sh:87-91,105-109)
+  targets : extractorfs --min-length 30 --orf-start-mode 0 -> translatenucs          (data/createsetdb.sh:92-95; CreateSetDb.cpp:9-11)
+  control : the targets' ORFs through reverseseqbycodon -> translatenucs             (data/createsetdb.sh:97-104)
+  search  : prefilter + align with the workflow's flags      (ref_harness: QueryMatcher, Matcher)
+  proteinaln2nucl -> combineprotnuclaln -> besthitperset -> mergeresultsbyset -> combinescore   (data/predictmatch.sh:27-75)
+  the same against the control set, then filtermatchbyfdr --fdr 0.05                (data/predictmatch.sh:77-125)
+  summarizeresults --fmt 1 on an alignment DB in convertalis' 13-column layout      (data/predictmatch.sh:166)
+
+usage: python tests/golden/make_examples.py
+"""
+import glob
+import gzip
+import json
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("SP_REFERENCE", "/root/reference")
+SETS = os.path.join(ROOT, "oracle", "_ref", "ref_sets")
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+DATA = os.path.join(REF, "lib/mmseqs/data")
+
+
+def read_fasta(path):
+    op = gzip.open if path.endswith(".gz") else open
+    out, name, seq = [], None, []
+    with op(path, "rt") as f:
+        for line in f:
+            line = line.rstrip("\r\n")
+            if line.startswith(">"):
+                if name is not None:
+                    out.append((name, "".join(seq)))
+                name, seq = line[1:], []
+            elif line:
+                seq.append(line.strip())
+    if name is not None:
+        out.append((name, "".join(seq)))
+    return out
+
+
+def write_db(path, entries, dbtype):
+    """entries: list of (key, bytes payload without the terminating NUL) in data order"""
+    off, idx = 0, []
+    with open(path, "wb") as f:
+        for k, payload in entries:
+            f.write(payload + b"\0")
+            idx.append((k, off, len(payload) + 1))
+            off += len(payload) + 1
+    with open(path + ".index", "w") as f:
+        for k, o, l in sorted(idx):
+            f.write("%d\t%d\t%d\n" % (k, o, l))
+    open(path + ".dbtype", "wb").write(struct.pack("<i", dbtype))
+
+
+def read_db(path):
+    files = [path] if os.path.exists(path) else sorted(glob.glob(path + ".[0-9]*"), key=lambda p: int(p.rsplit(".", 1)[1]))
+    data = b"".join(open(p, "rb").read() for p in files)
+    out = {}
+    for line in open(path + ".index"):
+        k, o, l = (int(x) for x in line.split("\t"))
+        out[k] = data[o:o + l - 1].decode()
+    return out, struct.unpack("<i", open(path + ".dbtype", "rb").read(4))[0]
+
+
+def nucl_db(path, files):
+    """what createdb leaves for a list of FASTA files: sequence DB (dbtype 1), header DB, lookup (key, accession, file number)"""
+    seqs, heads, lookup, source = [], [], [], []
+    k = 0
+    for fi, fn in enumerate(files):
+        source.append("%d\t%s" % (fi, os.path.basename(fn)))
+        for name, s in read_fasta(fn):
+            seqs.append((k, s.encode() + b"\n"))
+            heads.append((k, name.encode() + b"\n"))
+            lookup.append("%d\t%s\t%d" % (k, name.split()[0], fi))
+            k += 1
+    write_db(path, seqs, 1)
+    write_db(path + "_h", heads, 12)
+    open(path + ".lookup", "w").write("\n".join(lookup) + "\n")
+    open(path + ".source", "w").write("\n".join(source) + "\n")
+    return [s.decode().strip() for _, s in seqs], [int(l.split("\t")[2]) for l in lookup]
+
+
+def set_dbs(prefix, contig_set):
+    """<prefix>_member_to_set, _set_to_member, _set_size from <prefix>_nucl_orf.lookup (orf key, contig key, set) -- what
+    orftocontig / filterdb / swapdb / result2stats leave (data/createsetdb.sh:111-139); inputs of the aggregation steps"""
+    member_set = {}
+    for line in open(prefix + "_nucl_orf.lookup"):
+        orf, contig, _ = line.rstrip("\n").split("\t")
+        member_set[int(orf)] = contig_set[int(contig)]
+    write_db(prefix + "_member_to_set", [(m, b"%d\n" % s) for m, s in sorted(member_set.items())], 5)
+    sets = sorted(set(member_set.values()))
+    write_db(prefix + "_set_to_member", [(s, b"".join(b"%d\n" % m for m in sorted(member_set) if member_set[m] == s)) for s in sets], 5)
+    write_db(prefix + "_set_size", [(s, b"%d\n" % sum(1 for m in member_set if member_set[m] == s)) for s in sets], 12)
+    return member_set
+
+
+def run(*args, **kw):
+    return subprocess.run([str(a) for a in args], check=True, **kw)
+
+
+def search(d, q, t, out, max_seqs=300):
+    """prefilter + align of peptide DB q against peptide DB t through the reference classes; writes the pref / aln text DBs"""
+    qdb, _ = read_db(q)
+    tdb, _ = read_db(t)
+    assert sorted(qdb) == list(range(len(qdb))) and sorted(tdb) == list(range(len(tdb)))
+    tf, qf, of = (os.path.join(d, x) for x in ("t.txt", "q.txt", "o.json"))
+    open(tf, "w").write("".join(tdb[k] for k in range(len(tdb))))
+    open(qf, "w").write("".join(qdb[k] for k in range(len(qdb))))
+    run(HARNESS, os.path.join(DATA, "VTML80.out"), os.path.join(DATA, "VTML40.out"), tf, qf, of, "--dump-kmers", "0", "--max-seqs", max_seqs)
+    ref = json.load(open(of))
+    pref = {x["id"]: x["pref"] for x in ref["queries"]}
+    aln = {x["id"]: x["text"] for x in ref["aln"]}
+    write_db(out + "_pref", [(k, pref.get(k, "").encode()) for k in range(len(qdb))], 7)
+    write_db(out, [(k, aln.get(k, "").encode()) for k in range(len(qdb))], 5)
+    return {"aaDbSize": ref["aaDbSize"], "alpGapped": ref["alpGapped"], "binSize": ref["binSize"]}
+
+
+def main():
+    if not (os.path.exists(SETS) and os.path.exists(HARNESS)):
+        sys.exit("build the harnesses first: make -C oracle ref")
+    ex = os.path.join(REF, "examples")
+    qfiles = sorted(glob.glob(os.path.join(ex, "*.fas")))
+    tfiles = sorted(glob.glob(os.path.join(ex, "GCA*.fna.gz")))
+    doc = {"case": "examples", "query_files": [os.path.basename(f) for f in qfiles], "target_files": [os.path.basename(f) for f in tfiles], "db": {}, "info": {}}
+    with tempfile.TemporaryDirectory() as d:
+        P = lambda x: os.path.join(d, x)      # noqa: E731
+        _, qset = nucl_db(P("q_nucl"), qfiles)
+        _, tset = nucl_db(P("t_nucl"), tfiles)
+        run(SETS, "extractorfs", P("q_nucl"), P("q_nucl_orf"), 9, 1)
+        run(SETS, "translatenucs", P("q_nucl_orf"), P("q"))
+        run(SETS, "extractorfs", P("t_nucl"), P("t_nucl_orf"), 30, 0)
+        run(SETS, "translatenucs", P("t_nucl_orf"), P("t"))
+        run(SETS, "reverseseqbycodon", P("t_nucl_orf"), P("c_nucl_orf"))
+        for ext in (".lookup",):
+            open(P("c_nucl_orf") + ext, "w").write(open(P("t_nucl_orf") + ext).read())
+        run(SETS, "translatenucs", P("c_nucl_orf"), P("c"))
+        set_dbs(P("q"), qset)
+        set_dbs(P("t"), tset)
+        set_dbs(P("c"), tset)
+        nuc = os.path.join(DATA, "nucleotide.out")
+        for tag, T in (("", "t"), ("_rev", "c")):
+            doc["info"]["search" + tag] = search(d, P("q"), P(T), P("prot_result" + tag))
+            p = run(SETS, "proteinaln2nucl", P("q_nucl_orf"), P(T + "_nucl_orf"), P("q"), P(T), P("prot_result" + tag), P("nucl_result" + tag), nuc, 10, 2,
+                    capture_output=True, text=True)
+            doc["info"]["nucl_evalue" + tag] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+            run(SETS, "combineprotnuclaln", P("prot_result" + tag), P("nucl_result" + tag), P("result" + tag))
+            run(SETS, "besthitperset", P(T), P("result" + tag), P("aggregate" + tag), 1)
+            run(SETS, "mergeresultsbyset", P("q_set_to_member"), P("aggregate" + tag), P("aggregate_merged" + tag))
+            run(SETS, "combinescore", P("q"), P(T), P("aggregate_merged" + tag), P("cScore" + tag))
+        for fdr, rep, name in ((0.05, 0, "match"), (0.05, 1, "match_fdr"), (1.0, 0, "match_all")):
+            p = run(SETS, "filtermatchbyfdr", P("cScore"), P("cScore_rev"), P(name), fdr, rep, capture_output=True, text=True)
+            doc["info"][name] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        # the non-simple branch of besthitperset (second-best correction), not used by predictmatch but part of the module
+        run(SETS, "besthitperset", P("t"), P("result"), P("aggregate_full"), 0)
+        # summarizeresults: an alignment DB in the layout convertalis writes for
+        # --format-output tsetid,query,qset,target,evalue,qstart,qend,qlen,tstart,tend,qaln,taln,empty (data/predictmatch.sh:147-150),
+        # one line per best hit of a spacer, merged per query set; the numbers come from the aggregate DB
+        agg, _ = read_db(P("aggregate"))
+        qlook = [l.split("\t") for l in open(P("q_nucl_orf.lookup")).read().splitlines()]
+        qnames = [l.split("\t")[1] for l in open(P("q_nucl.lookup")).read().splitlines()]
+        tnames = [l.split("\t")[1] for l in open(P("t_nucl.lookup")).read().splitlines()]
+        tmember = {int(l.split("\t")[0]): int(l.split("\t")[1]) for l in open(P("t_nucl_orf.lookup")).read().splitlines()}
+        lines = {}
+        for orf, contig, _ in qlook:
+            for ln in agg.get(int(orf), "").splitlines():
+                f = ln.split("\t")
+                if len(f) < 10:
+                    continue
+                tcontig = tmember[int(f[0])]
+                s = qset[int(contig)]
+                lines.setdefault(s, []).append("\t".join([str(tset[tcontig]), qnames[int(contig)], doc["query_files"][s], tnames[tcontig], f[3], f[4], f[5], f[6], f[7], f[8],
+                                                          "ACGT" * 2, "ACGA" * 2, "-"]))
+        write_db(P("aln"), [(s, ("\n".join(v) + "\n").encode()) for s, v in sorted(lines.items())], 5)
+        for fmt in (0, 1, 2):
+            run(SETS, "summarizeresults", P("match"), P("aln"), P("summary%d" % fmt), fmt)
+        names = ["q_nucl", "t_nucl", "q_nucl_orf", "q_nucl_orf_h", "t_nucl_orf", "t_nucl_orf_h", "c_nucl_orf", "q", "t", "c", "aln", "summary0", "summary1", "summary2",
+                 "match", "match_fdr", "match_all", "aggregate_full"]
+        for base in ("q", "t", "c"):
+            names += [base + "_member_to_set", base + "_set_to_member", base + "_set_size"]
+        for tag in ("", "_rev"):
+            names += [x + tag for x in ("prot_result", "nucl_result", "result", "aggregate", "aggregate_merged", "cScore")] + ["prot_result" + tag + "_pref"]
+        for n in names:
+            content, dbtype = read_db(P(n))
+            doc["db"][n] = {"dbtype": dbtype, "entries": {str(k): v for k, v in sorted(content.items())}}
+        doc["lookup"] = {n: open(P(n + ".lookup")).read() for n in ("q_nucl", "t_nucl", "q_nucl_orf", "t_nucl_orf")}
+    out = os.path.join(HERE, "examples.json.gz")
+    with gzip.GzipFile(out, "wb", mtime=0) as f:
+        f.write(json.dumps(doc, separators=(",", ":")).encode())
+    print("examples ->", out, os.path.getsize(out), "bytes;", {n: len(v["entries"]) for n, v in doc["db"].items()})
+
+
+if __name__ == "__main__":
+    main()

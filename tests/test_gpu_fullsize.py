@@ -158,3 +158,83 @@ def test_sample_against_oracle_at_full_size(full):
 def lib_entries(o):
     from oracle_lib import lib
     return lib().spo_index_entries(o.ctx)
+
+
+def bench_mod():
+    import bench
+    return bench
+
+
+def _deliver(ctx, slot):
+    """one step exactly as bench.py's timed loop runs it; returns the delivered bytes (offsets, hits, records, backtrace pool)"""
+    ctx.set_hit_sink(slot.hits, slot.off, slot.cap)
+    ctx.prefilter()
+    n = slot.n = ctx.num_hits()
+    ctx.align_hits_begin(into=slot.into)
+    hp, _, cnt = ctx.hits_view()
+    assert C.cast(hp, C.c_void_p).value == slot.hits and cnt == n
+    ctx.align_hits_end()
+    return (C.string_at(slot.off, 4 * (slot.nq + 1)), C.string_at(slot.hits, 8 * n), bench_mod().record_fields(slot.rec, n), C.string_at(slot.cig, int(slot.used.value)))
+
+
+def test_two_contexts_in_flight_deliver_the_single_context_bytes():
+    """the configuration bench.py times: two search contexts on one GPU, each on its own host thread and HIP streams with its
+    own query batch, match_blocks_per_cu = 2, passes interleaving freely.  Every round of both contexts must deliver exactly
+    the bytes (hit list, offsets, sp_alignment records, backtrace pool) the same batch gives when its context has the GPU to
+    itself with default tuning."""
+    import threading
+    import bench
+    import spacepharer_amd as sa
+    L = sa.load_library()
+    batches = [bench.make_workload(10000, 50000, 200, 12345, qs) for qs in (None, 12345 + 104729)]
+    ctxs, slots, ref = [], [], []
+    for tres, toff, qres, qoff in batches:
+        c = sa.SearchContext()
+        c.set_targets_raw(tres.tobytes(), bench.u64p(toff), len(toff) - 1)
+        c.set_queries_raw(qres.tobytes(), bench.u64p(qoff), len(qoff) - 1)
+        c.prefilter()
+        s = bench.Slot(L, len(qoff) - 1, int(c.num_hits() * 1.05) + 1024, True)
+        ref.append(_deliver(c, s))                # alone on the GPU
+        ctxs.append(c); slots.append(s)
+    assert ref[0] != ref[1] and len(ref[0][1]) > 8 * 60000 and len(ref[1][2]) > 60 * 60000
+    for c in ctxs:
+        c.set_tuning("match_blocks_per_cu", 2)
+    rounds, bad, errors = 12, [], []
+    gate = threading.Barrier(2)
+
+    def run(i):
+        try:
+            gate.wait()
+            for r in range(rounds):
+                got = _deliver(ctxs[i], slots[i])
+                for part, (g, e) in enumerate(zip(got, ref[i])):
+                    if g != e:
+                        bad.append((i, r, part))
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    assert not bad, bad[:10]
+    for s in slots:
+        s.free()
+    for c in ctxs:
+        c.close()
+
+
+def test_bench_checks_every_delivered_result(tmp_path):
+    """bench.py digests the result of every timed step of every context after the clock stops and fails on a difference; the
+    line says how many it checked"""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "1", "--regions", "2", "--spacers", "1500",
+                        "--targets", "8000", "--cpu-sample", "0"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["results_checked"]["steps"] == 12 and out["results_checked"]["equal_to_single_context_result"] is True
+    assert out["config"]["distinct_query_batches"] == 2 and out["regions"]["n"] == 2
+    assert out["regions"]["min"] <= out["value"] <= out["regions"]["max"]

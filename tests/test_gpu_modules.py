@@ -138,3 +138,35 @@ def test_modules_fan_out_over_gpus_with_identical_results(tmp_path):
     keys = [int(l.split("\t")[0]) for l in open(aln + ".index")]
     assert keys == sorted(keys) and len(keys) == len(g["queries"])
     assert not [f for f in os.listdir(tmp_path) if f.endswith("part")]       # the private indexes are gone
+
+
+def test_module_fan_out_from_a_process_that_already_initialised_hip(tmp_path):
+    """SP_GPUS=2 through the C ABI of THIS process, which has initialised the HIP runtime long ago (sp_init, live contexts in
+    other tests): the workers are fresh processes of the front-end binary, never forks of the initialised runtime.  Stale
+    outputs of an earlier run (an unsplit data file, a part of a wider split) must not survive."""
+    import spacepharer_amd as sa
+    g = load_golden("small")
+    r = g["ref"]
+    q, t, pref = (str(tmp_path / x) for x in ("qdb", "tdb", "pref"))
+    write_seq_db(q, g["queries"])
+    write_seq_db(t, g["targets"])
+    c = sa.SearchContext()                     # the runtime is certainly up
+    open(pref, "wb").write(b"stale unsplit data file")
+    open(pref + ".5", "wb").write(b"stale part of an 8-way split")
+    os.environ["SP_GPUS"] = "2"
+    try:
+        sa.module_prefilter([q, t, pref] + (PREF_FLAGS % r["maxSeqs"]).split())
+    finally:
+        os.environ.pop("SP_GPUS", None)
+    c.close()
+    assert not os.path.exists(pref) and not os.path.exists(pref + ".5") and os.path.exists(pref + ".0") and os.path.exists(pref + ".1")
+    got, dbtype = read_db(pref)
+    assert dbtype == 7 and sorted(got) == list(range(len(g["queries"])))
+    for qq in r["queries"]:
+        assert got[qq["id"]] == qq["pref"], qq["id"]
+    # a later unsplit run over the same path removes the parts again
+    sa.module_prefilter([q, t, pref] + (PREF_FLAGS % r["maxSeqs"]).split())
+    assert os.path.exists(pref) and not os.path.exists(pref + ".0")
+    got, _ = read_db(pref)
+    for qq in r["queries"]:
+        assert got[qq["id"]] == qq["pref"], qq["id"]
