@@ -56,6 +56,19 @@ int sp_prefilter_run(int argc, const char **argv);        /* <i:queryDB> <i:targ
 int sp_align_run(int argc, const char **argv);            /* <i:queryDB> <i:targetDB> <i:resultDB> <o:alignmentDB> [flags] */
 int sp_rescorediagonal_run(int argc, const char **argv);  /* <i:queryDB> <i:targetDB> <i:resultDB> <o:resultDB> [flags]    */
 
+/* ---- (1b) set-level steps around the search: host-side module drop-ins with the reference modules' argv.
+   They need no device. ---- */
+int sp_extractorfs_run(int argc, const char **argv);           /* <i:nuclDB> <o:orfDB> [flags]   replaces lib/mmseqs/src/util/extractorfs.cpp:18-160 (CommandDeclarations.h:42) */
+int sp_translatenucs_run(int argc, const char **argv);         /* <i:nuclOrfDB> <o:aaDB> [flags]   replaces lib/mmseqs/src/util/translatenucs.cpp:16-115 (CommandDeclarations.h:117) */
+int sp_reverseseqbycodon_run(int argc, const char **argv);     /* <i:nuclOrfDB> <o:reversedDB> [flags]   replaces src/util/ReverseSeqByCodon.cpp:13-62 (src/LocalCommandDeclarations.h) */
+int sp_proteinaln2nucl_run(int argc, const char **argv);       /* <i:queryNuclDB> <i:targetNuclDB> <i:queryAADB> <i:targetAADB> <i:alnDB> <o:alnDB> [flags]   replaces lib/mmseqs/src/util/proteinaln2nucl.cpp:13-205 */
+int sp_combineprotnuclaln_run(int argc, const char **argv);    /* <i:protAlnDB> <i:nuclAlnDB> <o:alnDB> [flags]   replaces src/util/CombineProtNuclAln.cpp:13-106 */
+int sp_besthitperset_run(int argc, const char **argv);         /* <i:querySetDB> <i:targetSetDB> <i:resultDB> <o:resultDB> [flags]   replaces lib/mmseqs/src/multihit/besthitperset.cpp:122-129 */
+int sp_mergeresultsbyset_run(int argc, const char **argv);     /* <i:setToMemberDB> <i:resultDB> <o:resultDB> [flags]   replaces lib/mmseqs/src/util/mergeresultsbyset.cpp:10-58 */
+int sp_combinescore_run(int argc, const char **argv);          /* <i:querySetDB> <i:targetSetDB> <i:resultDB> <o:scoreDB> <tmpDir> [flags]   replaces src/util/CombineScore.cpp:106-113 */
+int sp_filtermatchbyfdr_run(int argc, const char **argv);      /* <i:scoreDB> <i:controlScoreDB> <o:matchDB> [flags]   replaces src/util/FilterMatchbyFdr.cpp:13-264 */
+int sp_summarizeresults_run(int argc, const char **argv);      /* <i:targetNuclDB> <i:matchDB> <i:alnDB> <o:report> [flags]   replaces src/util/SummarizeResults.cpp:13-197 */
+
 /* ---- (2) in-memory search context ---- */
 typedef struct sp_ctx sp_ctx;
 

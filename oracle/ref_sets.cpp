@@ -31,7 +31,11 @@
 #include "DBReader.h"
 #include "DBWriter.h"
 #include "Debug.h"
+// the evaluer member is private; the driver only READS the fitted Gumbel parameters out of it
+#include "sls_alignment_evaluer.hpp"
+#define private public
 #include "EvalueComputation.h"
+#undef private
 #include "FileUtil.h"
 #include "Matcher.h"
 #include "NucleotideMatrix.h"
@@ -154,9 +158,6 @@ static int stepReverse(const std::string &in, const std::string &out) {
 
 // ---- proteinaln2nucl <qNuclOrf> <tNuclOrf> <qAA> <tAA> <protAln> <out> <nucleotide.out> <gapOpen> <gapExtend>
 // (util/proteinaln2nucl.cpp:13-205).  Also prints the ALP parameters EvalueComputation fitted for the nucleotide matrix.
-struct EvalPeek : public EvalueComputation {       // reads the fitted Gumbel parameters (protected/private members are not touched otherwise)
-    using EvalueComputation::EvalueComputation;
-};
 static int stepProteinAln2Nucl(char **a) {
     const std::string qn = a[0], tn = a[1], qa = a[2], ta = a[3], aln = a[4], out = a[5];
     Reader qNuc(qn.c_str(), idx(qn).c_str(), 1, Reader::USE_INDEX | Reader::USE_DATA); qNuc.open(Reader::NOSORT);
@@ -220,10 +221,13 @@ static int stepProteinAln2Nucl(char **a) {
     }
     w.close();
     // probes of the nucleotide E-value statistics for the fixtures: evalue / bit score of a few raw scores at a few query lengths
-    printf("{\"dbResidues\":%zu,\"probes\":[", (size_t) tNuc.getAminoAcidDBSize());
+    {   const Sls::ALP_set_of_parameters &p = evaluer.evaluer.parameters();
+        printf("{\"alp\":[\"%a\",\"%a\",\"%a\",\"%a\",\"%a\",\"%a\",\"%a\",\"%a\",\"%a\",\"%a\",\"%a\",\"%a\"],", p.lambda, p.K, p.a_I, p.b_I, p.alpha_I, p.beta_I,
+               p.a_J, p.b_J, p.alpha_J, p.beta_J, p.sigma, p.tau); }
+    printf("\"dbResidues\":%zu,\"probes\":[", (size_t) tNuc.getAminoAcidDBSize());
     bool first = true;
     for (int s = -10; s <= 120; s += 7) for (int L = 27; L <= 60; L += 11) {
-        printf("%s[%d,%d,\"%a\",%d]", first ? "" : ",", s, L, evaluer.computeEvalue(s, L), evaluer.computeBitScore(s));
+        printf("%s[%d,%d,\"%a\",%d]", first ? "" : ",", s, L, evaluer.computeEvalue(s, L), (int) evaluer.computeBitScore(s));
         first = false;
     }
     printf("]}\n");

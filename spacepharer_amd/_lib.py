@@ -52,6 +52,9 @@ class Rescore(C.Structure):
                 ("diagonal", C.c_int32), ("dist_to_diagonal", C.c_uint32), ("evalue", C.c_double), ("bit_score", C.c_int32)]
 
 
+HOST_MODULES = ("extractorfs", "translatenucs", "reverseseqbycodon", "proteinaln2nucl", "combineprotnuclaln", "besthitperset", "mergeresultsbyset",
+                "combinescore", "filtermatchbyfdr", "summarizeresults")      # set-level steps: host-only module drop-ins
+
 _lib = None
 
 
@@ -112,7 +115,7 @@ def load_library():
     L.sp_host_alloc.argtypes = [C.c_uint64]
     L.sp_host_free.argtypes = [vp]
     L.sp_ctx_diag_stream_read.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
-    for f in ("sp_prefilter_run", "sp_align_run", "sp_rescorediagonal_run"):
+    for f in ("sp_prefilter_run", "sp_align_run", "sp_rescorediagonal_run") + tuple("sp_%s_run" % m for m in HOST_MODULES):
         getattr(L, f).argtypes = [C.c_int, C.POINTER(C.c_char_p)]
     _lib = L
     return L
@@ -141,6 +144,18 @@ def _run_module(fn, args):
     rc = getattr(L, fn)(len(args), arr)
     if rc != 0:
         raise SpError("%s failed: %s" % (fn, L.sp_last_error().decode()))
+    return rc
+
+
+def module_host(name, args):
+    """one of the set-level steps (HOST_MODULES) with the reference module's argv; needs no device"""
+    if name not in HOST_MODULES:
+        raise SpError("unknown host module " + name)
+    L = load_library()
+    arr = (C.c_char_p * len(args))(*[str(a).encode() for a in args])
+    rc = getattr(L, "sp_%s_run" % name)(len(args), arr)
+    if rc != 0:
+        raise SpError("%s failed: %s" % (name, L.sp_last_error().decode()))
     return rc
 
 

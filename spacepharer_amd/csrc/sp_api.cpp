@@ -18,6 +18,7 @@
 #include "sp_gpu.h"
 #include "sp_host.h"
 #include "sp_modules.h"
+#include "sp_sets.h"
 
 namespace {
 thread_local std::string g_err;
@@ -567,5 +568,15 @@ int sp_host_evalue(const char *matrixName, int gapOpen, int gapExtend, uint64_t 
 int sp_prefilter_run(int argc, const char **argv) { return sp::runPrefilterModule(argc, argv); }
 int sp_align_run(int argc, const char **argv) { return sp::runAlignModule(argc, argv); }
 int sp_rescorediagonal_run(int argc, const char **argv) { return sp::runRescoreDiagonalModule(argc, argv); }
+int sp_extractorfs_run(int argc, const char **argv) { return sp::sets::runExtractOrfs(argc, argv); }
+int sp_translatenucs_run(int argc, const char **argv) { return sp::sets::runTranslateNucs(argc, argv); }
+int sp_reverseseqbycodon_run(int argc, const char **argv) { return sp::sets::runReverseSeqByCodon(argc, argv); }
+int sp_proteinaln2nucl_run(int argc, const char **argv) { return sp::sets::runProteinAln2Nucl(argc, argv); }
+int sp_combineprotnuclaln_run(int argc, const char **argv) { return sp::sets::runCombineProtNuclAln(argc, argv); }
+int sp_besthitperset_run(int argc, const char **argv) { return sp::sets::runBestHitPerSet(argc, argv); }
+int sp_mergeresultsbyset_run(int argc, const char **argv) { return sp::sets::runMergeResultsBySet(argc, argv); }
+int sp_combinescore_run(int argc, const char **argv) { return sp::sets::runCombineScore(argc, argv); }
+int sp_filtermatchbyfdr_run(int argc, const char **argv) { return sp::sets::runFilterMatchByFdr(argc, argv); }
+int sp_summarizeresults_run(int argc, const char **argv) { return sp::sets::runSummarizeResults(argc, argv); }
 
 }  // extern "C"

@@ -1,0 +1,260 @@
+// MMseqs2 DB triples, module command lines and small formatting helpers shared by the module drivers
+// (sp_modules.cpp: prefilter / align / rescorediagonal; sp_sets.cpp: the set-level steps around them).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <set>
+#include <string>
+#include <sys/stat.h>
+#include <thread>
+#include <vector>
+
+#include "../../include/spacepharer_amd.h"
+#include "sp_modules.h"
+
+namespace sp {
+
+// ---------------------------------------------------------------------------------------------------------------
+// MMseqs2 DB triple: <p> (or <p>.0 .. <p>.N), <p>.index, <p>.dbtype     (commons/DBReader.cpp, DBWriter.cpp)
+// ---------------------------------------------------------------------------------------------------------------
+struct DbEntry { uint32_t key; uint64_t offset; uint64_t length; };   // length includes the terminating NUL
+
+struct Db {
+    std::vector<char> data;
+    std::vector<DbEntry> entries;     // sorted by data offset (DBReader::LINEAR_ACCCESS)
+    int dbtype = -1;
+    bool compressed() const { return dbtype >= 0 && (dbtype & (1 << 31)); }
+    int type() const { return dbtype & 0x7FFFFFFF; }
+
+    bool load(const std::string &path, std::string &err) {
+        {   // key \t offset \t length \n  -- parsed by hand: result DBs of 10^5 spacers have 6 x 10^5 lines per index
+            std::ifstream idx(path + ".index", std::ios::binary);
+            if (!idx.good()) { err = "cannot open " + path + ".index"; return false; }
+            idx.seekg(0, std::ios::end); const size_t sz = (size_t) idx.tellg(); idx.seekg(0);
+            std::vector<char> text(sz + 1, '\n');
+            idx.read(text.data(), (std::streamsize) sz);
+            const char *p = text.data(), *end = p + sz;
+            entries.reserve(sz / 12 + 1);
+            while (p < end) {
+                if (*p == '\n' || *p == '\r') { p++; continue; }
+                unsigned long long v[3];
+                for (int f = 0; f < 3; f++) {
+                    if (*p < '0' || *p > '9') { err = "malformed index line in " + path + ".index"; return false; }
+                    unsigned long long x = 0;
+                    while (*p >= '0' && *p <= '9') x = x * 10 + (unsigned long long) (*p++ - '0');
+                    v[f] = x;
+                    if (f < 2) { if (*p != '\t') { err = "malformed index line in " + path + ".index"; return false; } p++; }
+                }
+                while (p < end && *p != '\n') p++;
+                DbEntry e; e.key = (uint32_t) v[0]; e.offset = v[1]; e.length = v[2];
+                entries.push_back(e);
+            }
+        }
+        std::vector<std::string> files;
+        struct stat st;
+        if (stat(path.c_str(), &st) == 0) files.push_back(path);
+        else for (int i = 0;; i++) { std::string f = path + "." + std::to_string(i); if (stat(f.c_str(), &st) != 0) break; files.push_back(f); }
+        if (files.empty()) { err = "cannot open data file of " + path; return false; }
+        for (const std::string &f : files) {
+            std::ifstream in(f, std::ios::binary);
+            if (!in.good()) { err = "cannot read " + f; return false; }
+            in.seekg(0, std::ios::end); size_t sz = (size_t) in.tellg(); in.seekg(0);
+            size_t at = data.size(); data.resize(at + sz);
+            in.read(data.data() + at, (std::streamsize) sz);
+        }
+        std::ifstream t(path + ".dbtype", std::ios::binary);
+        if (t.good()) { int32_t v = 0; t.read((char *) &v, 4); dbtype = v; }
+        for (const DbEntry &e : entries) if (e.offset + e.length > data.size()) { err = "index of " + path + " points past the data file"; return false; }
+        std::sort(entries.begin(), entries.end(), [](const DbEntry &a, const DbEntry &b) { return a.offset < b.offset; });
+        return true;
+    }
+    // sequence entry = residues + '\n' + '\0'  (DBReader.h:191-211)
+    uint64_t seqLen(size_t i) const { return entries[i].length >= 2 ? entries[i].length - 2 : 0; }
+    const char *ptr(size_t i) const { return data.data() + entries[i].offset; }
+};
+
+// One module call can be spread over the GPUs of a node (SP_GPUS=N): the parent starts N worker processes, worker r takes slice r of the entries (DBReader::decomposeDomainByAminoAcid arithmetic) on GPU r and writes
+// the data file <out>.<r> -- the split-data-file form MMseqs2 DBs have anyway (DBWriter.cpp:117-123) -- plus a private index;
+// the parent merges the indexes into <out>.index (offsets shifted by the sizes of the preceding parts) and writes .dbtype last.
+struct Part { int rank = 0, count = 1; };
+inline Part currentPart() {
+    Part p;
+    if (const char *e = getenv("SP_PART")) { int r = 0, n = 1; if (sscanf(e, "%d/%d", &r, &n) == 2 && n >= 1 && r >= 0 && r < n) { p.rank = r; p.count = n; } }
+    return p;
+}
+// contiguous slice of `lengths.size()` entries for this part, balanced by data size (commons/DBReader.cpp:1171-1213)
+inline void partRange(const std::vector<uint64_t> &lengths, const Part &p, size_t &from, size_t &to) {
+    const size_t n = lengths.size();
+    from = 0; to = n;
+    if (p.count <= 1) return;
+    uint64_t total = 0; for (uint64_t l : lengths) total += l;
+    if (n <= (size_t) p.count) { from = std::min<size_t>(n, (size_t) p.rank); to = std::min<size_t>(n, from + 1); return; }
+    const uint64_t chunk = (total + (uint64_t) p.count - 1) / (uint64_t) p.count;
+    std::vector<size_t> per((size_t) p.count, 0);
+    size_t cur = 0; uint64_t acc = 0;
+    for (uint64_t l : lengths) { if (acc >= chunk && cur + 1 < (size_t) p.count) { acc = 0; cur++; } acc += l; per[cur]++; }
+    for (int r = 0; r < p.rank; r++) from += per[(size_t) r];
+    to = from + per[(size_t) p.rank];
+}
+
+struct DbWriter {
+    std::string path; int dbtype;
+    Part part = currentPart();
+    std::vector<char> data; std::vector<DbEntry> entries;
+    void add(uint32_t key, const std::string &payload) {
+        DbEntry e; e.key = key; e.offset = data.size(); e.length = payload.size() + 1;
+        data.insert(data.end(), payload.begin(), payload.end());
+        data.push_back('\0');
+        entries.push_back(e);
+    }
+    // a block of consecutive entries formatted elsewhere (payloads concatenated, each followed by its NUL)
+    void addBlock(const std::vector<uint32_t> &keys, const std::vector<uint64_t> &lengths, const std::string &block) {
+        uint64_t at = data.size();
+        data.insert(data.end(), block.begin(), block.end());
+        for (size_t i = 0; i < keys.size(); i++) { DbEntry e; e.key = keys[i]; e.offset = at; e.length = lengths[i]; entries.push_back(e); at += lengths[i]; }
+    }
+    bool close(std::string &err) {
+        const std::string dataPath = part.count > 1 ? path + "." + std::to_string(part.rank) : path;
+        const std::string indexPath = part.count > 1 ? dataPath + ".idxpart" : path + ".index";
+        const std::string typePath = part.count > 1 ? dataPath + ".typepart" : path + ".dbtype";
+        if (part.count <= 1)      // split parts left by an earlier fan-out run would be read in front of / behind this data file
+            for (int i = 0;; i++) { const std::string dp = path + "." + std::to_string(i); struct stat st; if (stat(dp.c_str(), &st) != 0) break; remove(dp.c_str()); }
+        { std::ofstream o(dataPath, std::ios::binary); if (!o.good()) { err = "cannot write " + dataPath; return false; } o.write(data.data(), (std::streamsize) data.size()); }
+        std::sort(entries.begin(), entries.end(), [](const DbEntry &a, const DbEntry &b) { return a.key < b.key; });   // DBWriter.cpp:645-660
+        { std::ofstream o(indexPath, std::ios::binary); if (!o.good()) { err = "cannot write " + indexPath; return false; }
+          std::string text; text.reserve(entries.size() * 24);
+          char buf[72];
+          for (const DbEntry &e : entries) {
+              char *q = buf + sizeof(buf); *--q = '\n';
+              uint64_t v = e.length; do { *--q = (char) ('0' + v % 10); v /= 10; } while (v); *--q = '\t';
+              v = e.offset; do { *--q = (char) ('0' + v % 10); v /= 10; } while (v); *--q = '\t';
+              v = e.key; do { *--q = (char) ('0' + v % 10); v /= 10; } while (v);
+              text.append(q, buf + sizeof(buf) - q);
+          }
+          o.write(text.data(), (std::streamsize) text.size()); }
+        // .dbtype is written LAST so that a crashed step is re-run by the workflow scripts (DBWriter.cpp:243)
+        { std::ofstream o(typePath, std::ios::binary); int32_t v = dbtype; o.write((const char *) &v, 4); if (!o.good()) { err = "cannot write " + typePath; return false; } }
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// flags (commons/Parameters.cpp:338-437): every flag of the module's list is accepted; values this implementation
+// cannot honour are rejected loudly rather than ignored
+// ---------------------------------------------------------------------------------------------------------------
+struct Flags {
+    std::vector<std::string> positional;
+    std::map<std::string, std::string> kv;
+    bool has(const std::string &k) const { return kv.count(k) != 0; }
+    std::string str(const std::string &k, const std::string &d) const { auto it = kv.find(k); return it == kv.end() ? d : it->second; }
+    long num(const std::string &k, long d) const { auto it = kv.find(k); return it == kv.end() ? d : strtol(it->second.c_str(), NULL, 10); }
+    double real(const std::string &k, double d) const { auto it = kv.find(k); return it == kv.end() ? d : strtod(it->second.c_str(), NULL); }
+};
+
+static const char *kBoolFlags[] = {"-a", "--add-self-matches", "--realign", "--wrapped-scoring", "--filter-hits", "--simple-best-hit", "--translate", "--use-all-table-starts",
+                                   "--create-lookup", "--add-orf-stop", "--report-fdr", "--db-output", NULL};
+
+inline bool parseFlags(int argc, const char **argv, const std::set<std::string> &allowed, size_t nPositional, Flags &f, std::string &err) {
+    for (int i = 0; i < argc; i++) {
+        std::string a = argv[i];
+        if (a.size() >= 2 && a[0] == '-' && !(a.size() > 1 && (isdigit((unsigned char) a[1])))) {
+            if (!allowed.count(a)) { err = "Unrecognized parameter \"" + a + "\""; return false; }      // fatal in the reference too (Parameters.cpp:1663-1666)
+            bool isBool = false;
+            for (const char **b = kBoolFlags; *b; b++) if (a == *b) isBool = true;
+            if (isBool) {
+                if (i + 1 < argc && (!strcmp(argv[i + 1], "0") || !strcmp(argv[i + 1], "1") || !strcmp(argv[i + 1], "true") || !strcmp(argv[i + 1], "false"))) {
+                    std::string v = argv[++i]; f.kv[a] = (v == "1" || v == "true") ? "1" : "0";
+                } else f.kv[a] = "1";
+            } else {
+                if (i + 1 >= argc) { err = "Missing argument for " + a; return false; }
+                f.kv[a] = argv[++i];
+            }
+        } else f.positional.push_back(a);
+    }
+    if (f.positional.size() != nPositional) { err = "expected " + std::to_string(nPositional) + " database arguments, got " + std::to_string(f.positional.size()); return false; }
+    return true;
+}
+
+// MultiParam "nucl:X,aa:Y" (commons/MultiParam.cpp:22-95): the amino-acid part
+inline std::string aaPart(const std::string &v) {
+    size_t p = v.find("aa:");
+    if (p == std::string::npos) return v;
+    size_t e = v.find(',', p);
+    return v.substr(p + 3, e == std::string::npos ? std::string::npos : e - p - 3);
+}
+
+inline bool requireValue(const Flags &f, const char *flag, const std::vector<std::string> &ok, std::string &err) {
+    if (!f.has(flag)) return true;
+    std::string v = aaPart(f.str(flag, ""));
+    for (const std::string &o : ok) if (v == o) return true;
+    err = std::string("unsupported value for ") + flag + ": " + v + " (the MI355X path implements SpacePHARER's search configuration only)";
+    return false;
+}
+
+inline char *u32toa(uint32_t v, char *p) { char t[12]; int n = 0; do { t[n++] = (char) ('0' + v % 10); v /= 10; } while (v); while (n) *p++ = t[--n]; return p; }
+inline char *i32toa(int32_t v, char *p) { if (v < 0) { *p++ = '-'; return u32toa((uint32_t) (-(int64_t) v), p); } return u32toa((uint32_t) v, p); }
+
+// DB key -> position: keys are usually dense (0 .. n-1), so a flat table; a sorted list otherwise
+struct KeyMap {
+    std::vector<uint32_t> lut; std::vector<std::pair<uint32_t, uint32_t>> sorted; bool dense = false;
+    void build(const std::vector<uint32_t> &keys) {
+        uint32_t mx = 0; for (uint32_t k : keys) mx = std::max(mx, k);
+        dense = !keys.empty() && (uint64_t) mx < 4ull * keys.size() + 1024;
+        if (dense) { lut.assign((size_t) mx + 1, 0xFFFFFFFFu); for (size_t i = 0; i < keys.size(); i++) lut[keys[i]] = (uint32_t) i; }
+        else { sorted.resize(keys.size()); for (size_t i = 0; i < keys.size(); i++) sorted[i] = {keys[i], (uint32_t) i}; std::sort(sorted.begin(), sorted.end()); }
+    }
+    bool find(uint32_t key, uint32_t &pos) const {
+        if (dense) { if (key >= lut.size() || lut[key] == 0xFFFFFFFFu) return false; pos = lut[key]; return true; }
+        auto it = std::lower_bound(sorted.begin(), sorted.end(), std::make_pair(key, 0u));
+        if (it == sorted.end() || it->first != key) return false;
+        pos = it->second; return true;
+    }
+};
+
+template <typename F>
+inline void parallelChunks(size_t n, int threads, F f) {      // f(chunkIndex, from, to), chunks in order
+    const size_t T = (size_t) std::max(1, std::min<int>(threads, (int) std::min<size_t>(n / 2048 + 1, 64)));
+    if (T == 1) { f(0, 0, n); return; }
+    std::vector<std::thread> pool; const size_t per = (n + T - 1) / T;
+    for (size_t t = 0; t < T; t++) pool.emplace_back(f, t, std::min(n, t * per), std::min(n, (t + 1) * per));
+    for (auto &th : pool) th.join();
+}
+inline size_t numChunks(size_t n, int threads) { return (size_t) std::max(1, std::min<int>(threads, (int) std::min<size_t>(n / 2048 + 1, 64))); }
+
+inline int fail(const std::string &e) { setLastError(e); fprintf(stderr, "%s\n", e.c_str()); return 1; }
+
+inline void appendAlnLine(std::string &out, const sp_alignment &r, const char *cigar, bool addBacktrace) {
+    char buf[256]; char *p = buf;
+    p = u32toa(r.db_key, p); *p++ = '\t';
+    p = i32toa(r.bit_score, p); *p++ = '\t';
+    // Util::fastSeqIdToBuffer (Util.cpp:278-306): for 1.0 the caller overwrites the third '0' with the tab
+    if (r.seq_id == 1.0) { memcpy(p, "1.00", 4); p += 4; }
+    else { *p++ = '0'; *p++ = '.'; if (r.seq_id < 0.10) *p++ = '0'; if (r.seq_id < 0.01) *p++ = '0'; p = i32toa((int) (r.seq_id * 1000), p); }
+    *p++ = '\t';
+    p += sprintf(p, "%.3E", r.evalue); *p++ = '\t';
+    p = i32toa(r.q_start, p); *p++ = '\t'; p = i32toa(r.q_end, p); *p++ = '\t'; p = i32toa((int) r.q_len, p); *p++ = '\t';
+    p = i32toa(r.db_start, p); *p++ = '\t'; p = i32toa(r.db_end, p); *p++ = '\t'; p = i32toa((int) r.db_len, p);
+    out.append(buf, p - buf);
+    if (addBacktrace) {          // Matcher::compressAlignment (Matcher.cpp:211-230)
+        out.push_back('\t');
+        char state = 'M'; size_t counter = 0; char nb[16];
+        for (const char *c = cigar; *c; c++) { if (*c != state) { char *e = u32toa((uint32_t) counter, nb); out.append(nb, e - nb); out.push_back(state); state = *c; counter = 1; } else counter++; }
+        char *e = u32toa((uint32_t) counter, nb); out.append(nb, e - nb); out.push_back(state);
+    }
+    out.push_back('\n');
+}
+
+inline bool alnLess(const sp_alignment &a, const sp_alignment &b) {      // Matcher::compareHits, Matcher.h:156-167
+    if (a.evalue != b.evalue) return a.evalue < b.evalue;
+    if (a.bit_score != b.bit_score) return a.bit_score > b.bit_score;
+    if (a.db_len != b.db_len) return a.db_len < b.db_len;
+    return a.db_key < b.db_key;
+}
+
+
+}  // namespace sp

@@ -366,6 +366,9 @@ static const AlpEntry kAlpTable[] = {
                            "0x1.c2f26d4420b5cp-3", "0x1.ade01ae0e75ap-6", "0x1.7a804890a2d29p-3", "0x1.b672cb9380acdp+0", "0x1.7674244e3b2f3p-3", "0x1.c8a96ebe530cp+0"}},
     {"VTML40.out", -1, -1, {"0x1.614cc810f4edcp-2", "0x1.15f37f76ce8e9p-2", "0x1.c47089cdcc2e1p-3", "0x0p+0", "0x1.dbef207886873p-3", "0x0p+0",
                             "0x1.c47089cdcc2e1p-3", "0x0p+0", "0x1.dbef207886873p-3", "0x0p+0", "0x1.dbef207886873p-3", "0x0p+0"}},
+    // proteinaln2nucl: NucleotideMatrix(nucleotide.out, 1.0, 0.0), gap open 10, extend 2 (tests/golden/examples.json.gz: info.nucl_evalue.alp)
+    {"nucleotide.out", 10, 2, {"0x1.4469d1f7ec6c4p-1", "0x1.af9f955180647p-2", "0x1.5f922abcb8de4p-1", "0x1.838e08750576p-3", "0x1.6cacd8a69e238p-1", "0x1.73f45a27d096ep+1",
+                               "0x1.5f922abcb8de4p-1", "0x1.838e08750576p-3", "0x1.6cacd8a69e238p-1", "0x1.73f45a27d096ep+1", "0x1.6cd5a205f28f5p-1", "0x1.72ffa1ebd61p+1"}},
 };
 
 bool Evaluer::init(const std::string &matrixName, int gapOpen, int gapExtend, uint64_t dbRes, std::string &err) {

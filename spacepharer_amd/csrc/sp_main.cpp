@@ -1,4 +1,5 @@
-// Front-end binary: `spacepharer-amd <module> <args...>` with module in {prefilter, align, rescorediagonal}.
+// Front-end binary: `spacepharer-amd <module> <args...>` with module in {prefilter, align, rescorediagonal} and the set-level
+// steps around them (extractorfs ... summarizeresults).
 // Point $MMSEQS at a wrapper that sends these three module names here and every other one to the stock
 // spacepharer binary, and the unmodified workflow scripts (lib/mmseqs/data/workflow/blastp.sh:33,41,48) land
 // in the MI355X implementation.
@@ -9,8 +10,12 @@
 #include "../../include/spacepharer_amd.h"
 
 int main(int argc, const char **argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s <prefilter|align|rescorediagonal> <args>\n", argv[0]); return 1; }
+    if (argc < 2) { fprintf(stderr, "usage: %s <prefilter|align|rescorediagonal|extractorfs|translatenucs|reverseseqbycodon|proteinaln2nucl|combineprotnuclaln|besthitperset|mergeresultsbyset|combinescore|filtermatchbyfdr|summarizeresults> <args>\n", argv[0]); return 1; }
     int rc;
+    // the set-level steps are host-only: no device is touched for them
+    struct HostModule { const char *name; int (*run)(int, const char **); };
+    static const HostModule hostModules[] = {{"extractorfs", sp_extractorfs_run}, {"translatenucs", sp_translatenucs_run}, {"reverseseqbycodon", sp_reverseseqbycodon_run}, {"proteinaln2nucl", sp_proteinaln2nucl_run}, {"combineprotnuclaln", sp_combineprotnuclaln_run}, {"besthitperset", sp_besthitperset_run}, {"mergeresultsbyset", sp_mergeresultsbyset_run}, {"combinescore", sp_combinescore_run}, {"filtermatchbyfdr", sp_filtermatchbyfdr_run}, {"summarizeresults", sp_summarizeresults_run}};
+    for (const HostModule &m : hostModules) if (!strcmp(argv[1], m.name)) { rc = m.run(argc - 2, argv + 2); if (rc != 0) fprintf(stderr, "%s\n", sp_last_error()); return rc; }
     // SP_GPUS=N: the module starts one worker process per GPU (this binary again, with SP_PART set); the parent only merges
     // the parts and has no use for a device
     const char *gpus = getenv("SP_GPUS");

@@ -1,0 +1,734 @@
+// Set-level steps around the search hot path: host-side text / integer transformations on
+// MMseqs2 DB triples, as module drop-ins (same argv as the reference modules) and as one in-memory pipeline fed with the
+// alignment records the device delivers (sp_ctx_set_scores, sp_api.cpp).  They replace the bodies of
+//   lib/mmseqs/src/util/extractorfs.cpp:18-160            (extractorfs; ORF finder: commons/Orf.cpp:150-330)
+//   lib/mmseqs/src/util/translatenucs.cpp:16-115          (translatenucs; codon tables: commons/TranslateNucl.h:334-503)
+//   src/util/ReverseSeqByCodon.cpp:13-62                  (reverseseqbycodon)
+//   lib/mmseqs/src/util/proteinaln2nucl.cpp:13-205        (proteinaln2nucl)
+//   src/util/CombineProtNuclAln.cpp:13-106                (combineprotnuclaln)
+//   lib/mmseqs/src/multihit/besthitperset.cpp:10-129 + Aggregation.cpp:24-91   (besthitperset)
+//   lib/mmseqs/src/util/mergeresultsbyset.cpp:10-58       (mergeresultsbyset)
+//   src/util/CombineScore.cpp:12-113                      (combinescore)
+//   src/util/FilterMatchbyFdr.cpp:13-264                  (filtermatchbyfdr)
+//   src/util/SummarizeResults.cpp:13-197                  (summarizeresults, without a taxonomy DB)
+// No kernels here: these steps move a few bytes per hit; what they gain on the MI355X path is that they can run on the
+// records in host memory without the DB round trips in between.
+#include "sp_sets.h"
+
+#include <cfloat>
+#include <climits>
+#include <cmath>
+
+#include "sp_db.h"
+#include "sp_host.h"
+
+namespace sp {
+namespace sets {
+
+// ------------------------------------------------------------------------------------------------------------------
+// small text helpers: the reference's number formats
+// ------------------------------------------------------------------------------------------------------------------
+static std::string fmtE(double x) { char b[40]; const int n = snprintf(b, sizeof(b), "%.3E", x); return std::string(b, (size_t) n); }      // SSTR(double), Util.cpp:713-718
+static inline bool isWs(char c) { return c == ' ' || c == '\t'; }
+// Util::getWordsOfLine (Util.h:232-246): word starts of one line; words[n] = the line end
+static size_t words(const char *p, const char **w, size_t maxW) {
+    size_t n = 0;
+    while (*p != '\n' && *p != '\0') {
+        while (isWs(*p)) p++;
+        w[n++] = p;
+        if (n >= maxW) return n;
+        while (*p != '\n' && *p != '\0' && !isWs(*p)) p++;
+    }
+    if (n < maxW) w[n] = p;
+    return n;
+}
+static const char *skipLine(const char *p) { while (*p != '\n' && *p != '\0') p++; return *p == '\n' ? p + 1 : p; }
+static unsigned long atou(const char *p) { unsigned long v = 0; while (*p >= '0' && *p <= '9') v = v * 10 + (unsigned long) (*p++ - '0'); return v; }
+static long atoiS(const char *p) { bool neg = *p == '-'; if (neg || *p == '+') p++; long v = (long) atou(p); return neg ? -v : v; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// ORFs (commons/Orf.cpp)
+// ------------------------------------------------------------------------------------------------------------------
+// IUPAC complement; anything else -> '.'  (Orf.cpp:46-50)
+static char complementOf(unsigned char c) {
+    static const char *upper = "TVGH..CD..M.KN...YSAABW.R";      // 'A' .. 'Y'
+    if (c >= 'A' && c <= 'Y') return upper[c - 'A'];
+    if (c >= 'a' && c <= 'y') { const char u = upper[c - 'a']; return u == '.' ? '.' : (char) (u | 0x20); }
+    return '.';
+}
+
+void OrfFinder::setSequence(const char *seq, size_t L) {
+    // Orf::setSequence (Orf.cpp:118-148): 'u' -> 't' (the 'U' -> 'T' assignment is overwritten there and has no effect);
+    // both strands are followed by a few CHAR_MAX sentinels so that the last codons read "incomplete"
+    len = L;
+    fwd.assign(L + 8, (char) CHAR_MAX); rev.assign(L + 8, (char) CHAR_MAX);
+    for (size_t i = 0; i < L; i++) fwd[i] = seq[i] == 'u' ? 't' : seq[i];
+    for (size_t i = 0; i < L; i++) { const char c = complementOf((unsigned char) fwd[L - 1 - i]); rev[i] = c == '.' ? 'N' : c; }
+}
+
+static inline bool codonIs(const char *c, const char *x) { return c[0] == x[0] && c[1] == x[1] && c[2] == x[2]; }
+
+// Orf::findForward (Orf.cpp:200-330), translation table 1: stop codons TAA TAG TGA, start codon ATG
+void OrfFinder::scan(const std::string &s, int strand, size_t minLen, size_t maxLen, size_t maxGaps, unsigned frames, unsigned startMode, std::vector<OrfLoc> &out) const {
+    if (len < 3) return;
+    bool inside[3] = {true, true, true}, hasStart[3] = {false, false, false};
+    size_t gaps[3] = {0, 0, 0}, count[3] = {0, 0, 0}, from[3] = {0, 1, 2};
+    auto incomplete = [](const char *c) { return c[0] == CHAR_MAX || c[1] == CHAR_MAX || c[2] == CHAR_MAX; };
+    for (size_t i = 0; i < len - 2; i += 3) {
+        for (size_t pos = i; pos < i + 3; pos++) {
+            char c[3];
+            for (int k = 0; k < 3; k++) c[k] = s[pos + k] == CHAR_MAX ? (char) CHAR_MAX : (char) (s[pos + k] & (char) ~0x20);
+            const size_t fr = pos % 3;
+            if (!(frames & (1u << fr))) continue;
+            const bool last = !incomplete(c) && incomplete(s.data() + pos + 3);
+            const bool isStartCodon = codonIs(c, "ATG");
+            bool start;
+            if (startMode == 0) start = !inside[fr] && isStartCodon;            // START_TO_STOP
+            else if (startMode == 1) start = !inside[fr];                      // ANY_TO_STOP
+            else start = isStartCodon;                                         // LAST_START_TO_STOP
+            if (start) { inside[fr] = true; hasStart[fr] = true; from[fr] = pos; gaps[fr] = 0; count[fr] = 0; }
+            const bool stop = codonIs(c, "TAA") || codonIs(c, "TAG") || codonIs(c, "TGA");
+            if (inside[fr]) {
+                if (!stop) count[fr]++;
+                if (c[0] == 'N' || complementOf((unsigned char) c[0]) == '.' || c[1] == 'N' || complementOf((unsigned char) c[1]) == '.' ||
+                    c[2] == 'N' || complementOf((unsigned char) c[2]) == '.') gaps[fr]++;
+            }
+            if (inside[fr] && (stop || last)) {
+                inside[fr] = false;
+                if (count[fr] == 0 && stop) continue;
+                const size_t to = (last && !stop) ? pos + 2 : pos - 1;
+                if (gaps[fr] > maxGaps || count[fr] > maxLen || count[fr] < minLen) continue;
+                out.push_back(OrfLoc{from[fr], to, !hasStart[fr], !stop, strand});
+            }
+        }
+    }
+}
+
+void OrfFinder::findAll(size_t minLen, size_t maxLen, size_t maxGaps, unsigned fwdFrames, unsigned revFrames, unsigned startMode, std::vector<OrfLoc> &out) const {
+    if (fwdFrames) scan(fwd, 1, minLen, maxLen, maxGaps, fwdFrames, startMode, out);
+    if (revFrames) scan(rev, -1, minLen, maxLen, maxGaps, revFrames, startMode, out);
+}
+
+// Orf::writeOrfHeader (Orf.cpp:437-457)
+std::string orfHeader(uint32_t key, size_t from, size_t to, bool incStart, bool incEnd) {
+    char b[96]; char *p = u32toa(key, b); *p++ = '\t';
+    p = u32toa((uint32_t) from, p); *p++ = from < to ? '+' : '-';
+    p = i32toa(abs((int) from - (int) to), p);
+    const int complete = (incStart ? 1 : 0) | (incEnd ? 2 : 0);
+    if (complete) { *p++ = '\t'; p = i32toa(complete, p); }
+    *p++ = '\n';
+    return std::string(b, (size_t) (p - b));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// translation (commons/TranslateNucl.h): a codon of IUPAC letters translates to the residue all its expansions agree on,
+// B / Z / J for Asx / Glx / Xle, X otherwise (and for letters outside the IUPAC alphabet); a lower-case base gives a
+// lower-case residue
+// ------------------------------------------------------------------------------------------------------------------
+struct CodonTable {
+    unsigned char base[256]; char aa[16][16][16];
+    CodonTable() {
+        memset(base, 0, sizeof(base));
+        const char *letters = "-ACMGRSVTWYHKDBN";      // ncbi4na: bit 0 = A, 1 = C, 2 = G, 3 = T
+        for (int i = 0; i < 16; i++) { base[(unsigned char) letters[i]] = (unsigned char) i; base[(unsigned char) tolower(letters[i])] = (unsigned char) i; }
+        base[(unsigned char) 'U'] = base[(unsigned char) 'u'] = 8; base[(unsigned char) 'X'] = base[(unsigned char) 'x'] = 15;
+        for (int i = 0; i < 16; i++) base[i] = (unsigned char) i;
+        const char *code = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";      // table 1, TCAG order
+        const int tcag[9] = {0, 2, 1, 0, 3, 0, 0, 0, 0};      // bit value -> position in TCAG
+        const int bits[4] = {1, 2, 4, 8};
+        for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) for (int k = 0; k < 16; k++) {
+            char a = 0;
+            for (int x : bits) if (x & i) for (int y : bits) if (y & j) for (int z : bits) if (z & k) {
+                const char ch = code[16 * tcag[x] + 4 * tcag[y] + tcag[z]];
+                if (!a) a = ch;
+                else if (a != ch) {
+                    if ((a == 'B' || a == 'D' || a == 'N') && (ch == 'D' || ch == 'N')) a = 'B';
+                    else if ((a == 'Z' || a == 'E' || a == 'Q') && (ch == 'E' || ch == 'Q')) a = 'Z';
+                    else if ((a == 'J' || a == 'I' || a == 'L') && (ch == 'I' || ch == 'L')) a = 'J';
+                    else a = 'X';
+                }
+            }
+            aa[i][j][k] = a ? a : 'X';
+        }
+    }
+};
+static const CodonTable &codonTable() { static const CodonTable t; return t; }
+
+void translate(const char *nucl, size_t len, char *aa) {
+    const CodonTable &t = codonTable();
+    for (size_t i = 0; i + 2 < len; i += 3) {
+        const unsigned char a = (unsigned char) nucl[i], b = (unsigned char) nucl[i + 1], c = (unsigned char) nucl[i + 2];
+        const char r = t.aa[t.base[a]][t.base[b]][t.base[c]];
+        aa[i / 3] = (islower(a) || islower(b) || islower(c)) ? (char) tolower(r) : r;
+    }
+}
+
+// translatenucs' length rule (translatenucs.cpp:77-92): data = the entry ("...\n\0"), entryLen includes the NUL; returns the
+// number of nucleotides to translate, 0 = skip the entry
+size_t translatableLength(const char *data, size_t entryLen, size_t maxSeqLen) {
+    size_t length = entryLen - 1;
+    if ((data[length] != '\n' && length % 3 != 0) && (data[length - 1] == '\n' && (length - 1) % 3 != 0)) length -= length % 3;
+    if (length < 3) return 0;
+    if (length > 3 * maxSeqLen) length = 3 * maxSeqLen;
+    return length;
+}
+
+// ReverseSeqByCodon.cpp:39-52: codons in reverse order, every codon read forward; a trailing partial codon is dropped
+void reverseByCodon(const char *seq, size_t L, std::string &out) {
+    out.clear();
+    for (size_t done = 0; done + 3 <= L; done += 3) out.append(seq + (L - done - 3), 3);
+    out.push_back('\n');
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// nucleotide scores + statistics (NucleotideMatrix.cpp, SubstitutionMatrix::createAsciiSubMat)
+// ------------------------------------------------------------------------------------------------------------------
+bool NuclScorer::init(const std::string &matrixName, int gapOpen_, int gapExtend_, uint64_t dbResidues, std::string &err) {
+    std::string base = matrixName; const size_t slash = base.find_last_of("/\\"); if (slash != std::string::npos) base = base.substr(slash + 1);
+    const size_t colon = base.find(".out:"); if (colon != std::string::npos) base = base.substr(0, colon + 4);
+    if (base != "nucleotide.out") { err = "proteinaln2nucl: only the embedded nucleotide.out matrix is supported, got " + matrixName; return false; }
+    // lib/mmseqs/data/nucleotide.out: letters A C T G X, background 0.2499975 x 4 + 0.00001, lambda 0.6337314, match 2, anything else -3
+    const int n = 5; const double lambda = 0.6337314;
+    double pBack[n] = {0.2499975, 0.2499975, 0.2499975, 0.2499975, 0.00001}, raw[n][n], prob[n][n];
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) raw[i][j] = (i == j && i < 4) ? 2.0 : -3.0;
+    for (int i = 0; i < n - 1; i++) pBack[i] = pBack[i] * (1.0 - pBack[n - 1]);                       // SubstitutionMatrix.cpp:395-399 (no positive X score)
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) prob[i][j] = std::exp(lambda * raw[i][j]) * pBack[i] * pBack[j];
+    double pb[n];                                                                                   // BaseMatrix::generateSubMatrix, bit factor 1.0, bias 0.0
+    for (int i = 0; i < n; i++) { pb[i] = 0; for (int j = 0; j < n; j++) pb[i] += prob[i][j]; }
+    pb[n - 1] = 1E-5;
+    int sub[n][n];
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) { const double v = 1.0 * std::log2(prob[i][j] / (pb[i] * pb[j])) + 0.0; sub[i][j] = (short) ((v < 0.0) ? v - 0.5 : v + 0.5); }
+    // NucleotideMatrix::setupLetterMapping (NucleotideMatrix.cpp:18-63): classes A=0 C=1 T=2 G=3 X=4
+    for (int c = 0; c < 256; c++) {
+        int cls;
+        switch (c < 128 ? toupper(c) : c) {
+            case 'A': cls = 0; break; case 'C': case 'M': case 'Y': case 'H': cls = 1; break;
+            case 'T': case 'U': case 'W': cls = 2; break;
+            case 'G': case 'K': case 'B': case 'D': case 'V': case 'R': case 'S': cls = 3; break;
+            default: cls = 4; break;
+        }
+        cls_[c] = (unsigned char) cls;
+    }
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) score_[i][j] = sub[i][j];
+    gapOpen = gapOpen_; gapExtend = gapExtend_;
+    return ev.init("nucleotide.out", gapOpen_, gapExtend_, dbResidues, err);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// f1  proteinaln2nucl: one alignment line of a protein search lifted to the nucleotide ORFs (proteinaln2nucl.cpp:99-187)
+// ------------------------------------------------------------------------------------------------------------------
+bool proteinLineToNucl(const char *line, const NuclScorer &sc, const char *qNuc, uint32_t qNucLen, bool qStartCodon, const char *tNuc, uint32_t tNucLen, bool tStartCodon,
+                       std::string &out, std::string &err) {
+    const char *w[16]; const size_t cols = words(line, w, 16);
+    if (cols < 11) { err = "proteinaln2nucl: this module needs alignment records with a backtrace"; return false; }
+    sp_alignment r; memset(&r, 0, sizeof(r));
+    r.db_key = (uint32_t) atou(w[0]);
+    long qs = atoiS(w[4]), qe = atoiS(w[5]), ts = atoiS(w[7]), te = atoiS(w[8]);
+    if ((qStartCodon && qs == 0) || (tStartCodon && ts == 0)) { err = "proteinaln2nucl: alignment contains an unalignable character"; return false; }
+    ts = ts * 3 + (tStartCodon ? -3 : 0); te = te * 3 + 2 + (tStartCodon ? -3 : 0);
+    qs = qs * 3 + (qStartCodon ? -3 : 0); qe = qe * 3 + 2 + (qStartCodon ? -3 : 0);
+    size_t ids = 0, alnLen = 0; long qPos = qs, tPos = ts; int score = 0;
+    std::string bt; char nb[16];
+    for (const char *p = w[10]; *p != '\n' && *p != '\0' && !isWs(*p); p++) {
+        int cnt = 0;
+        if (*p >= '0' && *p <= '9') { cnt = (int) atou(p); while (*p >= '0' && *p <= '9') p++; }
+        const char op = *p;
+        if (op == 'M') {
+            for (int b = 0; b < cnt * 3; b++) { const unsigned char a = (unsigned char) qNuc[qPos], c = (unsigned char) tNuc[tPos]; ids += (a == c); score += sc.score(a, c); qPos++; tPos++; }
+        } else if (op == 'D') { tPos += cnt * 3; score -= sc.gapOpen + ((cnt - 1) * 3) * sc.gapExtend; }
+        else if (op == 'I') { qPos += cnt * 3; score -= sc.gapOpen + ((cnt - 1) * 3) * sc.gapExtend; }
+        else { if (op == '\n' || op == '\0') break; continue; }
+        alnLen += (size_t) cnt * 3;
+        char *e = i32toa(cnt * 3, nb); bt.append(nb, (size_t) (e - nb)); bt.push_back(op);
+    }
+    r.bit_score = (int) sc.ev.bitScore(score);      // `res.score = evaluer.computeBitScore(score)`: a double assigned to an int (truncation, no rounding)
+    r.evalue = sc.ev.evalue(score, qNucLen);
+    r.seq_id = (float) ids / (float) alnLen;
+    r.q_start = (int) qs; r.q_end = (int) qe; r.q_len = qNucLen; r.db_start = (int) ts; r.db_end = (int) te; r.db_len = tNucLen;
+    appendAlnLine(out, r, "", false);
+    out.pop_back(); out.push_back('\t'); out += bt; out.push_back('\n');      // resultToBuffer(..., compress = false): the run-length string as it is
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// f2  combineprotnuclaln (CombineProtNuclAln.cpp:55-97): protein lines get the nucleotide identity and the combined E-value
+// ------------------------------------------------------------------------------------------------------------------
+bool combineProtNucl(const char *prot, const char *nucl, std::string &out, std::string &err) {
+    const char *pe[16], *ne[16];
+    while (*prot != '\0') {
+        if (words(prot, pe, 16) < 10) { err = "combineprotnuclaln: invalid alignment result record"; return false; }
+        const char *next = skipLine(prot);
+        const unsigned long target = atou(pe[0]);
+        const double protEval = strtod(pe[3], NULL);
+        double updated = FLT_MAX, nuclSeqId = 0;
+        for (const char *cur = nucl; *cur != '\0';) {
+            if (atou(cur) != target) { cur = skipLine(cur); continue; }
+            if (words(cur, ne, 16) < 10) { err = "combineprotnuclaln: invalid alignment result record"; return false; }
+            cur = skipLine(cur);
+            nuclSeqId = strtod(ne[2], NULL);
+            const double nuclEval = strtod(ne[3], NULL);
+            const double mean = std::log(protEval) * 0.5 + std::log(nuclEval) * 0.5;
+            updated = (mean < std::log(nuclEval)) ? std::exp(mean) : nuclEval;
+        }
+        out.append(pe[0], (size_t) (pe[2] - pe[0]));
+        out += fmtE(nuclSeqId); out.push_back('\t');
+        out += fmtE(updated); out.push_back('\t');
+        out.append(pe[4], (size_t) ((next - 1) - pe[4]));
+        out.push_back('\n');
+        prot = next;
+    }
+    return true;
+}
+
+// Aggregation::buildMap (Aggregation.cpp:24-45): lines grouped by the set of their first column, sets ascending, lines in order
+static bool groupBySet(const char *data, const SetLookup &memberToSet, std::map<uint32_t, std::vector<std::vector<std::string>>> &groups, std::string &err) {
+    while (*data != '\0') {
+        const char *next = skipLine(data);
+        size_t n = (size_t) (next - data); if (n && data[n - 1] == '\n') n--;
+        if (n) {
+            std::vector<std::string> cols; size_t at = 0;
+            const std::string line(data, n);
+            for (;;) { const size_t t = line.find('\t', at); if (t == std::string::npos) { cols.push_back(line.substr(at)); break; } cols.push_back(line.substr(at, t - at)); at = t + 1; }
+            uint32_t set;
+            if (!memberToSet.find((uint32_t) atou(cols[0].c_str()), set)) { err = "invalid target database key " + cols[0]; return false; }
+            groups[set].push_back(cols);
+        }
+        data = next;
+    }
+    return true;
+}
+
+// besthitperset (besthitperset.cpp:29-115): per target set the line with the best E-value; column 1 becomes the log of the
+// set-corrected P-value.  simple = --simple-best-hit (predictmatch: 1)
+bool bestHitPerSet(const char *entry, const SetLookup &memberToSet, const SetLookup &setSize, bool simple, std::string &out, std::string &err) {
+    std::map<uint32_t, std::vector<std::vector<std::string>>> groups;
+    if (!groupBySet(entry, memberToSet, groups, err)) return false;
+    for (auto &g : groups) {
+        uint32_t nGenes;
+        if (!setSize.find(g.first, nGenes)) { err = "invalid target size database key " + std::to_string(g.first); return false; }
+        const std::vector<std::vector<std::string>> &lines = g.second;
+        double bestScore = -DBL_MAX, second = -DBL_MAX, bestEval = DBL_MAX; const std::vector<std::string> *best = nullptr;
+        const bool single = simple || lines.size() < 2;
+        for (const std::vector<std::string> &l : lines) {
+            const double eval = strtod(l.size() > 3 ? l[3].c_str() : "", NULL);
+            double pval = eval / nGenes; if (pval == 0) pval = DBL_MIN;
+            const double score = -std::log(pval);
+            if (single) { if (bestEval > eval) { bestEval = eval; best = &l; } }
+            else if (score >= bestScore) { second = bestScore; bestScore = score; best = &l; }
+            else if (score > second) second = score;
+        }
+        double logP;
+        if (single) {
+            if (bestEval == 0) logP = std::log(DBL_MIN);
+            else if (bestEval > 0 && bestEval < 10e-4) logP = std::log(bestEval);
+            else logP = std::log(1 - std::exp(-bestEval));
+        } else logP = second - bestScore;
+        if (best) for (size_t i = 0; i < best->size(); i++) { out += (i == 1) ? fmtE(logP) : (*best)[i]; if (i + 1 != best->size()) out.push_back('\t'); }
+        out.push_back('\n');
+    }
+    return true;
+}
+
+// combinescore (CombineScore.cpp:41-98): per target set the truncated-product style score over a query set's best hits
+bool combineScore(const char *entry, uint32_t querySetSize, const SetLookup &memberToSet, std::string &out, std::string &err) {
+    std::map<uint32_t, std::vector<std::vector<std::string>>> groups;
+    if (!groupBySet(entry, memberToSet, groups, err)) return false;
+    const double logThr = std::log(1.0 / (querySetSize + 1));
+    char nb[16];
+    for (auto &g : groups) {
+        double minLogP = 0, sumLogP = 0, minSeqId = 0, sumSeqId = 0; size_t k = 0;
+        for (const std::vector<std::string> &l : g.second) {
+            const double logP = strtod(l.size() > 1 ? l[1].c_str() : "", NULL), seqId = strtod(l.size() > 2 ? l[2].c_str() : "", NULL);
+            if (logP < minLogP) { minLogP = (logP == 0) ? logP : -logP; minSeqId = seqId; }
+            if (logP < logThr) { sumLogP -= logP - logThr; sumSeqId += seqId; k++; }
+        }
+        char *e = u32toa(g.first, nb); out.append(nb, (size_t) (e - nb)); out.push_back('\t');
+        if (k == 0) { out += fmtE(minLogP); out.push_back('\t'); out += fmtE(minSeqId); }
+        else { out += fmtE(sumLogP - logThr); out.push_back('\t'); out += fmtE(sumSeqId / k); }
+        out.push_back('\n');
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// f4  filtermatchbyfdr (FilterMatchbyFdr.cpp:49-215): score threshold at a false-discovery rate from target and control scores
+// ------------------------------------------------------------------------------------------------------------------
+void fdrThreshold(std::vector<double> P, std::vector<double> N, bool haveControl, double cutoff, bool reportFdr, FdrResult &r) {
+    std::sort(P.begin(), P.end(), [](double a, double b) { return a > b; });
+    if (P.empty()) P.push_back(0);
+    r = FdrResult();
+    if (!haveControl) {
+        if (reportFdr) { double s = DBL_MIN; for (double p : P) if (s < p) { r.uniqueScores.push_back(p); r.fdr.push_back(0.0); s = p; } }
+        r.threshold = P.back();
+        return;
+    }
+    std::sort(N.begin(), N.end(), [](double a, double b) { return a > b; });
+    std::vector<double> x, y;
+    double cur = DBL_MAX; size_t nc = 0;
+    for (size_t pc = 0; pc < P.size(); pc++) {
+        if (P[pc] < cur) {
+            cur = P[pc];
+            while (nc < N.size() && cur < N[nc]) nc++;
+            r.uniqueScores.push_back(cur);
+            y.push_back(1.0 * pc / P.size());
+            x.push_back(1.0 * (nc + 0.5) / (N.size() + 1));
+        }
+    }
+    x.push_back(1.0); y.push_back(1.0);
+    std::vector<double> slopes; std::vector<size_t> hull;
+    for (size_t i = 0; i < x.size() - 1;) {
+        size_t jMax = i + 1; double best = 0;
+        for (size_t j = i + 1; j < x.size(); j++) { const double s = 1.0 * (y[j] - y[i]) / (x[j] - x[i]); if (s >= best) { jMax = j; best = s; } }
+        i = jMax; slopes.push_back(best); hull.push_back(jMax);
+    }
+    const double pi0 = (slopes.end()[-2] + slopes.end()[-1]) / 2;      // (a single-segment hull reads the element in front of the vector in the reference too)
+    size_t i = 0; double fdr = 0;
+    if (x[hull.back()] * pi0 / y[hull.back()] >= cutoff) while (fdr <= cutoff) { fdr = x[hull[i]] * pi0 / y[hull[i]]; i++; }
+    if (i < 2) r.threshold = P.back();
+    else {
+        size_t j = hull[i - 2];
+        double TPFP = y[j], FP = x[j] * pi0;
+        fdr = 0;
+        while (fdr <= cutoff) { j++; const double dx = x[j] - x[j - 1]; TPFP += dx * slopes[i - 1]; FP += dx * pi0; fdr = FP / TPFP; }
+        r.threshold = r.uniqueScores[j];
+    }
+    if (reportFdr) {
+        for (size_t j = 0; j < hull[0]; j++) r.fdr.push_back(0.0);
+        for (size_t h = 0; h + 1 < hull.size(); h++) {
+            double TPFP = y[hull[h]], FP = x[hull[h]] * pi0;
+            for (size_t j = hull[h]; j < hull[h + 1]; j++) {
+                if (std::isinf(slopes[h])) r.fdr.push_back(x[hull[h]] * pi0 / y[hull[h]]);
+                else { TPFP += (x[j] - x[j - 1]) * slopes[h]; FP += (x[j] - x[j - 1]) * pi0; r.fdr.push_back(FP / TPFP); }
+            }
+        }
+    }
+}
+
+static bool collectScores(const Db &db, std::vector<double> &v, std::string &err) {
+    const char *w[8];
+    for (size_t i = 0; i < db.entries.size(); i++)
+        for (const char *p = db.ptr(i); *p != '\0'; p = skipLine(p)) {
+            if (words(p, w, 8) < 2) { err = "invalid result record"; return false; }
+            v.push_back(strtod(w[1], NULL));
+        }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// module drivers
+// ------------------------------------------------------------------------------------------------------------------
+static const std::set<std::string> kCommon = {"--threads", "--compressed", "-v"};
+static std::set<std::string> with(std::initializer_list<const char *> more) { std::set<std::string> s = kCommon; for (const char *m : more) s.insert(m); return s; }
+
+static bool loadDb(const std::string &path, Db &db, std::string &err) {
+    if (!db.load(path, err)) return false;
+    if (db.compressed()) { err = path + ": compressed DBs are not supported (the workflows pass --compressed 0)"; return false; }
+    return true;
+}
+static bool uncompressedOnly(const Flags &f, std::string &err) { return requireValue(f, "--compressed", {"0"}, err); }
+
+bool SetLookup::fromDb(const Db &db) {
+    std::vector<uint32_t> keys(db.entries.size()); values.resize(db.entries.size());
+    for (size_t i = 0; i < db.entries.size(); i++) { keys[i] = db.entries[i].key; values[i] = (uint32_t) atou(db.ptr(i)); }
+    index.build(keys);
+    return true;
+}
+bool SetLookup::find(uint32_t key, uint32_t &v) const { uint32_t pos; if (!index.find(key, pos)) return false; v = values[pos]; return true; }
+void SetLookup::fromArrays(const std::vector<uint32_t> &keys, const std::vector<uint32_t> &vals) { values = vals; index.build(keys); }
+
+// entries of `db` in ascending key order (the order DBReader::getId / NOSORT readers present them in)
+static std::vector<size_t> byKey(const Db &db) {
+    std::vector<size_t> o(db.entries.size());
+    for (size_t i = 0; i < o.size(); i++) o[i] = i;
+    std::sort(o.begin(), o.end(), [&](size_t a, size_t b) { return db.entries[a].key < db.entries[b].key; });
+    return o;
+}
+
+int runExtractOrfs(int argc, const char **argv) {
+    Flags f; std::string err;
+    if (!parseFlags(argc, argv, with({"--min-length", "--max-length", "--max-gaps", "--contig-start-mode", "--contig-end-mode", "--orf-start-mode", "--forward-frames",
+                                      "--reverse-frames", "--translation-table", "--translate", "--use-all-table-starts", "--id-offset", "--create-lookup"}), 2, f, err))
+        return fail("extractorfs: " + err);
+    if (!uncompressedOnly(f, err) || !requireValue(f, "--translation-table", {"1"}, err) || !requireValue(f, "--translate", {"0"}, err) ||
+        !requireValue(f, "--use-all-table-starts", {"0"}, err) || !requireValue(f, "--id-offset", {"0"}, err))
+        return fail("extractorfs: " + err);
+    const size_t minLen = (size_t) f.num("--min-length", 30), maxLen = (size_t) f.num("--max-length", 32734), maxGaps = (size_t) f.num("--max-gaps", INT_MAX);
+    const int contigStart = (int) f.num("--contig-start-mode", 2), contigEnd = (int) f.num("--contig-end-mode", 2);
+    const unsigned startMode = (unsigned) f.num("--orf-start-mode", 1);
+    if (startMode == 1 && contigStart < 2) return fail("extractorfs: orf-start-mode 1 can only go with contig-start-mode 2");
+    auto frames = [&](const char *flag) { unsigned r = 0; const std::string v = f.str(flag, "1,2,3"); for (int k = 1; k <= 3; k++) if (("," + v + ",").find("," + std::to_string(k) + ",") != std::string::npos) r |= 1u << (k - 1); return r; };
+    const unsigned fwdFrames = frames("--forward-frames"), revFrames = frames("--reverse-frames");
+    Db in;
+    if (!loadDb(f.positional[0], in, err)) return fail("extractorfs: " + err);
+    // lookup of the contigs (key, name, set) for --create-lookup 1
+    std::map<uint32_t, std::string> setOf;
+    const bool createLookup = f.num("--create-lookup", 0) != 0;
+    if (createLookup) {
+        std::ifstream lk(f.positional[0] + ".lookup");
+        if (!lk.good()) return fail("extractorfs: cannot open " + f.positional[0] + ".lookup");
+        std::string line;
+        while (std::getline(lk, line)) { const size_t a = line.find('\t'), b = line.rfind('\t'); if (a == std::string::npos || b == a) continue; setOf[(uint32_t) atou(line.c_str())] = line.substr(b + 1); }
+    }
+    // contigs in key order; ORFs are numbered 0, 1, ... in (contig key, discovery) order (DBWriter::createRenumberedDB, DBWriter.cpp:681-739)
+    DbWriter seqW, hdrW; seqW.path = f.positional[1]; seqW.dbtype = 1; hdrW.path = f.positional[1] + "_h"; hdrW.dbtype = 12;
+    std::string lookup; uint32_t next = 0; OrfFinder orf; std::vector<OrfLoc> locs; char nb[16];
+    for (size_t i : byKey(in)) {
+        const uint32_t key = in.entries[i].key; const size_t L = (size_t) in.seqLen(i);
+        if (L < 3) continue;
+        orf.setSequence(in.ptr(i), L);
+        locs.clear();
+        orf.findAll(minLen, maxLen, maxGaps, fwdFrames, revFrames, startMode, locs);
+        for (const OrfLoc &loc : locs) {
+            if (contigStart < 2 && (int) loc.incStart == contigStart) continue;
+            if (contigEnd < 2 && (int) loc.incEnd == contigEnd) continue;
+            size_t from = loc.from, to = loc.to;
+            if (loc.strand < 0) { from = (L - 1) - loc.from; to = (L - 1) - loc.to; }
+            std::string s((loc.strand > 0 ? orf.fwd : orf.rev).data() + loc.from, loc.to - loc.from + 1); s.push_back('\n');
+            seqW.add(next, s);
+            hdrW.add(next, orfHeader(key, from, to, loc.incStart, loc.incEnd));
+            if (createLookup) { char *e = u32toa(next, nb); lookup.append(nb, (size_t) (e - nb)); lookup.push_back('\t'); e = u32toa(key, nb); lookup.append(nb, (size_t) (e - nb)); lookup.push_back('\t'); lookup += setOf.count(key) ? setOf[key] : std::string("0"); lookup.push_back('\n'); }
+            next++;
+        }
+    }
+    if (createLookup) { std::ofstream o(f.positional[1] + ".lookup", std::ios::binary); o.write(lookup.data(), (std::streamsize) lookup.size()); if (!o.good()) return fail("extractorfs: cannot write the lookup file"); }
+    { std::ifstream src(f.positional[0] + ".source", std::ios::binary); if (src.good()) { std::ofstream dst(f.positional[1] + ".source", std::ios::binary); dst << src.rdbuf(); } }
+    if (!hdrW.close(err) || !seqW.close(err)) return fail("extractorfs: " + err);
+    return 0;
+}
+
+int runTranslateNucs(int argc, const char **argv) {
+    Flags f; std::string err;
+    if (!parseFlags(argc, argv, with({"--translation-table", "--add-orf-stop"}), 2, f, err)) return fail("translatenucs: " + err);
+    if (!uncompressedOnly(f, err) || !requireValue(f, "--translation-table", {"1"}, err) || !requireValue(f, "--add-orf-stop", {"0"}, err)) return fail("translatenucs: " + err);
+    Db in;
+    if (!loadDb(f.positional[0], in, err)) return fail("translatenucs: " + err);
+    DbWriter w; w.path = f.positional[1]; w.dbtype = 0;
+    std::string aa;
+    for (size_t i = 0; i < in.entries.size(); i++) {
+        const char *data = in.ptr(i);
+        if (*data == '\0') continue;
+        const size_t length = translatableLength(data, (size_t) in.entries[i].length, 65535);
+        if (!length) continue;
+        aa.assign(length / 3 + 1, '\n');
+        translate(data, length, &aa[0]);
+        w.add(in.entries[i].key, aa);
+    }
+    for (const char *ext : {".lookup", ".source"}) { std::ifstream src(f.positional[0] + ext, std::ios::binary); if (src.good()) { std::ofstream dst(f.positional[1] + ext, std::ios::binary); dst << src.rdbuf(); } }
+    if (!w.close(err)) return fail("translatenucs: " + err);
+    return 0;
+}
+
+int runReverseSeqByCodon(int argc, const char **argv) {
+    Flags f; std::string err;
+    if (!parseFlags(argc, argv, kCommon, 2, f, err)) return fail("reverseseqbycodon: " + err);
+    if (!uncompressedOnly(f, err)) return fail("reverseseqbycodon: " + err);
+    Db in;
+    if (!loadDb(f.positional[0], in, err)) return fail("reverseseqbycodon: " + err);
+    DbWriter w; w.path = f.positional[1]; w.dbtype = in.dbtype;
+    std::string rev;
+    for (size_t i = 0; i < in.entries.size(); i++) { reverseByCodon(in.ptr(i), (size_t) in.seqLen(i), rev); w.add(in.entries[i].key, rev); }
+    for (const char *ext : {".lookup", ".source"}) { std::ifstream src(f.positional[0] + ext, std::ios::binary); if (src.good()) { std::ofstream dst(f.positional[1] + ext, std::ios::binary); dst << src.rdbuf(); } }
+    if (!w.close(err)) return fail("reverseseqbycodon: " + err);
+    return 0;
+}
+
+static bool keyIndex(const Db &db, KeyMap &m) { std::vector<uint32_t> k(db.entries.size()); for (size_t i = 0; i < k.size(); i++) k[i] = db.entries[i].key; m.build(k); return true; }
+static uint64_t residues(const Db &db) { uint64_t r = 0; for (size_t i = 0; i < db.entries.size(); i++) r += db.seqLen(i); return r; }      // DBReader::getAminoAcidDBSize
+
+int runProteinAln2Nucl(int argc, const char **argv) {
+    Flags f; std::string err;
+    if (!parseFlags(argc, argv, with({"--sub-mat", "--gap-open", "--gap-extend"}), 6, f, err)) return fail("proteinaln2nucl: " + err);
+    if (!uncompressedOnly(f, err)) return fail("proteinaln2nucl: " + err);
+    Db qNuc, tNuc, qAA, tAA, aln;
+    if (!loadDb(f.positional[0], qNuc, err) || !loadDb(f.positional[1], tNuc, err) || !loadDb(f.positional[2], qAA, err) || !loadDb(f.positional[3], tAA, err) || !loadDb(f.positional[4], aln, err))
+        return fail("proteinaln2nucl: " + err);
+    if (qNuc.type() != 1 || tNuc.type() != 1 || qAA.type() != 0 || tAA.type() != 0) return fail("proteinaln2nucl: wrong query and target database input");
+    auto nuclPart = [](const std::string &v, const char *d) { const size_t p = v.find("nucl:"); if (p == std::string::npos) return v.empty() ? std::string(d) : v; const size_t e = v.find(',', p); return v.substr(p + 5, e == std::string::npos ? std::string::npos : e - p - 5); };
+    NuclScorer sc;
+    if (!sc.init(nuclPart(f.str("--sub-mat", ""), "nucleotide.out"), (int) strtol(nuclPart(f.str("--gap-open", ""), "5").c_str(), NULL, 10),
+                 (int) strtol(nuclPart(f.str("--gap-extend", ""), "2").c_str(), NULL, 10), residues(tNuc), err)) return fail("proteinaln2nucl: " + err);
+    KeyMap qNucIdx, tNucIdx, qAAIdx, tAAIdx; keyIndex(qNuc, qNucIdx); keyIndex(tNuc, tNucIdx); keyIndex(qAA, qAAIdx); keyIndex(tAA, tAAIdx);
+    DbWriter w; w.path = f.positional[5]; w.dbtype = 5;
+    std::string out;
+    for (size_t i = 0; i < aln.entries.size(); i++) {
+        const uint32_t key = aln.entries[i].key; uint32_t qn, qa;
+        if (!qNucIdx.find(key, qn) || !qAAIdx.find(key, qa)) return fail("proteinaln2nucl: query " + std::to_string(key) + " is missing from the query DBs");
+        out.clear();
+        for (const char *p = aln.ptr(i); *p != '\0'; p = skipLine(p)) {
+            uint32_t tn, ta; const uint32_t tKey = (uint32_t) atou(p);
+            if (!tNucIdx.find(tKey, tn) || !tAAIdx.find(tKey, ta)) return fail("proteinaln2nucl: target " + std::to_string(tKey) + " is missing from the target DBs");
+            if (!proteinLineToNucl(p, sc, qNuc.ptr(qn), (uint32_t) qNuc.seqLen(qn), qAA.ptr(qa)[0] == '*', tNuc.ptr(tn), (uint32_t) tNuc.seqLen(tn), tAA.ptr(ta)[0] == '*', out, err)) return fail(err);
+        }
+        w.add(key, out);
+    }
+    if (!w.close(err)) return fail("proteinaln2nucl: " + err);
+    return 0;
+}
+
+int runCombineProtNuclAln(int argc, const char **argv) {
+    Flags f; std::string err;
+    if (!parseFlags(argc, argv, kCommon, 3, f, err)) return fail("combineprotnuclaln: " + err);
+    if (!uncompressedOnly(f, err)) return fail("combineprotnuclaln: " + err);
+    Db prot, nucl;
+    if (!loadDb(f.positional[0], prot, err) || !loadDb(f.positional[1], nucl, err)) return fail("combineprotnuclaln: " + err);
+    KeyMap nIdx; keyIndex(nucl, nIdx);
+    DbWriter w; w.path = f.positional[2]; w.dbtype = prot.dbtype;
+    std::string out;
+    for (size_t i = 0; i < prot.entries.size(); i++) {
+        uint32_t n;
+        if (!nIdx.find(prot.entries[i].key, n)) continue;      // "Missing nucleotide alignment result": the reference skips the key
+        out.clear();
+        if (!combineProtNucl(prot.ptr(i), nucl.ptr(n), out, err)) return fail(err);
+        w.add(prot.entries[i].key, out);
+    }
+    if (!w.close(err)) return fail("combineprotnuclaln: " + err);
+    return 0;
+}
+
+int runBestHitPerSet(int argc, const char **argv) {
+    Flags f; std::string err;
+    if (!parseFlags(argc, argv, with({"--simple-best-hit"}), 4, f, err)) return fail("besthitperset: " + err);
+    if (!uncompressedOnly(f, err)) return fail("besthitperset: " + err);
+    Db m2s, sizes, res;
+    if (!loadDb(f.positional[1] + "_member_to_set", m2s, err) || !loadDb(f.positional[1] + "_set_size", sizes, err) || !loadDb(f.positional[2], res, err)) return fail("besthitperset: " + err);
+    SetLookup memberToSet, setSize; memberToSet.fromDb(m2s); setSize.fromDb(sizes);
+    const bool simple = f.num("--simple-best-hit", 1) != 0;
+    DbWriter w; w.path = f.positional[3]; w.dbtype = 5;
+    std::string out;
+    for (size_t i = 0; i < res.entries.size(); i++) {
+        out.clear();
+        if (!bestHitPerSet(res.ptr(i), memberToSet, setSize, simple, out, err)) return fail("besthitperset: " + err);
+        w.add(res.entries[i].key, out);
+    }
+    if (!w.close(err)) return fail("besthitperset: " + err);
+    return 0;
+}
+
+int runMergeResultsBySet(int argc, const char **argv) {
+    Flags f; std::string err;
+    if (!parseFlags(argc, argv, kCommon, 3, f, err)) return fail("mergeresultsbyset: " + err);
+    if (!uncompressedOnly(f, err)) return fail("mergeresultsbyset: " + err);
+    Db sets, res;
+    if (!loadDb(f.positional[0], sets, err) || !loadDb(f.positional[1], res, err)) return fail("mergeresultsbyset: " + err);
+    KeyMap rIdx; keyIndex(res, rIdx);
+    DbWriter w; w.path = f.positional[2]; w.dbtype = res.dbtype;
+    std::string out;
+    for (size_t i = 0; i < sets.entries.size(); i++) {
+        out.clear();
+        for (const char *p = sets.ptr(i); *p != '\0'; p = skipLine(p)) {
+            uint32_t r;
+            if (!rIdx.find((uint32_t) atou(p), r)) return fail("mergeresultsbyset: invalid key " + std::to_string(atou(p)) + " in entry " + std::to_string(i));
+            out += res.ptr(r);
+        }
+        w.add(sets.entries[i].key, out);
+    }
+    if (!w.close(err)) return fail("mergeresultsbyset: " + err);
+    return 0;
+}
+
+int runCombineScore(int argc, const char **argv) {
+    Flags f; std::string err;
+    if (!parseFlags(argc, argv, kCommon, 5, f, err)) return fail("combinescore: " + err);       // <queryDB> <targetDB> <resultDB> <outDB> <tmpDir>
+    if (!uncompressedOnly(f, err)) return fail("combinescore: " + err);
+    Db qSizes, m2s, res;
+    if (!loadDb(f.positional[0] + "_set_size", qSizes, err) || !loadDb(f.positional[1] + "_member_to_set", m2s, err) || !loadDb(f.positional[2], res, err)) return fail("combinescore: " + err);
+    SetLookup querySize, memberToSet; querySize.fromDb(qSizes); memberToSet.fromDb(m2s);
+    DbWriter w; w.path = f.positional[3]; w.dbtype = 5;
+    std::string out;
+    for (size_t i = 0; i < res.entries.size(); i++) {
+        uint32_t n;
+        if (!querySize.find(res.entries[i].key, n)) return fail("combinescore: query set " + std::to_string(res.entries[i].key) + " has no size entry");
+        out.clear();
+        if (!combineScore(res.ptr(i), n, memberToSet, out, err)) return fail("combinescore: " + err);
+        w.add(res.entries[i].key, out);
+    }
+    if (!w.close(err)) return fail("combinescore: " + err);
+    return 0;
+}
+
+int runFilterMatchByFdr(int argc, const char **argv) {
+    Flags f; std::string err;
+    if (!parseFlags(argc, argv, with({"--fdr", "--report-fdr"}), 3, f, err)) return fail("filtermatchbyfdr: " + err);
+    if (!uncompressedOnly(f, err)) return fail("filtermatchbyfdr: " + err);
+    Db pos, neg;
+    if (!loadDb(f.positional[0], pos, err) || !loadDb(f.positional[1], neg, err)) return fail("filtermatchbyfdr: " + err);
+    std::vector<double> P, N;
+    if (!collectScores(pos, P, err) || !collectScores(neg, N, err)) return fail("filtermatchbyfdr: " + err);
+    const bool report = f.num("--report-fdr", 0) != 0;
+    FdrResult r;
+    fdrThreshold(P, N, !neg.entries.empty(), f.real("--fdr", 0.05), report, r);
+    DbWriter w; w.path = f.positional[2]; w.dbtype = 12;
+    std::string out; const char *c[8];
+    for (size_t i = 0; i < pos.entries.size(); i++) {
+        out.clear();
+        for (const char *p = pos.ptr(i); *p != '\0';) {
+            words(p, c, 8);
+            const double score = strtod(c[1], NULL);
+            p = skipLine(p);
+            if (score < r.threshold) continue;
+            out.append(c[0], (size_t) (c[3] - c[0]));
+            if (report) { out.push_back('\t'); const size_t at = (size_t) (std::find(r.uniqueScores.begin(), r.uniqueScores.end(), score) - r.uniqueScores.begin()); out += fmtE(at < r.fdr.size() ? r.fdr[at] : 0.0); }
+            out.push_back('\n');
+        }
+        w.add(pos.entries[i].key, out);
+    }
+    if (!w.close(err)) return fail("filtermatchbyfdr: " + err);
+    return 0;
+}
+
+// one match entry joined with the alignment lines of its query set (SummarizeResults.cpp:66-180); fmt: 0 short, 1 long, 2 long + alignment
+static bool summarizeEntry(const char *match, const char *aln, int fmt, std::string &out, std::string &err) {
+    const char *e[20]; std::string cScore, tmp; char nb[24];
+    for (const char *m = match; *m != '\0';) {
+        if (words(m, e, 20) < 2) { err = "summarizeresults: invalid match record"; return false; }
+        m = skipLine(m);
+        const unsigned long targetSet = atou(e[0]);
+        size_t lines = 0;
+        for (const char *cur = aln; *cur != '\0';) {
+            if (atou(cur) != targetSet) { cur = skipLine(cur); continue; }
+            if (lines == 0) cScore.assign(e[1], (size_t) (e[2] - e[1]));
+            const size_t columns = words(cur, e, 20);
+            if (columns < 10) { err = "summarizeresults: invalid alignment result record"; return false; }
+            cur = skipLine(cur);
+            if (lines == 0) { out.push_back('#'); out.append(e[2], (size_t) (e[3] - e[2] - 1)); out.push_back('\t'); out.append(e[3], (size_t) (e[4] - e[3] - 1)); out.push_back('\t'); out += cScore; }
+            lines++;
+            if (fmt != 1 && fmt != 2) continue;
+            tmp.push_back('>'); tmp.append(e[1], (size_t) (e[2] - e[1] - 1));
+            for (int c : {3, 4, 5, 6, 8, 9}) { tmp.push_back('\t'); tmp.append(e[c], (size_t) (e[c + 1] - e[c] - 1)); }
+            if (columns == 15) { tmp.push_back('\t'); tmp.append(e[13], (size_t) (e[14] - e[13] - 1)); tmp.push_back('\t'); tmp.append(e[14], (size_t) (e[15] - e[14])); }
+            if (fmt == 2) { tmp.push_back('\n'); tmp.append(e[10], (size_t) (e[11] - e[10] - 1)); tmp.push_back('\n'); tmp.append(e[11], (size_t) (e[12] - e[11] - 1)); }
+            tmp.push_back('\n');
+        }
+        if (lines > 0) { char *x = u32toa((uint32_t) lines, nb); out.append(nb, (size_t) (x - nb)); out.push_back('\n'); out += tmp; }
+        tmp.clear();
+    }
+    return true;
+}
+
+int runSummarizeResults(int argc, const char **argv) {
+    Flags f; std::string err;
+    if (!parseFlags(argc, argv, with({"--fmt", "--report-fdr", "--lca-ranks", "--tax-lineage", "--db-output"}), 4, f, err)) return fail("summarizeresults: " + err);
+    if (!uncompressedOnly(f, err) || !requireValue(f, "--report-fdr", {"0"}, err)) return fail("summarizeresults: " + err);
+    { struct stat st; if (stat((f.positional[0] + "_nodes.dmp").c_str(), &st) == 0) return fail("summarizeresults: target sets with a taxonomy DB are not supported by the MI355X path (no taxonomy report)"); }
+    Db match, aln;
+    if (!loadDb(f.positional[1], match, err) || !loadDb(f.positional[2], aln, err)) return fail("summarizeresults: " + err);
+    KeyMap aIdx; keyIndex(aln, aIdx);
+    const int fmt = (int) f.num("--fmt", 1); const bool dbOut = f.num("--db-output", 0) != 0;
+    DbWriter w; w.path = f.positional[3]; w.dbtype = 12;
+    std::string out, flat;
+    for (size_t i = 0; i < match.entries.size(); i++) {
+        uint32_t a;
+        if (!aIdx.find(match.entries[i].key, a)) continue;
+        out.clear();
+        if (!summarizeEntry(match.ptr(i), aln.ptr(a), fmt, out, err)) return fail(err);
+        if (dbOut) w.add(match.entries[i].key, out); else flat += out;
+    }
+    if (dbOut) { if (!w.close(err)) return fail("summarizeresults: " + err); return 0; }
+    // --db-output 0 (the workflow's default): one flat text file, no index (SummarizeResults.cpp:188-191)
+    std::ofstream o(f.positional[3], std::ios::binary); o.write(flat.data(), (std::streamsize) flat.size());
+    if (!o.good()) return fail("summarizeresults: cannot write " + f.positional[3]);
+    return 0;
+}
+
+}  // namespace sets
+}  // namespace sp

@@ -188,8 +188,48 @@ def main():
         write_db(P("aln"), [(s, ("\n".join(v) + "\n").encode()) for s, v in sorted(lines.items())], 5)
         for fmt in (0, 1, 2):
             run(SETS, "summarizeresults", P("match"), P("aln"), P("summary%d" % fmt), fmt)
+        # corner cases of the ORF finder and the translation that real genomes rarely show: IUPAC codes, N runs, lower case, U / u,
+        # lengths that are not multiples of three, sequences shorter than a codon
+        rngc = __import__("random").Random(99)
+        corner = ["ATGAAATAG", "atgAAATAG", "ATGRAYTARCCC", "ATGNNNAAATGA", "ATGAAATA", "ATGAAAT", "AT", "ATG", "TTATTTCATGGG", "AUGAAAUAG", "augaaauag",
+                  "ATGAAANNNNNNNNNNNNAAATAGATGCCCTAA", "CCCATGAAATTTGGGTAGCCCATGCCCAAATGACC", "ATGXXXAAA---CCCTAA", "TAATAGTGA", "ATGATGATGTAA"]
+        for _ in range(12):
+            corner.append("".join(rngc.choice("ACGTACGTACGTNRYacgtU") for _ in range(rngc.randint(3, 90))))
+        write_db(P("x_nucl"), [(k, sq.encode() + b"\n") for k, sq in enumerate(corner)], 1)
+        open(P("x_nucl.lookup"), "w").write("".join("%d\tc%d\t%d\n" % (k, k, k % 3) for k in range(len(corner))))
+        run(SETS, "translatenucs", P("x_nucl"), P("x_aa"))
+        run(SETS, "extractorfs", P("x_nucl"), P("x_orf0"), 1, 0)
+        run(SETS, "extractorfs", P("x_nucl"), P("x_orf1"), 2, 1)
+        run(SETS, "extractorfs", P("x_nucl"), P("x_orf2"), 1, 2)
+        run(SETS, "translatenucs", P("x_orf1"), P("x_orf1_aa"))
+        run(SETS, "reverseseqbycodon", P("x_nucl"), P("x_rev"))
+        doc["lookup_x"] = {n: open(P(n + ".lookup")).read() for n in ("x_nucl", "x_orf0", "x_orf1", "x_orf2")}
+        # filtermatchbyfdr beyond the examples (whose score lists are too short to leave its trivial branch): seeded synthetic
+        # score DBs -- many null-like scores in both lists, a tail of true matches in the target list only
+        import random
+        doc["fdr_cases"] = []
+        for ci, (seed, n_pos, n_neg, n_true, fdr, rep) in enumerate([(1, 400, 400, 60, 0.05, 0), (2, 400, 400, 60, 0.05, 1), (3, 1500, 900, 150, 0.2, 1), (4, 80, 300, 10, 0.05, 0),
+                                                                      (5, 600, 40, 30, 0.1, 1), (6, 300, 300, 0, 0.05, 0), (7, 200, 0, 20, 0.05, 1), (8, 500, 500, 100, 0.01, 0)]):
+            rng = random.Random(seed)
+            def score_db(n, n_true):
+                vals = [rng.expovariate(0.35) if rng.random() < 0.7 else 0.0 for _ in range(n)] + [8.0 + rng.expovariate(0.08) for _ in range(n_true)]
+                rng.shuffle(vals)
+                ent, k = {}, 0
+                while vals:
+                    m = rng.randint(1, 6)
+                    ent[k] = "".join("%d\t%.3E\t%.3E\n" % (j, v, rng.random()) for j, v in enumerate(vals[:m]))
+                    vals = vals[m:]
+                    k += 1
+                return ent
+            pos, neg = score_db(n_pos, n_true), (score_db(n_neg, 0) if n_neg else {})
+            write_db(P("fdr_pos"), [(k, v.encode()) for k, v in pos.items()], 5)
+            write_db(P("fdr_neg"), [(k, v.encode()) for k, v in neg.items()], 5)
+            pr = run(SETS, "filtermatchbyfdr", P("fdr_pos"), P("fdr_neg"), P("fdr_out"), fdr, rep, capture_output=True, text=True)
+            out, _ = read_db(P("fdr_out"))
+            doc["fdr_cases"].append({"fdr": fdr, "report": rep, "pos": {str(k): v for k, v in pos.items()}, "neg": {str(k): v for k, v in neg.items()},
+                                     "out": {str(k): v for k, v in out.items()}, "threshold": json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])["threshold"]})
         names = ["q_nucl", "t_nucl", "q_nucl_orf", "q_nucl_orf_h", "t_nucl_orf", "t_nucl_orf_h", "c_nucl_orf", "q", "t", "c", "aln", "summary0", "summary1", "summary2",
-                 "match", "match_fdr", "match_all", "aggregate_full"]
+                 "match", "match_fdr", "match_all", "aggregate_full", "x_nucl", "x_aa", "x_orf0", "x_orf0_h", "x_orf1", "x_orf1_h", "x_orf2", "x_orf2_h", "x_orf1_aa", "x_rev"]
         for base in ("q", "t", "c"):
             names += [base + "_member_to_set", base + "_set_to_member", base + "_set_size"]
         for tag in ("", "_rev"):

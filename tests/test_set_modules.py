@@ -1,0 +1,173 @@
+"""The set-level module drop-ins (host-only, so they run without a GPU) on BASELINE.json
+configs[0] -- the reference's bundled examples -- against the DBs the reference code produced for the same inputs
+(tests/golden/examples.json.gz, made by tests/golden/make_examples.py through oracle/_ref/ref_sets).  Every output entry must be
+byte-identical."""
+import os
+import struct
+
+import pytest
+
+from conftest import load_golden
+
+
+def write_db(path, db):
+    off, idx = 0, []
+    with open(path, "wb") as f:
+        for k, v in db["entries"].items():
+            b = v.encode() + b"\0"
+            f.write(b)
+            idx.append((int(k), off, len(b)))
+            off += len(b)
+    with open(path + ".index", "w") as f:
+        for k, o, l in sorted(idx):
+            f.write("%d\t%d\t%d\n" % (k, o, l))
+    open(path + ".dbtype", "wb").write(struct.pack("<i", db["dbtype"]))
+
+
+def read_db(path):
+    data = open(path, "rb").read()
+    out = {}
+    for line in open(path + ".index"):
+        k, o, l = (int(x) for x in line.split("\t"))
+        assert data[o + l - 1] == 0
+        out[str(k)] = data[o:o + l - 1].decode()
+    return out, struct.unpack("<i", open(path + ".dbtype", "rb").read(4))[0]
+
+
+@pytest.fixture(scope="module")
+def ex(tmp_path_factory):
+    g = load_golden("examples")
+    d = tmp_path_factory.mktemp("examples")
+    for name, db in g["db"].items():
+        write_db(str(d / name), db)
+    for name, text in list(g["lookup"].items()) + list(g["lookup_x"].items()):
+        open(str(d / (name + ".lookup")), "w").write(text)
+    return g, d
+
+
+def check(g, d, produced, golden_name):
+    got, dbtype = read_db(str(d / produced))
+    exp = g["db"][golden_name]
+    assert dbtype == exp["dbtype"], (produced, dbtype)
+    assert sorted(got, key=int) == sorted(exp["entries"], key=int), produced
+    for k, v in exp["entries"].items():
+        assert got[k] == v, (produced, k, got[k][:300], v[:300])
+
+
+THREADS = ["--threads", "4", "--compressed", "0", "-v", "3"]
+
+
+def test_extractorfs_translatenucs_reverseseqbycodon(ex):
+    """createsetdb's target- and query-side preparation (data/createsetdb.sh:87-109)"""
+    import spacepharer_amd as sa
+    g, d = ex
+    P = lambda x: str(d / x)      # noqa: E731
+    sa.module_host("extractorfs", [P("q_nucl"), P("o_q_nucl_orf"), "--min-length", "9", "--orf-start-mode", "1", "--create-lookup", "1"] + THREADS)
+    check(g, d, "o_q_nucl_orf", "q_nucl_orf")
+    check(g, d, "o_q_nucl_orf_h", "q_nucl_orf_h")
+    assert open(P("o_q_nucl_orf.lookup")).read() == g["lookup"]["q_nucl_orf"]
+    sa.module_host("extractorfs", [P("t_nucl"), P("o_t_nucl_orf"), "--min-length", "30", "--orf-start-mode", "0", "--create-lookup", "1"] + THREADS)
+    check(g, d, "o_t_nucl_orf", "t_nucl_orf")
+    check(g, d, "o_t_nucl_orf_h", "t_nucl_orf_h")
+    assert open(P("o_t_nucl_orf.lookup")).read() == g["lookup"]["t_nucl_orf"]
+    sa.module_host("translatenucs", [P("o_q_nucl_orf"), P("o_q"), "--translation-table", "1", "--add-orf-stop", "0"] + THREADS)
+    check(g, d, "o_q", "q")
+    sa.module_host("translatenucs", [P("o_t_nucl_orf"), P("o_t"), "--translation-table", "1", "--add-orf-stop", "0"] + THREADS)
+    check(g, d, "o_t", "t")
+    sa.module_host("reverseseqbycodon", [P("o_t_nucl_orf"), P("o_c_nucl_orf")] + THREADS)
+    check(g, d, "o_c_nucl_orf", "c_nucl_orf")
+    sa.module_host("translatenucs", [P("o_c_nucl_orf"), P("o_c"), "--translation-table", "1", "--add-orf-stop", "0"] + THREADS)
+    check(g, d, "o_c", "c")
+
+
+def test_orf_and_translation_corners(ex):
+    """crafted entries: IUPAC codes, N runs, lower case, U / u, lengths not divisible by three, sequences shorter than a codon; all three
+    --orf-start-mode values"""
+    import spacepharer_amd as sa
+    g, d = ex
+    P = lambda x: str(d / x)      # noqa: E731
+    sa.module_host("translatenucs", [P("x_nucl"), P("o_x_aa")] + THREADS)
+    check(g, d, "o_x_aa", "x_aa")
+    for name, min_len, mode in (("x_orf0", 1, 0), ("x_orf1", 2, 1), ("x_orf2", 1, 2)):
+        sa.module_host("extractorfs", [P("x_nucl"), P("o_" + name), "--min-length", str(min_len), "--orf-start-mode", str(mode), "--create-lookup", "1"] + THREADS)
+        check(g, d, "o_" + name, name)
+        check(g, d, "o_" + name + "_h", name + "_h")
+        assert open(P("o_" + name + ".lookup")).read() == g["lookup_x"][name]
+    sa.module_host("translatenucs", [P("o_x_orf1"), P("o_x_orf1_aa")] + THREADS)
+    check(g, d, "o_x_orf1_aa", "x_orf1_aa")
+    sa.module_host("reverseseqbycodon", [P("x_nucl"), P("o_x_rev")] + THREADS)
+    check(g, d, "o_x_rev", "x_rev")
+
+
+@pytest.mark.parametrize("tag,T", [("", "t"), ("_rev", "c")])
+def test_proteinaln2nucl_to_combinescore(ex, tag, T):
+    """predictmatch's chain after the search (data/predictmatch.sh:34-75), target set and reversed control set"""
+    import spacepharer_amd as sa
+    g, d = ex
+    P = lambda x: str(d / x)      # noqa: E731
+    sa.module_host("proteinaln2nucl", [P("q_nucl_orf"), P(T + "_nucl_orf"), P("q"), P(T), P("prot_result" + tag), P("o_nucl_result" + tag),
+                                       "--sub-mat", "nucl:nucleotide.out,aa:VTML40.out", "--gap-open", "nucl:10,aa:16", "--gap-extend", "2"] + THREADS)
+    check(g, d, "o_nucl_result" + tag, "nucl_result" + tag)
+    sa.module_host("combineprotnuclaln", [P("prot_result" + tag), P("o_nucl_result" + tag), P("o_result" + tag)] + THREADS)
+    check(g, d, "o_result" + tag, "result" + tag)
+    sa.module_host("besthitperset", [P("q"), P(T), P("o_result" + tag), P("o_aggregate" + tag), "--simple-best-hit", "1"] + THREADS)
+    check(g, d, "o_aggregate" + tag, "aggregate" + tag)
+    sa.module_host("mergeresultsbyset", [P("q_set_to_member"), P("o_aggregate" + tag), P("o_aggregate_merged" + tag)] + THREADS)
+    check(g, d, "o_aggregate_merged" + tag, "aggregate_merged" + tag)
+    sa.module_host("combinescore", [P("q"), P(T), P("o_aggregate_merged" + tag), P("o_cScore" + tag), str(d)] + THREADS)
+    check(g, d, "o_cScore" + tag, "cScore" + tag)
+
+
+def test_besthitperset_second_best_correction(ex):
+    import spacepharer_amd as sa
+    g, d = ex
+    P = lambda x: str(d / x)      # noqa: E731
+    sa.module_host("besthitperset", [P("q"), P("t"), P("result"), P("o_aggregate_full"), "--simple-best-hit", "0"] + THREADS)
+    check(g, d, "o_aggregate_full", "aggregate_full")
+
+
+def test_filtermatchbyfdr_and_summarizeresults(ex):
+    import spacepharer_amd as sa
+    g, d = ex
+    P = lambda x: str(d / x)      # noqa: E731
+    for name, fdr, rep in (("match", "0.05", "0"), ("match_fdr", "0.05", "1"), ("match_all", "1", "0")):
+        sa.module_host("filtermatchbyfdr", [P("cScore"), P("cScore_rev"), P("o_" + name), "--fdr", fdr, "--report-fdr", rep] + THREADS)
+        check(g, d, "o_" + name, name)
+    for fmt in (0, 1, 2):
+        sa.module_host("summarizeresults", [P("t_nucl"), P("match"), P("aln"), P("o_summary%d" % fmt), "--fmt", str(fmt), "--report-fdr", "0", "--db-output", "1"] + THREADS)
+        check(g, d, "o_summary%d" % fmt, "summary%d" % fmt)
+    # the workflow's form: one flat report file, entries in match-DB order
+    sa.module_host("summarizeresults", [P("t_nucl"), P("match"), P("aln"), P("o_report.tsv"), "--fmt", "1", "--report-fdr", "0"] + THREADS)
+    exp = g["db"]["summary1"]["entries"]
+    assert open(P("o_report.tsv")).read() == "".join(exp[k] for k in sorted(exp, key=int))
+    assert not os.path.exists(P("o_report.tsv.index"))
+
+
+def test_unknown_flags_and_unsupported_values_fail_loudly(ex):
+    import spacepharer_amd as sa
+    g, d = ex
+    P = lambda x: str(d / x)      # noqa: E731
+    with pytest.raises(sa.SpError):
+        sa.module_host("translatenucs", [P("q_nucl_orf"), P("o_x"), "--no-such-flag", "1"])
+    with pytest.raises(sa.SpError):
+        sa.module_host("translatenucs", [P("q_nucl_orf"), P("o_x"), "--translation-table", "11"])
+    with pytest.raises(sa.SpError):
+        sa.module_host("filtermatchbyfdr", [P("cScore"), P("missing"), P("o_x")])
+    assert not os.path.exists(P("o_x.dbtype"))
+
+
+def test_filtermatchbyfdr_on_long_score_lists(tmp_path):
+    """seeded synthetic score DBs that reach the hull / interpolation branches of filtermatchbyfdr (FilterMatchbyFdr.cpp:109-200),
+    with and without --report-fdr, with an empty control DB, with no true matches"""
+    import spacepharer_amd as sa
+    g = load_golden("examples")
+    nontrivial = 0
+    for i, c in enumerate(g["fdr_cases"]):
+        P = lambda x: str(tmp_path / ("%d_%s" % (i, x)))      # noqa: E731
+        write_db(P("pos"), {"dbtype": 5, "entries": c["pos"]})
+        write_db(P("neg"), {"dbtype": 5, "entries": c["neg"]})
+        sa.module_host("filtermatchbyfdr", [P("pos"), P("neg"), P("out"), "--fdr", repr(c["fdr"]), "--report-fdr", str(c["report"])] + THREADS)
+        got, dbtype = read_db(P("out"))
+        assert dbtype == 12 and got == c["out"], i
+        nontrivial += float.fromhex(c["threshold"]) > 0
+    assert nontrivial >= 4
