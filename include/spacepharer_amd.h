@@ -154,6 +154,29 @@ int sp_ctx_align_hits_end(sp_ctx *c);
 int sp_ctx_rescore(sp_ctx *c, const uint32_t *query_idx, const uint32_t *target_idx, const int16_t *diagonal, uint64_t n,
                    int mode, sp_rescore *results);
 
+/* ---- the chain after the search without DB round trips (SURVEY.md section 8 rows f1 + f2; data/predictmatch.sh:27-75) ----
+ * Takes the alignment records of the last sp_ctx_prefilter() + sp_ctx_align_hits*() as they lie in host memory (aln[i] / cigars belong
+ * to hit i) through: align-module text (Alignment.cpp:255-549) -> proteinaln2nucl (util/proteinaln2nucl.cpp:99-187) ->
+ * combineprotnuclaln (src/util/CombineProtNuclAln.cpp:55-97) -> besthitperset (multihit/besthitperset.cpp:29-115) ->
+ * mergeresultsbyset (util/mergeresultsbyset.cpp:32-50) -> combinescore (src/util/CombineScore.cpp:41-98).  The resident queries and
+ * targets are the peptides of nucleotide ORFs; the layout says which ORF and which set each belongs to.  Set sizes are the member
+ * counts (what createsetdb's result2stats counts), the nucleotide E-values use the sum of the target ORF lengths.
+ * stage selects what is returned: 0 = combined score per query set (the cScore DB), 1 = align text, 2 = nucleotide alignments,
+ * 3 = combined alignments, 4 = best hit per target set (1-4: one entry per query, key = query index), 5 = best hits merged per
+ * query set.  Entries are what the reference modules write into the respective DB, NUL-terminated. */
+typedef struct {
+    const char *q_nucl; const uint64_t *q_nucl_off;   /* nucleotide ORF of resident query i: q_nucl[q_nucl_off[i] .. q_nucl_off[i+1]) */
+    const char *t_nucl; const uint64_t *t_nucl_off;   /* nucleotide ORF of target i */
+    const uint32_t *q_set;                            /* set key of query i (spacer array / file) */
+    const uint32_t *t_set;                            /* set key of target i (phage genome) */
+    const char *nucl_sub_mat;                         /* NULL = "nucleotide.out" */
+    int nucl_gap_open, nucl_gap_extend;               /* 0 = 10 / 2 (predictmatch) */
+    int simple_best_hit;                              /* --simple-best-hit (predictmatch: 1) */
+} sp_set_layout;
+typedef struct { uint64_t n; uint32_t *keys; uint64_t *offsets; char *text; } sp_text_db;   /* entry i: text + offsets[i], key keys[i]; offsets[n] = bytes */
+int sp_ctx_set_scores(sp_ctx *c, const sp_set_layout *l, const sp_alignment *aln, const char *cigars, int stage, sp_text_db *out);
+void sp_text_db_free(sp_text_db *db);
+
 /* ---- target-sharded search (one context per GPU) ----
  * Every GPU holds all target residues (align needs them) but masks and indexes only targets [shard_from, shard_to);
  * sequence ids stay global.  Per query batch: sp_ctx_prefilter_candidates() on every shard, gather the candidate lists of

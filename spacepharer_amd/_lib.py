@@ -55,6 +55,16 @@ class Rescore(C.Structure):
 HOST_MODULES = ("extractorfs", "translatenucs", "reverseseqbycodon", "proteinaln2nucl", "combineprotnuclaln", "besthitperset", "mergeresultsbyset",
                 "combinescore", "filtermatchbyfdr", "summarizeresults")      # set-level steps: host-only module drop-ins
 
+class SetLayout(C.Structure):
+    _fields_ = [("q_nucl", C.c_char_p), ("q_nucl_off", C.POINTER(C.c_uint64)), ("t_nucl", C.c_char_p), ("t_nucl_off", C.POINTER(C.c_uint64)),
+                ("q_set", C.POINTER(C.c_uint32)), ("t_set", C.POINTER(C.c_uint32)), ("nucl_sub_mat", C.c_char_p),
+                ("nucl_gap_open", C.c_int), ("nucl_gap_extend", C.c_int), ("simple_best_hit", C.c_int)]
+
+
+class TextDb(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("keys", C.POINTER(C.c_uint32)), ("offsets", C.POINTER(C.c_uint64)), ("text", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -86,6 +96,8 @@ def load_library():
     L.sp_ctx_get_hits_compact.argtypes = [vp, C.POINTER(Hit), C.POINTER(C.c_uint64)]
     L.sp_ctx_hits_view.argtypes = [vp, C.POINTER(C.POINTER(HitPacked)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint64)]
     L.sp_ctx_set_hit_sink.argtypes = [vp, vp, vp, C.c_uint64]
+    L.sp_ctx_set_scores.argtypes = [vp, C.POINTER(SetLayout), C.POINTER(Alignment), C.c_char_p, C.c_int, C.POINTER(TextDb)]
+    L.sp_text_db_free.argtypes = [C.POINTER(TextDb)]
     L.sp_ctx_align.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(Alignment), C.c_char_p,
                                C.c_uint64, C.POINTER(C.c_uint64)]
     L.sp_ctx_align_hits.argtypes = [vp, C.POINTER(Alignment), C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -433,6 +445,19 @@ class SearchContext:
     def align_hits_end(self):
         _check(self.L.sp_ctx_align_hits_end(self.ctx))
         return getattr(self, "_aln", None), getattr(self, "_cig", None)
+
+    def set_scores(self, q_nucl, t_nucl, q_set, t_set, aln, cig, stage=0, simple_best_hit=True):
+        """predictmatch's chain after the search on the records in memory (sp_ctx_set_scores); q_nucl / t_nucl: lists of nucleotide
+        ORFs, q_set / t_set: set key per query / target, aln / cig: what align_hits_raw() returned.  -> {key: entry text}"""
+        qb, qo = _concat(q_nucl)
+        tb, to = _concat(t_nucl)
+        lay = SetLayout(qb, qo, tb, to, (C.c_uint32 * max(1, len(q_set)))(*q_set), (C.c_uint32 * max(1, len(t_set)))(*t_set), None, 0, 0, 1 if simple_best_hit else 0)
+        out = TextDb()
+        _check(self.L.sp_ctx_set_scores(self.ctx, C.byref(lay), aln, C.cast(cig, C.c_char_p), stage, C.byref(out)))
+        try:
+            return {int(out.keys[i]): C.string_at(out.text + out.offsets[i]).decode() for i in range(out.n)}
+        finally:
+            self.L.sp_text_db_free(C.byref(out))
 
     def rescore(self, triples, mode):
         n = len(triples)

@@ -56,6 +56,7 @@ struct sp_ctx {
     std::vector<int32_t> bitRow;                           // int(bitScore(score) + 0.5)
     bool tablesUp = false, kmerTablesUp = false;
     sp::GateTable gate; bool gateValid = false; uint64_t gateSerial = 0;    // E-value tables of the resident query batch / target set
+    std::vector<char> targetFirst;                         // first letter of every target (proteinaln2nucl's '*' test)
     sp::AlignHost alnHost;                                 // pinned staging, reused; declared last = released before the device context
 };
 
@@ -166,6 +167,8 @@ static int setTargets(sp_ctx *c, const char *residues, const uint64_t *offsets, 
     ts.offsets.assign(offsets, offsets + n + 1);
     ts.keys.resize((size_t) n);
     for (size_t i = 0; i < (size_t) n; i++) { ts.keys[i] = keys ? keys[i] : (uint32_t) i; ts.maxLen = std::max<unsigned>(ts.maxLen, (unsigned) (offsets[i + 1] - offsets[i])); }
+    c->targetFirst.resize((size_t) n);
+    for (size_t i = 0; i < (size_t) n; i++) c->targetFirst[i] = offsets[i + 1] > offsets[i] ? residues[offsets[i]] : '\0';
     sp::Gpu::TargetBuild tb;
     if (!c->gpu.buildTargets(residues, ts, c->seed, c->kmerThr, c->par.mask != 0 && !noIndex, !noIndex, (size_t) from, (size_t) to, tb, err)) { g_err = err; return SP_ERR_DEVICE; }
     ts.maskedCount = tb.maskedResidues;
@@ -471,6 +474,43 @@ int sp_ctx_rescore(sp_ctx *c, const uint32_t *qidx, const uint32_t *tidx, const 
     }
     return SP_OK;
 }
+
+/* the chain after the search on the records in host memory (rows f1 + f2): see include/spacepharer_amd.h */
+int sp_ctx_set_scores(sp_ctx *c, const sp_set_layout *l, const sp_alignment *aln, const char *cigars, int stage, sp_text_db *out) {
+    if (!c || !l || !out || !l->q_set || !l->t_set) { g_err = "sp_ctx_set_scores: null argument"; return SP_ERR_ARG; }
+    c->gpu.makeCurrent();
+    memset(out, 0, sizeof(*out));
+    const sp::GpuHit *h = nullptr; const uint32_t *off = nullptr; size_t n = 0; std::string err;
+    if (!c->gpu.hostHits(h, off, n, err)) { g_err = err; return SP_ERR_DEVICE; }
+    if (n && (!aln || !cigars)) { g_err = "sp_ctx_set_scores: no alignment records"; return SP_ERR_ARG; }
+    if (stage != 1 && (!l->q_nucl || !l->q_nucl_off || !l->t_nucl || !l->t_nucl_off)) { g_err = "sp_ctx_set_scores: the nucleotide ORFs are missing"; return SP_ERR_ARG; }
+    sp::sets::SetInputs in;
+    in.nq = c->gpu.numQueries(); in.nt = c->targets.n;
+    in.aln = aln; in.cigars = cigars; in.hitOffsets = off;
+    std::vector<uint32_t> hitTarget(n); for (size_t i = 0; i < n; i++) hitTarget[i] = h[i].seqId;
+    in.hitTarget = hitTarget.data();
+    in.qNucl = l->q_nucl; in.qNuclOff = l->q_nucl_off; in.tNucl = l->t_nucl; in.tNuclOff = l->t_nucl_off;
+    in.qSet = l->q_set; in.tSet = l->t_set; in.tKeys = c->targets.keys.data();
+    std::vector<char> qFirst(in.nq); for (size_t q = 0; q < in.nq; q++) qFirst[q] = c->qasciiOff[q + 1] > c->qasciiOff[q] ? c->qascii[c->qasciiOff[q]] : '\0';
+    in.qFirst = qFirst.data(); in.tFirst = c->targetFirst.data();
+    if (l->nucl_sub_mat) in.nuclMatrix = l->nucl_sub_mat;
+    if (l->nucl_gap_open > 0) in.gapOpen = l->nucl_gap_open;
+    if (l->nucl_gap_extend > 0) in.gapExtend = l->nucl_gap_extend;
+    in.simpleBestHit = l->simple_best_hit != 0; in.threads = c->threads;
+    std::vector<uint32_t> keys; std::vector<std::string> entries;
+    if (!sp::sets::setScores(in, stage, keys, entries, err)) { g_err = err; return SP_ERR_ARG; }
+    uint64_t total = 0; for (const std::string &e : entries) total += e.size() + 1;
+    out->n = keys.size();
+    out->keys = (uint32_t *) malloc(sizeof(uint32_t) * std::max<size_t>(1, keys.size()));
+    out->offsets = (uint64_t *) malloc(sizeof(uint64_t) * (keys.size() + 1));
+    out->text = (char *) malloc(std::max<uint64_t>(1, total));
+    if (!out->keys || !out->offsets || !out->text) { sp_text_db_free(out); g_err = "sp_ctx_set_scores: out of memory"; return SP_ERR_ARG; }
+    uint64_t at = 0;
+    for (size_t i = 0; i < keys.size(); i++) { out->keys[i] = keys[i]; out->offsets[i] = at; memcpy(out->text + at, entries[i].c_str(), entries[i].size() + 1); at += entries[i].size() + 1; }
+    out->offsets[keys.size()] = at;
+    return SP_OK;
+}
+void sp_text_db_free(sp_text_db *db) { if (!db) return; free(db->keys); free(db->offsets); free(db->text); memset(db, 0, sizeof(*db)); }
 
 double sp_ctx_stat(const sp_ctx *c, const char *name) {
     auto it = c->stats.find(name);

@@ -415,6 +415,72 @@ static bool collectScores(const Db &db, std::vector<double> &v, std::string &err
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// the chain after the search on records in memory
+// ------------------------------------------------------------------------------------------------------------------
+bool setScores(const SetInputs &in, int stage, std::vector<uint32_t> &keys, std::vector<std::string> &entries, std::string &err) {
+    keys.clear(); entries.clear();
+    if (stage < 0 || stage > 5) { err = "set scores: unknown stage"; return false; }
+    const size_t nq = in.nq, nt = in.nt;
+    NuclScorer sc;
+    if (stage != 1 && !sc.init(in.nuclMatrix, in.gapOpen, in.gapExtend, nt ? in.tNuclOff[nt] : 0, err)) return false;
+    // set tables from the per-sequence set keys: member -> set, set -> number of members (what createsetdb's result2stats counts)
+    SetLookup tMemberToSet, tSetSize;
+    {   std::vector<uint32_t> k(nt), v(nt); std::map<uint32_t, uint32_t> cnt;
+        for (size_t t = 0; t < nt; t++) { k[t] = in.tKeys ? in.tKeys[t] : (uint32_t) t; v[t] = in.tSet[t]; cnt[in.tSet[t]]++; }
+        tMemberToSet.fromArrays(k, v);
+        std::vector<uint32_t> sk, sv; for (auto &c : cnt) { sk.push_back(c.first); sv.push_back(c.second); }
+        tSetSize.fromArrays(sk, sv); }
+    std::vector<std::string> perQuery(nq);
+    std::vector<std::string> errs((size_t) std::max(1, in.threads) + 64);
+    parallelChunks(nq, in.threads, [&](size_t ci, size_t from, size_t to) {
+        std::vector<std::pair<sp_alignment, const char *>> ok; std::string prot, nucl, comb; std::string &e = errs[ci];
+        for (size_t q = from; q < to && e.empty(); q++) {
+            ok.clear();
+            for (uint32_t i = in.hitOffsets[q]; i < in.hitOffsets[q + 1]; i++) { const sp_alignment &r = in.aln[i]; if (r.passed && r.seq_id >= 0.0) ok.push_back({r, in.cigars + r.cigar_offset}); }
+            std::sort(ok.begin(), ok.end(), [](const std::pair<sp_alignment, const char *> &a, const std::pair<sp_alignment, const char *> &b) { return alnLess(a.first, b.first); });
+            prot.clear();
+            for (auto &x : ok) appendAlnLine(prot, x.first, x.second, true);
+            if (stage == 1) { perQuery[q] = prot; continue; }
+            // the records carry target KEYS; the nucleotide ORFs are addressed by target index: look the index up among this query's hits
+            nucl.clear();
+            const char *p = prot.c_str();
+            for (auto &x : ok) {
+                uint32_t t = 0xFFFFFFFFu;
+                for (uint32_t i = in.hitOffsets[q]; i < in.hitOffsets[q + 1]; i++) if ((in.tKeys ? in.tKeys[in.hitTarget[i]] : in.hitTarget[i]) == x.first.db_key) { t = in.hitTarget[i]; break; }
+                if (t == 0xFFFFFFFFu) { e = "set scores: alignment record without a hit"; break; }
+                if (!proteinLineToNucl(p, sc, in.qNucl + in.qNuclOff[q], (uint32_t) (in.qNuclOff[q + 1] - in.qNuclOff[q]), in.qFirst && in.qFirst[q] == '*',
+                                       in.tNucl + in.tNuclOff[t], (uint32_t) (in.tNuclOff[t + 1] - in.tNuclOff[t]), in.tFirst && in.tFirst[t] == '*', nucl, e)) break;
+                p = skipLine(p);
+            }
+            if (!e.empty()) break;
+            if (stage == 2) { perQuery[q] = nucl; continue; }
+            comb.clear();
+            if (!combineProtNucl(prot.c_str(), nucl.c_str(), comb, e)) break;
+            if (stage == 3) { perQuery[q] = comb; continue; }
+            if (!bestHitPerSet(comb.c_str(), tMemberToSet, tSetSize, in.simpleBestHit, perQuery[q], e)) break;
+        }
+    });
+    for (const std::string &e : errs) if (!e.empty()) { err = e; return false; }
+    if (stage >= 1 && stage <= 4) {
+        keys.resize(nq); entries.swap(perQuery);
+        for (size_t q = 0; q < nq; q++) keys[q] = in.qKeys ? in.qKeys[q] : (uint32_t) q;
+        return true;
+    }
+    // mergeresultsbyset + combinescore: query sets ascending, members in query order
+    std::map<uint32_t, std::vector<uint32_t>> members;
+    for (size_t q = 0; q < nq; q++) members[in.qSet[q]].push_back((uint32_t) q);
+    for (auto &m : members) {
+        std::string merged, out;
+        for (uint32_t q : m.second) merged += perQuery[q];
+        keys.push_back(m.first);
+        if (stage == 5) { entries.push_back(merged); continue; }
+        if (!combineScore(merged.c_str(), (uint32_t) m.second.size(), tMemberToSet, out, err)) return false;
+        entries.push_back(out);
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // module drivers
 // ------------------------------------------------------------------------------------------------------------------
 static const std::set<std::string> kCommon = {"--threads", "--compressed", "-v"};

@@ -48,6 +48,20 @@ bool combineScore(const char *entry, uint32_t querySetSize, const SetLookup &mem
 struct FdrResult { double threshold = 0; std::vector<double> uniqueScores, fdr; };
 void fdrThreshold(std::vector<double> P, std::vector<double> N, bool haveControl, double cutoff, bool reportFdr, FdrResult &r);
 
+// In-memory form of predictmatch's chain after the search (data/predictmatch.sh:27-75): alignment records of a query batch ->
+// align-module text -> proteinaln2nucl -> combineprotnuclaln -> besthitperset -> mergeresultsbyset -> combinescore, no DB in between.
+struct SetInputs {
+    size_t nq = 0, nt = 0;
+    const sp_alignment *aln = nullptr; const char *cigars = nullptr;      // records of hit i, uncompressed backtraces
+    const uint32_t *hitOffsets = nullptr; const uint32_t *hitTarget = nullptr;      // hits of query q: [hitOffsets[q], hitOffsets[q+1]); target index of hit i
+    const char *qNucl = nullptr; const uint64_t *qNuclOff = nullptr; const char *tNucl = nullptr; const uint64_t *tNuclOff = nullptr;
+    const uint32_t *qSet = nullptr, *tSet = nullptr, *qKeys = nullptr, *tKeys = nullptr;      // set key per query / target; DB keys (nullptr: the index)
+    const char *qFirst = nullptr, *tFirst = nullptr;      // first residue of every query / target peptide ('*' = ORF with a start codon marker)
+    std::string nuclMatrix = "nucleotide.out"; int gapOpen = 10, gapExtend = 2; bool simpleBestHit = true; int threads = 1;
+};
+// stage: 0 cScore per query set | 1 align text | 2 nucleotide alignment | 3 combined | 4 best hit per set (1-4: per query) | 5 merged per query set
+bool setScores(const SetInputs &in, int stage, std::vector<uint32_t> &keys, std::vector<std::string> &entries, std::string &err);
+
 int runExtractOrfs(int argc, const char **argv);
 int runTranslateNucs(int argc, const char **argv);
 int runReverseSeqByCodon(int argc, const char **argv);

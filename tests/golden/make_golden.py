@@ -86,7 +86,34 @@ CASES = {
     "spacer":  (12345, 2000, 400, 50, 300, 9, 12, 0, ["--dump-kmers", "4"]),
     "family":  (77, 1500, 120, 40, 250, 10, 40, 6, ["--dump-kmers", "0", "--max-seqs", "20"]),
     "longq":   (5, 600, 40, 100, 1200, 40, 300, 2, ["--dump-kmers", "0"]),
+    # the family case with CacheFriendlyOperations<16> forced (this host's L2 would pick <2> for any DB below 4 M sequences): the bin a
+    # target falls into decides which of several equal-score hits survive the --max-seqs cut (QueryMatcher.cpp:383-411)
+    "family16": (77, 1500, 120, 40, 250, 10, 40, 6, ["--dump-kmers", "0", "--max-seqs", "20", "--bin-size", "16"]),
+    # targets beyond 32 768 residues: 16-bit diagonals wrap and UngappedAlignment scores such diagonals in pieces
+    # (UngappedAlignment.cpp:216-233 computeLongScore); see make_long_target_case
+    "longt":   (31, 40, 60, 50, 300, 10, 40, 0, ["--dump-kmers", "0"]),
 }
+
+
+def make_long_target_case(seed, n_targets, n_queries, tmin, tmax, qmin, qmax):
+    """a few ordinary targets plus one of 40 000 and one of 33 500 residues; most queries are windows of the long ones, spread over
+    their whole length (so that target positions below and above 32 768 / 65 536 - query length occur), with 0-2 substitutions"""
+    rng = random.Random(seed)
+    T = [rand_seq(rng, rng.randint(tmin, tmax)) for _ in range(n_targets)]
+    T[3] = rand_seq(rng, 40000)
+    T[17] = rand_seq(rng, 33500)
+    Q = []
+    for i in range(n_queries):
+        L = rng.randint(qmin, qmax)
+        if i % 6 == 5:
+            Q.append(rand_seq(rng, L))
+            continue
+        t = T[3] if i % 2 == 0 else T[17]
+        edge = [0, 5, 32760, 32768 - L // 2, 32768, 32770, len(t) - L]
+        p = edge[(i // 2) % len(edge)] if i < 28 else rng.randrange(0, len(t) - L + 1)
+        p = max(0, min(len(t) - L, p))
+        Q.append(mutate(rng, t[p:p + L], rng.choice([0, 1, 1, 2])))
+    return T, Q
 
 
 def main():
@@ -96,7 +123,7 @@ def main():
     for name, (seed, nt, nq, tmin, tmax, qmin, qmax, fam, flags) in CASES.items():
         if only and name not in only:
             continue
-        T, Q = make_case(seed, nt, nq, tmin, tmax, qmin, qmax, fam)
+        T, Q = make_long_target_case(seed, nt, nq, tmin, tmax, qmin, qmax) if name == "longt" else make_case(seed, nt, nq, tmin, tmax, qmin, qmax, fam)
         with tempfile.TemporaryDirectory() as d:
             tf, qf, of = (os.path.join(d, x) for x in ("t.txt", "q.txt", "o.json"))
             open(tf, "w").write("\n".join(T) + "\n")

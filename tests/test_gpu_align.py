@@ -6,7 +6,7 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["small", "spacer", "family", "longq"]
+CASES = ["small", "spacer", "family", "longq", "family16", "longt"]
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -23,8 +23,24 @@ ALN_FLAGS = ("--sub-mat nucl:nucleotide.out,aa:VTML40.out -a 1 --alignment-mode 
              "--threads 8 --compressed 0 -v 3")
 
 
-def write_seq_db(path, seqs, key0=0, split=False):
-    """MMseqs2 sequence DB: residues + '\\n' + NUL per entry; index key\\toffset\\tlength; 4-byte dbtype (0 = amino acids)."""
+def write_seq_db(path, seqs, key0=0, split=False, keys=None, order=None):
+    """MMseqs2 sequence DB: residues + '\\n' + NUL per entry; index key\\toffset\\tlength; 4-byte dbtype (0 = amino acids).
+    keys: DB key of sequence i (default key0 + i); order: the sequences' order in the data file (default 0..n-1) -- the index is
+    always sorted by key, as DBWriter leaves it"""
+    if keys is not None or order is not None:
+        keys = keys if keys is not None else [key0 + i for i in range(len(seqs))]
+        order = order if order is not None else list(range(len(seqs)))
+        off, idx = 0, []
+        with open(path, "wb") as f:
+            for i in order:
+                f.write(seqs[i].encode() + b"\n\0")
+                idx.append((keys[i], off, len(seqs[i]) + 2))
+                off += len(seqs[i]) + 2
+        with open(path + ".index", "w") as f:
+            for k, o, l in sorted(idx):
+                f.write("%d\t%d\t%d\n" % (k, o, l))
+        open(path + ".dbtype", "wb").write(struct.pack("<i", 0))
+        return
     data = b"".join(s.encode() + b"\n\0" for s in seqs)
     if split:     # exercise the <p>.0 / <p>.1 split data files the real workflow leaves behind
         half = len(data) // 2
@@ -170,3 +186,62 @@ def test_module_fan_out_from_a_process_that_already_initialised_hip(tmp_path):
     got, _ = read_db(pref)
     for qq in r["queries"]:
         assert got[qq["id"]] == qq["pref"], qq["id"]
+
+
+def test_rescorediagonal_module_alignment_format(tmp_path):
+    """--rescore-mode 2 -a 1, what `search --alignment-mode 4` passes (lib/mmseqs/src/workflow/Search.cpp:339): the alignment-format
+    branch of rescorediagonal (rescorediagonal.cpp:254-342) -- Matcher::resultToBuffer lines with an `<n>M` backtrace -- unsorted and
+    with --sort-results 1"""
+    import spacepharer_amd as sa
+    for name in ("small", "longt"):
+        g = load_golden(name)
+        r = g["ref"]
+        q, t, pref = (str(tmp_path / (name + x)) for x in ("qdb", "tdb", "pref"))
+        write_seq_db(q, g["queries"])
+        write_seq_db(t, g["targets"])
+        sa.module_prefilter([q, t, pref] + (PREF_FLAGS % r["maxSeqs"]).split())
+        for sort, key in (("0", "rescore2"), ("1", "rescore2sorted")):
+            out = str(tmp_path / (name + "resc2_" + sort))
+            sa.module_rescorediagonal([q, t, pref, out, "--sub-mat", "nucl:nucleotide.out,aa:VTML40.out", "--rescore-mode", "2", "-a", "1", "-e", "200", "-c", "0",
+                                       "--min-seq-id", "0", "--sort-results", sort, "--threads", "4", "--compressed", "0", "-v", "3"])
+            got, dbtype = read_db(out)
+            assert dbtype == 5
+            n = 0
+            for a in r["aln"]:
+                assert got[a["id"]] == a[key], (name, key, a["id"])
+                n += a[key].count("\n")
+            assert n > 10
+
+
+def test_modules_with_sparse_keys_and_shuffled_entries(tmp_path):
+    """DB keys are not positions: target keys sparse (the sorted-list branch of the key lookup), query keys neither dense nor monotone, the
+    query entries shuffled in the data file, the index sorted by key as DBWriter leaves it.  Results are keyed by query key and name
+    targets by their keys; inside an entry nothing changes (sequence ids are positions in data order, Prefiltering.cpp:164)."""
+    import random
+    import spacepharer_amd as sa
+    g = load_golden("family")
+    r = g["ref"]
+    rng = random.Random(5)
+    nq, nt = len(g["queries"]), len(g["targets"])
+    tkeys = [1000 * i + 17 for i in range(nt)]
+    qkeys = rng.sample(range(3, 5 * 10 ** 6), nq)
+    order = list(range(nq))
+    rng.shuffle(order)
+    q, t, pref, aln, resc = (str(tmp_path / x) for x in ("qdb", "tdb", "pref", "aln", "resc"))
+    write_seq_db(q, g["queries"], keys=qkeys, order=order)
+    write_seq_db(t, g["targets"], keys=tkeys)
+    tmap = lambda text: "".join(str(tkeys[int(ln.split("\t", 1)[0])]) + "\t" + ln.split("\t", 1)[1] + "\n" for ln in text.splitlines())      # noqa: E731
+    sa.module_prefilter([q, t, pref] + (PREF_FLAGS % r["maxSeqs"]).split())
+    got, _ = read_db(pref)
+    assert sorted(got) == sorted(qkeys)
+    for qq in r["queries"]:
+        assert got[qkeys[qq["id"]]] == tmap(qq["pref"]), qq["id"]
+    sa.module_align([q, t, pref, aln] + ALN_FLAGS.split())
+    got, _ = read_db(aln)
+    for a in r["aln"]:
+        assert got[qkeys[a["id"]]] == tmap(a["text"]), a["id"]
+    sa.module_rescorediagonal([q, t, pref, resc, "--sub-mat", "nucl:nucleotide.out,aa:VTML40.out", "--rescore-mode", "2", "-a", "1", "-e", "200", "-c", "0",
+                               "--min-seq-id", "0", "--threads", "4", "--compressed", "0", "-v", "3"])
+    got, _ = read_db(resc)
+    for a in r["aln"]:
+        assert got[qkeys[a["id"]]] == tmap(a["rescore2"]), a["id"]

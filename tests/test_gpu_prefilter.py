@@ -6,12 +6,12 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["small", "spacer", "family", "longq"]
+CASES = ["small", "spacer", "family", "longq", "family16", "longt"]
 
 
 def _ctx(r):
     import spacepharer_amd as sa
-    return sa.SearchContext(sensitivity=r["sens"], max_seqs=r["maxSeqs"])
+    return sa.SearchContext(sensitivity=r["sens"], max_seqs=r["maxSeqs"], bin_size=r["binSize"])
 
 
 @pytest.mark.parametrize("name", CASES)

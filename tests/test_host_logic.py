@@ -72,7 +72,7 @@ def test_host_ext3_table(lib):
     assert list(sc) == g["rows"]["4321"]["score"] and list(ix) == g["rows"]["4321"]["index"]
 
 
-@pytest.mark.parametrize("name", ["small", "spacer", "family", "longq"])
+@pytest.mark.parametrize("name", ["small", "spacer", "family", "longq", "longt"])
 def test_host_masking_and_index(lib, name):
     g = load_golden(name)
     r = g["ref"]

@@ -8,7 +8,7 @@ import pytest
 from conftest import load_golden
 from oracle_lib import Alp, Oracle, lib
 
-CASES = ["small", "spacer", "family", "longq"]
+CASES = ["small", "spacer", "family", "longq", "family16", "longt"]
 _or = {}
 
 
@@ -16,7 +16,7 @@ def oracle_for(name):
     if name not in _or:
         g = load_golden(name)
         r = g["ref"]
-        o = Oracle(sens=r["sens"], max_seqs=r["maxSeqs"], l2=r["l2cache"])
+        o = Oracle(sens=r["sens"], max_seqs=r["maxSeqs"], l2=r["l2cache"], bin_size=r["binSize"])      # family16: a bin size this host would not pick
         o.set_targets(g["targets"])
         if "alpGapped" in r:
             o.set_alp(Alp.from_ref(r["alpGapped"]), Alp.from_ref(r["alpGapless"]))
