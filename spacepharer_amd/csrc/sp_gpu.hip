@@ -396,6 +396,9 @@ constexpr int kWavesPerBlock = 4;
 constexpr uint32_t kDiagChunk = 64;   // diagonal records reserved per atomic in k_match
 constexpr uint32_t kQueryChunk = 4;
 constexpr int kDeferCap = 128;       // multi-entry index lists per wave whose entries are fetched together (k_match)
+constexpr int kOccRegs = 4;         // occupied slots per lane and batch in k_match's fetch phase (64 x kOccRegs slot words in flight per wave)
+constexpr int kWalkStep = 4;        // list positions per step when long lists are walked on the spot (kOccRegs x kWalkStep entry loads in flight)
+constexpr int kTailKeys = 3;        // keys per lane and step when the pre-filter reads spilled hits back from HBM
 constexpr int kSuper = 1024;         // similar k-mers per enumeration super-round in k_match   // queries per work-queue pop in k_match
 
 struct DiagRec { uint32_t seqId; uint16_t diag; uint16_t idx; };
@@ -714,10 +717,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                     }
                     waveSync();
                     SP_T(4);
-                    for (uint32_t ob = 0; ob < nOcc; ob += 256) {
-                        uint64_t slotR[4] = {0, 0, 0, 0}; uint32_t lenR[4] = {0, 0, 0, 0}, hR[4], ordR[4] = {0, 0, 0, 0}, rankR[4] = {0, 0, 0, 0};
+                    for (uint32_t ob = 0; ob < nOcc; ob += 64u * kOccRegs) {
+                        uint64_t slotR[kOccRegs]; uint32_t lenR[kOccRegs], hR[kOccRegs], ordR[kOccRegs], rankR[kOccRegs];
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
+                        for (int r = 0; r < kOccRegs; r++) { slotR[r] = 0ull; lenR[r] = 0u; ordR[r] = 0u; rankR[r] = 0u; }
+#pragma unroll
+                        for (int r = 0; r < kOccRegs; r++) {
                             const uint32_t at = ob + 64u * r + lane;
                             if (at < nOcc) {
                                 const uint32_t e = occList[at], km = e & 0x3FFFFFFu;
@@ -726,12 +731,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                             }
                         }
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
+                        for (int r = 0; r < kOccRegs; r++) {
                             if (ob + 64u * r + lane < nOcc) { slotR[r] = a.slots[rankR[r]]; lenR[r] = (slotR[r] >> 63) ? ((uint32_t) (slotR[r] >> 32) & 0x7FFFFFFFu) : 1u; }
                         }
                         uint32_t lenMulti = 0, run = M;
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
+                        for (int r = 0; r < kOccRegs; r++) {
                             hR[r] = run;
                             if (ob + 64u * r >= nOcc) continue;                    // (uniform: no slot in this register)
                             const uint32_t incl = waveInclusiveScan(lenR[r], lane);
@@ -742,7 +747,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                         // one-entry lists (the rule while the index is sparse) are complete with the slot word
                         uint32_t nMulti = 0;
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
+                        for (int r = 0; r < kOccRegs; r++) {
                             if (lenR[r] == 1u && !(slotR[r] >> 63)) emit(slotR[r], hR[r], ordR[r], i);
                             nMulti += (uint32_t) __popcll(__ballot((slotR[r] >> 63) != 0ull));
                         }
@@ -750,20 +755,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                             // dense index (or the parking area is full): most lists are long, the batch amortises the walk by itself.  Four list positions per
                             // step: 16 independent entry loads in flight (lists of 3 on average, the longest of 256 decides the
                             // trip count)
-                            for (uint32_t e0 = 0; e0 < lenMulti; e0 += 4) {
-                                uint64_t ent[4][4];
+                            for (uint32_t e0 = 0; e0 < lenMulti; e0 += kWalkStep) {
+                                uint64_t ent[kWalkStep][kOccRegs];
 #pragma unroll
-                                for (int u = 0; u < 4; u++)
+                                for (int u = 0; u < kWalkStep; u++)
 #pragma unroll
-                                    for (int r = 0; r < 4; r++) ent[u][r] = ((slotR[r] >> 63) && e0 + u < lenR[r]) ? a.ientries[(uint32_t) slotR[r] + e0 + u] : 0ull;
+                                    for (int r = 0; r < kOccRegs; r++) ent[u][r] = ((slotR[r] >> 63) && e0 + u < lenR[r]) ? a.ientries[(uint32_t) slotR[r] + e0 + u] : 0ull;
 #pragma unroll
-                                for (int u = 0; u < 4; u++)
+                                for (int u = 0; u < kWalkStep; u++)
 #pragma unroll
-                                    for (int r = 0; r < 4; r++) if ((slotR[r] >> 63) && e0 + u < lenR[r]) emit(ent[u][r], hR[r] + e0 + u, ordR[r], i);
+                                    for (int r = 0; r < kOccRegs; r++) if ((slotR[r] >> 63) && e0 + u < lenR[r]) emit(ent[u][r], hR[r] + e0 + u, ordR[r], i);
                             }
                         } else if (nMulti > 0) {
 #pragma unroll
-                            for (int r = 0; r < 4; r++) {
+                            for (int r = 0; r < kOccRegs; r++) {
                                 const bool multi = (slotR[r] >> 63) != 0ull && hR[r] < (uint32_t) kSpillCap;
                                 const uint64_t m = __ballot(multi);
                                 if (multi) {
@@ -792,31 +797,55 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
             // Cheap exact pre-filter before the sort: a target hit only once in this query can only be recorded when its
             // 8-bit diagonal is 0 (previous := 0).  Two bitmaps of 16 384 hashed targets in LDS -- "seen" and "seen again" --
             // keep the hits whose bucket was hit at least twice or whose diag8 == 0; bucket collisions merely let a few extra
-            // hits through to the exact automaton (0.7 % at 100 hits per query, 13 % at 2 000).
+            // hits through to the exact automaton (0.7 % at 100 hits per query, 13 % at 2 000).  The filter is exact under ANY
+            // hash, so while the survivors do not fit the register path it runs again on them with another hash: on a dense
+            // index (2 000 - 60 000 hits per query) the chance collisions fall geometrically (2 200 -> 300 -> 120 -> the true
+            // double hits) and nothing is ever sorted in HBM.
             uint32_t *seen = occList, *again = occList + kSuper / 2;     // 2 x 512 words; the enumeration arrays are free now
-            for (uint32_t t = lane * 4; t < (uint32_t) kSuper; t += 256) *reinterpret_cast<uint4 *>(occList + t) = make_uint4(0u, 0u, 0u, 0u);
-            waveSync();
             static_assert(kSuper == 1024, "the pre-filter bitmaps use the kSuper words of the occupied-slot list");
             // (hits beyond the LDS buffer live in the per-wave HBM scratch; the survivors usually fit LDS again)
-            auto keyAt = [&](uint32_t t) -> uint64_t { return t < (uint32_t) kHitCap ? keys[t] : spillKeys[t]; };
-            auto bucket = [](uint64_t k) -> uint32_t { return ((uint32_t) (k >> 32) * 2654435761u) >> 18; };     // 14 bits
-            for (uint32_t t = lane; t < M; t += 64) {
-                const uint32_t bkt = bucket(keyAt(t)), bit = 1u << (bkt & 31u);
-                if (atomicOr(&seen[bkt >> 5], bit) & bit) atomicOr(&again[bkt >> 5], bit);
+#pragma nounroll
+            for (int round = 0; round < 6; round++) {
+                const uint32_t mul = uni(2654435761u + (uint32_t) round * 0x3C6EF372u);      // odd multipliers, a different one per round
+                for (uint32_t t = lane * 4; t < (uint32_t) kSuper; t += 256) *reinterpret_cast<uint4 *>(occList + t) = make_uint4(0u, 0u, 0u, 0u);
+                waveSync();
+                // hits beyond the LDS buffer come from the per-wave HBM scratch: those chunks are read kTailKeys keys per lane at a
+                // time (independent loads; one load per step would pay the memory latency 35 times for 2 200 hits)
+                auto mark = [&](uint64_t k) {
+                    const uint32_t bkt = ((uint32_t) (k >> 32) * mul) >> 18, bit = 1u << (bkt & 31u);      // 14 bits
+                    if (atomicOr(&seen[bkt >> 5], bit) & bit) atomicOr(&again[bkt >> 5], bit);
+                };
+                const uint32_t mLds = M < (uint32_t) kHitCap ? M : (uint32_t) kHitCap;
+                for (uint32_t t = lane; t < mLds; t += 64) mark(keys[t]);
+                for (uint32_t base = (uint32_t) kHitCap; base < M; base += 64u * kTailKeys) {
+                    uint64_t k4[kTailKeys];
+#pragma unroll
+                    for (int u = 0; u < kTailKeys; u++) { const uint32_t t = base + 64u * u + lane; k4[u] = t < M ? spillKeys[t] : 0ull; }
+#pragma unroll
+                    for (int u = 0; u < kTailKeys; u++) if (base + 64u * u + lane < M) mark(k4[u]);
+                }
+                waveSync();
+                uint32_t wr = 0;
+                auto sift = [&](uint64_t k, bool valid) {
+                    const uint32_t bkt = ((uint32_t) (k >> 32) * mul) >> 18;
+                    const bool keep = valid && (((again[bkt >> 5] >> (bkt & 31u)) & 1u) || (k & 0xFF) == 0);
+                    const uint64_t m = __ballot(keep);
+                    if (keep) { const uint32_t at = wr + (uint32_t) __popcll(m & laneMaskLt(lane)); if (at < (uint32_t) kHitCap) keys[at] = k; else spillKeys[at] = k; }
+                    wr += (uint32_t) __popcll(m);
+                };
+                for (uint32_t base = 0; base < mLds; base += 64) { const uint32_t t = base + lane; sift(t < mLds ? keys[t] : 0ull, t < mLds); }
+                for (uint32_t base = (uint32_t) kHitCap; base < M; base += 64u * kTailKeys) {
+                    uint64_t k4[kTailKeys];
+#pragma unroll
+                    for (int u = 0; u < kTailKeys; u++) { const uint32_t t = base + 64u * u + lane; k4[u] = t < M ? spillKeys[t] : 0ull; }
+#pragma unroll
+                    for (int u = 0; u < kTailKeys; u++) { if (base + 64u * u >= M) break; sift(k4[u], base + 64u * u + lane < M); }
+                }
+                waveSync();
+                const uint32_t before = M;
+                M = wr;
+                if (M <= 64u || (uint64_t) M * 8u > (uint64_t) before * 7u) break;      // fits the register path, or what is left are real multi-hit targets
             }
-            waveSync();
-            uint32_t wr = 0;
-            for (uint32_t base = 0; base < M; base += 64) {
-                const uint32_t t = base + lane;
-                const uint64_t k = t < M ? keyAt(t) : 0ull;
-                const uint32_t bkt = bucket(k);
-                const bool keep = t < M && (((again[bkt >> 5] >> (bkt & 31u)) & 1u) || (k & 0xFF) == 0);
-                const uint64_t m = __ballot(keep);
-                if (keep) { const uint32_t at = wr + (uint32_t) __popcll(m & laneMaskLt(lane)); if (at < (uint32_t) kHitCap) keys[at] = k; else spillKeys[at] = k; }
-                wr += (uint32_t) __popcll(m);
-            }
-            waveSync();
-            M = wr;
         }
         const bool spilled = M > (uint32_t) kHitCap;
         // reserve room for D diagonal records: kDiagChunk at a time per wave (one atomic per query on a single word would
