@@ -249,6 +249,7 @@ def main():
                          "(1 = strictly one pass at a time)")
     ap.add_argument("--shard", default=None, choices=["queries", "targets"],
                     help="decomposition: target shards + RCCL all-gather (default at N > 1) or query partition with replicated index (default at N = 1)")
+    ap.add_argument("--no-module-e2e", action="store_true", help="N = 1: skip the files-to-files timing of the module drop-ins (tools/module_e2e.py)")
     ap.add_argument("--no-replica", action="store_true", help="N > 1: skip the additional query-partition (replica) measurement")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "gloo"], help="transport of the candidate all-gather (gloo: through host memory; tests)")
     ap.add_argument("--same-gpu", action="store_true", help="all ranks use HIP device 0 (tests of the N > 1 path on a one-GPU box; needs --exchange gloo)")
@@ -545,6 +546,20 @@ def main():
             out["cpu_baseline"] = cpu_baseline(tres, toff, qres, qoff, min(args.cpu_sample, nq))
         out["cpu_baseline"]["nproc"] = hi["nproc"]
         out["cpu_baseline"]["cpu_model"] = hi["cpu_model"]
+    if world == 1 and not args.no_module_e2e and not sharded and (n_spacers, args.targets, args.target_len) == (10000, 50000, 200):
+        # the boundary the workflow scripts use: module calls on DB triples, "DBs on disk" -> "result DB written", as fresh processes
+        # of the front-end binary and warm inside one process; two modules (prefilter, align) and the fused search
+        import subprocess
+        try:
+            pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "module_e2e.py"), "10000", "100000"], capture_output=True, text=True, timeout=1200)
+            doc = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])["module_e2e"]
+            out["module_e2e"] = {"what": "spacer-queries/s files-to-files on the bench targets (1e7 residues): module argv in, alignment DB on disk out; 'process' = fresh processes of "
+                                         "spacepharer_amd/spacepharer-amd per module call (process start + HIP runtime start-up + tables included), 'warm' = repeated call inside one process",
+                                 "runs": [{"spacers": r["spacers"], "mode": r["mode"], "threads": r["threads"], "process_s": r["process_total_s"], "process_spacer_queries_per_s": r["process_spacer_queries_per_s"],
+                                           "in_process_s": [x["total_s"] for x in r["runs"]], "warm_spacer_queries_per_s": r["warm_spacer_queries_per_s"], "aln_db_bytes": r["aln_db_bytes"],
+                                           "aln_db_crc": r["aln_db_crc"]} for r in doc]}
+        except Exception as e:      # noqa: BLE001
+            out["module_e2e"] = {"error": repr(e)[:300]}
     C.CDLL(None).fflush(None)      # library chatter buffered in C stdio (RCCL prints its path) goes out BEFORE the result line
     print(json.dumps(out), flush=True)
 

@@ -55,6 +55,10 @@ const char *sp_version(void);
 int sp_prefilter_run(int argc, const char **argv);        /* <i:queryDB> <i:targetDB> <o:prefilterDB> [flags]              */
 int sp_align_run(int argc, const char **argv);            /* <i:queryDB> <i:targetDB> <i:resultDB> <o:alignmentDB> [flags] */
 int sp_rescorediagonal_run(int argc, const char **argv);  /* <i:queryDB> <i:targetDB> <i:resultDB> <o:resultDB> [flags]    */
+/* prefilter + align fused, IN ADDITION to the three above: the argv of the reference's `search` workflow command for a sequence-sequence
+   search (int search(int, const char **, const Command&), lib/mmseqs/src/CommandDeclarations.h:93; lib/mmseqs/src/workflow/Search.cpp),
+   same alignment DB as `prefilter` followed by `align`, without the prefilter DB in between and with one resident context */
+int sp_search_run(int argc, const char **argv);           /* <i:queryDB> <i:targetDB> <o:alignmentDB> <tmpDir> [flags]           */
 
 /* ---- (1b) set-level steps around the search: host-side module drop-ins with the reference modules' argv.
    They need no device. ---- */

@@ -127,7 +127,7 @@ def load_library():
     L.sp_host_alloc.argtypes = [C.c_uint64]
     L.sp_host_free.argtypes = [vp]
     L.sp_ctx_diag_stream_read.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
-    for f in ("sp_prefilter_run", "sp_align_run", "sp_rescorediagonal_run") + tuple("sp_%s_run" % m for m in HOST_MODULES):
+    for f in ("sp_prefilter_run", "sp_align_run", "sp_rescorediagonal_run", "sp_search_run") + tuple("sp_%s_run" % m for m in HOST_MODULES):
         getattr(L, f).argtypes = [C.c_int, C.POINTER(C.c_char_p)]
     _lib = L
     return L
@@ -182,6 +182,11 @@ def module_align(args):
 
 def module_rescorediagonal(args):
     return _run_module("sp_rescorediagonal_run", list(args))
+
+
+def module_search(args):
+    """`search <queryDB> <targetDB> <alignmentDB> <tmpDir> [flags]`: prefilter + align on one resident context"""
+    return _run_module("sp_search_run", list(args))
 
 
 class SearchContext:

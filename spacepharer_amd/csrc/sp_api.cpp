@@ -198,7 +198,13 @@ int sp_ctx_set_queries(sp_ctx *c, const char *residues, const uint64_t *offsets,
     c->qascii.assign(residues, residues + offsets[n]);
     c->qasciiOff.assign(offsets, offsets + n + 1);
     for (uint64_t i = 0; i <= n; i++) c->qoff[i] = (uint32_t) offsets[i];
-    for (uint64_t i = 0; i < offsets[n]; i++) c->qres[i] = c->seed.aa2num[(uint8_t) residues[i]];
+    {   // letters -> residue classes, a few threads for batches of millions of residues
+        const uint64_t R = offsets[n];
+        const size_t T = (size_t) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::min(16, std::max(1, c->threads)), R / (1u << 19) + 1));
+        auto map = [&](size_t t) { for (uint64_t i = R * t / T, e = R * (t + 1) / T; i < e; i++) c->qres[i] = c->seed.aa2num[(uint8_t) residues[i]]; };
+        if (T == 1) map(0);
+        else { std::vector<std::thread> pool; for (size_t t = 0; t < T; t++) pool.emplace_back(map, t); for (auto &th : pool) th.join(); }
+    }
     std::string err;
     if (!c->gpu.uploadQueries(c->qres.data(), c->qoff.data(), (size_t) n, err)) { g_err = err; return SP_ERR_DEVICE; }
     return SP_OK;
@@ -608,6 +614,7 @@ int sp_host_evalue(const char *matrixName, int gapOpen, int gapExtend, uint64_t 
 int sp_prefilter_run(int argc, const char **argv) { return sp::runPrefilterModule(argc, argv); }
 int sp_align_run(int argc, const char **argv) { return sp::runAlignModule(argc, argv); }
 int sp_rescorediagonal_run(int argc, const char **argv) { return sp::runRescoreDiagonalModule(argc, argv); }
+int sp_search_run(int argc, const char **argv) { return sp::runSearchModule(argc, argv); }
 int sp_extractorfs_run(int argc, const char **argv) { return sp::sets::runExtractOrfs(argc, argv); }
 int sp_translatenucs_run(int argc, const char **argv) { return sp::sets::runTranslateNucs(argc, argv); }
 int sp_reverseseqbycodon_run(int argc, const char **argv) { return sp::sets::runReverseSeqByCodon(argc, argv); }

@@ -2,6 +2,8 @@
 // (sp_modules.cpp: prefilter / align / rescorediagonal; sp_sets.cpp: the set-level steps around them).
 #pragma once
 #include <algorithm>
+#include <charconv>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -10,7 +12,10 @@
 #include <map>
 #include <set>
 #include <string>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -24,58 +29,94 @@ namespace sp {
 // ---------------------------------------------------------------------------------------------------------------
 struct DbEntry { uint32_t key; uint64_t offset; uint64_t length; };   // length includes the terminating NUL
 
+// a file mapped read-only (sequence and result DBs are read once, front to back: no copy into a vector)
+struct MappedFile {
+    const char *p = nullptr; size_t n = 0;
+    MappedFile() = default;
+    MappedFile(const MappedFile &) = delete; MappedFile &operator=(const MappedFile &) = delete;
+    ~MappedFile() { if (p && n) munmap(const_cast<char *>(p), n); }
+    bool open(const std::string &path) {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st; if (fstat(fd, &st) != 0) { ::close(fd); return false; }
+        n = (size_t) st.st_size;
+        if (n) { void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0); if (m == MAP_FAILED) { ::close(fd); n = 0; return false; } p = static_cast<const char *>(m); }
+        ::close(fd);
+        return true;
+    }
+};
+
 struct Db {
-    std::vector<char> data;
     std::vector<DbEntry> entries;     // sorted by data offset (DBReader::LINEAR_ACCCESS)
     int dbtype = -1;
     bool compressed() const { return dbtype >= 0 && (dbtype & (1 << 31)); }
     int type() const { return dbtype & 0x7FFFFFFF; }
+    size_t dataSize() const { return size_; }
 
     bool load(const std::string &path, std::string &err) {
-        {   // key \t offset \t length \n  -- parsed by hand: result DBs of 10^5 spacers have 6 x 10^5 lines per index
-            std::ifstream idx(path + ".index", std::ios::binary);
-            if (!idx.good()) { err = "cannot open " + path + ".index"; return false; }
-            idx.seekg(0, std::ios::end); const size_t sz = (size_t) idx.tellg(); idx.seekg(0);
-            std::vector<char> text(sz + 1, '\n');
-            idx.read(text.data(), (std::streamsize) sz);
-            const char *p = text.data(), *end = p + sz;
-            entries.reserve(sz / 12 + 1);
-            while (p < end) {
-                if (*p == '\n' || *p == '\r') { p++; continue; }
-                unsigned long long v[3];
-                for (int f = 0; f < 3; f++) {
-                    if (*p < '0' || *p > '9') { err = "malformed index line in " + path + ".index"; return false; }
-                    unsigned long long x = 0;
-                    while (*p >= '0' && *p <= '9') x = x * 10 + (unsigned long long) (*p++ - '0');
-                    v[f] = x;
-                    if (f < 2) { if (*p != '\t') { err = "malformed index line in " + path + ".index"; return false; } p++; }
+        {   // key \t offset \t length \n  -- parsed by hand and in parallel: result DBs of 10^5 spacers have 6 x 10^5 lines per index
+            MappedFile idx;
+            if (!idx.open(path + ".index")) { err = "cannot open " + path + ".index"; return false; }
+            const char *text = idx.p; const size_t sz = idx.n;
+            const size_t T = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), sz / (1 << 20) + 1));
+            std::vector<std::vector<DbEntry>> part(T); std::vector<int> bad(T, 0);
+            auto parse = [&](size_t t) {
+                size_t from = sz * t / T, to = sz * (t + 1) / T;
+                if (t > 0) { while (from < sz && text[from - 1] != '\n') from++; }      // a chunk starts behind a line end ...
+                while (to < sz && to > 0 && text[to - 1] != '\n') to++;                 // ... and runs to the end of its last line
+                const char *p = text + from, *end = text + to;
+                part[t].reserve((to - from) / 12 + 1);
+                while (p < end) {
+                    if (*p == '\n' || *p == '\r') { p++; continue; }
+                    unsigned long long v[3];
+                    for (int f = 0; f < 3; f++) {
+                        if (p >= end || *p < '0' || *p > '9') { bad[t] = 1; return; }
+                        unsigned long long x = 0;
+                        while (p < end && *p >= '0' && *p <= '9') x = x * 10 + (unsigned long long) (*p++ - '0');
+                        v[f] = x;
+                        if (f < 2) { if (p >= end || *p != '\t') { bad[t] = 1; return; } p++; }
+                    }
+                    while (p < end && *p != '\n') p++;
+                    DbEntry e; e.key = (uint32_t) v[0]; e.offset = v[1]; e.length = v[2];
+                    part[t].push_back(e);
                 }
-                while (p < end && *p != '\n') p++;
-                DbEntry e; e.key = (uint32_t) v[0]; e.offset = v[1]; e.length = v[2];
-                entries.push_back(e);
-            }
+            };
+            if (T == 1) parse(0);
+            else { std::vector<std::thread> pool; for (size_t t = 0; t < T; t++) pool.emplace_back(parse, t); for (auto &th : pool) th.join(); }
+            for (size_t t = 0; t < T; t++) if (bad[t]) { err = "malformed index line in " + path + ".index"; return false; }
+            size_t total = 0; for (auto &v : part) total += v.size();
+            entries.reserve(total);
+            for (auto &v : part) entries.insert(entries.end(), v.begin(), v.end());
         }
         std::vector<std::string> files;
         struct stat st;
         if (stat(path.c_str(), &st) == 0) files.push_back(path);
         else for (int i = 0;; i++) { std::string f = path + "." + std::to_string(i); if (stat(f.c_str(), &st) != 0) break; files.push_back(f); }
         if (files.empty()) { err = "cannot open data file of " + path; return false; }
-        for (const std::string &f : files) {
-            std::ifstream in(f, std::ios::binary);
-            if (!in.good()) { err = "cannot read " + f; return false; }
-            in.seekg(0, std::ios::end); size_t sz = (size_t) in.tellg(); in.seekg(0);
-            size_t at = data.size(); data.resize(at + sz);
-            in.read(data.data() + at, (std::streamsize) sz);
+        if (files.size() == 1) {
+            if (!map_.open(files[0])) { err = "cannot read " + files[0]; return false; }
+            base_ = map_.p; size_ = map_.n;
+        } else {      // split data files <p>.0 .. <p>.N are one logical file (DBWriter.cpp:117-123): read back to back
+            for (const std::string &f : files) {
+                MappedFile m;
+                if (!m.open(f)) { err = "cannot read " + f; return false; }
+                owned_.insert(owned_.end(), m.p, m.p + m.n);
+            }
+            base_ = owned_.data(); size_ = owned_.size();
         }
         std::ifstream t(path + ".dbtype", std::ios::binary);
         if (t.good()) { int32_t v = 0; t.read((char *) &v, 4); dbtype = v; }
-        for (const DbEntry &e : entries) if (e.offset + e.length > data.size()) { err = "index of " + path + " points past the data file"; return false; }
-        std::sort(entries.begin(), entries.end(), [](const DbEntry &a, const DbEntry &b) { return a.offset < b.offset; });
+        for (const DbEntry &e : entries) if (e.offset + e.length > size_ || e.length == 0) { err = "index of " + path + " points past the data file"; return false; }
+        bool sorted = true;
+        for (size_t i = 1; i < entries.size() && sorted; i++) sorted = entries[i - 1].offset <= entries[i].offset;
+        if (!sorted) std::sort(entries.begin(), entries.end(), [](const DbEntry &a, const DbEntry &b) { return a.offset < b.offset; });
         return true;
     }
     // sequence entry = residues + '\n' + '\0'  (DBReader.h:191-211)
     uint64_t seqLen(size_t i) const { return entries[i].length >= 2 ? entries[i].length - 2 : 0; }
-    const char *ptr(size_t i) const { return data.data() + entries[i].offset; }
+    const char *ptr(size_t i) const { return base_ + entries[i].offset; }
+private:
+    MappedFile map_; std::vector<char> owned_; const char *base_ = nullptr; size_t size_ = 0;
 };
 
 // One module call can be spread over the GPUs of a node (SP_GPUS=N): the parent starts N worker processes, worker r takes slice r of the entries (DBReader::decomposeDomainByAminoAcid arithmetic) on GPU r and writes
@@ -107,16 +148,27 @@ struct DbWriter {
     Part part = currentPart();
     std::vector<char> data; std::vector<DbEntry> entries;
     void add(uint32_t key, const std::string &payload) {
-        DbEntry e; e.key = key; e.offset = data.size(); e.length = payload.size() + 1;
+        DbEntry e; e.key = key; e.offset = blockBytes + data.size(); e.length = payload.size() + 1;
         data.insert(data.end(), payload.begin(), payload.end());
         data.push_back('\0');
         entries.push_back(e);
     }
-    // a block of consecutive entries formatted elsewhere (payloads concatenated, each followed by its NUL)
-    void addBlock(const std::vector<uint32_t> &keys, const std::vector<uint64_t> &lengths, const std::string &block) {
-        uint64_t at = data.size();
-        data.insert(data.end(), block.begin(), block.end());
+    // a block of consecutive entries formatted elsewhere (payloads concatenated, each followed by its NUL); the block is kept as it
+    // is and written behind what came before it (no copy into one buffer)
+    std::vector<std::string> blocks; uint64_t blockBytes = 0;
+    void addBlock(const std::vector<uint32_t> &keys, const std::vector<uint64_t> &lengths, std::string &&block) {
+        if (!data.empty()) { blocks.emplace_back(data.begin(), data.end()); blockBytes += data.size(); data.clear(); }
+        uint64_t at = blockBytes;
         for (size_t i = 0; i < keys.size(); i++) { DbEntry e; e.key = keys[i]; e.offset = at; e.length = lengths[i]; entries.push_back(e); at += lengths[i]; }
+        blockBytes += block.size();
+        blocks.push_back(std::move(block));
+    }
+    static bool writeAll(int fd, const char *p, size_t n) { while (n) { const ssize_t k = ::write(fd, p, n); if (k <= 0) return false; p += k; n -= (size_t) k; } return true; }
+    static bool writeFile(const std::string &path, const char *p, size_t n) {
+        const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) return false;
+        const bool ok = writeAll(fd, p, n);
+        return (::close(fd) == 0) && ok;
     }
     bool close(std::string &err) {
         const std::string dataPath = part.count > 1 ? path + "." + std::to_string(part.rank) : path;
@@ -124,21 +176,40 @@ struct DbWriter {
         const std::string typePath = part.count > 1 ? dataPath + ".typepart" : path + ".dbtype";
         if (part.count <= 1)      // split parts left by an earlier fan-out run would be read in front of / behind this data file
             for (int i = 0;; i++) { const std::string dp = path + "." + std::to_string(i); struct stat st; if (stat(dp.c_str(), &st) != 0) break; remove(dp.c_str()); }
-        { std::ofstream o(dataPath, std::ios::binary); if (!o.good()) { err = "cannot write " + dataPath; return false; } o.write(data.data(), (std::streamsize) data.size()); }
-        std::sort(entries.begin(), entries.end(), [](const DbEntry &a, const DbEntry &b) { return a.key < b.key; });   // DBWriter.cpp:645-660
-        { std::ofstream o(indexPath, std::ios::binary); if (!o.good()) { err = "cannot write " + indexPath; return false; }
-          std::string text; text.reserve(entries.size() * 24);
-          char buf[72];
-          for (const DbEntry &e : entries) {
-              char *q = buf + sizeof(buf); *--q = '\n';
-              uint64_t v = e.length; do { *--q = (char) ('0' + v % 10); v /= 10; } while (v); *--q = '\t';
-              v = e.offset; do { *--q = (char) ('0' + v % 10); v /= 10; } while (v); *--q = '\t';
-              v = e.key; do { *--q = (char) ('0' + v % 10); v /= 10; } while (v);
-              text.append(q, buf + sizeof(buf) - q);
-          }
-          o.write(text.data(), (std::streamsize) text.size()); }
+        {   const int fd = ::open(dataPath.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            bool ok = fd >= 0;
+            for (const std::string &b : blocks) ok = ok && writeAll(fd, b.data(), b.size());
+            ok = ok && writeAll(fd, data.data(), data.size());
+            if (fd >= 0) ok = (::close(fd) == 0) && ok;
+            if (!ok) { err = "cannot write " + dataPath; return false; } }
+        bool sorted = true;
+        for (size_t i = 1; i < entries.size() && sorted; i++) sorted = entries[i - 1].key <= entries[i].key;
+        if (!sorted) std::sort(entries.begin(), entries.end(), [](const DbEntry &a, const DbEntry &b) { return a.key < b.key; });   // DBWriter.cpp:645-660
+        {   // index text: formatted by a few threads over contiguous ranges, written with one call
+            const size_t n = entries.size();
+            const size_t T = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), n / 65536 + 1));
+            std::vector<std::string> texts(T);
+            auto fmt = [&](size_t t) {
+                std::string &text = texts[t]; const size_t from = n * t / T, to = n * (t + 1) / T;
+                text.reserve((to - from) * 24);
+                char buf[72];
+                for (size_t i = from; i < to; i++) {
+                    const DbEntry &e = entries[i];
+                    char *q = buf + sizeof(buf); *--q = '\n';
+                    uint64_t v = e.length; do { *--q = (char) ('0' + v % 10); v /= 10; } while (v); *--q = '\t';
+                    v = e.offset; do { *--q = (char) ('0' + v % 10); v /= 10; } while (v); *--q = '\t';
+                    v = e.key; do { *--q = (char) ('0' + v % 10); v /= 10; } while (v);
+                    text.append(q, (size_t) (buf + sizeof(buf) - q));
+                }
+            };
+            if (T == 1) fmt(0);
+            else { std::vector<std::thread> pool; for (size_t t = 0; t < T; t++) pool.emplace_back(fmt, t); for (auto &th : pool) th.join(); }
+            std::string all; size_t total = 0; for (auto &t : texts) total += t.size();
+            all.reserve(total); for (auto &t : texts) all += t;
+            if (!writeFile(indexPath, all.data(), all.size())) { err = "cannot write " + indexPath; return false; }
+        }
         // .dbtype is written LAST so that a crashed step is re-run by the workflow scripts (DBWriter.cpp:243)
-        { std::ofstream o(typePath, std::ios::binary); int32_t v = dbtype; o.write((const char *) &v, 4); if (!o.good()) { err = "cannot write " + typePath; return false; } }
+        { const int32_t v = dbtype; if (!writeFile(typePath, (const char *) &v, 4)) { err = "cannot write " + typePath; return false; } }
         return true;
     }
 };
@@ -228,6 +299,15 @@ inline size_t numChunks(size_t n, int threads) { return (size_t) std::max(1, std
 
 inline int fail(const std::string &e) { setLastError(e); fprintf(stderr, "%s\n", e.c_str()); return 1; }
 
+// "%.3E" of a double (Matcher::resultToBuffer prints E-values that way): std::to_chars with a precision is defined to give exactly
+// what printf gives, several times faster -- the formatting of 10^6 alignment lines is a visible part of a module run
+inline char *fmtE3(double x, char *p) {
+    if (!std::isfinite(x)) return p + sprintf(p, "%.3E", x);
+    const std::to_chars_result r = std::to_chars(p, p + 32, x, std::chars_format::scientific, 3);
+    for (char *c = p; c < r.ptr; c++) if (*c == 'e') { *c = 'E'; break; }
+    return r.ptr;
+}
+
 inline void appendAlnLine(std::string &out, const sp_alignment &r, const char *cigar, bool addBacktrace) {
     char buf[256]; char *p = buf;
     p = u32toa(r.db_key, p); *p++ = '\t';
@@ -236,7 +316,7 @@ inline void appendAlnLine(std::string &out, const sp_alignment &r, const char *c
     if (r.seq_id == 1.0) { memcpy(p, "1.00", 4); p += 4; }
     else { *p++ = '0'; *p++ = '.'; if (r.seq_id < 0.10) *p++ = '0'; if (r.seq_id < 0.01) *p++ = '0'; p = i32toa((int) (r.seq_id * 1000), p); }
     *p++ = '\t';
-    p += sprintf(p, "%.3E", r.evalue); *p++ = '\t';
+    p = fmtE3(r.evalue, p); *p++ = '\t';
     p = i32toa(r.q_start, p); *p++ = '\t'; p = i32toa(r.q_end, p); *p++ = '\t'; p = i32toa((int) r.q_len, p); *p++ = '\t';
     p = i32toa(r.db_start, p); *p++ = '\t'; p = i32toa(r.db_end, p); *p++ = '\t'; p = i32toa((int) r.db_len, p);
     out.append(buf, p - buf);

@@ -10,7 +10,7 @@
 #include "../../include/spacepharer_amd.h"
 
 int main(int argc, const char **argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s <prefilter|align|rescorediagonal|extractorfs|translatenucs|reverseseqbycodon|proteinaln2nucl|combineprotnuclaln|besthitperset|mergeresultsbyset|combinescore|filtermatchbyfdr|summarizeresults> <args>\n", argv[0]); return 1; }
+    if (argc < 2) { fprintf(stderr, "usage: %s <prefilter|align|rescorediagonal|search|extractorfs|translatenucs|reverseseqbycodon|proteinaln2nucl|combineprotnuclaln|besthitperset|mergeresultsbyset|combinescore|filtermatchbyfdr|summarizeresults> <args>\n", argv[0]); return 1; }
     int rc;
     // the set-level steps are host-only: no device is touched for them
     struct HostModule { const char *name; int (*run)(int, const char **); };
@@ -24,6 +24,7 @@ int main(int argc, const char **argv) {
     if (!strcmp(argv[1], "prefilter")) rc = sp_prefilter_run(argc - 2, argv + 2);
     else if (!strcmp(argv[1], "align")) rc = sp_align_run(argc - 2, argv + 2);
     else if (!strcmp(argv[1], "rescorediagonal")) rc = sp_rescorediagonal_run(argc - 2, argv + 2);
+    else if (!strcmp(argv[1], "search")) rc = sp_search_run(argc - 2, argv + 2);
     else { fprintf(stderr, "unknown module %s\n", argv[1]); return 1; }
     if (rc != 0) fprintf(stderr, "%s\n", sp_last_error());
     sp_shutdown();

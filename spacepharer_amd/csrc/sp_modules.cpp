@@ -62,7 +62,7 @@ static bool loadSeqDb(const std::string &path, Db &db, std::string &err) {
 
 static void flatten(const Db &db, std::vector<char> &res, std::vector<uint64_t> &off, std::vector<uint32_t> &keys) {
     off.assign(1, 0); keys.clear(); res.clear();
-    off.reserve(db.entries.size() + 1); keys.reserve(db.entries.size()); res.reserve(db.data.size());
+    off.reserve(db.entries.size() + 1); keys.reserve(db.entries.size()); res.reserve(db.dataSize());
     for (size_t i = 0; i < db.entries.size(); i++) {
         const char *p = db.ptr(i); uint64_t L = db.seqLen(i);
         uint64_t l = L;                                                            // Sequence::mapSequence stops at \n / \0
@@ -232,7 +232,7 @@ struct Triples { std::vector<uint32_t> q, t; std::vector<int16_t> d; std::vector
 
 static bool collectTriples(const Db &res, const KeyMap &qIndex, const KeyMap &tIndex, Triples &tr, std::string &err) {
     tr.perQuery.assign(1, 0);
-    tr.q.reserve(res.data.size() / 12); tr.t.reserve(res.data.size() / 12); tr.d.reserve(res.data.size() / 12);
+    tr.q.reserve(res.dataSize() / 12); tr.t.reserve(res.dataSize() / 12); tr.d.reserve(res.dataSize() / 12);
     size_t eFrom = 0, eTo = res.entries.size();
     { std::vector<uint64_t> lens(res.entries.size()); for (size_t i = 0; i < lens.size(); i++) lens[i] = res.entries[i].length; partRange(lens, currentPart(), eFrom, eTo); }   // this GPU's entries
     for (size_t i = eFrom; i < eTo; i++) {
@@ -320,25 +320,145 @@ int runAlignModule(int argc, const char **argv) {
     std::vector<std::string> blocks(nChunks); std::vector<std::vector<uint32_t>> bKeys(nChunks); std::vector<std::vector<uint64_t>> bLens(nChunks);
     parallelChunks(nEntries, threads, [&](size_t ci, size_t from, size_t to) {
         std::string &block = blocks[ci];
-        std::vector<std::pair<sp_alignment, const char *>> ok;
+        std::vector<uint64_t> ok;
         for (size_t e = from; e < to; e++) {
             ok.clear();
             long passed = 0, rejected = 0;
             for (uint64_t i = tr.perQuery[e]; i < tr.perQuery[e + 1] && passed < maxAccept && rejected < maxRejected; i++) {
                 const sp_alignment &r = res[i];
                 const bool good = r.passed && r.seq_id >= minSeqId && (long) r.aln_len >= minAlnLen;    // Alignment::checkCriteria, Alignment.cpp:555-574
-                if (good) { ok.push_back({r, cig.data() + r.cigar_offset}); passed++; rejected = 0; } else rejected++;
+                if (good) { ok.push_back(i); passed++; rejected = 0; } else rejected++;
             }
-            std::sort(ok.begin(), ok.end(), [](const std::pair<sp_alignment, const char *> &a, const std::pair<sp_alignment, const char *> &b) { return alnLess(a.first, b.first); });
+            if (ok.size() > 1) std::sort(ok.begin(), ok.end(), [&](uint64_t a, uint64_t b) { return alnLess(res[a], res[b]); });
             const size_t before = block.size();
-            for (auto &x : ok) appendAlnLine(block, x.first, x.second, true);
+            for (uint64_t i : ok) appendAlnLine(block, res[i], cig.data() + res[i].cigar_offset, true);
             block.push_back('\0');
             bKeys[ci].push_back(tr.entryKey[e]); bLens[ci].push_back(block.size() - before);
         }
     });
-    for (size_t ci = 0; ci < nChunks; ci++) w.addBlock(bKeys[ci], bLens[ci], blocks[ci]);
+    for (size_t ci = 0; ci < nChunks; ci++) w.addBlock(bKeys[ci], bLens[ci], std::move(blocks[ci]));
     laps.lap("format records");
     if (!w.close(err)) return fail("align: " + err);
+    laps.lap("write DB");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// search <queryDB> <targetDB> <alignmentDB> <tmpDir>: prefilter + align in one process on one resident context
+// (lib/mmseqs/src/workflow/Search.cpp:200-420 writes blastp.sh, which calls the two modules through $MMSEQS --
+// lib/mmseqs/data/workflow/blastp.sh:28-45 -- with the prefilter DB on disk in between).  Same flags as the reference
+// `search` (Parameters::searchworkflow), same alignment DB as running `prefilter` then `align`; the prefilter DB is never
+// formatted, written, read back or parsed, the target set and the queries are staged once, and the hits go from the
+// prefilter kernels to the aligner without leaving the device.
+// ---------------------------------------------------------------------------------------------------------------
+static const std::set<std::string> kSearchOnlyFlags = {
+    "--add-orf-stop", "--allow-deletion", "--chain-alignments", "--contig-end-mode", "--contig-start-mode", "--cov", "--create-lookup", "--diff", "--disk-space-limit",
+    "--e-profile", "--exhaustive-search", "--exhaustive-search-filter", "--filter-hits", "--filter-msa", "--force-reuse", "--forward-frames", "--headers-split-mode", "--id-offset",
+    "--lca-search", "--mask-profile", "--max-gaps", "--max-length", "--max-seq-id", "--merge-query", "--min-length", "--num-iterations", "--orf-start-mode", "--qid", "--qsc",
+    "--remove-tmp-files", "--rescore-mode", "--reverse-frames", "--search-type", "--sens-steps", "--sequence-overlap", "--sequence-split-mode", "--sort-results", "--start-sens",
+    "--strand", "--translate", "--translation-table", "--use-all-table-starts", "--wg", "--reuse-latest"};
+
+int runSearchModule(int argc, const char **argv) {
+    Flags f; std::string err;
+    std::set<std::string> allowed = kPrefilterFlags; allowed.insert(kAlignFlags.begin(), kAlignFlags.end()); allowed.insert(kSearchOnlyFlags.begin(), kSearchOnlyFlags.end());
+    if (!parseFlags(argc, argv, allowed, 4, f, err)) return fail("search: " + err);
+    if (!requireValue(f, "-k", {"6", "0"}, err) || !requireValue(f, "--alph-size", {"21"}, err) || !requireValue(f, "--comp-bias-corr", {"1"}, err) ||
+        !requireValue(f, "--diag-score", {"1"}, err) || !requireValue(f, "--exact-kmer-matching", {"0"}, err) || !requireValue(f, "--spaced-kmer-mode", {"1"}, err) ||
+        !requireValue(f, "--spaced-kmer-pattern", {"11011101", ""}, err) || !requireValue(f, "--mask-lower-case", {"0"}, err) || !requireValue(f, "--compressed", {"0"}, err) ||
+        !requireValue(f, "--add-self-matches", {"0"}, err) || !requireValue(f, "--split", {"0", "1"}, err) || !requireValue(f, "-c", {"0", "0.0", "0.000"}, err) ||
+        !requireValue(f, "--alignment-mode", {"0", "1", "2", "3"}, err) || !requireValue(f, "--alt-ali", {"0"}, err) || !requireValue(f, "--realign", {"0"}, err) ||
+        !requireValue(f, "--wrapped-scoring", {"0"}, err) || !requireValue(f, "--alignment-output-mode", {"0"}, err) || !requireValue(f, "--score-bias", {"0", "0.0", "0.000"}, err) ||
+        !requireValue(f, "--seq-id-mode", {"0"}, err) || !requireValue(f, "--num-iterations", {"1"}, err) || !requireValue(f, "--search-type", {"0", "1"}, err) ||
+        !requireValue(f, "--exhaustive-search", {"0"}, err) || !requireValue(f, "--lca-search", {"0"}, err) || !requireValue(f, "--start-sens", {"4", "4.0", "4.000"}, err) ||
+        !requireValue(f, "--sens-steps", {"1"}, err) || !requireValue(f, "--translate", {"0"}, err))
+        return fail("search: " + err);
+    if (f.num("-a", 0) != 1) return fail("search: only -a 1 (backtrace => score, coverage and sequence identity) is implemented, which is what predictmatch passes");
+    { const int rc = fanOut("search", argc, argv, f.positional[2]); if (rc >= 0) return rc; }
+    Laps laps("search");
+    Db qdb, tdb;
+    if (!loadSeqDb(f.positional[0], qdb, err) || !loadSeqDb(f.positional[1], tdb, err)) return fail("search: " + err);
+    laps.lap("read DBs");
+    sp_search_params p; sp_default_params(&p);
+    std::string seed = aaPart(f.str("--seed-sub-mat", "VTML80.out")), sub = aaPart(f.str("--sub-mat", "VTML40.out"));
+    p.seed_sub_mat = seed.c_str(); p.sub_mat = sub.c_str();
+    p.sensitivity = (float) f.real("-s", 5.7);
+    p.kmer_score = (int) f.num("--k-score", INT_MAX);
+    p.max_seqs = (int) f.num("--max-seqs", 300);
+    p.min_ungapped_score = (int) f.num("--min-ungapped-score", 15);
+    p.mask = (int) f.num("--mask", 1);
+    p.evalue = f.real("-e", 0.001);
+    p.gap_open = (int) strtol(aaPart(f.str("--gap-open", "11")).c_str(), NULL, 10);
+    p.gap_extend = (int) strtol(aaPart(f.str("--gap-extend", "1")).c_str(), NULL, 10);
+    p.threads = (int) f.num("--threads", 0);
+    Ctx ctx; ctx.c = sp_ctx_create(&p);
+    if (!ctx.c) return fail(std::string("search: ") + sp_last_error());
+    laps.lap("context (matrices, tables)");
+    std::vector<char> tres, qres; std::vector<uint64_t> toff, qoff; std::vector<uint32_t> tkeys, qkeys;
+    flatten(tdb, tres, toff, tkeys);
+    if (sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) return fail(std::string("search: ") + sp_last_error());
+    laps.lap("targets -> device, index");
+    flatten(qdb, qres, qoff, qkeys);
+    const double minSeqId = f.real("--min-seq-id", 0.0); const long minAlnLen = f.num("--min-aln-len", 0);
+    const long maxAccept = f.num("--max-accept", INT_MAX), maxRejected = f.num("--max-rejected", INT_MAX);
+    const int threads = (int) f.num("--threads", 0) > 0 ? (int) f.num("--threads", 0) : (int) std::max(1u, std::thread::hardware_concurrency());
+    DbWriter w; w.path = f.positional[2]; w.dbtype = 5;       // DBTYPE_ALIGNMENT_RES
+    const size_t batch = 1u << 20;
+    size_t qFrom = 0, nq = qkeys.size();
+    { std::vector<uint64_t> lens(qkeys.size()); for (size_t i = 0; i < lens.size(); i++) lens[i] = qoff[i + 1] - qoff[i] + 2; partRange(lens, w.part, qFrom, nq); }   // this GPU's queries
+    // result buffers in ordinary memory: page-locking tens of megabytes costs more (0.23 ms per MB) than a one-shot module run gains
+    // from the faster copy
+    sp_alignment *res = nullptr; char *cig = nullptr; uint64_t resCap = 0, cigCap = 0;
+    auto freeBufs = [&]() { free(res); free(cig); res = nullptr; cig = nullptr; };
+    for (size_t b0 = qFrom; b0 < nq; b0 += batch) {
+        const size_t b1 = std::min(nq, b0 + batch);
+        std::vector<uint64_t> off(qoff.begin() + b0, qoff.begin() + b1 + 1);
+        for (uint64_t &o : off) o -= qoff[b0];
+        if (sp_ctx_set_queries(ctx.c, qres.data() + qoff[b0], off.data(), b1 - b0) != SP_OK || sp_ctx_prefilter(ctx.c) != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+        laps.lap("queries -> device, prefilter");
+        const uint64_t nHits = sp_ctx_num_hits(ctx.c);
+        if (nHits + 16 > resCap || 24 * (nHits + 16) > cigCap) {
+            freeBufs();
+            resCap = nHits + nHits / 4 + 1024; cigCap = 24 * resCap;
+            res = static_cast<sp_alignment *>(malloc(resCap * sizeof(sp_alignment))); cig = static_cast<char *>(malloc(cigCap));
+            if (!res || !cig) { freeBufs(); return fail("search: out of memory"); }
+        }
+        uint64_t used = 0;
+        int rc = sp_ctx_align_hits(ctx.c, res, cig, cigCap, &used);
+        if (rc == SP_ERR_OVERFLOW && used > cigCap) {
+            free(cig); cigCap = used + 1024; cig = static_cast<char *>(malloc(cigCap));
+            rc = sp_ctx_align_hits(ctx.c, res, cig, cigCap, &used);
+        }
+        if (rc != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+        const sp_hit_packed *hits = nullptr; const uint32_t *ho = nullptr; uint64_t nh = 0;
+        if (sp_ctx_hits_view(ctx.c, &hits, &ho, &nh) != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+        laps.lap("align on the device");
+        const size_t nEntries = b1 - b0;
+        const size_t nChunks = numChunks(nEntries, threads);
+        std::vector<std::string> blocks(nChunks); std::vector<std::vector<uint32_t>> bKeys(nChunks); std::vector<std::vector<uint64_t>> bLens(nChunks);
+        parallelChunks(nEntries, threads, [&](size_t ci, size_t from, size_t to) {
+            std::string &block = blocks[ci];
+            block.reserve((size_t) ((to - from) * 40 + (ho[to] - ho[from]) * 64));
+            std::vector<uint64_t> ok;
+            for (size_t e = from; e < to; e++) {
+                ok.clear();
+                long passed = 0, rejected = 0;
+                for (uint64_t i = ho[e]; i < ho[e + 1] && passed < maxAccept && rejected < maxRejected; i++) {
+                    const sp_alignment &r = res[i];
+                    const bool good = r.passed && r.seq_id >= minSeqId && (long) r.aln_len >= minAlnLen;    // Alignment::checkCriteria, Alignment.cpp:555-574
+                    if (good) { ok.push_back(i); passed++; rejected = 0; } else rejected++;
+                }
+                if (ok.size() > 1) std::sort(ok.begin(), ok.end(), [&](uint64_t a, uint64_t b) { return alnLess(res[a], res[b]); });
+                const size_t before = block.size();
+                for (uint64_t i : ok) appendAlnLine(block, res[i], cig + res[i].cigar_offset, true);
+                block.push_back('\0');
+                bKeys[ci].push_back(qkeys[b0 + e]); bLens[ci].push_back(block.size() - before);
+            }
+        });
+        for (size_t ci = 0; ci < nChunks; ci++) w.addBlock(bKeys[ci], bLens[ci], std::move(blocks[ci]));
+        laps.lap("format records");
+    }
+    freeBufs();
+    if (!w.close(err)) return fail("search: " + err);
     laps.lap("write DB");
     return 0;
 }

@@ -7,4 +7,5 @@ int currentDevice();
 int runPrefilterModule(int argc, const char **argv);
 int runAlignModule(int argc, const char **argv);
 int runRescoreDiagonalModule(int argc, const char **argv);
+int runSearchModule(int argc, const char **argv);
 }  // namespace sp

@@ -245,3 +245,30 @@ def test_modules_with_sparse_keys_and_shuffled_entries(tmp_path):
     got, _ = read_db(resc)
     for a in r["aln"]:
         assert got[qkeys[a["id"]]] == tmap(a["rescore2"]), a["id"]
+
+
+@pytest.mark.parametrize("name", ["small", "family", "longq"])
+def test_fused_search_module_writes_the_align_db(name, tmp_path):
+    """`search <queryDB> <targetDB> <alnDB> <tmp>` = prefilter + align on one resident context, with the reference's search flag list
+    (lib/mmseqs/src/workflow/Search.cpp): the alignment DB must be the one the reference's two modules produce -- the golden text --
+    and byte-identical, index included, to this implementation's own two-step run"""
+    import spacepharer_amd as sa
+    g = load_golden(name)
+    r = g["ref"]
+    q, t, pref, aln, fused = (str(tmp_path / x) for x in ("qdb", "tdb", "pref", "aln", "fused"))
+    write_seq_db(q, g["queries"], key0=11)
+    write_seq_db(t, g["targets"], split=True)
+    flags = (PREF_FLAGS % r["maxSeqs"]).split() + ["-a", "1", "--alignment-mode", "2", "-e", "200", "--min-seq-id", "0", "--min-aln-len", "0", "--max-rejected", "2147483647",
+                                                   "--max-accept", "2147483647", "--gap-open", "nucl:10,aa:16", "--gap-extend", "2", "--num-iterations", "1", "--search-type", "0",
+                                                   "--start-sens", "4", "--sens-steps", "1", "--exhaustive-search", "0", "--remove-tmp-files", "0", "--rescore-mode", "0", "--strand", "1"]
+    sa.module_search([q, t, fused, str(tmp_path)] + flags)
+    got, dbtype = read_db(fused)
+    assert dbtype == 5 and sorted(got) == [11 + i for i in range(len(g["queries"]))]
+    for a in r["aln"]:
+        assert got[11 + a["id"]] == a["text"], a["id"]
+    sa.module_prefilter([q, t, pref] + (PREF_FLAGS % r["maxSeqs"]).split())
+    sa.module_align([q, t, pref, aln] + ALN_FLAGS.split())
+    assert open(aln, "rb").read() == open(fused, "rb").read() and open(aln + ".index").read() == open(fused + ".index").read()
+    with pytest.raises(sa.SpError):
+        sa.module_search([q, t, fused + "x", str(tmp_path)] + flags + ["--num-iterations", "3"])      # iterative profile search: not this path
+    assert not os.path.exists(fused + "x.dbtype")

@@ -1,7 +1,12 @@
-"""End-to-end timing of the module drop-ins on MMseqs2 DB triples: `prefilter` then `align` with the workflow's command
-lines on the bench.py workload.  Wall clock per module = process start of the module call to
-result DB written (reading the DBs, target set preparation on the device, search, formatting, writing)."""
+"""End-to-end timing of the module drop-ins on MMseqs2 DB triples ("DBs on disk" -> "result DB written"): `prefilter` then `align`
+with the workflow's command lines, and the fused `search`, on the bench.py workload.  Wall clock per call =
+entry into the module function to result DB written (reading the DBs, target set preparation on the device, search, formatting,
+writing).  `cold` = the first call of a fresh process (pays the HIP runtime start-up and the similar-3-mer table), `warm` = the
+same call again in the same process.  One JSON line; bench.py embeds it under "module_e2e".
+usage: python tools/module_e2e.py [spacers ...]"""
+import json
 import os
+import subprocess
 import sys
 import tempfile
 import time
@@ -9,27 +14,75 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import bench  # noqa: E402
-import spacepharer_amd as sa  # noqa: E402
-from test_gpu_modules import ALN_FLAGS, PREF_FLAGS, write_seq_db  # noqa: E402
 
-n_spacers = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-tres, toff, qres, qoff = bench.make_workload(n_spacers, 50000, 200, 12345)
-T = [tres[int(toff[i]):int(toff[i + 1])].tobytes().decode() for i in range(len(toff) - 1)]
-Q = [qres[int(qoff[i]):int(qoff[i + 1])].tobytes().decode() for i in range(len(qoff) - 1)]
-with tempfile.TemporaryDirectory() as d:
+
+def worker(n_spacers, d, mode):
+    import bench
+    import spacepharer_amd as sa
+    from test_gpu_modules import ALN_FLAGS, PREF_FLAGS, write_seq_db
+    threads = str(min(64, os.cpu_count() or 1))
+    pf = [x if x != "8" or PREF_FLAGS.split()[i - 1] != "--threads" else threads for i, x in enumerate((PREF_FLAGS % 300).split())]
+    af = [x if x != "8" or ALN_FLAGS.split()[i - 1] != "--threads" else threads for i, x in enumerate(ALN_FLAGS.split())]
+    sf = pf + [x for i, x in enumerate(af) if not (x in pf and x.startswith("-")) and not (i > 0 and af[i - 1] in pf and af[i - 1].startswith("-"))]
+    tres, toff, qres, qoff = bench.make_workload(n_spacers, 50000, 200, 12345)
+    T = [tres[int(toff[i]):int(toff[i + 1])].tobytes().decode() for i in range(len(toff) - 1)]
+    Q = [qres[int(qoff[i]):int(qoff[i + 1])].tobytes().decode() for i in range(len(qoff) - 1)]
     q, t, pref, aln = (os.path.join(d, x) for x in ("qdb", "tdb", "pref", "aln"))
     write_seq_db(q, Q)
     write_seq_db(t, T)
+    out = {"spacers": n_spacers, "threads": int(threads), "mode": mode, "runs": []}
+    for rep in range(3):
+        for f in os.listdir(d):
+            if f.startswith("pref") or f.startswith("aln"):
+                os.remove(os.path.join(d, f))
+        t0 = time.perf_counter()
+        if mode == "two_step":
+            sa.module_prefilter([q, t, pref] + pf)
+            t1 = time.perf_counter()
+            sa.module_align([q, t, pref, aln] + af)
+            out["runs"].append({"prefilter_s": round(t1 - t0, 4), "align_s": round(time.perf_counter() - t1, 4), "total_s": round(time.perf_counter() - t0, 4)})
+        else:
+            sa.module_search([q, t, aln, d] + sf)
+            out["runs"].append({"total_s": round(time.perf_counter() - t0, 4)})
+    # the same calls as fresh PROCESSES of the front-end binary -- what a workflow script pays per module call: process start, HIP
+    # runtime start-up, similar-3-mer table, first touch of every device buffer
+    exe = os.path.join(ROOT, "spacepharer_amd", "spacepharer-amd")
+    procs = []
     for rep in range(2):
         for f in os.listdir(d):
             if f.startswith("pref") or f.startswith("aln"):
                 os.remove(os.path.join(d, f))
         t0 = time.perf_counter()
-        assert sa.module_prefilter([q, t, pref] + (PREF_FLAGS % 300).split()) == 0
-        t1 = time.perf_counter()
-        assert sa.module_align([q, t, pref, aln] + ALN_FLAGS.split()) == 0
-        t2 = time.perf_counter()
-        print("run %d: prefilter module %.3f s, align module %.3f s -> %.0f spacer-queries/s end to end (files in tmpfs/disk: %s)" %
-              (rep, t1 - t0, t2 - t1, n_spacers / (t2 - t0), d))
-    print("pref DB %d bytes, aln DB %d bytes" % (os.path.getsize(pref), os.path.getsize(aln)))
+        if mode == "two_step":
+            subprocess.run([exe, "prefilter", q, t, pref] + pf, check=True, capture_output=True)
+            subprocess.run([exe, "align", q, t, pref, aln] + af, check=True, capture_output=True)
+        else:
+            subprocess.run([exe, "search", q, t, aln, d] + sf, check=True, capture_output=True)
+        procs.append(round(time.perf_counter() - t0, 4))
+    out["process_total_s"] = procs
+    out["process_spacer_queries_per_s"] = n_spacers / min(procs)
+    import zlib
+    out["aln_db_bytes"] = os.path.getsize(aln)
+    out["aln_db_crc"] = "%08x" % zlib.crc32(open(aln + ".index", "rb").read(), zlib.crc32(open(aln, "rb").read()))
+    out["cold_spacer_queries_per_s"] = n_spacers / out["runs"][0]["total_s"]
+    out["warm_spacer_queries_per_s"] = n_spacers / min(r["total_s"] for r in out["runs"][1:])
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--worker":
+        worker(int(sys.argv[2]), sys.argv[3], sys.argv[4])
+        sys.exit(0)
+    sizes = [int(a) for a in sys.argv[1:]] or [10000, 100000]
+    res = []
+    for n in sizes:      # a fresh process per size and mode: its first call is the cold one
+        for mode in ("two_step", "fused"):
+            with tempfile.TemporaryDirectory() as d:
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", str(n), d, mode], capture_output=True, text=True, timeout=1800)
+                if p.returncode != 0:
+                    sys.exit(p.stderr[-3000:])
+                res.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]))
+                sys.stderr.write(p.stderr[-6000:] if os.environ.get("SP_MODULE_TIMES") else "")
+    for a, b in zip(res[0::2], res[1::2]):
+        assert a["aln_db_crc"] == b["aln_db_crc"], "the fused search wrote a different alignment DB than prefilter + align"
+    print(json.dumps({"module_e2e": res}))
