@@ -90,7 +90,20 @@ def host_info():
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
-    return {"nproc": os.cpu_count() or 1, "usable_cores": usable, "cpu_model": model, "mem_available_bytes": avail}
+    quota = None      # cgroup CPU quota of this container (cpu.max: "<quota> <period>" in microseconds, or "max")
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            f = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota = None if f[0] == "max" else float(f[0]) / float(f[1])
+            else:
+                q = float(f[0])
+                quota = None if q <= 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    cores = usable if quota is None else max(1, min(usable, int(quota + 0.5)))
+    return {"nproc": os.cpu_count() or 1, "usable_cores": usable, "cpu_quota_cores": quota, "cores_for_cpu_baseline": cores, "cpu_model": model, "mem_available_bytes": avail}
 
 
 def cpu_baseline_reference(tres, toff, qres, qoff, n_sample, threads, target_s=4.0):
@@ -530,7 +543,9 @@ def main():
         # the reference itself when its harness travelled with the repo (oracle/_ref, built by __graft_entry__.build()), else
         # the scalar port; either way a bounded sample
         hi = out["host"]
-        cores = args.cpu_cores if args.cpu_cores > 0 else hi["usable_cores"]
+        # all the cores this container may use: the affinity mask, capped by its cgroup CPU quota (256 hardware threads are visible on
+        # the pool's boxes but cpu.max grants 16 CPUs: 256 threads just get throttled -- 27 k spacer-queries/s, 8 of them do 21 k)
+        cores = args.cpu_cores if args.cpu_cores > 0 else hi["cores_for_cpu_baseline"]
         cores = max(1, min(cores, hi["usable_cores"], 512))
         tres, toff, qres, qoff = m["batches"][0]
         if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_harness")):
@@ -545,6 +560,7 @@ def main():
         else:
             out["cpu_baseline"] = cpu_baseline(tres, toff, qres, qoff, min(args.cpu_sample, nq))
         out["cpu_baseline"]["nproc"] = hi["nproc"]
+        out["cpu_baseline"]["cpu_quota_cores"] = hi["cpu_quota_cores"]
         out["cpu_baseline"]["cpu_model"] = hi["cpu_model"]
     if world == 1 and not args.no_module_e2e and not sharded and (n_spacers, args.targets, args.target_len) == (10000, 50000, 200):
         # the boundary the workflow scripts use: module calls on DB triples, "DBs on disk" -> "result DB written", as fresh processes
@@ -554,9 +570,10 @@ def main():
             pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "module_e2e.py"), "10000", "100000"], capture_output=True, text=True, timeout=1200)
             doc = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])["module_e2e"]
             out["module_e2e"] = {"what": "spacer-queries/s files-to-files on the bench targets (1e7 residues): module argv in, alignment DB on disk out; 'process' = fresh processes of "
-                                         "spacepharer_amd/spacepharer-amd per module call (process start + HIP runtime start-up + tables included), 'warm' = repeated call inside one process",
+                                         "spacepharer_amd/spacepharer-amd per module call (process start + HIP runtime start-up + tables included), 'warm' = repeated call inside one process, 'served' = client processes of the same binary forwarding to a resident `spacepharer-amd serve` (runtime, tables and target set stay up)",
                                  "runs": [{"spacers": r["spacers"], "mode": r["mode"], "threads": r["threads"], "process_s": r["process_total_s"], "process_spacer_queries_per_s": r["process_spacer_queries_per_s"],
-                                           "in_process_s": [x["total_s"] for x in r["runs"]], "warm_spacer_queries_per_s": r["warm_spacer_queries_per_s"], "aln_db_bytes": r["aln_db_bytes"],
+                                           "in_process_s": [x["total_s"] for x in r["runs"]], "warm_spacer_queries_per_s": r["warm_spacer_queries_per_s"],
+                                           "served_s": r["served_total_s"], "served_spacer_queries_per_s": r["served_spacer_queries_per_s"], "aln_db_bytes": r["aln_db_bytes"],
                                            "aln_db_crc": r["aln_db_crc"]} for r in doc]}
         except Exception as e:      # noqa: BLE001
             out["module_e2e"] = {"error": repr(e)[:300]}

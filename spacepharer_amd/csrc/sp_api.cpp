@@ -89,7 +89,7 @@ int sp_init(int device_mask) {
     return SP_OK;
 }
 
-void sp_shutdown(void) { std::lock_guard<std::mutex> lk(g_mu); g_device = -1; }
+void sp_shutdown(void) { sp::releaseCachedContexts(); std::lock_guard<std::mutex> lk(g_mu); g_device = -1; }
 
 int sp_device_count(void) { sp::Gpu probe; return probe.deviceCount(); }
 
@@ -116,7 +116,7 @@ sp_ctx *sp_ctx_create(const sp_search_params *p) {
     c->subName = p->sub_mat ? p->sub_mat : "VTML40.out";
     c->par.seed_sub_mat = c->seedName.c_str();
     c->par.sub_mat = c->subName.c_str();
-    c->threads = p->threads > 0 ? p->threads : (int) std::max(1u, std::thread::hardware_concurrency());
+    c->threads = p->threads > 0 ? p->threads : sp::defaultThreads();
     std::string err;
     const bool laps = getenv("SP_MODULE_TIMES") != nullptr; const double tc0 = nowMs();
     // bit factors / score biases: prefiltering/Prefiltering.cpp:63-67, alignment/Alignment.cpp:157-162
@@ -581,7 +581,7 @@ int sp_host_matrix(const char *spec, double bitFactor, double scoreBias, int16_t
 int sp_host_ext3_digest(const char *seedSpec, uint64_t *digest, int16_t *scoreHead64, uint32_t *indexHead64, uint32_t row) {
     sp::SubMat m; std::string err;
     if (!m.load(seedSpec, (double) 8.0f, (double) -0.2f, err)) { g_err = err; return SP_ERR_ARG; }
-    std::vector<uint32_t> packed; sp::buildExt3(m, packed, (int) std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<uint32_t> packed; sp::buildExt3(m, packed, sp::defaultThreads());
     *digest = ext3Digest(packed, scoreHead64, indexHead64, row);
     return SP_OK;
 }
@@ -590,7 +590,7 @@ int sp_host_index_digest(const char *seedSpec, float sensitivity, int mask, cons
                          uint64_t *entries, uint64_t *maskedResidues, uint64_t *digest, char *maskedOut) {
     sp::SubMat m; std::string err;
     if (!m.load(seedSpec, (double) 8.0f, (double) -0.2f, err)) { g_err = err; return SP_ERR_ARG; }
-    const int threads = (int) std::max(1u, std::thread::hardware_concurrency());
+    const int threads = sp::defaultThreads();
     sp::TargetSet ts; sp::KmerIndex idx;
     sp::prepareTargets(m, residues, offsets, nullptr, (size_t) n, mask != 0, threads, ts);
     sp::buildIndex(m, ts, sp::kmerThreshold(sensitivity, INT_MAX, sp::kKmer), threads, idx);

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/spacepharer_amd.h"
+#include "sp_host.h"
 #include "sp_modules.h"
 
 namespace sp {
@@ -58,7 +59,7 @@ struct Db {
             MappedFile idx;
             if (!idx.open(path + ".index")) { err = "cannot open " + path + ".index"; return false; }
             const char *text = idx.p; const size_t sz = idx.n;
-            const size_t T = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), sz / (1 << 20) + 1));
+            const size_t T = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, (size_t) defaultThreads()), sz / (1 << 20) + 1));
             std::vector<std::vector<DbEntry>> part(T); std::vector<int> bad(T, 0);
             auto parse = [&](size_t t) {
                 size_t from = sz * t / T, to = sz * (t + 1) / T;
@@ -187,7 +188,7 @@ struct DbWriter {
         if (!sorted) std::sort(entries.begin(), entries.end(), [](const DbEntry &a, const DbEntry &b) { return a.key < b.key; });   // DBWriter.cpp:645-660
         {   // index text: formatted by a few threads over contiguous ranges, written with one call
             const size_t n = entries.size();
-            const size_t T = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), n / 65536 + 1));
+            const size_t T = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, (size_t) defaultThreads()), n / 65536 + 1));
             std::vector<std::string> texts(T);
             auto fmt = [&](size_t t) {
                 std::string &text = texts[t]; const size_t from = n * t / T, to = n * (t + 1) / T;

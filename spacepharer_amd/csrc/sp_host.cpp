@@ -12,6 +12,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <sched.h>
 #include <thread>
 #include <unistd.h>
 
@@ -432,5 +433,18 @@ double Evaluer::evalue(double score, double qLen) const {
 }
 
 double Evaluer::bitScore(double score) const { return (p.lambda * score - logK) / std::log(2.0); }
+
+int defaultThreads() {
+    static const int n = [] {
+        int hw = (int) std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set; CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int k = CPU_COUNT(&set); if (k > 0) hw = std::min(hw, k); }
+        std::ifstream f("/sys/fs/cgroup/cpu.max");       // "<quota> <period>" or "max <period>"
+        std::string q; double period = 0;
+        if (f.good() && (f >> q >> period) && q != "max" && period > 0) { const int k = (int) (strtod(q.c_str(), NULL) / period + 0.5); if (k >= 1) hw = std::min(hw, k); }
+        return std::max(1, hw);
+    }();
+    return n;
+}
 
 }  // namespace sp

@@ -70,6 +70,9 @@ void prepareTargets(const SubMat &seed, const char *residues, const uint64_t *of
                     bool mask, int threads, TargetSet &ts, size_t from = 0, size_t to = (size_t) -1);
 void buildIndex(const SubMat &seed, const TargetSet &ts, int kmerThr, int threads, KmerIndex &idx, size_t from = 0, size_t to = (size_t) -1);
 
+// host threads to use when the caller does not say: the CPUs this process may run on, capped by the cgroup CPU quota of its container
+int defaultThreads();
+
 // Prefiltering::getKmerThreshold (prefiltering/Prefiltering.cpp:987-1021), sequence search
 int kmerThreshold(float sensitivity, int kmerScore, int kmerSize);
 

@@ -24,6 +24,7 @@
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -48,10 +49,58 @@ static const std::set<std::string> kRescoreFlags = {
     "--sub-mat", "--rescore-mode", "--wrapped-scoring", "--filter-hits", "-e", "-c", "-a", "--cov-mode", "--min-seq-id", "--min-aln-len",
     "--seq-id-mode", "--add-self-matches", "--sort-results", "--db-load-mode", "--threads", "--compressed", "-v"};
 
+// A search context with its target set staged (index, masked residues, similar-k-mer tables in HBM).  In a one-shot module process
+// it lives for the call.  In a serving process (`spacepharer-amd serve`, SP_CONTEXT_CACHE=<n>) the last n of them stay resident,
+// keyed by the search parameters and the identity of the target DB files, so that the next call against the same target set -- the
+// control search of predictmatch, the next batch of spacers -- finds its index in HBM: 288 GB hold hundreds of phage-scale sets.
 struct Ctx {
-    sp_ctx *c = nullptr;
-    ~Ctx() { if (c) sp_ctx_destroy(c); }
+    sp_ctx *c = nullptr; bool cached = false; bool targetsStaged = false;
+    ~Ctx() { if (c && !cached) sp_ctx_destroy(c); }
 };
+struct CachedCtx { std::string key; sp_ctx *c; uint64_t stamp; };
+static std::vector<CachedCtx> g_ctxCache; static uint64_t g_ctxStamp = 0; static std::mutex g_ctxMutex;
+static size_t ctxCacheSize() { const char *e = getenv("SP_CONTEXT_CACHE"); return e ? (size_t) std::max(0, atoi(e)) : 0; }
+static std::string fileIdentity(const std::string &path) {
+    std::string id; struct stat st;
+    for (const char *ext : {"", ".0", ".index", ".dbtype"}) if (stat((path + ext).c_str(), &st) == 0) id += std::to_string((long long) st.st_size) + ":" + std::to_string((long long) st.st_mtim.tv_sec) + "." + std::to_string((long long) st.st_mtim.tv_nsec) + ";";
+    char real[4096]; return std::string(realpath(path.c_str(), real) ? real : path.c_str()) + "|" + id;
+}
+// a context for (params, target DB): from the cache when serving, else a fresh one.  what = "index" (searchable) or "residues"
+static bool acquireCtx(const sp_search_params &p, const std::string &targetPath, const char *what, Ctx &ctx, std::string &err) {
+    const size_t cap = ctxCacheSize();
+    std::string key;
+    if (cap) {
+        key = std::string(what) + "|" + p.seed_sub_mat + "|" + p.sub_mat + "|" + std::to_string(p.sensitivity) + "|" + std::to_string(p.kmer_score) + "|" + std::to_string(p.max_seqs) + "|" +
+              std::to_string(p.min_ungapped_score) + "|" + std::to_string(p.mask) + "|" + std::to_string(p.gap_open) + "|" + std::to_string(p.gap_extend) + "|" + std::to_string(p.evalue) + "|" +
+              std::to_string(p.threads) + "|" + fileIdentity(targetPath);
+        std::lock_guard<std::mutex> lk(g_ctxMutex);
+        for (CachedCtx &e : g_ctxCache) if (e.key == key) { e.stamp = ++g_ctxStamp; ctx.c = e.c; ctx.cached = true; ctx.targetsStaged = true; return true; }
+    }
+    ctx.c = sp_ctx_create(&p);
+    if (!ctx.c) { err = sp_last_error(); return false; }
+    if (cap) {
+        std::lock_guard<std::mutex> lk(g_ctxMutex);
+        if (g_ctxCache.size() >= cap) {      // evict the least recently used
+            size_t lru = 0; for (size_t i = 1; i < g_ctxCache.size(); i++) if (g_ctxCache[i].stamp < g_ctxCache[lru].stamp) lru = i;
+            sp_ctx_destroy(g_ctxCache[lru].c); g_ctxCache.erase(g_ctxCache.begin() + (long) lru);
+        }
+        g_ctxCache.push_back({key, ctx.c, ++g_ctxStamp});
+        ctx.cached = true;
+    }
+    return true;
+}
+// a cached context whose staging failed must not be handed out again
+static void dropCtx(Ctx &ctx) {
+    if (!ctx.cached || !ctx.c) return;
+    std::lock_guard<std::mutex> lk(g_ctxMutex);
+    for (size_t i = 0; i < g_ctxCache.size(); i++) if (g_ctxCache[i].c == ctx.c) { g_ctxCache.erase(g_ctxCache.begin() + (long) i); break; }
+    sp_ctx_destroy(ctx.c); ctx.c = nullptr; ctx.cached = false;
+}
+void releaseCachedContexts() {
+    std::lock_guard<std::mutex> lk(g_ctxMutex);
+    for (CachedCtx &e : g_ctxCache) sp_ctx_destroy(e.c);
+    g_ctxCache.clear();
+}
 
 static bool loadSeqDb(const std::string &path, Db &db, std::string &err) {
     if (!db.load(path, err)) return false;
@@ -114,7 +163,7 @@ static int fanOut(const char *module, int argc, const char **argv, const std::st
     auto reap = [&](bool kill9) { bool ok = true; for (pid_t k : kids) { if (kill9) kill(k, SIGKILL); int st = 0; if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) ok = false; } kids.clear(); return ok; };
     for (int r = 0; r < n; r++) {
         std::vector<std::string> envs;
-        for (char **ev = environ; *ev; ev++) if (strncmp(*ev, "SP_PART=", 8) && strncmp(*ev, "LOCAL_RANK=", 11)) envs.push_back(*ev);
+        for (char **ev = environ; *ev; ev++) if (strncmp(*ev, "SP_PART=", 8) && strncmp(*ev, "LOCAL_RANK=", 11) && strncmp(*ev, "SP_SERVER=", 10)) envs.push_back(*ev);      // (a worker runs its part itself: no forwarding to a server)
         envs.push_back("SP_PART=" + std::to_string(r) + "/" + std::to_string(n));
         envs.push_back("LOCAL_RANK=" + std::to_string(r));          // device = LOCAL_RANK mod visible devices (sp_init)
         std::vector<char *> envp; for (std::string &s : envs) envp.push_back(&s[0]); envp.push_back(nullptr);
@@ -187,12 +236,12 @@ int runPrefilterModule(int argc, const char **argv) {
     p.min_ungapped_score = (int) f.num("--min-ungapped-score", 15);
     p.mask = (int) f.num("--mask", 1);
     p.threads = (int) f.num("--threads", 0);
-    Ctx ctx; ctx.c = sp_ctx_create(&p);
-    if (!ctx.c) return fail(std::string("prefilter: ") + sp_last_error());
+    Ctx ctx;
+    if (!acquireCtx(p, f.positional[1], "index", ctx, err)) return fail("prefilter: " + err);
     laps.lap("context (matrices, tables)");
     std::vector<char> tres, qres; std::vector<uint64_t> toff, qoff; std::vector<uint32_t> tkeys, qkeys;
     flatten(tdb, tres, toff, tkeys);
-    if (sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) return fail(std::string("prefilter: ") + sp_last_error());
+    if (!ctx.targetsStaged && sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) { const std::string e = sp_last_error(); dropCtx(ctx); return fail("prefilter: " + e); }
     laps.lap("targets -> device, index");
     flatten(qdb, qres, qoff, qkeys);
     DbWriter w; w.path = f.positional[2]; w.dbtype = 7;      // DBTYPE_PREFILTER_RES
@@ -315,7 +364,7 @@ int runAlignModule(int argc, const char **argv) {
     DbWriter w; w.path = f.positional[3]; w.dbtype = 5;       // DBTYPE_ALIGNMENT_RES
     // entries are formatted by --threads workers over contiguous ranges and appended in order
     const size_t nEntries = tr.perQuery.size() - 1;
-    const int threads = (int) f.num("--threads", 0) > 0 ? (int) f.num("--threads", 0) : (int) std::max(1u, std::thread::hardware_concurrency());
+    const int threads = (int) f.num("--threads", 0) > 0 ? (int) f.num("--threads", 0) : defaultThreads();
     const size_t nChunks = numChunks(nEntries, threads);
     std::vector<std::string> blocks(nChunks); std::vector<std::vector<uint32_t>> bKeys(nChunks); std::vector<std::vector<uint64_t>> bLens(nChunks);
     parallelChunks(nEntries, threads, [&](size_t ci, size_t from, size_t to) {
@@ -390,17 +439,17 @@ int runSearchModule(int argc, const char **argv) {
     p.gap_open = (int) strtol(aaPart(f.str("--gap-open", "11")).c_str(), NULL, 10);
     p.gap_extend = (int) strtol(aaPart(f.str("--gap-extend", "1")).c_str(), NULL, 10);
     p.threads = (int) f.num("--threads", 0);
-    Ctx ctx; ctx.c = sp_ctx_create(&p);
-    if (!ctx.c) return fail(std::string("search: ") + sp_last_error());
+    Ctx ctx;
+    if (!acquireCtx(p, f.positional[1], "index", ctx, err)) return fail("search: " + err);
     laps.lap("context (matrices, tables)");
     std::vector<char> tres, qres; std::vector<uint64_t> toff, qoff; std::vector<uint32_t> tkeys, qkeys;
     flatten(tdb, tres, toff, tkeys);
-    if (sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) return fail(std::string("search: ") + sp_last_error());
+    if (!ctx.targetsStaged && sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) { const std::string e = sp_last_error(); dropCtx(ctx); return fail("search: " + e); }
     laps.lap("targets -> device, index");
     flatten(qdb, qres, qoff, qkeys);
     const double minSeqId = f.real("--min-seq-id", 0.0); const long minAlnLen = f.num("--min-aln-len", 0);
     const long maxAccept = f.num("--max-accept", INT_MAX), maxRejected = f.num("--max-rejected", INT_MAX);
-    const int threads = (int) f.num("--threads", 0) > 0 ? (int) f.num("--threads", 0) : (int) std::max(1u, std::thread::hardware_concurrency());
+    const int threads = (int) f.num("--threads", 0) > 0 ? (int) f.num("--threads", 0) : defaultThreads();
     DbWriter w; w.path = f.positional[2]; w.dbtype = 5;       // DBTYPE_ALIGNMENT_RES
     const size_t batch = 1u << 20;
     size_t qFrom = 0, nq = qkeys.size();

@@ -8,4 +8,5 @@ int runPrefilterModule(int argc, const char **argv);
 int runAlignModule(int argc, const char **argv);
 int runRescoreDiagonalModule(int argc, const char **argv);
 int runSearchModule(int argc, const char **argv);
+void releaseCachedContexts();
 }  // namespace sp

@@ -272,3 +272,47 @@ def test_fused_search_module_writes_the_align_db(name, tmp_path):
     with pytest.raises(sa.SpError):
         sa.module_search([q, t, fused + "x", str(tmp_path)] + flags + ["--num-iterations", "3"])      # iterative profile search: not this path
     assert not os.path.exists(fused + "x.dbtype")
+
+
+def test_module_calls_through_a_resident_server(tmp_path):
+    """`spacepharer-amd serve <socket>` + clients with SP_SERVER set: the client forwards argv and working directory, the server runs
+    the module with its runtime up and the target set cached in HBM, the exit status and the error text come back.  Same DB bytes as
+    a direct call; relative paths resolve in the client's directory; an error leaves no .dbtype and a non-zero status; without a
+    reachable server the client runs the module itself."""
+    import subprocess
+    import time
+    g = load_golden("small")
+    r = g["ref"]
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spacepharer_amd", "spacepharer-amd")
+    write_seq_db(str(tmp_path / "qdb"), g["queries"])
+    write_seq_db(str(tmp_path / "tdb"), g["targets"])
+    sock = str(tmp_path / "sp.sock")
+    srv = subprocess.Popen([exe, "serve", sock], stderr=subprocess.PIPE, text=True)
+    try:
+        for _ in range(3000):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.01)
+        assert os.path.exists(sock)
+        env = dict(os.environ, SP_SERVER=sock)
+        flags = (PREF_FLAGS % r["maxSeqs"]).split() + ["-a", "1", "--alignment-mode", "2", "-e", "200", "--gap-open", "nucl:10,aa:16", "--gap-extend", "2"]
+        for rep in range(3):          # the second and third call find the target set resident
+            p = subprocess.run([exe, "search", "qdb", "tdb", "aln%d" % rep, "."] + flags, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0, p.stderr
+            got, dbtype = read_db(str(tmp_path / ("aln%d" % rep)))
+            assert dbtype == 5
+            for a in r["aln"]:
+                assert got[a["id"]] == a["text"], a["id"]
+        p = subprocess.run([exe, "prefilter", "qdb", "missing", "pref"], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+        assert p.returncode != 0 and "missing" in p.stderr and not os.path.exists(str(tmp_path / "pref.dbtype"))
+        p = subprocess.run([exe, "translatenucs", "qdb", "x", "--no-such-flag", "1"], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+        assert p.returncode != 0 and "Unrecognized" in p.stderr
+        subprocess.run([exe, "shutdown"], env=env, capture_output=True, timeout=60)
+        assert srv.wait(timeout=120) == 0 and not os.path.exists(sock)
+        # no server any more: the same command line runs in the client process
+        p = subprocess.run([exe, "search", "qdb", "tdb", "aln_direct", "."] + flags, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr
+        assert open(str(tmp_path / "aln_direct"), "rb").read() == open(str(tmp_path / "aln0"), "rb").read()
+    finally:
+        if srv.poll() is None:
+            srv.kill()

@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 : > gpurun_out/sizes.txt
 one() {
-  timeout 600 python bench.py --steps 40 --warmup 3 --cpu-sample 0 "$@" 2>&1 | grep '^{' | tail -1 | python -c "
+  timeout 600 python bench.py --steps 40 --warmup 3 --regions 3 --cpu-sample 0 --no-module-e2e "$@" 2>&1 | grep '^{' | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print('$*', '|', round(d['value']), d['ms_per_step'], d['kernels_ms_per_step'], d['roofline']['frac'])" | tee -a gpurun_out/sizes.txt
 }
 one --spacers 20000

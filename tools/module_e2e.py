@@ -20,7 +20,7 @@ def worker(n_spacers, d, mode):
     import bench
     import spacepharer_amd as sa
     from test_gpu_modules import ALN_FLAGS, PREF_FLAGS, write_seq_db
-    threads = str(min(64, os.cpu_count() or 1))
+    threads = str(bench.host_info()["cores_for_cpu_baseline"])      # what this container may use (affinity mask, cgroup quota)
     pf = [x if x != "8" or PREF_FLAGS.split()[i - 1] != "--threads" else threads for i, x in enumerate((PREF_FLAGS % 300).split())]
     af = [x if x != "8" or ALN_FLAGS.split()[i - 1] != "--threads" else threads for i, x in enumerate(ALN_FLAGS.split())]
     sf = pf + [x for i, x in enumerate(af) if not (x in pf and x.startswith("-")) and not (i > 0 and af[i - 1] in pf and af[i - 1].startswith("-"))]
@@ -61,6 +61,30 @@ def worker(n_spacers, d, mode):
         procs.append(round(time.perf_counter() - t0, 4))
     out["process_total_s"] = procs
     out["process_spacer_queries_per_s"] = n_spacers / min(procs)
+    # the same client processes against a resident server (`spacepharer-amd serve`): runtime, tables and the target set stay up
+    sock = os.path.join(d, "sp.sock")
+    srv = subprocess.Popen([exe, "serve", sock], stderr=subprocess.DEVNULL)
+    for _ in range(600):
+        if os.path.exists(sock):
+            break
+        time.sleep(0.01)
+    served = []
+    env = dict(os.environ, SP_SERVER=sock)
+    for rep in range(4):
+        for f in os.listdir(d):
+            if f.startswith("pref") or f.startswith("aln"):
+                os.remove(os.path.join(d, f))
+        t0 = time.perf_counter()
+        if mode == "two_step":
+            subprocess.run([exe, "prefilter", q, t, pref] + pf, check=True, capture_output=True, env=env)
+            subprocess.run([exe, "align", q, t, pref, aln] + af, check=True, capture_output=True, env=env)
+        else:
+            subprocess.run([exe, "search", q, t, aln, d] + sf, check=True, capture_output=True, env=env)
+        served.append(round(time.perf_counter() - t0, 4))
+    subprocess.run([exe, "shutdown"], env=env, capture_output=True)
+    srv.wait(timeout=60)
+    out["served_total_s"] = served
+    out["served_spacer_queries_per_s"] = n_spacers / min(served[1:])
     import zlib
     out["aln_db_bytes"] = os.path.getsize(aln)
     out["aln_db_crc"] = "%08x" % zlib.crc32(open(aln + ".index", "rb").read(), zlib.crc32(open(aln, "rb").read()))
