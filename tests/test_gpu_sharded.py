@@ -109,3 +109,37 @@ def test_bench_sharded_path_over_rccl_single_rank():
     assert a["config"]["pairs_aligned_per_step"] == b["config"]["pairs_aligned_per_step"] > 0
     assert a["counters_per_step"]["hits"] == b["counters_per_step"]["hits"]
     assert a["counters_per_step"]["similar_kmers"] == b["counters_per_step"]["similar_kmers"]
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_bench_self_launches_the_target_sharded_run_with_several_ranks(ranks):
+    """`python bench.py --gpus N` without a launcher starts its N ranks itself.  On a one-GPU box the ranks share the device
+    (--same-gpu) and the candidates travel through host memory (--exchange gloo: RCCL refuses two ranks on one device); everything
+    else is the N > 1 path the driver runs on a multi-GPU node: target shards, all-gather, selection on the union by query slice,
+    align by query slice, the query-partition (replica) leg afterwards.  Every step's delivered bytes are checked inside bench.py
+    against a single-context pass of the same rank; here the aligned pairs over all ranks must add up to the unsplit search's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "3", "--warmup", "1", "--regions", "2", "--spacers", "1500", "--targets", "6000", "--cpu-sample", "0", "--no-module-e2e"]
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    one = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--same-gpu", "--exchange", "gloo"] + common,
+                       capture_output=True, text=True, timeout=1800, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 alone prints the line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == ranks and out["scaling"] == "strong" and "target shards x%d" % ranks in out["config"]["parallelism"]
+    assert out["exchange"]["ranks"] == ranks and out["exchange"]["allgather_bytes_per_step"] > 0 and out["exchange"]["exchange_ms_per_step"] > 0
+    assert out["config"]["pairs_aligned_per_step"] == one["config"]["pairs_aligned_per_step"]
+    assert out["results_checked"]["steps"] == 6
+    assert out["replica"]["scaling"] == "weak" and out["replica"]["value"] > 0 and out["replica"]["results_checked"] > 0
+    # a --gpus that disagrees with the launcher's WORLD_SIZE is refused instead of silently measuring something else
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"] + common, capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
