@@ -399,6 +399,7 @@ constexpr int kDeferCap = 128;       // multi-entry index lists per wave whose e
 constexpr int kOccRegs = 4;         // occupied slots per lane and batch in k_match's fetch phase (64 x kOccRegs slot words in flight per wave)
 constexpr int kWalkStep = 4;        // list positions per step when long lists are walked on the spot (kOccRegs x kWalkStep entry loads in flight)
 constexpr int kTailKeys = 3;        // keys per lane and step when the pre-filter reads spilled hits back from HBM
+constexpr int kMapGroup = 4;         // rounds of the (a, b) mapping whose LDS lookups are issued together
 constexpr int kSuper = 1024;         // similar k-mers per enumeration super-round in k_match   // queries per work-queue pop in k_match
 
 struct DiagRec { uint32_t seqId; uint16_t diag; uint16_t idx; };
@@ -679,21 +680,49 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                     const unsigned long long myW = lane < kSuper / 64 ? hflag[lane] : 0ull;
                     uint32_t carry = 0;
                     uint32_t kmerR[kSuper / 64];
+                    // The rounds are mapped in groups of kMapGroup WITHOUT per-round branches: three dependent LDS lookups per round
+                    // (list start of the a, partner index, a's 3-mer) cost a few hundred cycles when every round waits for its own;
+                    // issued for kMapGroup rounds back to back they overlap.  Lanes beyond the list compute with the last a (their map
+                    // bits are zero) and are masked at the end; partners beyond the LDS copy of row B (rare) are patched afterwards.
 #pragma unroll
-                    for (int r = 0; r < kSuper / 64; r++) {
-                        const uint32_t kr0 = s0 + 64u * r;
-                        kmerR[r] = 0xFFFFFFFFu;
-                        if (kr0 < tileK) {
-                            const uint32_t k = kr0 + lane;
-                            const unsigned long long word = ((unsigned long long) (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (myW >> 32), r) << 32) |
-                                                            (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) myW, r);
-                            const uint32_t ai = aBefore + carry + (uint32_t) __popcll(word & (~0ull >> (63 - lane))) - 1u;
+                    for (int g = 0; g < kSuper / 64; g += kMapGroup) {
+                        if (g > 0 && s0 + 64u * (uint32_t) g >= tileK) {
+#pragma unroll
+                            for (int r = g; r < g + kMapGroup; r++) kmerR[r] = 0xFFFFFFFFu;
+                            continue;
+                        }
+                        uint32_t aiG[kMapGroup], bbG[kMapGroup];
+#pragma unroll
+                        for (int r = 0; r < kMapGroup; r++) {
+                            const unsigned long long word = ((unsigned long long) (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (myW >> 32), g + r) << 32) |
+                                                            (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) myW, g + r);
+                            uint32_t ai = aBefore + carry + (uint32_t) __popcll(word & (~0ull >> (63 - lane))) - 1u;
                             carry += (uint32_t) __popcll(word);
-                            if (k < tileK) {
-                                const uint32_t bb = k - aStart[ai];
-                                const uint32_t bi = (bb < (uint32_t) kBTile) ? bIdx[bb] : extIndex(rowB[bb]);
-                                kmerR[r] = slotOfKmer(aIdx[ai], bi);
+                            aiG[r] = ai < nATile ? ai : nATile - 1u;         // (only lanes in front of the first list start can be out of range: never inside the list)
+                        }
+#pragma unroll
+                        for (int r = 0; r < kMapGroup; r++) bbG[r] = aStart[aiG[r]];
+                        uint32_t far = 0;
+#pragma unroll
+                        for (int r = 0; r < kMapGroup; r++) {
+                            const uint32_t k = s0 + 64u * (uint32_t) (g + r) + (uint32_t) lane;
+                            bbG[r] = k - bbG[r];
+                            far |= (k < tileK && bbG[r] >= (uint32_t) kBTile) ? 1u : 0u;
+                        }
+                        uint32_t biG[kMapGroup], a3G[kMapGroup];
+#pragma unroll
+                        for (int r = 0; r < kMapGroup; r++) { biG[r] = bIdx[bbG[r] < (uint32_t) kBTile ? bbG[r] : 0u]; a3G[r] = aIdx[aiG[r]]; }
+                        if (__ballot(far != 0u) != 0ull) {
+#pragma unroll
+                            for (int r = 0; r < kMapGroup; r++) {
+                                const uint32_t k = s0 + 64u * (uint32_t) (g + r) + (uint32_t) lane;
+                                if (k < tileK && bbG[r] >= (uint32_t) kBTile) biG[r] = extIndex(rowB[bbG[r]]);
                             }
+                        }
+#pragma unroll
+                        for (int r = 0; r < kMapGroup; r++) {
+                            const uint32_t k = s0 + 64u * (uint32_t) (g + r) + (uint32_t) lane;
+                            kmerR[g + r] = k < tileK ? slotOfKmer(a3G[r], biG[r]) : 0xFFFFFFFFu;
                         }
                     }
                     SP_T(3);
