@@ -454,9 +454,12 @@ class SearchContext:
     def set_scores(self, q_nucl, t_nucl, q_set, t_set, aln, cig, stage=0, simple_best_hit=True):
         """predictmatch's chain after the search on the records in memory (sp_ctx_set_scores); q_nucl / t_nucl: lists of nucleotide
         ORFs, q_set / t_set: set key per query / target, aln / cig: what align_hits_raw() returned.  -> {key: entry text}"""
-        qb, qo = _concat(q_nucl)
-        tb, to = _concat(t_nucl)
-        lay = SetLayout(qb, qo, tb, to, (C.c_uint32 * max(1, len(q_set)))(*q_set), (C.c_uint32 * max(1, len(t_set)))(*t_set), None, 0, 0, 1 if simple_best_hit else 0)
+        return self.set_scores_raw(_concat(q_nucl), _concat(t_nucl), (C.c_uint32 * max(1, len(q_set)))(*q_set), (C.c_uint32 * max(1, len(t_set)))(*t_set), aln, cig, stage, simple_best_hit)
+
+    def set_scores_raw(self, q_nucl, t_nucl, q_set, t_set, aln, cig, stage=0, simple_best_hit=True):
+        """set_scores() on buffers the caller already holds: q_nucl / t_nucl = (bytes, ctypes uint64 offsets[n + 1]) as _concat()
+        returns them, q_set / t_set = ctypes uint32 arrays"""
+        lay = SetLayout(q_nucl[0], q_nucl[1], t_nucl[0], t_nucl[1], q_set, t_set, None, 0, 0, 1 if simple_best_hit else 0)
         out = TextDb()
         _check(self.L.sp_ctx_set_scores(self.ctx, C.byref(lay), aln, C.cast(cig, C.c_char_p), stage, C.byref(out)))
         try:

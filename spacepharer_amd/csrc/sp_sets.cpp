@@ -18,6 +18,10 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <thread>
 
 #include "sp_db.h"
 #include "sp_host.h"
@@ -28,7 +32,7 @@ namespace sets {
 // ------------------------------------------------------------------------------------------------------------------
 // small text helpers: the reference's number formats
 // ------------------------------------------------------------------------------------------------------------------
-static std::string fmtE(double x) { char b[40]; const int n = snprintf(b, sizeof(b), "%.3E", x); return std::string(b, (size_t) n); }      // SSTR(double), Util.cpp:713-718
+static std::string fmtE(double x) { char b[40]; return std::string(b, (size_t) (fmtE3(x, b) - b)); }      // SSTR(double), Util.cpp:713-718
 static inline bool isWs(char c) { return c == ' ' || c == '\t'; }
 // Util::getWordsOfLine (Util.h:232-246): word starts of one line; words[n] = the line end
 static size_t words(const char *p, const char **w, size_t maxW) {
@@ -57,49 +61,65 @@ static char complementOf(unsigned char c) {
     return '.';
 }
 
+// per byte: its upper-case form (the CHAR_MAX sentinel stays), whether it counts as a gap (N or not an IUPAC letter, Orf.cpp:268-272)
+// and its complement on the reverse strand (non-IUPAC -> 'N')
+struct BaseTables {
+    unsigned char up[256], gap[256]; char comp[256];
+    BaseTables() {
+        for (int c = 0; c < 256; c++) {
+            up[c] = c == CHAR_MAX ? (unsigned char) CHAR_MAX : (unsigned char) ((char) c & (char) ~0x20);
+            const char k = complementOf((unsigned char) c); comp[c] = k == '.' ? 'N' : k;
+        }
+        for (int c = 0; c < 256; c++) gap[c] = (c == 'N' || complementOf((unsigned char) c) == '.') ? 1 : 0;      // indexed by the upper-cased byte
+    }
+};
+static const BaseTables &baseTables() { static const BaseTables t; return t; }
+
 void OrfFinder::setSequence(const char *seq, size_t L) {
     // Orf::setSequence (Orf.cpp:118-148): 'u' -> 't' (the 'U' -> 'T' assignment is overwritten there and has no effect);
     // both strands are followed by a few CHAR_MAX sentinels so that the last codons read "incomplete"
+    const BaseTables &t = baseTables();
     len = L;
-    fwd.assign(L + 8, (char) CHAR_MAX); rev.assign(L + 8, (char) CHAR_MAX);
-    for (size_t i = 0; i < L; i++) fwd[i] = seq[i] == 'u' ? 't' : seq[i];
-    for (size_t i = 0; i < L; i++) { const char c = complementOf((unsigned char) fwd[L - 1 - i]); rev[i] = c == '.' ? 'N' : c; }
+    fwd.resize(L + 8); rev.resize(L + 8);
+    char *f = &fwd[0], *r = &rev[0];
+    for (size_t i = 0; i < L; i++) f[i] = seq[i] == 'u' ? 't' : seq[i];
+    for (size_t i = 0; i < L; i++) r[i] = t.comp[(unsigned char) f[L - 1 - i]];
+    memset(f + L, CHAR_MAX, 8); memset(r + L, CHAR_MAX, 8);
 }
 
-static inline bool codonIs(const char *c, const char *x) { return c[0] == x[0] && c[1] == x[1] && c[2] == x[2]; }
-
-// Orf::findForward (Orf.cpp:200-330), translation table 1: stop codons TAA TAG TGA, start codon ATG
+// Orf::findForward (Orf.cpp:200-330), translation table 1: stop codons TAA TAG TGA, start codon ATG.  The reference walks the
+// strand codon by codon and visits the three frames of each codon position; that is every position 0 .. 3 * ceil((len - 2) / 3) - 1
+// in turn, frame = position % 3.  A codon is "incomplete" when it reaches into the sentinels, i.e. position + 2 >= len.
 void OrfFinder::scan(const std::string &s, int strand, size_t minLen, size_t maxLen, size_t maxGaps, unsigned frames, unsigned startMode, std::vector<OrfLoc> &out) const {
     if (len < 3) return;
+    const BaseTables &t = baseTables();
+    const unsigned char *p = (const unsigned char *) s.data();
     bool inside[3] = {true, true, true}, hasStart[3] = {false, false, false};
     size_t gaps[3] = {0, 0, 0}, count[3] = {0, 0, 0}, from[3] = {0, 1, 2};
-    auto incomplete = [](const char *c) { return c[0] == CHAR_MAX || c[1] == CHAR_MAX || c[2] == CHAR_MAX; };
-    for (size_t i = 0; i < len - 2; i += 3) {
-        for (size_t pos = i; pos < i + 3; pos++) {
-            char c[3];
-            for (int k = 0; k < 3; k++) c[k] = s[pos + k] == CHAR_MAX ? (char) CHAR_MAX : (char) (s[pos + k] & (char) ~0x20);
-            const size_t fr = pos % 3;
-            if (!(frames & (1u << fr))) continue;
-            const bool last = !incomplete(c) && incomplete(s.data() + pos + 3);
-            const bool isStartCodon = codonIs(c, "ATG");
-            bool start;
-            if (startMode == 0) start = !inside[fr] && isStartCodon;            // START_TO_STOP
-            else if (startMode == 1) start = !inside[fr];                      // ANY_TO_STOP
-            else start = isStartCodon;                                         // LAST_START_TO_STOP
-            if (start) { inside[fr] = true; hasStart[fr] = true; from[fr] = pos; gaps[fr] = 0; count[fr] = 0; }
-            const bool stop = codonIs(c, "TAA") || codonIs(c, "TAG") || codonIs(c, "TGA");
-            if (inside[fr]) {
-                if (!stop) count[fr]++;
-                if (c[0] == 'N' || complementOf((unsigned char) c[0]) == '.' || c[1] == 'N' || complementOf((unsigned char) c[1]) == '.' ||
-                    c[2] == 'N' || complementOf((unsigned char) c[2]) == '.') gaps[fr]++;
-            }
-            if (inside[fr] && (stop || last)) {
-                inside[fr] = false;
-                if (count[fr] == 0 && stop) continue;
-                const size_t to = (last && !stop) ? pos + 2 : pos - 1;
-                if (gaps[fr] > maxGaps || count[fr] > maxLen || count[fr] < minLen) continue;
-                out.push_back(OrfLoc{from[fr], to, !hasStart[fr], !stop, strand});
-            }
+    const size_t end = ((len - 2 + 2) / 3) * 3;
+    unsigned char c0 = t.up[p[0]], c1 = t.up[p[1]];
+    unsigned fr = 0;
+    for (size_t pos = 0; pos < end; pos++, fr = fr == 2 ? 0 : fr + 1) {
+        const unsigned char a = c0, b = c1, c = t.up[p[pos + 2]];
+        c0 = b; c1 = c;
+        if (!(frames & (1u << fr))) continue;
+        const bool last = pos + 2 < len && pos + 5 >= len;
+        const bool isStartCodon = a == 'A' && b == 'T' && c == 'G';
+        bool start;
+        if (startMode == 0) start = !inside[fr] && isStartCodon;            // START_TO_STOP
+        else if (startMode == 1) start = !inside[fr];                      // ANY_TO_STOP
+        else start = isStartCodon;                                         // LAST_START_TO_STOP
+        if (start) { inside[fr] = true; hasStart[fr] = true; from[fr] = pos; gaps[fr] = 0; count[fr] = 0; }
+        if (!inside[fr]) continue;
+        const bool stop = a == 'T' && ((b == 'A' && (c == 'A' || c == 'G')) || (b == 'G' && c == 'A'));
+        if (!stop) count[fr]++;
+        gaps[fr] += (size_t) (t.gap[a] | t.gap[b] | t.gap[c]);
+        if (stop || last) {
+            inside[fr] = false;
+            if (count[fr] == 0 && stop) continue;
+            const size_t to = (last && !stop) ? pos + 2 : pos - 1;
+            if (gaps[fr] > maxGaps || count[fr] > maxLen || count[fr] < minLen) continue;
+            out.push_back(OrfLoc{from[fr], to, !hasStart[fr], !stop, strand});
         }
     }
 }
@@ -281,36 +301,52 @@ bool combineProtNucl(const char *prot, const char *nucl, std::string &out, std::
 }
 
 // Aggregation::buildMap (Aggregation.cpp:24-45): lines grouped by the set of their first column, sets ascending, lines in order
-static bool groupBySet(const char *data, const SetLookup &memberToSet, std::map<uint32_t, std::vector<std::vector<std::string>>> &groups, std::string &err) {
+// the non-empty lines of an entry with the set of their first column, ordered by set (lines of one set keep their order): what
+// the reference collects into a std::map<set, vector<columns>> (besthitperset.cpp:35-52, CombineScore.cpp:47-62) -- kept as
+// views into the entry, no per-column copies
+struct SetLine { const char *p; uint32_t n; uint32_t set; };
+static bool groupBySet(const char *data, const SetLookup &memberToSet, std::vector<SetLine> &lines, std::string &err) {
+    lines.clear();
+    bool ordered = true;
     while (*data != '\0') {
         const char *next = skipLine(data);
         size_t n = (size_t) (next - data); if (n && data[n - 1] == '\n') n--;
         if (n) {
-            std::vector<std::string> cols; size_t at = 0;
-            const std::string line(data, n);
-            for (;;) { const size_t t = line.find('\t', at); if (t == std::string::npos) { cols.push_back(line.substr(at)); break; } cols.push_back(line.substr(at, t - at)); at = t + 1; }
             uint32_t set;
-            if (!memberToSet.find((uint32_t) atou(cols[0].c_str()), set)) { err = "invalid target database key " + cols[0]; return false; }
-            groups[set].push_back(cols);
+            if (!memberToSet.find((uint32_t) atou(data), set)) { size_t k = 0; while (k < n && data[k] != '\t') k++; err = "invalid target database key " + std::string(data, k); return false; }
+            if (!lines.empty() && lines.back().set > set) ordered = false;
+            lines.push_back(SetLine{data, (uint32_t) n, set});
         }
         data = next;
     }
+    if (!ordered) std::stable_sort(lines.begin(), lines.end(), [](const SetLine &a, const SetLine &b) { return a.set < b.set; });
     return true;
+}
+// column i of a tab-separated line ("" when the line has fewer columns); the text ends at a tab / the line end, which stops strtod
+static const char *column(const SetLine &l, size_t i) {
+    const char *p = l.p, *e = l.p + l.n;
+    for (; i > 0; i--) { while (p < e && *p != '\t') p++; if (p == e) return ""; p++; }
+    return p;
+}
+static double columnValue(const SetLine &l, size_t i) {      // strtod must not run past the line into the next one when the column is the (empty) last one
+    const char *c = column(l, i);
+    return (c == l.p + l.n) ? 0.0 : strtod(c, NULL);
 }
 
 // besthitperset (besthitperset.cpp:29-115): per target set the line with the best E-value; column 1 becomes the log of the
 // set-corrected P-value.  simple = --simple-best-hit (predictmatch: 1)
 bool bestHitPerSet(const char *entry, const SetLookup &memberToSet, const SetLookup &setSize, bool simple, std::string &out, std::string &err) {
-    std::map<uint32_t, std::vector<std::vector<std::string>>> groups;
-    if (!groupBySet(entry, memberToSet, groups, err)) return false;
-    for (auto &g : groups) {
+    std::vector<SetLine> lines; char nb[40];
+    if (!groupBySet(entry, memberToSet, lines, err)) return false;
+    for (size_t from = 0, to; from < lines.size(); from = to) {
+        for (to = from + 1; to < lines.size() && lines[to].set == lines[from].set; to++) {}
         uint32_t nGenes;
-        if (!setSize.find(g.first, nGenes)) { err = "invalid target size database key " + std::to_string(g.first); return false; }
-        const std::vector<std::vector<std::string>> &lines = g.second;
-        double bestScore = -DBL_MAX, second = -DBL_MAX, bestEval = DBL_MAX; const std::vector<std::string> *best = nullptr;
-        const bool single = simple || lines.size() < 2;
-        for (const std::vector<std::string> &l : lines) {
-            const double eval = strtod(l.size() > 3 ? l[3].c_str() : "", NULL);
+        if (!setSize.find(lines[from].set, nGenes)) { err = "invalid target size database key " + std::to_string(lines[from].set); return false; }
+        double bestScore = -DBL_MAX, second = -DBL_MAX, bestEval = DBL_MAX; const SetLine *best = nullptr;
+        const bool single = simple || to - from < 2;
+        for (size_t k = from; k < to; k++) {
+            const SetLine &l = lines[k];
+            const double eval = columnValue(l, 3);
             double pval = eval / nGenes; if (pval == 0) pval = DBL_MIN;
             const double score = -std::log(pval);
             if (single) { if (bestEval > eval) { bestEval = eval; best = &l; } }
@@ -323,7 +359,16 @@ bool bestHitPerSet(const char *entry, const SetLookup &memberToSet, const SetLoo
             else if (bestEval > 0 && bestEval < 10e-4) logP = std::log(bestEval);
             else logP = std::log(1 - std::exp(-bestEval));
         } else logP = second - bestScore;
-        if (best) for (size_t i = 0; i < best->size(); i++) { out += (i == 1) ? fmtE(logP) : (*best)[i]; if (i + 1 != best->size()) out.push_back('\t'); }
+        if (best) {      // the line with column 1 replaced
+            const char *b = best->p, *e = best->p + best->n, *c1 = b;
+            while (c1 < e && *c1 != '\t') c1++;
+            out.append(b, (size_t) (c1 - b));
+            if (c1 < e) {
+                out.push_back('\t'); out.append(nb, (size_t) (fmtE3(logP, nb) - nb));
+                const char *c2 = c1 + 1; while (c2 < e && *c2 != '\t') c2++;
+                out.append(c2, (size_t) (e - c2));
+            }
+        }
         out.push_back('\n');
     }
     return true;
@@ -331,20 +376,21 @@ bool bestHitPerSet(const char *entry, const SetLookup &memberToSet, const SetLoo
 
 // combinescore (CombineScore.cpp:41-98): per target set the truncated-product style score over a query set's best hits
 bool combineScore(const char *entry, uint32_t querySetSize, const SetLookup &memberToSet, std::string &out, std::string &err) {
-    std::map<uint32_t, std::vector<std::vector<std::string>>> groups;
-    if (!groupBySet(entry, memberToSet, groups, err)) return false;
+    std::vector<SetLine> lines;
+    if (!groupBySet(entry, memberToSet, lines, err)) return false;
     const double logThr = std::log(1.0 / (querySetSize + 1));
-    char nb[16];
-    for (auto &g : groups) {
+    char nb[40];
+    for (size_t from = 0, to; from < lines.size(); from = to) {
+        for (to = from + 1; to < lines.size() && lines[to].set == lines[from].set; to++) {}
         double minLogP = 0, sumLogP = 0, minSeqId = 0, sumSeqId = 0; size_t k = 0;
-        for (const std::vector<std::string> &l : g.second) {
-            const double logP = strtod(l.size() > 1 ? l[1].c_str() : "", NULL), seqId = strtod(l.size() > 2 ? l[2].c_str() : "", NULL);
+        for (size_t i = from; i < to; i++) {
+            const double logP = columnValue(lines[i], 1), seqId = columnValue(lines[i], 2);
             if (logP < minLogP) { minLogP = (logP == 0) ? logP : -logP; minSeqId = seqId; }
             if (logP < logThr) { sumLogP -= logP - logThr; sumSeqId += seqId; k++; }
         }
-        char *e = u32toa(g.first, nb); out.append(nb, (size_t) (e - nb)); out.push_back('\t');
-        if (k == 0) { out += fmtE(minLogP); out.push_back('\t'); out += fmtE(minSeqId); }
-        else { out += fmtE(sumLogP - logThr); out.push_back('\t'); out += fmtE(sumSeqId / k); }
+        char *e = u32toa(lines[from].set, nb); out.append(nb, (size_t) (e - nb)); out.push_back('\t');
+        const double a = k == 0 ? minLogP : sumLogP - logThr, b = k == 0 ? minSeqId : sumSeqId / k;
+        out.append(nb, (size_t) (fmtE3(a, nb) - nb)); out.push_back('\t'); out.append(nb, (size_t) (fmtE3(b, nb) - nb));
         out.push_back('\n');
     }
     return true;
@@ -467,16 +513,33 @@ bool setScores(const SetInputs &in, int stage, std::vector<uint32_t> &keys, std:
         return true;
     }
     // mergeresultsbyset + combinescore: query sets ascending, members in query order
-    std::map<uint32_t, std::vector<uint32_t>> members;
-    for (size_t q = 0; q < nq; q++) members[in.qSet[q]].push_back((uint32_t) q);
-    for (auto &m : members) {
-        std::string merged, out;
-        for (uint32_t q : m.second) merged += perQuery[q];
-        keys.push_back(m.first);
-        if (stage == 5) { entries.push_back(merged); continue; }
-        if (!combineScore(merged.c_str(), (uint32_t) m.second.size(), tMemberToSet, out, err)) return false;
-        entries.push_back(out);
-    }
+    std::vector<std::pair<uint32_t, uint32_t>> bySet(nq);      // (set, query), sorted: the members of a set are consecutive and in query order
+    for (size_t q = 0; q < nq; q++) bySet[q] = {in.qSet[q], (uint32_t) q};
+    if (!std::is_sorted(bySet.begin(), bySet.end())) std::sort(bySet.begin(), bySet.end());
+    std::vector<size_t> first;      // first[s] = where set number s starts in bySet
+    for (size_t i = 0; i < nq; i++) if (i == 0 || bySet[i].first != bySet[i - 1].first) first.push_back(i);
+    first.push_back(nq);
+    const size_t ns = first.size() - 1;
+    keys.resize(ns); entries.resize(ns);
+    const size_t T = (size_t) std::max(1, std::min<int>(in.threads, (int) (ns / 16 + 1)));
+    std::vector<std::string> setErrs(T);
+    std::atomic<size_t> nextSet{0};
+    auto work = [&](size_t t) {      // sets are handed out in runs of 16: a set's cost is the number of best-hit lines of its members
+        std::string merged;
+        for (;;) {
+            const size_t from = nextSet.fetch_add(16), to = std::min(ns, from + 16);
+            if (from >= ns || !setErrs[t].empty()) break;
+            for (size_t s = from; s < to && setErrs[t].empty(); s++) {
+                merged.clear();
+                for (size_t i = first[s]; i < first[s + 1]; i++) merged += perQuery[bySet[i].second];
+                keys[s] = bySet[first[s]].first;
+                if (stage == 5) { entries[s] = merged; continue; }
+                combineScore(merged.c_str(), (uint32_t) (first[s + 1] - first[s]), tMemberToSet, entries[s], setErrs[t]);
+            }
+        }
+    };
+    {   std::vector<std::thread> pool; for (size_t t = 1; t < T; t++) pool.emplace_back(work, t); work(0); for (auto &th : pool) th.join(); }
+    for (const std::string &e : setErrs) if (!e.empty()) { err = e; return false; }
     return true;
 }
 
@@ -510,6 +573,37 @@ static std::vector<size_t> byKey(const Db &db) {
     return o;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// entry-parallel drivers: the input entries [0, n) are cut into chunks of about equal input bytes, worker threads take the chunks
+// in turn and format their output entries into one block per chunk, the blocks go to the writer in chunk order (so the data
+// file has the layout a single thread would have written)
+// ------------------------------------------------------------------------------------------------------------------
+struct ChunkOut {
+    std::string block; std::vector<uint32_t> keys; std::vector<uint64_t> lengths; std::string err;
+    void add(uint32_t key, const char *p, size_t n) { block.append(p, n); block.push_back('\0'); keys.push_back(key); lengths.push_back(n + 1); }
+    void add(uint32_t key, const std::string &e) { add(key, e.data(), e.size()); }
+};
+static int threadsOf(const Flags &f) { return (int) std::max(1L, std::min(256L, f.num("--threads", defaultThreads()))); }
+template <class Out, class W, class F>
+static bool forChunks(size_t n, W weight, int threads, std::vector<Out> &outs, F fn, std::string &err) {
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; i++) total += weight(i);
+    const size_t T = (size_t) std::max(1, threads);
+    const uint64_t per = std::max<uint64_t>(1u << 18, total / (T * 4) + 1);
+    std::vector<size_t> cut{0}; uint64_t acc = 0;
+    for (size_t i = 0; i < n; i++) { acc += weight(i); if (acc >= per) { cut.push_back(i + 1); acc = 0; } }
+    if (cut.back() != n) cut.push_back(n);
+    const size_t C = cut.size() - 1;
+    outs.clear(); outs.resize(C);
+    std::atomic<size_t> next{0};
+    auto work = [&]() { for (;;) { const size_t c = next.fetch_add(1); if (c >= C) break; Out &o = outs[c]; for (size_t i = cut[c]; i < cut[c + 1] && o.err.empty(); i++) fn(i, o); } };
+    if (C <= 1 || T == 1) work();
+    else { std::vector<std::thread> pool; for (size_t t = 1; t < std::min(T, C); t++) pool.emplace_back(work); work(); for (auto &th : pool) th.join(); }
+    for (const Out &o : outs) if (!o.err.empty()) { err = o.err; return false; }
+    return true;
+}
+static void flushChunks(std::vector<ChunkOut> &outs, DbWriter &w) { for (ChunkOut &o : outs) if (!o.keys.empty()) w.addBlock(o.keys, o.lengths, std::move(o.block)); }
+
 int runExtractOrfs(int argc, const char **argv) {
     Flags f; std::string err;
     if (!parseFlags(argc, argv, with({"--min-length", "--max-length", "--max-gaps", "--contig-start-mode", "--contig-end-mode", "--orf-start-mode", "--forward-frames",
@@ -524,41 +618,90 @@ int runExtractOrfs(int argc, const char **argv) {
     if (startMode == 1 && contigStart < 2) return fail("extractorfs: orf-start-mode 1 can only go with contig-start-mode 2");
     auto frames = [&](const char *flag) { unsigned r = 0; const std::string v = f.str(flag, "1,2,3"); for (int k = 1; k <= 3; k++) if (("," + v + ",").find("," + std::to_string(k) + ",") != std::string::npos) r |= 1u << (k - 1); return r; };
     const unsigned fwdFrames = frames("--forward-frames"), revFrames = frames("--reverse-frames");
+    const bool tm = getenv("SP_MODULE_TIMING") != nullptr; auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (tm) { auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "extractorfs %-10s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; } };
     Db in;
     if (!loadDb(f.positional[0], in, err)) return fail("extractorfs: " + err);
+    lap("load");
     // lookup of the contigs (key, name, set) for --create-lookup 1
-    std::map<uint32_t, std::string> setOf;
+    // (contig key -> the text of its set column), sorted by key
+    std::string lookupFile; std::vector<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> setOf;
     const bool createLookup = f.num("--create-lookup", 0) != 0;
     if (createLookup) {
-        std::ifstream lk(f.positional[0] + ".lookup");
-        if (!lk.good()) return fail("extractorfs: cannot open " + f.positional[0] + ".lookup");
-        std::string line;
-        while (std::getline(lk, line)) { const size_t a = line.find('\t'), b = line.rfind('\t'); if (a == std::string::npos || b == a) continue; setOf[(uint32_t) atou(line.c_str())] = line.substr(b + 1); }
+        MappedFile lk;
+        if (!lk.open(f.positional[0] + ".lookup")) return fail("extractorfs: cannot open " + f.positional[0] + ".lookup");
+        lookupFile.assign(lk.p, lk.n);
+        const char *b = lookupFile.data(), *e = b + lookupFile.size();
+        for (const char *p = b; p < e;) {
+            const char *eol = (const char *) memchr(p, '\n', (size_t) (e - p)); if (!eol) eol = e;
+            const char *first = (const char *) memchr(p, '\t', (size_t) (eol - p)); const char *lastTab = first;
+            if (first) for (const char *q = eol; q > first; q--) if (q[-1] == '\t') { lastTab = q - 1; break; }
+            if (first && lastTab != first) setOf.push_back({(uint32_t) atou(p), {(uint32_t) (lastTab + 1 - b), (uint32_t) (eol - lastTab - 1)}});
+            p = eol + 1;
+        }
+        bool sorted = true;
+        for (size_t i = 1; i < setOf.size() && sorted; i++) sorted = setOf[i - 1].first < setOf[i].first;
+        if (!sorted) std::stable_sort(setOf.begin(), setOf.end(), [](const auto &a, const auto &b) { return a.first < b.first; });      // a key listed twice: the last line wins, as with the map the reference fills
     }
+    auto setText = [&](uint32_t key, std::string &to) {
+        auto it = std::upper_bound(setOf.begin(), setOf.end(), key, [](uint32_t k, const auto &x) { return k < x.first; });
+        if (it == setOf.begin() || (it - 1)->first != key) { to.push_back('0'); return; }
+        to.append(lookupFile.data() + (it - 1)->second.first, (it - 1)->second.second);
+    };
+    lap("lookup");
     // contigs in key order; ORFs are numbered 0, 1, ... in (contig key, discovery) order (DBWriter::createRenumberedDB, DBWriter.cpp:681-739)
     DbWriter seqW, hdrW; seqW.path = f.positional[1]; seqW.dbtype = 1; hdrW.path = f.positional[1] + "_h"; hdrW.dbtype = 12;
-    std::string lookup; uint32_t next = 0; OrfFinder orf; std::vector<OrfLoc> locs; char nb[16];
-    for (size_t i : byKey(in)) {
-        const uint32_t key = in.entries[i].key; const size_t L = (size_t) in.seqLen(i);
-        if (L < 3) continue;
-        orf.setSequence(in.ptr(i), L);
-        locs.clear();
-        orf.findAll(minLen, maxLen, maxGaps, fwdFrames, revFrames, startMode, locs);
-        for (const OrfLoc &loc : locs) {
+    struct OrfChunk { ChunkOut seq, hdr; std::vector<uint32_t> contig; std::string err, lookup; OrfFinder orf; std::vector<OrfLoc> locs; };
+    const std::vector<size_t> order = byKey(in);
+    std::vector<OrfChunk> chunks;
+    if (!forChunks(order.size(), [&](size_t k) { return in.entries[order[k]].length; }, threadsOf(f), chunks, [&](size_t k, OrfChunk &o) {
+        const size_t i = order[k]; const uint32_t key = in.entries[i].key; const size_t L = (size_t) in.seqLen(i);
+        if (L < 3) return;
+        o.orf.setSequence(in.ptr(i), L);
+        o.locs.clear();
+        o.orf.findAll(minLen, maxLen, maxGaps, fwdFrames, revFrames, startMode, o.locs);
+        for (const OrfLoc &loc : o.locs) {
             if (contigStart < 2 && (int) loc.incStart == contigStart) continue;
             if (contigEnd < 2 && (int) loc.incEnd == contigEnd) continue;
             size_t from = loc.from, to = loc.to;
             if (loc.strand < 0) { from = (L - 1) - loc.from; to = (L - 1) - loc.to; }
-            std::string s((loc.strand > 0 ? orf.fwd : orf.rev).data() + loc.from, loc.to - loc.from + 1); s.push_back('\n');
-            seqW.add(next, s);
-            hdrW.add(next, orfHeader(key, from, to, loc.incStart, loc.incEnd));
-            if (createLookup) { char *e = u32toa(next, nb); lookup.append(nb, (size_t) (e - nb)); lookup.push_back('\t'); e = u32toa(key, nb); lookup.append(nb, (size_t) (e - nb)); lookup.push_back('\t'); lookup += setOf.count(key) ? setOf[key] : std::string("0"); lookup.push_back('\n'); }
-            next++;
+            const size_t n = loc.to - loc.from + 1;
+            o.seq.block.append((loc.strand > 0 ? o.orf.fwd : o.orf.rev).data() + loc.from, n); o.seq.block.push_back('\n'); o.seq.block.push_back('\0'); o.seq.lengths.push_back(n + 2);
+            o.hdr.add(0, orfHeader(key, from, to, loc.incStart, loc.incEnd));
+            o.contig.push_back(key);
         }
+    }, err)) return fail("extractorfs: " + err);
+    lap("scan");
+    // ORF ids: chunk bases first, then keys and lookup lines chunk by chunk in parallel
+    std::vector<uint32_t> base(chunks.size() + 1, 0);
+    for (size_t c = 0; c < chunks.size(); c++) base[c + 1] = base[c] + (uint32_t) chunks[c].contig.size();
+    {   std::atomic<size_t> nextChunk{0};
+        auto work = [&]() { char nb[16]; for (;;) { const size_t c = nextChunk.fetch_add(1); if (c >= chunks.size()) break; OrfChunk &o = chunks[c]; const size_t n = o.contig.size();
+            o.seq.keys.resize(n); for (size_t k = 0; k < n; k++) o.seq.keys[k] = base[c] + (uint32_t) k;
+            o.hdr.keys = o.seq.keys;
+            if (createLookup) { size_t setAt = 0, setLen = 0; for (size_t k = 0; k < n; k++) {
+                char *e = u32toa(base[c] + (uint32_t) k, nb); o.lookup.append(nb, (size_t) (e - nb)); o.lookup.push_back('\t'); e = u32toa(o.contig[k], nb); o.lookup.append(nb, (size_t) (e - nb)); o.lookup.push_back('\t');
+                if (k == 0 || o.contig[k] != o.contig[k - 1]) { setAt = o.lookup.size(); setText(o.contig[k], o.lookup); setLen = o.lookup.size() - setAt; }
+                else { o.lookup.reserve(o.lookup.size() + setLen + 1); o.lookup.append(o.lookup.data() + setAt, setLen); }
+                o.lookup.push_back('\n'); } } } };
+        std::vector<std::thread> pool; for (int t = 1; t < std::min<int>(threadsOf(f), (int) chunks.size()); t++) pool.emplace_back(work); work(); for (auto &th : pool) th.join(); }
+    std::string lookup;
+    for (OrfChunk &o : chunks) {
+        if (o.contig.empty()) continue;
+        lookup += o.lookup;
+        seqW.addBlock(o.seq.keys, o.seq.lengths, std::move(o.seq.block));
+        hdrW.addBlock(o.hdr.keys, o.hdr.lengths, std::move(o.hdr.block));
     }
+    lap("number");
     if (createLookup) { std::ofstream o(f.positional[1] + ".lookup", std::ios::binary); o.write(lookup.data(), (std::streamsize) lookup.size()); if (!o.good()) return fail("extractorfs: cannot write the lookup file"); }
     { std::ifstream src(f.positional[0] + ".source", std::ios::binary); if (src.good()) { std::ofstream dst(f.positional[1] + ".source", std::ios::binary); dst << src.rdbuf(); } }
-    if (!hdrW.close(err) || !seqW.close(err)) return fail("extractorfs: " + err);
+    {   std::string hdrErr; bool hdrOk = true;
+        std::thread hdrThread([&]() { hdrOk = hdrW.close(hdrErr); });
+        const bool seqOk = seqW.close(err);
+        hdrThread.join();
+        if (!hdrOk) return fail("extractorfs: " + hdrErr);
+        if (!seqOk) return fail("extractorfs: " + err); }
+    lap("write");
     return 0;
 }
 
@@ -569,16 +712,18 @@ int runTranslateNucs(int argc, const char **argv) {
     Db in;
     if (!loadDb(f.positional[0], in, err)) return fail("translatenucs: " + err);
     DbWriter w; w.path = f.positional[1]; w.dbtype = 0;
-    std::string aa;
-    for (size_t i = 0; i < in.entries.size(); i++) {
+    std::vector<ChunkOut> outs;
+    if (!forChunks(in.entries.size(), [&](size_t i) { return in.entries[i].length; }, threadsOf(f), outs, [&](size_t i, ChunkOut &o) {
         const char *data = in.ptr(i);
-        if (*data == '\0') continue;
+        if (*data == '\0') return;
         const size_t length = translatableLength(data, (size_t) in.entries[i].length, 65535);
-        if (!length) continue;
-        aa.assign(length / 3 + 1, '\n');
-        translate(data, length, &aa[0]);
-        w.add(in.entries[i].key, aa);
-    }
+        if (!length) return;
+        const size_t at = o.block.size(), n = length / 3 + 1;
+        o.block.append(n, '\n'); o.block.push_back('\0');
+        translate(data, length, &o.block[at]);
+        o.keys.push_back(in.entries[i].key); o.lengths.push_back(n + 1);
+    }, err)) return fail("translatenucs: " + err);
+    flushChunks(outs, w);
     for (const char *ext : {".lookup", ".source"}) { std::ifstream src(f.positional[0] + ext, std::ios::binary); if (src.good()) { std::ofstream dst(f.positional[1] + ext, std::ios::binary); dst << src.rdbuf(); } }
     if (!w.close(err)) return fail("translatenucs: " + err);
     return 0;
@@ -591,8 +736,14 @@ int runReverseSeqByCodon(int argc, const char **argv) {
     Db in;
     if (!loadDb(f.positional[0], in, err)) return fail("reverseseqbycodon: " + err);
     DbWriter w; w.path = f.positional[1]; w.dbtype = in.dbtype;
-    std::string rev;
-    for (size_t i = 0; i < in.entries.size(); i++) { reverseByCodon(in.ptr(i), (size_t) in.seqLen(i), rev); w.add(in.entries[i].key, rev); }
+    std::vector<ChunkOut> outs;
+    if (!forChunks(in.entries.size(), [&](size_t i) { return in.entries[i].length; }, threadsOf(f), outs, [&](size_t i, ChunkOut &o) {
+        const char *seq = in.ptr(i); const size_t L = (size_t) in.seqLen(i), at = o.block.size();
+        for (size_t done = 0; done + 3 <= L; done += 3) o.block.append(seq + (L - done - 3), 3);
+        o.block.push_back('\n'); o.block.push_back('\0');
+        o.keys.push_back(in.entries[i].key); o.lengths.push_back(o.block.size() - at);
+    }, err)) return fail("reverseseqbycodon: " + err);
+    flushChunks(outs, w);
     for (const char *ext : {".lookup", ".source"}) { std::ifstream src(f.positional[0] + ext, std::ios::binary); if (src.good()) { std::ofstream dst(f.positional[1] + ext, std::ios::binary); dst << src.rdbuf(); } }
     if (!w.close(err)) return fail("reverseseqbycodon: " + err);
     return 0;
@@ -615,18 +766,19 @@ int runProteinAln2Nucl(int argc, const char **argv) {
                  (int) strtol(nuclPart(f.str("--gap-extend", ""), "2").c_str(), NULL, 10), residues(tNuc), err)) return fail("proteinaln2nucl: " + err);
     KeyMap qNucIdx, tNucIdx, qAAIdx, tAAIdx; keyIndex(qNuc, qNucIdx); keyIndex(tNuc, tNucIdx); keyIndex(qAA, qAAIdx); keyIndex(tAA, tAAIdx);
     DbWriter w; w.path = f.positional[5]; w.dbtype = 5;
-    std::string out;
-    for (size_t i = 0; i < aln.entries.size(); i++) {
+    std::vector<ChunkOut> outs;
+    if (!forChunks(aln.entries.size(), [&](size_t i) { return aln.entries[i].length; }, threadsOf(f), outs, [&](size_t i, ChunkOut &o) {
         const uint32_t key = aln.entries[i].key; uint32_t qn, qa;
-        if (!qNucIdx.find(key, qn) || !qAAIdx.find(key, qa)) return fail("proteinaln2nucl: query " + std::to_string(key) + " is missing from the query DBs");
-        out.clear();
+        if (!qNucIdx.find(key, qn) || !qAAIdx.find(key, qa)) { o.err = "proteinaln2nucl: query " + std::to_string(key) + " is missing from the query DBs"; return; }
+        const size_t at = o.block.size();
         for (const char *p = aln.ptr(i); *p != '\0'; p = skipLine(p)) {
             uint32_t tn, ta; const uint32_t tKey = (uint32_t) atou(p);
-            if (!tNucIdx.find(tKey, tn) || !tAAIdx.find(tKey, ta)) return fail("proteinaln2nucl: target " + std::to_string(tKey) + " is missing from the target DBs");
-            if (!proteinLineToNucl(p, sc, qNuc.ptr(qn), (uint32_t) qNuc.seqLen(qn), qAA.ptr(qa)[0] == '*', tNuc.ptr(tn), (uint32_t) tNuc.seqLen(tn), tAA.ptr(ta)[0] == '*', out, err)) return fail(err);
+            if (!tNucIdx.find(tKey, tn) || !tAAIdx.find(tKey, ta)) { o.err = "proteinaln2nucl: target " + std::to_string(tKey) + " is missing from the target DBs"; return; }
+            if (!proteinLineToNucl(p, sc, qNuc.ptr(qn), (uint32_t) qNuc.seqLen(qn), qAA.ptr(qa)[0] == '*', tNuc.ptr(tn), (uint32_t) tNuc.seqLen(tn), tAA.ptr(ta)[0] == '*', o.block, o.err)) return;
         }
-        w.add(key, out);
-    }
+        o.block.push_back('\0'); o.keys.push_back(key); o.lengths.push_back(o.block.size() - at);
+    }, err)) return fail(err);
+    flushChunks(outs, w);
     if (!w.close(err)) return fail("proteinaln2nucl: " + err);
     return 0;
 }
@@ -639,14 +791,15 @@ int runCombineProtNuclAln(int argc, const char **argv) {
     if (!loadDb(f.positional[0], prot, err) || !loadDb(f.positional[1], nucl, err)) return fail("combineprotnuclaln: " + err);
     KeyMap nIdx; keyIndex(nucl, nIdx);
     DbWriter w; w.path = f.positional[2]; w.dbtype = prot.dbtype;
-    std::string out;
-    for (size_t i = 0; i < prot.entries.size(); i++) {
+    std::vector<ChunkOut> outs;
+    if (!forChunks(prot.entries.size(), [&](size_t i) { return prot.entries[i].length; }, threadsOf(f), outs, [&](size_t i, ChunkOut &o) {
         uint32_t n;
-        if (!nIdx.find(prot.entries[i].key, n)) continue;      // "Missing nucleotide alignment result": the reference skips the key
-        out.clear();
-        if (!combineProtNucl(prot.ptr(i), nucl.ptr(n), out, err)) return fail(err);
-        w.add(prot.entries[i].key, out);
-    }
+        if (!nIdx.find(prot.entries[i].key, n)) return;      // "Missing nucleotide alignment result": the reference skips the key
+        const size_t at = o.block.size();
+        if (!combineProtNucl(prot.ptr(i), nucl.ptr(n), o.block, o.err)) return;
+        o.block.push_back('\0'); o.keys.push_back(prot.entries[i].key); o.lengths.push_back(o.block.size() - at);
+    }, err)) return fail(err);
+    flushChunks(outs, w);
     if (!w.close(err)) return fail("combineprotnuclaln: " + err);
     return 0;
 }
@@ -660,12 +813,13 @@ int runBestHitPerSet(int argc, const char **argv) {
     SetLookup memberToSet, setSize; memberToSet.fromDb(m2s); setSize.fromDb(sizes);
     const bool simple = f.num("--simple-best-hit", 1) != 0;
     DbWriter w; w.path = f.positional[3]; w.dbtype = 5;
-    std::string out;
-    for (size_t i = 0; i < res.entries.size(); i++) {
-        out.clear();
-        if (!bestHitPerSet(res.ptr(i), memberToSet, setSize, simple, out, err)) return fail("besthitperset: " + err);
-        w.add(res.entries[i].key, out);
-    }
+    std::vector<ChunkOut> outs;
+    if (!forChunks(res.entries.size(), [&](size_t i) { return res.entries[i].length; }, threadsOf(f), outs, [&](size_t i, ChunkOut &o) {
+        const size_t at = o.block.size();
+        if (!bestHitPerSet(res.ptr(i), memberToSet, setSize, simple, o.block, o.err)) return;
+        o.block.push_back('\0'); o.keys.push_back(res.entries[i].key); o.lengths.push_back(o.block.size() - at);
+    }, err)) return fail("besthitperset: " + err);
+    flushChunks(outs, w);
     if (!w.close(err)) return fail("besthitperset: " + err);
     return 0;
 }
@@ -678,16 +832,17 @@ int runMergeResultsBySet(int argc, const char **argv) {
     if (!loadDb(f.positional[0], sets, err) || !loadDb(f.positional[1], res, err)) return fail("mergeresultsbyset: " + err);
     KeyMap rIdx; keyIndex(res, rIdx);
     DbWriter w; w.path = f.positional[2]; w.dbtype = res.dbtype;
-    std::string out;
-    for (size_t i = 0; i < sets.entries.size(); i++) {
-        out.clear();
+    std::vector<ChunkOut> outs;
+    if (!forChunks(sets.entries.size(), [&](size_t i) { return sets.entries[i].length * 16; }, threadsOf(f), outs, [&](size_t i, ChunkOut &o) {
+        const size_t at = o.block.size();
         for (const char *p = sets.ptr(i); *p != '\0'; p = skipLine(p)) {
             uint32_t r;
-            if (!rIdx.find((uint32_t) atou(p), r)) return fail("mergeresultsbyset: invalid key " + std::to_string(atou(p)) + " in entry " + std::to_string(i));
-            out += res.ptr(r);
+            if (!rIdx.find((uint32_t) atou(p), r)) { o.err = "mergeresultsbyset: invalid key " + std::to_string(atou(p)) + " in entry " + std::to_string(i); return; }
+            o.block.append(res.ptr(r), (size_t) res.entries[r].length - 1);
         }
-        w.add(sets.entries[i].key, out);
-    }
+        o.block.push_back('\0'); o.keys.push_back(sets.entries[i].key); o.lengths.push_back(o.block.size() - at);
+    }, err)) return fail(err);
+    flushChunks(outs, w);
     if (!w.close(err)) return fail("mergeresultsbyset: " + err);
     return 0;
 }
@@ -700,14 +855,15 @@ int runCombineScore(int argc, const char **argv) {
     if (!loadDb(f.positional[0] + "_set_size", qSizes, err) || !loadDb(f.positional[1] + "_member_to_set", m2s, err) || !loadDb(f.positional[2], res, err)) return fail("combinescore: " + err);
     SetLookup querySize, memberToSet; querySize.fromDb(qSizes); memberToSet.fromDb(m2s);
     DbWriter w; w.path = f.positional[3]; w.dbtype = 5;
-    std::string out;
-    for (size_t i = 0; i < res.entries.size(); i++) {
+    std::vector<ChunkOut> outs;
+    if (!forChunks(res.entries.size(), [&](size_t i) { return res.entries[i].length; }, threadsOf(f), outs, [&](size_t i, ChunkOut &o) {
         uint32_t n;
-        if (!querySize.find(res.entries[i].key, n)) return fail("combinescore: query set " + std::to_string(res.entries[i].key) + " has no size entry");
-        out.clear();
-        if (!combineScore(res.ptr(i), n, memberToSet, out, err)) return fail("combinescore: " + err);
-        w.add(res.entries[i].key, out);
-    }
+        if (!querySize.find(res.entries[i].key, n)) { o.err = "query set " + std::to_string(res.entries[i].key) + " has no size entry"; return; }
+        const size_t at = o.block.size();
+        if (!combineScore(res.ptr(i), n, memberToSet, o.block, o.err)) return;
+        o.block.push_back('\0'); o.keys.push_back(res.entries[i].key); o.lengths.push_back(o.block.size() - at);
+    }, err)) return fail("combinescore: " + err);
+    flushChunks(outs, w);
     if (!w.close(err)) return fail("combinescore: " + err);
     return 0;
 }
