@@ -964,7 +964,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
             waveSync();
         }
         if (lane == 0) {
-            a.qDiagBase[qi] = dbase;
+            a.qDiagBase[qi] = overflow ? 0xFFFFFFFFu : dbase;      // (the marker names the query in the error text; it has no records)
             a.qDiagCnt[qi] = D;
             if (overflow) atomicAdd(&a.counters[2], 1ull);
         }
@@ -1920,7 +1920,12 @@ bool Gpu::finishPrefilter(bool matched, std::string &err) {
     }
     times_.select = evMs(d.timing, 2, d.ev[3], d.ev[4]);
     if (counters_.overflowQueries) {
-        err = std::to_string(counters_.overflowQueries) + " queries produced more index hits, diagonals or candidates than the device buffers hold";
+        // error path only: name the first offending query (k_match marks them in qDiagBase)
+        std::vector<uint32_t> base(nq_); std::string which;
+        if (hipMemcpy(base.data(), d.qDiagBase.p, nq_ * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess)
+            for (size_t q = 0; q < nq_; q++) if (base[q] == 0xFFFFFFFFu) { which = ", first the query at position " + std::to_string(q) + " of the batch"; break; }
+        err = std::to_string(counters_.overflowQueries) + " queries produced more index hits (limit 65535 per query), diagonals or candidates than the device buffers hold" + which +
+              "; search such queries in a batch of their own against target shards (sp_ctx_set_targets_shard / sp_ctx_merge_candidates)";
         return false;
     }
     return true;

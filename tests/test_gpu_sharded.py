@@ -143,3 +143,40 @@ def test_bench_self_launches_the_target_sharded_run_with_several_ranks(ranks):
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"] + common, capture_output=True, text=True, timeout=300,
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_query_beyond_the_hit_stream_limit_is_named_and_searchable_through_shards():
+    """one query with more than 65 535 index hits (the 16-bit stream position of k_match; the reference's own buffer holds 2 x 10^6):
+    the unsplit call refuses the batch and names the query, the same batch against target shards gives the oracle's hits"""
+    import random
+    import spacepharer_amd as sa
+    from oracle_lib import Oracle
+    rnd = random.Random(11)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    core = "".join(rnd.choice(aa) for _ in range(60))
+    T = []
+    for i in range(2400):
+        s = list(core)
+        for _ in range(3):
+            s[rnd.randrange(60)] = rnd.choice(aa)
+        T.append("".join(rnd.choice(aa) for _ in range(rnd.randrange(0, 20))) + "".join(s) + "".join(rnd.choice(aa) for _ in range(20)))
+    Q = ["".join(rnd.choice(aa) for _ in range(12)), core, "".join(rnd.choice(aa) for _ in range(10))]
+    c = sa.SearchContext()
+    c.set_targets(T)
+    c.set_queries(Q)
+    with pytest.raises(sa.SpError) as e:
+        c.prefilter()
+    assert "position 1 of the batch" in str(e.value) and "65535" in str(e.value)
+    c.set_queries([Q[0], Q[2]])      # the context stays usable
+    c.prefilter()
+    o = Oracle()
+    o.set_targets(T)
+    assert [[list(h) for h in hs] for hs in c.hits()] == [o.prefilter_list(Q[0]), o.prefilter_list(Q[2])]
+    c.close()
+    got, ctxs = _sharded_hits(sa, T, Q, 8)
+    for q in range(3):
+        assert [list(h) for h in got[q]] == o.prefilter_list(Q[q]), q
+    assert len(got[1]) == 300
+    for x in ctxs:
+        x.close()
+    o.close()
