@@ -44,3 +44,5 @@ def test_match_and_sw_kernels_keep_their_occupancy(tmp_path):
     for gl in (10, 12, 16, 32):                               # the packed Smith-Waterman kernels: eight waves per SIMD
         sw = kernel("k_sw_byte1pILi%dE" % gl)
         assert sw["Occupancy [waves/SIMD]"] >= 8, (gl, sw)
+        fwd = kernel("k_sw_fwd1pILi%dE" % gl)                 # the forward pass: 128-byte profile lines, 25 KB of LDS per block -> six
+        assert fwd["Occupancy [waves/SIMD]"] >= 6 and fwd.get("VGPRs Spill", 0) == 0 and fwd["VGPRs"] <= 80, (gl, fwd)
