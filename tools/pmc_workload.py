@@ -11,7 +11,8 @@ import bench  # noqa: E402
 import spacepharer_amd as sa  # noqa: E402
 
 GIB = 1 << 30
-tres, toff, qres, qoff = bench.make_workload(10000, 50000, 200, 12345)
+DENSE = "dense" in sys.argv[1:]          # 10 000 spacers vs 2e8 residues (the survey's estimate of GenBank_phage_2018_09) instead of the bench proxy
+tres, toff, qres, qoff = bench.make_workload(10000, 1000000 if DENSE else 50000, 200, 12345)
 ctx = sa.SearchContext()
 for width in (4, 16):
     for _ in range(3):
@@ -19,7 +20,7 @@ for width in (4, 16):
     print("calibration read %2d B/lane: %.3f ms -> %.0f GB/s" % (width, ms, GIB / ms / 1e6))
 ctx.set_targets_raw(tres.tobytes(), bench.u64p(toff), len(toff) - 1)
 ctx.set_queries_raw(qres.tobytes(), bench.u64p(qoff), len(qoff) - 1)
-stage = sys.argv[1] if len(sys.argv) > 1 else "prefilter"
+stage = "full" if "full" in sys.argv[1:] else "prefilter"
 for _ in range(3):
     ctx.prefilter()
     if stage == "full":
