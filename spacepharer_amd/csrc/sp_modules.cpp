@@ -425,8 +425,8 @@ int runSearchModule(int argc, const char **argv) {
     { const int rc = fanOut("search", argc, argv, f.positional[2]); if (rc >= 0) return rc; }
     Laps laps("search");
     Db qdb, tdb;
-    if (!loadSeqDb(f.positional[0], qdb, err) || !loadSeqDb(f.positional[1], tdb, err)) return fail("search: " + err);
-    laps.lap("read DBs");
+    if (!loadSeqDb(f.positional[0], qdb, err)) return fail("search: " + err);
+    laps.lap("read query DB");
     sp_search_params p; sp_default_params(&p);
     std::string seed = aaPart(f.str("--seed-sub-mat", "VTML80.out")), sub = aaPart(f.str("--sub-mat", "VTML40.out"));
     p.seed_sub_mat = seed.c_str(); p.sub_mat = sub.c_str();
@@ -443,8 +443,11 @@ int runSearchModule(int argc, const char **argv) {
     if (!acquireCtx(p, f.positional[1], "index", ctx, err)) return fail("search: " + err);
     laps.lap("context (matrices, tables)");
     std::vector<char> tres, qres; std::vector<uint64_t> toff, qoff; std::vector<uint32_t> tkeys, qkeys;
-    flatten(tdb, tres, toff, tkeys);
-    if (!ctx.targetsStaged && sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) { const std::string e = sp_last_error(); dropCtx(ctx); return fail("search: " + e); }
+    if (!ctx.targetsStaged) {      // (a cached context -- the resident server -- holds the target set of this very DB: nothing to read)
+        if (!loadSeqDb(f.positional[1], tdb, err)) { dropCtx(ctx); return fail("search: " + err); }
+        flatten(tdb, tres, toff, tkeys);
+        if (sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) { const std::string e = sp_last_error(); dropCtx(ctx); return fail("search: " + e); }
+    }
     laps.lap("targets -> device, index");
     flatten(qdb, qres, qoff, qkeys);
     const double minSeqId = f.real("--min-seq-id", 0.0); const long minAlnLen = f.num("--min-aln-len", 0);
