@@ -199,6 +199,11 @@ int sp_ctx_get_candidates(sp_ctx *c, sp_candidate *out);            /* copy of t
 const void *sp_ctx_candidates_device(const sp_ctx *c);              /* the same list in HBM (sp_candidate[num]) */
 /* candidates: the union (host or device memory, on_device says which); records with query == 0xFFFFFFFF are padding */
 int sp_ctx_merge_candidates(sp_ctx *c, const sp_candidate *candidates, uint64_t n, int on_device, uint64_t q_from, uint64_t q_to);
+/* After sp_ctx_prefilter() / sp_ctx_prefilter_candidates() returned SP_ERR_OVERFLOW: the positions (in the batch) of the queries whose
+ * hit stream does not fit one pass (more than 65 535 index hits; QueryMatcher's own buffer, prefiltering/QueryMatcher.cpp:39-50, holds
+ * 2 x 10^6 and is evaluated in place when it fills, :254-283).  Returns their number, writes at most cap of them.  The module drop-ins
+ * search the batch again without them and take them through target shards (exact union), so a module call never fails on them. */
+uint64_t sp_ctx_overflow_queries(const sp_ctx *c, uint32_t *out, uint64_t cap);
 
 /* counters / timings of the last call, by name: "kmers", "db_matches", "diagonals", "diag_residues",
    "hits", "index_entries", "masked_residues", "target_residues", "kmer_thr", "bin_size",

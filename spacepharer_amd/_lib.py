@@ -108,6 +108,8 @@ def load_library():
     L.sp_ctx_set_targets_shard.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint64, C.c_uint64, C.c_uint64]
     L.sp_ctx_prefilter_candidates.argtypes = [vp]
     L.sp_ctx_num_candidates.restype = C.c_uint64
+    L.sp_ctx_overflow_queries.restype = C.c_uint64
+    L.sp_ctx_overflow_queries.argtypes = [vp, C.POINTER(C.c_uint32), C.c_uint64]
     L.sp_ctx_num_candidates.argtypes = [vp]
     L.sp_ctx_get_candidates.argtypes = [vp, C.c_void_p]
     L.sp_ctx_candidates_device.restype = vp
@@ -475,6 +477,13 @@ class SearchContext:
         res = (Rescore * max(1, n))()
         _check(self.L.sp_ctx_rescore(self.ctx, q, t, d, n, mode, res))
         return [res[i] for i in range(n)]
+
+    def overflow_queries(self):
+        """positions of the queries the last prefilter() refused (SP_ERR_OVERFLOW)"""
+        n = int(self.L.sp_ctx_overflow_queries(self.ctx, None, 0))
+        out = (C.c_uint32 * max(1, n))()
+        self.L.sp_ctx_overflow_queries(self.ctx, out, n)
+        return [int(out[i]) for i in range(n)]
 
     def stat(self, name):
         return self.L.sp_ctx_stat(self.ctx, name.encode())

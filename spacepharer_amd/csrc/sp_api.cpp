@@ -243,6 +243,11 @@ int sp_ctx_prefilter_candidates(sp_ctx *c) {
 }
 
 uint64_t sp_ctx_num_candidates(const sp_ctx *c) { return (uint64_t) c->gpu.numCandidates(); }
+uint64_t sp_ctx_overflow_queries(const sp_ctx *c, uint32_t *out, uint64_t cap) {
+    const std::vector<uint32_t> &l = c->gpu.overflowQueries();
+    for (uint64_t i = 0; i < l.size() && i < cap; i++) out[i] = l[i];
+    return (uint64_t) l.size();
+}
 const void *sp_ctx_candidates_device(const sp_ctx *c) { return c->gpu.candidatesDevice(); }
 
 int sp_ctx_get_candidates(sp_ctx *c, sp_candidate *out) {

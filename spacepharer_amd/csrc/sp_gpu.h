@@ -97,6 +97,7 @@ public:
     // selection over the union of all shards' candidates (gathered by the caller, e.g. RCCL all-gather)
     bool prefilterCandidates(int kmerThr, int minDiagScore, std::string &err);
     size_t numCandidates() const;
+    const std::vector<uint32_t> &overflowQueries() const { return overflowList_; }      // positions (in the batch) of the queries the last pass refused
     const Candidate *candidatesDevice() const;
     bool downloadCandidates(Candidate *out, std::string &err);
     bool mergeCandidates(const Candidate *src, size_t n, bool onDevice, size_t qFrom, size_t qTo, unsigned binSize, int maxHits, int minDiagScore, std::string &err);
@@ -145,6 +146,7 @@ private:
     int maxHits_ = 0;
     size_t alignRetries_ = 0;
     PrefilterCounters counters_{};
+    std::vector<uint32_t> overflowList_;
     KernelTimes times_{};
 };
 

@@ -1829,6 +1829,7 @@ bool Gpu::uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std:
 // k_prep, k_match, k_score for every resident query; leaves the scored double-hit diagonals in HBM (events 0..3)
 bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     Impl &d = *d_;
+    overflowList_.clear();
     if (!d.ext3.p || !d.pbits.p) { err = "tables/targets not resident"; return false; }
     if (d.hitsInFlight) { (void) hipEventSynchronize(d.hitsOnHost); d.hitsInFlight = false; }     // the previous pass's hit list is still being copied
     // persistent match grid: as many blocks per CU as the LDS footprint admits.  512 hits per query live in LDS; more go to
@@ -1922,8 +1923,10 @@ bool Gpu::finishPrefilter(bool matched, std::string &err) {
     if (counters_.overflowQueries) {
         // error path only: name the first offending query (k_match marks them in qDiagBase)
         std::vector<uint32_t> base(nq_); std::string which;
+        overflowList_.clear();
         if (hipMemcpy(base.data(), d.qDiagBase.p, nq_ * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess)
-            for (size_t q = 0; q < nq_; q++) if (base[q] == 0xFFFFFFFFu) { which = ", first the query at position " + std::to_string(q) + " of the batch"; break; }
+            for (size_t q = 0; q < nq_; q++) if (base[q] == 0xFFFFFFFFu) overflowList_.push_back((uint32_t) q);
+        if (!overflowList_.empty()) which = ", first the query at position " + std::to_string(overflowList_[0]) + " of the batch";
         err = std::to_string(counters_.overflowQueries) + " queries produced more index hits (limit 65535 per query), diagonals or candidates than the device buffers hold" + which +
               "; search such queries in a batch of their own against target shards (sp_ctx_set_targets_shard / sp_ctx_merge_candidates)";
         return false;

@@ -212,6 +212,58 @@ struct Laps {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
+// Queries whose hit stream does not fit one pass (sp_ctx_overflow_queries; never a spacer peptide -- a few hundred residues against a
+// dense index) are searched against target shards: a second context indexes one target range after the other, the candidates of all
+// ranges are merged by sp_ctx_merge_candidates, whose result equals the unsplit search bit for bit.  The context returned is in the
+// state sp_ctx_prefilter() leaves for the sub-batch `which` (in that order); the caller formats / aligns from it and destroys it.
+// ---------------------------------------------------------------------------------------------------------------
+static sp_ctx *searchByShards(const sp_search_params &p, const std::vector<char> &tres, const std::vector<uint64_t> &toff, const std::vector<uint32_t> &tkeys,
+                              const char *qres, const uint64_t *qoff /* offsets of the whole batch */, const std::vector<uint32_t> &which, std::string &err) {
+    std::vector<char> sub; std::vector<uint64_t> subOff(1, 0);
+    for (uint32_t q : which) { sub.insert(sub.end(), qres + qoff[q], qres + qoff[q + 1]); subOff.push_back(sub.size()); }
+    if (sub.empty()) sub.push_back('X');
+    const size_t nt = tkeys.size();
+    for (size_t shards = 8; shards <= 512; shards *= 2) {
+        sp_ctx *c = sp_ctx_create(&p);
+        if (!c) { err = sp_last_error(); return nullptr; }
+        std::vector<sp_candidate> all; bool again = false, failed = false;
+        const uint64_t total = toff[nt];
+        size_t from = 0;
+        for (size_t s = 0; s < shards && !again && !failed; s++) {      // contiguous target ranges of about equal residue counts
+            size_t to = from;
+            const uint64_t upTo = total * (s + 1) / shards;
+            while (to < nt && (toff[to + 1] <= upTo || to == from)) to++;
+            if (s + 1 == shards) to = nt;
+            if (to == from) continue;
+            if (sp_ctx_set_targets_shard(c, tres.data(), toff.data(), tkeys.data(), nt, from, to) != SP_OK || sp_ctx_set_queries(c, sub.data(), subOff.data(), which.size()) != SP_OK) { failed = true; break; }
+            const int rc = sp_ctx_prefilter_candidates(c);
+            if (rc == SP_ERR_OVERFLOW) { again = true; break; }
+            if (rc != SP_OK) { failed = true; break; }
+            const size_t n = (size_t) sp_ctx_num_candidates(c), at = all.size();
+            all.resize(at + n);
+            if (n && sp_ctx_get_candidates(c, all.data() + at) != SP_OK) { failed = true; break; }
+            from = to;
+        }
+        if (!again && !failed) {
+            if (all.empty()) all.push_back(sp_candidate{0xFFFFFFFFu, 0, 0, 0, 0});      // (padding record: nothing matched)
+            if (sp_ctx_merge_candidates(c, all.data(), all.size(), 0, 0, which.size()) == SP_OK) return c;
+            failed = true;
+        }
+        if (failed) { err = sp_last_error(); sp_ctx_destroy(c); return nullptr; }
+        sp_ctx_destroy(c);      // a range still overflowed: twice as many, narrower ranges
+    }
+    err = "a query exceeds the hit stream of one pass even against 1/512 of the target set";
+    return nullptr;
+}
+// the batch without the refused queries: residues, offsets and the positions (in the batch) that remain
+static void withoutQueries(const char *qres, const uint64_t *qoff, size_t n, const std::vector<uint32_t> &refused, std::vector<char> &res, std::vector<uint64_t> &off, std::vector<uint32_t> &kept) {
+    std::vector<char> drop(n, 0); for (uint32_t q : refused) if (q < n) drop[q] = 1;
+    res.clear(); off.assign(1, 0); kept.clear();
+    for (size_t q = 0; q < n; q++) if (!drop[q]) { res.insert(res.end(), qres + qoff[q], qres + qoff[q + 1]); off.push_back(res.size()); kept.push_back((uint32_t) q); }
+    if (res.empty()) res.push_back('X');
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // prefilter <queryDB> <targetDB> <outDB>
 // ---------------------------------------------------------------------------------------------------------------
 int runPrefilterModule(int argc, const char **argv) {
@@ -249,24 +301,48 @@ int runPrefilterModule(int argc, const char **argv) {
     size_t qFrom = 0, nq = qkeys.size();
     { std::vector<uint64_t> lens(qkeys.size()); for (size_t i = 0; i < lens.size(); i++) lens[i] = qoff[i + 1] - qoff[i] + 2; partRange(lens, w.part, qFrom, nq); }   // this GPU's queries
     std::string payload; char buf[64];
-    for (size_t b0 = qFrom; b0 < nq; b0 += batch) {
-        const size_t b1 = std::min(nq, b0 + batch);
-        std::vector<uint64_t> off(qoff.begin() + b0, qoff.begin() + b1 + 1);
-        for (uint64_t &o : off) o -= qoff[b0];
-        if (sp_ctx_set_queries(ctx.c, qres.data() + qoff[b0], off.data(), b1 - b0) != SP_OK || sp_ctx_prefilter(ctx.c) != SP_OK) return fail(std::string("prefilter: ") + sp_last_error());
-        laps.lap("queries -> device, search");
-        std::vector<sp_hit> hits(std::max<uint64_t>(1, sp_ctx_num_hits(ctx.c))); std::vector<uint64_t> ho(b1 - b0 + 1);
-        if (sp_ctx_get_hits_compact(ctx.c, hits.data(), ho.data()) != SP_OK) return fail(std::string("prefilter: ") + sp_last_error());
-        for (size_t q = b0; q < b1; q++) {
+    // hits of the context's current batch -> one entry per query key (QueryMatcher::prefilterHitToBuffer, QueryMatcher.h:114-126)
+    auto writeBatch = [&](sp_ctx *c, const std::vector<uint32_t> &keys) -> bool {
+        std::vector<sp_hit> hits(std::max<uint64_t>(1, sp_ctx_num_hits(c))); std::vector<uint64_t> ho(keys.size() + 1);
+        if (sp_ctx_get_hits_compact(c, hits.data(), ho.data()) != SP_OK) return false;
+        for (size_t q = 0; q < keys.size(); q++) {
             payload.clear();
-            for (uint64_t h = ho[q - b0]; h < ho[q - b0 + 1]; h++) {       // QueryMatcher::prefilterHitToBuffer, QueryMatcher.h:114-126
+            for (uint64_t h = ho[q]; h < ho[q + 1]; h++) {
                 char *e = u32toa(tkeys[hits[h].seq_id], buf); *e++ = '\t';
                 e = i32toa(hits[h].score, e); *e++ = '\t';
                 e = i32toa((int32_t) hits[h].diagonal, e); *e++ = '\n';
                 payload.append(buf, e - buf);
             }
-            w.add(qkeys[q], payload);     // every query key gets an entry, empty ones too
+            w.add(keys[q], payload);     // every query key gets an entry, empty ones too
         }
+        return true;
+    };
+    for (size_t b0 = qFrom; b0 < nq; b0 += batch) {
+        const size_t b1 = std::min(nq, b0 + batch);
+        std::vector<uint64_t> off(qoff.begin() + b0, qoff.begin() + b1 + 1);
+        for (uint64_t &o : off) o -= qoff[b0];
+        std::vector<uint32_t> keys(qkeys.begin() + b0, qkeys.begin() + b1);
+        if (sp_ctx_set_queries(ctx.c, qres.data() + qoff[b0], off.data(), b1 - b0) != SP_OK) return fail(std::string("prefilter: ") + sp_last_error());
+        int rc = sp_ctx_prefilter(ctx.c);
+        std::vector<uint32_t> refused(rc == SP_ERR_OVERFLOW ? sp_ctx_overflow_queries(ctx.c, nullptr, 0) : 0);
+        if (rc == SP_ERR_OVERFLOW && !refused.empty()) {      // search the batch without them, then them against target shards
+            sp_ctx_overflow_queries(ctx.c, refused.data(), refused.size());
+            std::vector<char> res2; std::vector<uint64_t> off2; std::vector<uint32_t> kept;
+            withoutQueries(qres.data() + qoff[b0], off.data(), b1 - b0, refused, res2, off2, kept);
+            if (sp_ctx_set_queries(ctx.c, res2.data(), off2.data(), kept.size()) != SP_OK || sp_ctx_prefilter(ctx.c) != SP_OK) return fail(std::string("prefilter: ") + sp_last_error());
+            keys.clear(); for (uint32_t q : kept) keys.push_back(qkeys[b0 + q]);
+            if (!writeBatch(ctx.c, keys)) return fail(std::string("prefilter: ") + sp_last_error());
+            sp_ctx *r = searchByShards(p, tres, toff, tkeys, qres.data() + qoff[b0], off.data(), refused, err);
+            if (!r) return fail("prefilter: " + err);
+            keys.clear(); for (uint32_t q : refused) keys.push_back(qkeys[b0 + q]);
+            const bool ok = writeBatch(r, keys);
+            sp_ctx_destroy(r);
+            if (!ok) return fail(std::string("prefilter: ") + sp_last_error());
+            continue;
+        }
+        if (rc != SP_OK) return fail(std::string("prefilter: ") + sp_last_error());
+        laps.lap("queries -> device, search");
+        if (!writeBatch(ctx.c, keys)) return fail(std::string("prefilter: ") + sp_last_error());
     }
     laps.lap("format hits");
     if (!w.close(err)) return fail("prefilter: " + err);
@@ -461,30 +537,26 @@ int runSearchModule(int argc, const char **argv) {
     // from the faster copy
     sp_alignment *res = nullptr; char *cig = nullptr; uint64_t resCap = 0, cigCap = 0;
     auto freeBufs = [&]() { free(res); free(cig); res = nullptr; cig = nullptr; };
-    for (size_t b0 = qFrom; b0 < nq; b0 += batch) {
-        const size_t b1 = std::min(nq, b0 + batch);
-        std::vector<uint64_t> off(qoff.begin() + b0, qoff.begin() + b1 + 1);
-        for (uint64_t &o : off) o -= qoff[b0];
-        if (sp_ctx_set_queries(ctx.c, qres.data() + qoff[b0], off.data(), b1 - b0) != SP_OK || sp_ctx_prefilter(ctx.c) != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
-        laps.lap("queries -> device, prefilter");
-        const uint64_t nHits = sp_ctx_num_hits(ctx.c);
+    // align the hits of the context's current batch, filter / sort / format them, one entry per key
+    auto alignAndFormat = [&](sp_ctx *c, const std::vector<uint32_t> &keys) -> bool {
+        const uint64_t nHits = sp_ctx_num_hits(c);
         if (nHits + 16 > resCap || 24 * (nHits + 16) > cigCap) {
             freeBufs();
             resCap = nHits + nHits / 4 + 1024; cigCap = 24 * resCap;
             res = static_cast<sp_alignment *>(malloc(resCap * sizeof(sp_alignment))); cig = static_cast<char *>(malloc(cigCap));
-            if (!res || !cig) { freeBufs(); return fail("search: out of memory"); }
+            if (!res || !cig) { sp::setLastError("search: out of memory"); return false; }
         }
         uint64_t used = 0;
-        int rc = sp_ctx_align_hits(ctx.c, res, cig, cigCap, &used);
+        int rc = sp_ctx_align_hits(c, res, cig, cigCap, &used);
         if (rc == SP_ERR_OVERFLOW && used > cigCap) {
             free(cig); cigCap = used + 1024; cig = static_cast<char *>(malloc(cigCap));
-            rc = sp_ctx_align_hits(ctx.c, res, cig, cigCap, &used);
+            rc = sp_ctx_align_hits(c, res, cig, cigCap, &used);
         }
-        if (rc != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+        if (rc != SP_OK) return false;
         const sp_hit_packed *hits = nullptr; const uint32_t *ho = nullptr; uint64_t nh = 0;
-        if (sp_ctx_hits_view(ctx.c, &hits, &ho, &nh) != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+        if (sp_ctx_hits_view(c, &hits, &ho, &nh) != SP_OK) return false;
         laps.lap("align on the device");
-        const size_t nEntries = b1 - b0;
+        const size_t nEntries = keys.size();
         const size_t nChunks = numChunks(nEntries, threads);
         std::vector<std::string> blocks(nChunks); std::vector<std::vector<uint32_t>> bKeys(nChunks); std::vector<std::vector<uint64_t>> bLens(nChunks);
         parallelChunks(nEntries, threads, [&](size_t ci, size_t from, size_t to) {
@@ -503,11 +575,44 @@ int runSearchModule(int argc, const char **argv) {
                 const size_t before = block.size();
                 for (uint64_t i : ok) appendAlnLine(block, res[i], cig + res[i].cigar_offset, true);
                 block.push_back('\0');
-                bKeys[ci].push_back(qkeys[b0 + e]); bLens[ci].push_back(block.size() - before);
+                bKeys[ci].push_back(keys[e]); bLens[ci].push_back(block.size() - before);
             }
         });
         for (size_t ci = 0; ci < nChunks; ci++) w.addBlock(bKeys[ci], bLens[ci], std::move(blocks[ci]));
         laps.lap("format records");
+        return true;
+    };
+    for (size_t b0 = qFrom; b0 < nq; b0 += batch) {
+        const size_t b1 = std::min(nq, b0 + batch);
+        std::vector<uint64_t> off(qoff.begin() + b0, qoff.begin() + b1 + 1);
+        for (uint64_t &o : off) o -= qoff[b0];
+        std::vector<uint32_t> keys(qkeys.begin() + b0, qkeys.begin() + b1);
+        if (sp_ctx_set_queries(ctx.c, qres.data() + qoff[b0], off.data(), b1 - b0) != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+        const int rc = sp_ctx_prefilter(ctx.c);
+        std::vector<uint32_t> refused(rc == SP_ERR_OVERFLOW ? sp_ctx_overflow_queries(ctx.c, nullptr, 0) : 0);
+        if (rc == SP_ERR_OVERFLOW && !refused.empty()) {      // the batch without the queries one pass cannot hold, then those against target shards (searchByShards)
+            sp_ctx_overflow_queries(ctx.c, refused.data(), refused.size());
+            std::vector<char> res2; std::vector<uint64_t> off2; std::vector<uint32_t> kept;
+            withoutQueries(qres.data() + qoff[b0], off.data(), b1 - b0, refused, res2, off2, kept);
+            if (sp_ctx_set_queries(ctx.c, res2.data(), off2.data(), kept.size()) != SP_OK || sp_ctx_prefilter(ctx.c) != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+            keys.clear(); for (uint32_t q : kept) keys.push_back(qkeys[b0 + q]);
+            if (!alignAndFormat(ctx.c, keys)) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+            if (tkeys.empty()) {      // (a cached context: the target DB was not read for staging)
+                if (!loadSeqDb(f.positional[1], tdb, err)) { freeBufs(); return fail("search: " + err); }
+                flatten(tdb, tres, toff, tkeys);
+            }
+            sp_ctx *r = searchByShards(p, tres, toff, tkeys, qres.data() + qoff[b0], off.data(), refused, err);
+            if (!r) { freeBufs(); return fail("search: " + err); }
+            keys.clear(); for (uint32_t q : refused) keys.push_back(qkeys[b0 + q]);
+            const bool ok = alignAndFormat(r, keys);
+            const std::string e = ok ? std::string() : std::string(sp_last_error());
+            sp_ctx_destroy(r);
+            if (!ok) { freeBufs(); return fail("search: " + e); }
+            continue;
+        }
+        if (rc != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+        laps.lap("queries -> device, prefilter");
+        if (!alignAndFormat(ctx.c, keys)) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
     }
     freeBufs();
     if (!w.close(err)) return fail("search: " + err);

@@ -316,3 +316,41 @@ def test_module_calls_through_a_resident_server(tmp_path):
     finally:
         if srv.poll() is None:
             srv.kill()
+
+
+def test_modules_take_a_query_beyond_the_hit_stream_limit_through_target_shards(tmp_path):
+    """a query with more than 65 535 index hits (tests/test_gpu_sharded.py builds the same case): the in-memory call refuses its batch,
+    the module drop-ins search the batch without it and take it through target shards -- every entry equals the oracle's / the
+    two-step run's, the refused query included"""
+    import random
+    import spacepharer_amd as sa
+    from oracle_lib import Oracle
+    rnd = random.Random(11)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    core = "".join(rnd.choice(aa) for _ in range(60))
+    T = []
+    for i in range(2400):
+        s = list(core)
+        for _ in range(3):
+            s[rnd.randrange(60)] = rnd.choice(aa)
+        T.append("".join(rnd.choice(aa) for _ in range(rnd.randrange(0, 20))) + "".join(s) + "".join(rnd.choice(aa) for _ in range(20)))
+    Q = ["".join(rnd.choice(aa) for _ in range(12)), core, "".join(rnd.choice(aa) for _ in range(10)), core[5:55]]
+    q, t, pref, aln, fused = (str(tmp_path / x) for x in ("qdb", "tdb", "pref", "aln", "fused"))
+    write_seq_db(q, Q, key0=3)
+    write_seq_db(t, T)
+    sa.module_prefilter([q, t, pref] + (PREF_FLAGS % 300).split())
+    got, dbtype = read_db(pref)
+    o = Oracle()
+    o.set_targets(T)
+    assert dbtype == 7 and sorted(got) == [3, 4, 5, 6]
+    for i, s in enumerate(Q):
+        assert got[3 + i] == o.prefilter_text(s), i
+    assert got[4].count("\n") == 300
+    o.close()
+    sa.module_align([q, t, pref, aln] + ALN_FLAGS.split())
+    flags = (PREF_FLAGS % 300).split() + ["-a", "1", "--alignment-mode", "2", "-e", "200", "--min-seq-id", "0", "--min-aln-len", "0", "--max-rejected", "2147483647",
+                                          "--max-accept", "2147483647", "--gap-open", "nucl:10,aa:16", "--gap-extend", "2"]
+    sa.module_search([q, t, fused, str(tmp_path)] + flags)
+    two, _ = read_db(aln)
+    one, dbtype = read_db(fused)
+    assert dbtype == 5 and one == two and one[4].count("\n") > 100
