@@ -257,6 +257,8 @@ def main():
     ap.add_argument("--stage", default="full", choices=["full", "prefilter"])
     ap.add_argument("--cpu-sample", type=int, default=3000, help="0 = skip the CPU baseline; < 3000: that many peptides per core instead of the whole workload")
     ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the reference CPU baseline (one process each); 0 = all usable cores")
+    ap.add_argument("--match-blocks", type=int, default=3, help="k_match blocks per CU while several search contexts share the GPU (0 = all that fit); "
+                    "the small footprint fits four, three leave room for the other context's aligner")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="search contexts per GPU, each on its own HIP streams and host thread with its own query batch, taking the steps in turn "
                          "(1 = strictly one pass at a time)")
@@ -393,7 +395,7 @@ def main():
             ref.append(ref_slot[i].digest(full))
         if n_pipe > 1:
             for c in ctxs:
-                c.set_tuning("match_blocks_per_cu", 2)     # leaves LDS for the other context's aligner on every CU
+                c.set_tuning("match_blocks_per_cu", args.match_blocks)     # leaves LDS / registers for the other context's aligner on every CU
         for i, c in enumerate(ctxs):
             for _ in range(warmup):
                 step(c, slots[i][0])

@@ -396,11 +396,9 @@ constexpr int kWavesPerBlock = 4;
 constexpr uint32_t kDiagChunk = 64;   // diagonal records reserved per atomic in k_match
 constexpr uint32_t kQueryChunk = 4;
 constexpr int kDeferCap = 128;       // multi-entry index lists per wave whose entries are fetched together (k_match)
-constexpr int kOccRegs = 4;         // occupied slots per lane and batch in k_match's fetch phase (64 x kOccRegs slot words in flight per wave)
 constexpr int kWalkStep = 4;        // list positions per step when long lists are walked on the spot (kOccRegs x kWalkStep entry loads in flight)
 constexpr int kTailKeys = 3;        // keys per lane and step when the pre-filter reads spilled hits back from HBM
 constexpr int kMapGroup = 4;         // rounds of the (a, b) mapping whose LDS lookups are issued together
-constexpr int kSuper = 1024;         // similar k-mers per enumeration super-round in k_match   // queries per work-queue pop in k_match
 
 struct DiagRec { uint32_t seqId; uint16_t diag; uint16_t idx; };
 
@@ -468,8 +466,16 @@ __device__ void markKept(const uint64_t *keys, uint32_t M, uint32_t *bits, int l
 }
 
 // HITCAP = hits per query held in LDS; more spill to the per-wave HBM scratch.  Smaller HITCAP = more resident waves.
-template <int kHitCap, bool kOrd>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
+// kSmall: the footprint for a sparse index (phage scale: 1.1 entries per occupied k-mer, ~110 hits per query) -- super-rounds of 512
+// similar k-mers, 256 hits in LDS, two slot registers per lane: 9 KB of LDS and <= 128 VGPRs per wave, i.e. FOUR waves per SIMD or three
+// plus room for another context's aligner on the same CU.  Alone it runs as fast as the large footprint (what the fourth wave hides,
+// the second super-round of a window above 512 k-mers costs); with two search contexts per GPU it is 6 % faster per step.  A dense index
+// (2 200 hits per query) needs the large one: its pre-filter bitmaps and hit buffer are sized by kSuper / kHitCap.
+template <int kHitCap, bool kOrd, bool kSmall>
+__global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? 4 : 1) void k_match(MatchArgs a) {
+    constexpr int kSuper = kSmall ? 512 : 1024;         // similar k-mers per enumeration super-round
+    constexpr int kOccRegs = kSmall ? 2 : 4;            // occupied slots per lane and batch in the fetch phase (64 x kOccRegs slot words in flight per wave)
+    static_assert(kHitCap == (kSmall ? 256 : 512), "hit buffer and footprint go together");
     __shared__ uint16_t s_occOrd[kWavesPerBlock][kOrd ? kSuper : 1];
     __shared__ uint32_t s_ordL[kWavesPerBlock][kOrd ? kHitCap : 1];
     __shared__ uint64_t s_keys[kWavesPerBlock][kHitCap];
@@ -831,7 +837,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
             // index (2 000 - 60 000 hits per query) the chance collisions fall geometrically (2 200 -> 300 -> 120 -> the true
             // double hits) and nothing is ever sorted in HBM.
             uint32_t *seen = occList, *again = occList + kSuper / 2;     // 2 x 512 words; the enumeration arrays are free now
-            static_assert(kSuper == 1024, "the pre-filter bitmaps use the kSuper words of the occupied-slot list");
+            constexpr int kBktShift = kSuper == 1024 ? 18 : 19;      // two bitmaps of kSuper / 2 words in the (then idle) occupied-slot list: 16 384 or 8 192 buckets each
             // (hits beyond the LDS buffer live in the per-wave HBM scratch; the survivors usually fit LDS again)
 #pragma nounroll
             for (int round = 0; round < 6; round++) {
@@ -841,7 +847,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                 // hits beyond the LDS buffer come from the per-wave HBM scratch: those chunks are read kTailKeys keys per lane at a
                 // time (independent loads; one load per step would pay the memory latency 35 times for 2 200 hits)
                 auto mark = [&](uint64_t k) {
-                    const uint32_t bkt = ((uint32_t) (k >> 32) * mul) >> 18, bit = 1u << (bkt & 31u);      // 14 bits
+                    const uint32_t bkt = ((uint32_t) (k >> 32) * mul) >> kBktShift, bit = 1u << (bkt & 31u);
                     if (atomicOr(&seen[bkt >> 5], bit) & bit) atomicOr(&again[bkt >> 5], bit);
                 };
                 const uint32_t mLds = M < (uint32_t) kHitCap ? M : (uint32_t) kHitCap;
@@ -856,7 +862,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_match(MatchArgs a) {
                 waveSync();
                 uint32_t wr = 0;
                 auto sift = [&](uint64_t k, bool valid) {
-                    const uint32_t bkt = ((uint32_t) (k >> 32) * mul) >> 18;
+                    const uint32_t bkt = ((uint32_t) (k >> 32) * mul) >> kBktShift;
                     const bool keep = valid && (((again[bkt >> 5] >> (bkt & 31u)) & 1u) || (k & 0xFF) == 0);
                     const uint64_t m = __ballot(keep);
                     if (keep) { const uint32_t at = wr + (uint32_t) __popcll(m & laneMaskLt(lane)); if (at < (uint32_t) kHitCap) keys[at] = k; else spillKeys[at] = k; }
@@ -1603,6 +1609,7 @@ struct Gpu::Impl {
     size_t qTotal = 0; uint32_t maxQLen = 0;
     std::vector<uint32_t> hQoff;
     // match / select
+    bool denseIndex = false;      // 1.5+ entries per occupied k-mer on average: k_match runs with its large footprint
     DevBuf<uint64_t> spill; DevBuf<uint32_t> heavyList; DevBuf<uint32_t> heavyCnt; DevBuf<uint8_t> heavyFlag; DevBuf<unsigned long long> wavePartial; DevBuf<uint32_t> queue; DevBuf<DiagRec> diagRec; DevBuf<uint32_t> diagQuery; DevBuf<uint16_t> diagScore; DevBuf<uint8_t> diagFlag;
     DevBuf<uint32_t> qDiagBase; DevBuf<uint32_t> qDiagCnt; DevBuf<unsigned long long> counters;
     DevBuf<GpuHit> outHits; DevBuf<GpuHit> outStage; DevBuf<uint32_t> outQuery; DevBuf<uint32_t> outCount; DevBuf<uint32_t> outBase; DevBuf<uint32_t> outOffset;
@@ -1835,14 +1842,17 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     // persistent match grid: as many blocks per CU as the LDS footprint admits.  512 hits per query live in LDS; more go to
     // the per-wave HBM scratch and come back through the pre-filter (faster than a larger LDS buffer even for dense indices:
     // 45 vs 51 ms at 2 x 10^8 residues, because three blocks per CU stay resident instead of one).
-    constexpr int hitCap = 512;
-    const void *fn = withOrd ? (const void *) k_match<512, true> : (const void *) k_match<512, false>;
+    // footprint by index density (SP_MATCH_SMALL=0/1 overrides): sparse -> small, dense -> large; the sharded search always small
+    // (its ordinal arrays push the large footprint to two blocks per CU)
+    const bool small = getenv("SP_MATCH_SMALL") ? atoi(getenv("SP_MATCH_SMALL")) != 0 : (withOrd || !d.denseIndex);
+    const void *fn = small ? (withOrd ? (const void *) k_match<256, true, true> : (const void *) k_match<256, false, true>)
+                           : (withOrd ? (const void *) k_match<512, true, false> : (const void *) k_match<512, false, false>);
     int perCU = 2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, fn, 64 * kWavesPerBlock, 0) != hipSuccess || perCU < 1) perCU = 2;
     if (d.matchPerCU > 0) perCU = std::min(perCU, d.matchPerCU);
     if (const char *e = getenv("SP_MATCH_PERCU")) perCU = std::max(1, atoi(e));
     const bool dbg = getenv("SP_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[sp] k_match hitCap=%d ord=%d blocks/CU=%d\n", hitCap, (int) withOrd, perCU);
+    if (dbg) fprintf(stderr, "[sp] k_match footprint=%s ord=%d blocks/CU=%d\n", small ? "small" : "large", (int) withOrd, perCU);
     const uint32_t blocks = (uint32_t) std::min<size_t>((nq_ + kWavesPerBlock - 1) / kWavesPerBlock, (size_t) d.numCU * perCU);
     d.matchBlocks = blocks;
     if (!d.spill.ensure((size_t) blocks * kWavesPerBlock * kSpillWordsPerWave, err)) return false;
@@ -1879,8 +1889,11 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
                  (uint32_t) (getenv("SP_MATCH_STATIC") ? atoi(getenv("SP_MATCH_STATIC")) : 4), (uint32_t) (getenv("SP_MATCH_DCHUNK") ? std::max(1, atoi(getenv("SP_MATCH_DCHUNK"))) : 4),
                  d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p, d.wavePartial.p};
-    if (withOrd) hipLaunchKernelGGL((k_match<512, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
-    else hipLaunchKernelGGL((k_match<512, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+    if (small) {
+        if (withOrd) hipLaunchKernelGGL((k_match<256, true, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+        else hipLaunchKernelGGL((k_match<256, false, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+    } else if (withOrd) hipLaunchKernelGGL((k_match<512, true, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+    else hipLaunchKernelGGL((k_match<512, false, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     SP_DBG_SYNC("k_match");
     SP_EV(2, 1);
     ScoreArgs sa{d.diagRec.p, d.diagQuery.p, d.queue.p + 1, (uint32_t) diagCap, d.qres.p, d.qoff.p, d.qcorr.p, d.tmasked.p, d.toff.p, d.ungSub.p, d.diagScore.p, d.counters.p, d.wavePartial.p, blocks * (uint32_t) kWavesPerBlock};
@@ -2049,6 +2062,7 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
     }
     HIP_OK(hipEventRecord(d.ev[1], d.stream));
     const size_t words = kTableSize / 64;
+    d.denseIndex = false;
     if (!d.pbits.ensure(words, err) || !d.prank.ensure(words, err) || !d.prow.ensure(kTableSize / 8000, err) || !d.slots.ensure(1, err) || !d.ientries.ensure(1, err)) return false;
     HIP_OK(hipMemsetAsync(d.pbits.p, 0, words * sizeof(uint64_t), d.stream));
     HIP_OK(hipMemsetAsync(d.prank.p, 0, words * sizeof(uint16_t), d.stream));
@@ -2105,6 +2119,7 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
             HIP_OK(hipcub::DeviceScan::ExclusiveSum(d.ixTemp.p, sb, d.ixCnt.p, d.ixBefore.p, (int) words, d.stream));
             hipLaunchKernelGGL(k_idx_ranks, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, d.ixBefore.p, (uint32_t) words, d.prank.p, d.prow.p);
             HIP_OK(hipGetLastError());
+            d.denseIndex = (uint64_t) E * 2 >= (uint64_t) nSlots * 3;
             d.indexEntries = E; out.indexEntries = E; out.indexSlots = nSlots;
         }
     }

@@ -1,8 +1,9 @@
 """Register / LDS budget of the kernels whose speed hangs on occupancy (cross-compiled for gfx950, no GPU needed).
 
-k_match is latency-bound and runs three waves per SIMD only while it stays at or below 168 VGPRs and 53 KB of LDS per
-block of four waves; it sits at 167.  A change that pushes it over the edge costs a third of the
-occupancy and 15-50 % of the kernel time without failing any parity test -- this test fails instead."""
+k_match is latency-bound: its large footprint (dense index) runs three waves per SIMD only while it stays at or below 168 VGPRs and
+53 KB of LDS per block of four waves, its small footprint (sparse index) four waves at 128 VGPRs and 40 KB.  A
+change that pushes either over the edge costs a third / a quarter of the occupancy and 15-50 % of the kernel time without failing any
+parity test -- this test fails instead."""
 import os
 import re
 import shutil
@@ -37,10 +38,15 @@ def test_match_and_sw_kernels_keep_their_occupancy(tmp_path):
         assert hits, (fragment, list(info)[:5])
         return hits[0]
 
-    match = kernel("k_matchILi512ELb0")                       # k_match<512, false>: the unsharded search
+    match = kernel("k_matchILi512ELb0ELb0")                   # k_match<512, false, false>: the unsharded search on a dense index (large footprint)
     assert match["Occupancy [waves/SIMD]"] >= 3, match
     assert match["VGPRs"] <= 168 and match.get("VGPRs Spill", 0) == 0, match
     assert match["LDS Size [bytes/block]"] * 3 <= 160 * 1024, match
+    small = kernel("k_matchILi256ELb0ELb1")                   # k_match<256, false, true>: sparse index -- four waves per SIMD, or three and room for an aligner
+    assert small["Occupancy [waves/SIMD]"] >= 4 and small["VGPRs"] <= 128 and small.get("VGPRs Spill", 0) <= 4, small
+    assert small["LDS Size [bytes/block]"] * 4 <= 160 * 1024, small
+    shard = kernel("k_matchILi256ELb1ELb1")                   # k_match<256, true, true>: the target-sharded search (ordinals recorded): three blocks per CU
+    assert shard["Occupancy [waves/SIMD]"] >= 3 and shard["LDS Size [bytes/block]"] * 3 <= 160 * 1024, shard
     for gl in (10, 12, 16, 32):                               # the packed Smith-Waterman kernels: eight waves per SIMD
         sw = kernel("k_sw_byte1pILi%dE" % gl)
         assert sw["Occupancy [waves/SIMD]"] >= 8, (gl, sw)
