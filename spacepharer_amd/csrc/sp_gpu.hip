@@ -389,7 +389,6 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
 // Only windows [0, lastWindow) are scanned (CacheFriendlyOperations.cpp:43 with QueryMatcher.cpp:285-291).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kSpillCap = 65535;     // hits per query in the per-wave HBM scratch (16-bit stream index)
-constexpr int kATile = 256;
 constexpr int kBTile = 512;
 constexpr uint32_t kMaxKmerResult = 262144u * 32u;   // KmerGenerator.h:45
 constexpr int kWavesPerBlock = 4;
@@ -472,9 +471,10 @@ __device__ void markKept(const uint64_t *keys, uint32_t M, uint32_t *bits, int l
 // the second super-round of a window above 512 k-mers costs); with two search contexts per GPU it is 6 % faster per step.  A dense index
 // (2 200 hits per query) needs the large one: its pre-filter bitmaps and hit buffer are sized by kSuper / kHitCap.
 template <int kHitCap, bool kOrd, bool kSmall>
-__global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? 4 : 1) void k_match(MatchArgs a) {
+__global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) void k_match(MatchArgs a) {
     constexpr int kSuper = kSmall ? 512 : 1024;         // similar k-mers per enumeration super-round
     constexpr int kOccRegs = kSmall ? 2 : 4;            // occupied slots per lane and batch in the fetch phase (64 x kOccRegs slot words in flight per wave)
+    constexpr int kATile = kSmall ? 128 : 256;          // a's per tile of row A (a window of a spacer peptide has 20-60)
     static_assert(kHitCap == (kSmall ? 256 : 512), "hit buffer and footprint go together");
     __shared__ uint16_t s_occOrd[kWavesPerBlock][kOrd ? kSuper : 1];
     __shared__ uint32_t s_ordL[kWavesPerBlock][kOrd ? kHitCap : 1];
