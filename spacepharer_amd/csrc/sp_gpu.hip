@@ -265,12 +265,19 @@ __global__ __launch_bounds__(256) void k_weigh(WeighArgs a) {
 // residues / bias values / thresholds staged in LDS, so the chains of dependent global round trips of the one-lane-per-query
 // kernels (store bias -> load it back per window, threshold -> table heads -> count rows) shrink to three.  Same
 // arithmetic, in the same order, as k_prep; same counts as k_weigh.
-struct Prep8Args { PrepArgs p; WeighArgs w; };
+struct Prep8Args { PrepArgs p; WeighArgs w; uint32_t stride; };
 __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
     const PrepArgs &a = a8.p; const WeighArgs &wa = a8.w;
     __shared__ short s_seed[kAlph * kAlph]; __shared__ double s_back[kAlph]; __shared__ signed char s_ung[kAlph * kAlph];
-    __shared__ uint8_t s_q[32][64]; __shared__ float s_b[32][64]; __shared__ short s_t[32][64]; __shared__ signed char s_c[32][64];
-    __shared__ uint32_t s_top[32][64];
+    // per-query staging rows are as long as the longest query of the batch (rounded up to 8), not 64: a spacer batch needs 4 KB of LDS
+    // per block instead of 24, so the kernel squeezes onto CUs that another context's k_match already occupies
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    const int S = (int) a8.stride;
+    float *const s_bA = reinterpret_cast<float *>(s_dyn);                       // [32][S]
+    uint32_t *const s_topA = reinterpret_cast<uint32_t *>(s_bA + 32 * S);       // [32][S]
+    short *const s_tA = reinterpret_cast<short *>(s_topA + 32 * S);             // [32][S]
+    uint8_t *const s_qA = reinterpret_cast<uint8_t *>(s_tA + 32 * S);           // [32][S]
+    signed char *const s_cA = reinterpret_cast<signed char *>(s_qA + 32 * S);   // [32][S]
     __shared__ uint32_t s_list[1024]; __shared__ uint32_t s_n, s_base;
     for (int x = threadIdx.x; x < kAlph * kAlph; x += blockDim.x) { s_seed[x] = a.seedSub[x]; s_ung[x] = a.ungSub[x]; }
     if (threadIdx.x < kAlph) s_back[threadIdx.x] = a.seedBack[threadIdx.x];
@@ -283,24 +290,24 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
         const bool have = qi < qTo;
         const uint32_t o = have ? a.qoff[qi] : 0u;
         const int L = have ? (int) (a.qoff[qi + 1] - o) : 0;
-        for (int i = sub; i < L; i += 8) s_q[slot][i] = a.qres[o + i];
+        for (int i = sub; i < L; i += 8) s_qA[slot * S + (i)] = a.qres[o + i];
         __syncthreads();
         // local amino-acid bias (SubstitutionMatrix::calcLocalAaBiasCorrection, SubstitutionMatrix.cpp:85-114)
         int aaBias = 0;
         for (int i = sub; i < L; i += 8) {
             const int minPos = max(0, i - 20), maxPos = min(L, i + 20);
-            const short *row = s_seed + s_q[slot][i] * kAlph;
+            const short *row = s_seed + s_qA[slot * S + (i)] * kAlph;
             int sum = 0;
-            for (int j = minPos; j < maxPos; j++) sum += row[s_q[slot][j]];
-            sum -= row[s_q[slot][i]];
+            for (int j = minPos; j < maxPos; j++) sum += row[s_qA[slot * S + (j)]];
+            sum -= row[s_qA[slot * S + (i)]];
             float d = (float) sum;
             d = (float) ((double) d / (-1.0 * (double) (float) (maxPos - minPos)));
             for (int x = 0; x < kAlph; x++) d = (float) ((double) d + s_back[x] * (double) (float) row[x]);
-            a.biasf[o + i] = d; s_b[slot][i] = d;
+            a.biasf[o + i] = d; s_bA[slot * S + (i)] = d;
             float c = d;
             c = (float) ((c < 0.0) ? (double) (c / 4) - 0.5 : (double) (c / 4) + 0.5);
             const signed char cc = (signed char) c;
-            a.qcorr[o + i] = cc; s_c[slot][i] = cc;
+            a.qcorr[o + i] = cc; s_cA[slot * S + (i)] = cc;
             aaBias = (cc < aaBias) ? cc : aaBias;
         }
 #pragma unroll
@@ -314,37 +321,37 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
                 float bc = 0; bool hasX = false;
                 const int pp[6] = {0, 1, 3, 4, 5, 7};
 #pragma unroll
-                for (int p = 0; p < 6; p++) { bc += s_b[slot][i + pp[p]]; hasX |= (s_q[slot][i + pp[p]] == kX); }
+                for (int p = 0; p < 6; p++) { bc += s_bA[slot * S + (i + pp[p])]; hasX |= (s_qA[slot * S + (i + pp[p])] == kX); }
                 if (!hasX) {
                     const short b = (short) ((bc < 0.0) ? (double) bc - 0.5 : (double) bc + 0.5);
                     int v = a.kmerThr - b; if (v < 0) v = 0;
                     t = (short) v;
                 }
             }
-            a.qthr[o + i] = t; s_t[slot][i] = t;
+            a.qthr[o + i] = t; s_tA[slot * S + (i)] = t;
         }
         // self score on diagonal 0 (QueryMatcher::rescoreHits, prefiltering/QueryMatcher.cpp:489-494)
         if (have && sub == 0) {
             int mx = 0, sc = 0;
-            for (int i = 0; i < L; i++) { sc += s_ung[s_q[slot][i] * kAlph + s_q[slot][i]] + s_c[slot][i]; sc = sc < 0 ? 0 : sc; mx = sc > mx ? sc : mx; }
+            for (int i = 0; i < L; i++) { sc += s_ung[s_qA[slot * S + (i)] * kAlph + s_qA[slot * S + (i)]] + s_cA[slot * S + (i)]; sc = sc < 0 ? 0 : sc; mx = sc > mx ? sc : mx; }
             a.qself[qi] = mx;
         }
         __syncthreads();
         // similar k-mers the query will generate (see k_weigh); the best scores of all windows' rows are fetched together
         const bool weigh = wa.heavyThr != 0xFFFFFFFFu;        // off for large batches (see matchAndScore)
         for (int i = sub; i < (weigh ? L - 8 : 0); i += 8) {
-            const uint8_t *q = s_q[slot];
+            const uint8_t *q = s_qA + slot * S;
             const uint32_t ia = q[i] + 20u * q[i + 1] + 400u * q[i + 3], ib = q[i + 4] + 20u * q[i + 5] + 400u * q[i + 7];
-            s_top[slot][i] = s_t[slot][i] < 0 ? 0u : (wa.ext3[(size_t) ia * 8000u] >> 16) | (wa.ext3[(size_t) ib * 8000u] & 0xFFFF0000u);
+            s_topA[slot * S + (i)] = s_tA[slot * S + (i)] < 0 ? 0u : (wa.ext3[(size_t) ia * 8000u] >> 16) | (wa.ext3[(size_t) ib * 8000u] & 0xFFFF0000u);
         }
         __syncthreads();
         uint32_t K = 0;
         for (int i = 0; i < (weigh ? L - 8 : 0); i++) {
-            const int thr = s_t[slot][i];
+            const int thr = s_tA[slot * S + (i)];
             if (thr < 0) continue;
-            const uint8_t *q = s_q[slot];
+            const uint8_t *q = s_qA + slot * S;
             const uint32_t ia = q[i] + 20u * q[i + 1] + 400u * q[i + 3], ib = q[i + 4] + 20u * q[i + 5] + 400u * q[i + 7];
-            const int sA0 = (int) (s_top[slot][i] & 0xFFFFu) - 32768, sB0 = (int) (s_top[slot][i] >> 16) - 32768;
+            const int sA0 = (int) (s_topA[slot * S + (i)] & 0xFFFFu) - 32768, sB0 = (int) (s_topA[slot * S + (i)] >> 16) - 32768;
             const uint16_t *cA = wa.ext3cnt + (size_t) ia * kCntW, *cB = wa.ext3cnt + (size_t) ib * kCntW;
             auto at = [&](const uint16_t *row, int c) -> uint32_t { int x = c - wa.cntMin; x = x < 0 ? 0 : (x > kCntW - 1 ? kCntW - 1 : x); return row[x]; };
             const int lo = thr - sB0 > wa.cntMin ? thr - sB0 : wa.cntMin;
@@ -1873,8 +1880,9 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     WeighArgs wa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, heavyThr ? heavyThr : 0xFFFFFFFFu, d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p};
     const unsigned weighBlocks = (unsigned) std::min<size_t>((nq_ + 31) / 32, (size_t) d.numCU * 8);
     if (d.maxQLen <= 64 && !getenv("SP_PREP_SPLIT")) {
-        Prep8Args p8{pa, wa};
-        hipLaunchKernelGGL(k_prep8, dim3(weighBlocks), dim3(256), 0, d.stream, p8);
+        const uint32_t stride = std::max<uint32_t>(16u, (d.maxQLen + 7u) & ~7u);      // staging row per query (<= 64)
+        Prep8Args p8{pa, wa, stride};
+        hipLaunchKernelGGL(k_prep8, dim3(weighBlocks), dim3(256), (size_t) 32 * stride * 12, d.stream, p8);
         SP_DBG_SYNC("k_prep8");
     } else {
         hipLaunchKernelGGL(k_prep, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, pa);
