@@ -86,6 +86,8 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
 }
 
 __device__ __forceinline__ uint64_t laneMaskLt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
+// number of set bits of a wave mask below this lane: v_mbcnt_lo + v_mbcnt_hi on the mask's scalar halves (popcount(m & laneMaskLt) builds the lane mask first: 4 instructions)
+__device__ __forceinline__ uint32_t lanePrefixCount(uint64_t m) { return (uint32_t) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)); }
 
 // bitonic sort of n (power of two) u64 keys by one wave; keys may live in LDS or in global scratch
 __device__ void waveBitonicSort(uint64_t *keys, uint32_t n, int lane) {
@@ -750,7 +752,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
                         const bool occ = kmerR[r] != 0xFFFFFFFFu && ((prR[r] >> bit) & 1ull);
                         const uint64_t m = __ballot(occ);
                         if (occ) {
-                            const uint32_t at = nOcc + (uint32_t) __popcll(m & laneMaskLt(lane));
+                            const uint32_t at = nOcc + lanePrefixCount(m);
                             // slot number (< 2^26) | occupied slots of its word below it: the rest of the rank is looked up in phase 2
                             occList[at] = kmerR[r] | ((uint32_t) __popcll(prR[r] & ((1ull << bit) - 1ull)) << 26);
                             if (kOrd) occOrd[at] = (uint16_t) (r * 64 + lane);
@@ -814,7 +816,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
                                 const bool multi = (slotR[r] >> 63) != 0ull && hR[r] < (uint32_t) kSpillCap;
                                 const uint64_t m = __ballot(multi);
                                 if (multi) {
-                                    const uint32_t at = defN + (uint32_t) __popcll(m & laneMaskLt(lane));
+                                    const uint32_t at = defN + lanePrefixCount(m);
                                     defSlot[at] = slotR[r]; defMeta[at] = hR[r] | ((uint32_t) i << 16); if (kOrd) defOrd[at] = ordR[r];
                                 }
                                 defN += (uint32_t) __popcll(m);
@@ -872,7 +874,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
                     const uint32_t bkt = ((uint32_t) (k >> 32) * mul) >> kBktShift;
                     const bool keep = valid && (((again[bkt >> 5] >> (bkt & 31u)) & 1u) || (k & 0xFF) == 0);
                     const uint64_t m = __ballot(keep);
-                    if (keep) { const uint32_t at = wr + (uint32_t) __popcll(m & laneMaskLt(lane)); if (at < (uint32_t) kHitCap) keys[at] = k; else spillKeys[at] = k; }
+                    if (keep) { const uint32_t at = wr + lanePrefixCount(m); if (at < (uint32_t) kHitCap) keys[at] = k; else spillKeys[at] = k; }
                     wr += (uint32_t) __popcll(m);
                 };
                 for (uint32_t base = 0; base < mLds; base += 64) { const uint32_t t = base + lane; sift(t < mLds ? keys[t] : 0ull, t < mLds); }
@@ -932,7 +934,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
             D = (uint32_t) __popcll(keptMask);
             if (D > 0) reserve(D);
             if (D > 0 && kept) {
-                const uint32_t at = dbase + (uint32_t) __popcll(keptMask & laneMaskLt(lane));
+                const uint32_t at = dbase + lanePrefixCount(keptMask);
                 DiagRec r; r.seqId = id; r.diag = (uint16_t) (sLo & 0xFFFF); r.idx = (uint16_t) ((sLo >> 16) & 0xFFFF);
                 a.diagRec[at] = r;
                 a.diagQuery[at] = qi;
@@ -965,7 +967,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
                     const uint64_t m = __ballot(kept);
                     if (kept) {
                         const uint64_t k = K[t];
-                        const uint32_t at = outPos + __popcll(m & laneMaskLt(lane));
+                        const uint32_t at = outPos + lanePrefixCount(m);
                         DiagRec r; r.seqId = (uint32_t) (k >> 32); r.diag = (uint16_t) (k & 0xFFFF); r.idx = (uint16_t) ((k >> 16) & 0xFFFF);
                         a.diagRec[at] = r;
                         a.diagQuery[at] = qi;
