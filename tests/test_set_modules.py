@@ -171,3 +171,45 @@ def test_filtermatchbyfdr_on_long_score_lists(tmp_path):
         assert dbtype == 12 and got == c["out"], i
         nontrivial += float.fromhex(c["threshold"]) > 0
     assert nontrivial >= 4
+
+
+def test_threaded_drivers_write_the_bytes_a_single_thread_writes(tmp_path):
+    """the host modules cut their input into chunks of about equal bytes and format them on --threads workers: data file, index, lookup and
+    headers must not depend on the thread count (a few large genomes + thousands of small entries, so that chunks split both ways)"""
+    import filecmp
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import predictmatch_e2e as pm
+    import spacepharer_amd as sa
+    genomes, arrays, _ = pm.make_data(40, 30000, 300, 12, seed=5)
+    outs = {}
+    for th in ("1", "7"):
+        d = tmp_path / ("t" + th)
+        d.mkdir()
+        P = lambda x: str(d / x)      # noqa: E731
+        common = ["--threads", th, "--compressed", "0", "-v", "3"]
+        pm.nucl_db(P("q_nucl"), arrays)
+        pm.nucl_db(P("t_nucl"), [[g] for g in genomes])
+        sa.module_host("extractorfs", [P("q_nucl"), P("q_orf"), "--min-length", "9", "--orf-start-mode", "1", "--create-lookup", "1"] + common)
+        sa.module_host("extractorfs", [P("t_nucl"), P("t_orf"), "--min-length", "30", "--orf-start-mode", "0", "--create-lookup", "1"] + common)
+        sa.module_host("translatenucs", [P("t_orf"), P("t_aa")] + common)
+        sa.module_host("reverseseqbycodon", [P("t_orf"), P("c_orf")] + common)
+        sa.module_host("translatenucs", [P("q_orf"), P("q_aa")] + common)
+        outs[th] = d
+    names = ["q_orf", "q_orf.index", "q_orf.lookup", "q_orf_h", "q_orf_h.index", "t_orf", "t_orf.index", "t_orf.lookup", "t_orf_h", "t_aa", "t_aa.index", "c_orf", "c_orf.index", "q_aa", "q_aa.index"]
+    for n in names:
+        assert filecmp.cmp(str(outs["1"] / n), str(outs["7"] / n), shallow=False), n
+    assert os.path.getsize(str(outs["1"] / "t_orf")) > 500000 and sum(1 for _ in open(str(outs["1"] / "q_orf.index"))) > 10000
+
+
+def test_a_failing_chunk_fails_the_module_and_leaves_no_dbtype(tmp_path):
+    import spacepharer_amd as sa
+    P = lambda x: str(tmp_path / x)      # noqa: E731
+    seq = {"entries": {str(k): "ATGAAATTTGGGCCC\n" for k in range(3000)}, "dbtype": 1}
+    aa = {"entries": {str(k): "MKFGP\n" for k in range(3000)}, "dbtype": 0}
+    write_db(P("qn"), seq); write_db(P("tn"), seq); write_db(P("qa"), aa); write_db(P("ta"), aa)
+    aln = {"entries": {str(k): "%d\t20\t1.00\t1.0E-03\t0\t4\t5\t0\t4\t5\t5M\n" % (k if k != 2500 else 999999) for k in range(3000)}, "dbtype": 5}
+    write_db(P("aln"), aln)
+    with pytest.raises(sa.SpError) as e:
+        sa.module_host("proteinaln2nucl", [P("qn"), P("tn"), P("qa"), P("ta"), P("aln"), P("out"), "--gap-open", "nucl:10,aa:16", "--gap-extend", "2", "--threads", "4", "--compressed", "0", "-v", "3"])
+    assert "999999" in str(e.value) and not os.path.exists(P("out.dbtype"))
