@@ -265,6 +265,8 @@ def main():
     ap.add_argument("--shard", default=None, choices=["queries", "targets"],
                     help="decomposition: target shards + RCCL all-gather (default at N > 1) or query partition with replicated index (default at N = 1)")
     ap.add_argument("--no-module-e2e", action="store_true", help="N = 1: skip the files-to-files timing of the module drop-ins (tools/module_e2e.py)")
+    ap.add_argument("--shards", type=int, default=0, help="N > 1, target-sharded: S target shards x N / S query groups (all-gather within a group); 0 = N shards, every rank matches all queries (BASELINE configs[3])")
+    ap.add_argument("--no-hybrid", action="store_true", help="N >= 4: skip the additional 2-shard x N/2-group measurement")
     ap.add_argument("--no-replica", action="store_true", help="N > 1: skip the additional query-partition (replica) measurement")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "gloo"], help="transport of the candidate all-gather (gloo: through host memory; tests)")
     ap.add_argument("--same-gpu", action="store_true", help="all ranks use HIP device 0 (tests of the N > 1 path on a one-GPU box; needs --exchange gloo)")
@@ -315,9 +317,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
-    def measure(shard_targets, spacers, steps, regions, warmup, want_breakdown):
-        """one decomposition on this rank: set-up, reference digests, `regions` timed K-step regions with digest checks."""
+    def measure(shard_targets, spacers, steps, regions, warmup, want_breakdown, shards=0):
+        """one decomposition on this rank: set-up, reference digests, `regions` timed K-step regions with digest checks.
+        shards (target-sharded mode): S target shards x world / S query groups -- group g = rank // S searches query slice g against the
+        S shards and all-gathers within the group; 0 / world = every rank is a shard and matches all queries (BASELINE configs[3])."""
         n_pipe = 1 if shard_targets else max(1, min(args.pipeline, steps))
+        S = (shards or world) if shard_targets else 1
+        G = world // S if shard_targets else 1
+        sub = None
+        if shard_targets and G > 1:
+            assert world % S == 0, "--shards must divide the number of ranks"
+            groups = [dist.new_group(ranks=list(range(g * S, (g + 1) * S))) for g in range(G)]      # (every rank creates every group, in the same order)
+            sub = groups[rank // S]
         # batch b is searched by context b: batch 0 = the single-GPU workload's spacers; further batches / ranks draw their own
         batches = []
         for b in range(n_pipe):
@@ -327,6 +338,12 @@ def main():
                 qs = None if (rank == 0 and b == 0) else 12345 + 7919 * rank + 104729 * b
             batches.append(make_workload(spacers, args.targets, args.target_len, 12345, qs))
         tres, toff = batches[0][0], batches[0][1]
+        if shard_targets and G > 1:      # this rank's group holds query slice g of every batch only
+            for b in range(n_pipe):
+                tr, to, qr, qo = batches[b]
+                g_from, g_cnt = decompose_by_residues(np.diff(qo).astype(np.int64) + 2, rank // S, G)
+                lo, hi = int(qo[g_from]), int(qo[g_from + g_cnt])
+                batches[b] = (tr, to, qr[lo:hi].copy(), (qo[g_from:g_from + g_cnt + 1] - qo[g_from]).astype(qo.dtype))
         nq = len(batches[0][3]) - 1
         q_from, q_to = 0, nq
         ctxs = []
@@ -334,9 +351,9 @@ def main():
         for b in range(n_pipe):
             c = sa.SearchContext(device_mask=1 << local_rank)
             if shard_targets:
-                t_from, t_cnt = decompose_by_residues(np.diff(toff).astype(np.int64) + 2, rank, world)
+                t_from, t_cnt = decompose_by_residues(np.diff(toff).astype(np.int64) + 2, rank % S, S)
                 c.set_targets_shard_raw(tres.tobytes(), u64p(toff), len(toff) - 1, t_from, t_from + t_cnt)
-                q_from, q_cnt = decompose_by_residues(np.diff(batches[b][3]).astype(np.int64) + 2, rank, world)
+                q_from, q_cnt = decompose_by_residues(np.diff(batches[b][3]).astype(np.int64) + 2, rank % S, S)
                 q_to = q_from + q_cnt
             else:
                 c.set_targets_raw(tres.tobytes(), u64p(toff), len(toff) - 1)
@@ -349,7 +366,7 @@ def main():
 
         def search(c):
             if shard_targets:
-                info = sharded_prefilter(c, q_from, q_to, device=gpu_dev)     # own shard -> all-gather -> selection on the union
+                info = sharded_prefilter(c, q_from, q_to, group=sub, device=gpu_dev)     # own shard -> all-gather (within the query group) -> selection on the union
                 xch["s"] += info["exchange_s"]
                 xch["bytes"] += info["bytes"]
                 xch["n"] += 1
@@ -463,10 +480,13 @@ def main():
             c.close()
         return out
 
-    m = measure(sharded, n_spacers, args.steps, args.regions, args.warmup, True)
-    rep = None
+    m = measure(sharded, n_spacers, args.steps, args.regions, args.warmup, True, shards=args.shards)
+    rep = hyb = None
     if world > 1 and sharded and not args.no_replica:
         rep = measure(False, 10000, max(4, args.steps // 2), max(1, min(3, args.regions)), args.warmup, False)
+    if world >= 4 and world % 2 == 0 and sharded and not args.shards and not args.no_hybrid:
+        # the same job with TWO target shards x world / 2 query groups: the enumeration of the similar k-mers is replicated twice, not world times
+        hyb = measure(True, n_spacers, max(4, args.steps // 2), max(1, min(3, args.regions)), args.warmup, False, shards=2)
     pairs_total = all_sum(float(m["pairs"][0]))      # batch 0 of every rank (sharded: the ranks' query slices add up to the batch)
     if dist is not None:
         dist.barrier()
@@ -505,7 +525,7 @@ def main():
                                                             ("targets sharded over %d x MI355X" % world) if sharded else "1xMI355X per rank",
                                                             "prefilter + ungapped + banded-SW align" if full else "prefilter only"),
                    "stage": args.stage, "pairs_aligned_per_step": int(pairs_total), "pairs_aligned_per_step_by_batch_rank0": m["pairs"], "sensitivity": 5.7, "max_seqs": 300,
-                   "parallelism": ("target shards x%d, %s all-gather of candidates, selection + align by query slice" % (world, "RCCL" if args.exchange == "rccl" else "gloo")) if sharded
+                   "parallelism": ("target shards x%d%s, %s all-gather of candidates, selection + align by query slice" % (args.shards or world, (" x %d query groups" % (world // args.shards)) if args.shards and args.shards != world else "", "RCCL" if args.exchange == "rccl" else "gloo")) if sharded
                                   else ("query partition x%d, index replicated" % world),
                    "passes_in_flight_per_gpu": n_pipe, "distinct_query_batches": n_pipe,
                    "index_build_s": round(m["t_index"], 3)},
@@ -536,6 +556,11 @@ def main():
                            "allgather_bytes_per_step": x["bytes"] / max(1, x["n"]),
                            "exchange_ms_per_step": 1e3 * x["s"] / max(1, x["n"]),
                            "query_slice_of_rank0": list(m["q_slice"])}
+    if hyb is not None:
+        hdt, hregions = region_summary(hyb, n_spacers * max(4, args.steps // 2))
+        out["hybrid"] = {"value": n_spacers * max(4, args.steps // 2) / hdt, "unit": "spacer-queries/s", "scaling": "strong", "ms_per_step": hdt / max(4, args.steps // 2) * 1e3,
+                         "regions": hregions, "results_checked": hyb["checked"],
+                         "parallelism": "2 target shards x %d query groups: RCCL all-gather of the candidates within each pair of ranks" % (world // 2)}
     if rep is not None:
         rdt, rregions = region_summary(rep, 10000 * world * max(4, args.steps // 2))
         out["replica"] = {"value": 10000 * world * max(4, args.steps // 2) / rdt, "unit": "spacer-queries/s", "scaling": "weak",

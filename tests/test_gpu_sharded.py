@@ -180,3 +180,31 @@ def test_query_beyond_the_hit_stream_limit_is_named_and_searchable_through_shard
     for x in ctxs:
         x.close()
     o.close()
+
+
+def test_bench_two_shards_times_two_query_groups_on_four_ranks():
+    """four ranks as 2 target shards x 2 query groups (`--shards 2`): every group searches its half of the queries against both shards
+    and all-gathers within the group -- the aligned pairs of all ranks add up to the unsplit search's; the default run of four ranks
+    reports the same decomposition under the `hybrid` key next to the four-shard line"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "3", "--warmup", "1", "--regions", "2", "--spacers", "1500", "--targets", "6000", "--cpu-sample", "0", "--no-module-e2e"]
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    one = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--same-gpu", "--exchange", "gloo", "--shards", "2", "--no-replica"] + common,
+                       capture_output=True, text=True, timeout=1800, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 4 and "target shards x2 x 2 query groups" in out["config"]["parallelism"]
+    assert out["config"]["pairs_aligned_per_step"] == one["config"]["pairs_aligned_per_step"]
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--same-gpu", "--exchange", "gloo", "--no-replica"] + common,
+                       capture_output=True, text=True, timeout=1800, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "target shards x4" in out["config"]["parallelism"] and out["hybrid"]["value"] > 0 and out["hybrid"]["results_checked"] > 0
+    assert out["config"]["pairs_aligned_per_step"] == one["config"]["pairs_aligned_per_step"]
