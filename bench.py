@@ -23,7 +23,9 @@ N > 1 (BASELINE.json configs[3]): 100 000 spacers (600 000 peptides) against the
 N GPUs: rank g indexes range g, all ranks match all queries against their shard, the per-shard candidates are all-gathered
 over RCCL/xGMI (HBM -> xGMI -> HBM) and each rank finishes (selection on the union + align) its slice of the queries --
 strong scaling, value = spacers / max time over ranks.  The same run then also measures the query partition (every rank
-holds the full index and searches its own 10 000 spacers, no data-path collective; key "replica", weak scaling).
+holds the full index and searches its own 10 000 spacers, no data-path collective; key "replica", weak scaling) and, at N >= 4,
+the same job as 2 target shards x N / 2 query groups (key "hybrid": the similar-k-mer enumeration is replicated per SHARD, so two shards
+replicate it twice instead of N times; --shards S chooses any split).
 `python bench.py --gpus N` starts the N ranks itself (child processes, started before anything touches the GPU); under
 torchrun it uses the ranks it is given.
 """
