@@ -625,7 +625,7 @@ int runExtractOrfs(int argc, const char **argv) {
     lap("load");
     // lookup of the contigs (key, name, set) for --create-lookup 1
     // (contig key -> the text of its set column), sorted by key
-    std::string lookupFile; std::vector<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> setOf;
+    std::string lookupFile; std::vector<std::pair<uint32_t, std::pair<uint64_t, uint32_t>>> setOf;
     const bool createLookup = f.num("--create-lookup", 0) != 0;
     if (createLookup) {
         MappedFile lk;
@@ -636,7 +636,7 @@ int runExtractOrfs(int argc, const char **argv) {
             const char *eol = (const char *) memchr(p, '\n', (size_t) (e - p)); if (!eol) eol = e;
             const char *first = (const char *) memchr(p, '\t', (size_t) (eol - p)); const char *lastTab = first;
             if (first) for (const char *q = eol; q > first; q--) if (q[-1] == '\t') { lastTab = q - 1; break; }
-            if (first && lastTab != first) setOf.push_back({(uint32_t) atou(p), {(uint32_t) (lastTab + 1 - b), (uint32_t) (eol - lastTab - 1)}});
+            if (first && lastTab != first) setOf.push_back({(uint32_t) atou(p), {(uint64_t) (lastTab + 1 - b), (uint32_t) (eol - lastTab - 1)}});
             p = eol + 1;
         }
         bool sorted = true;
