@@ -22,6 +22,7 @@ Reference lines restated (paths under /root/reference):
   summarize            src/util/SummarizeResults.cpp:66-180 (no taxonomy DB, --report-fdr 0)
 """
 import math
+import struct
 import sys
 
 DBL_MIN = sys.float_info.min
@@ -444,14 +445,13 @@ def _div(a, b):
 def fdr_threshold(P, N, have_control, cutoff, report):
     P = sorted(P, reverse=True) or [0.0]
     uniq, fdr_list = [], []
+    cutoff = struct.unpack("f", struct.pack("f", cutoff))[0]      # a float in the reference (LocalParameters.h:57)
     if not have_control:
-        if report:
-            s = DBL_MIN
+        if report:      # FilterMatchbyFdr.cpp:203-211: the running score is declared INSIDE the loop, so every score above DBL_MIN is listed
             for p in P:
-                if s < p:
+                if DBL_MIN < p:
                     uniq.append(p)
                     fdr_list.append(0.0)
-                    s = p
         return P[-1], uniq, fdr_list
     N = sorted(N, reverse=True)
     x, y, cur, nc = [], [], DBL_MAX, 0
@@ -516,15 +516,15 @@ def fdr_filter(pos_db, neg_db, cutoff, report):
             score = strtod(line.split()[1])
             if score >= threshold:
                 f = line.split("\t")
-                # (a score that is not in the unique-score list -- possible only without a control DB, where the reference lists just
-                # the best score -- makes the reference read one element past its FDR vector; the harness run printed 0 there)
+                # (a score that is not in the unique-score list -- possible only without a control DB and for scores <= DBL_MIN -- makes the
+                # reference read one element past its FDR vector; not pinned, 0 here)
                 fdr = fdr_list[uniq.index(score)] if (report and score in uniq and uniq.index(score) < len(fdr_list)) else 0.0
                 kept.append("\t".join(f[:3]) + ("\t" + fmt_e(fdr) if report else "") + "\n")
         out[k] = "".join(kept)
     return out, threshold
 
 
-def summarize(match_entry, aln_entry, fmt):
+def summarize(match_entry, aln_entry, fmt, report_fdr=False):
     out = []
     aln_lines = aln_entry.splitlines()
     for m in match_entry.splitlines():
@@ -535,7 +535,7 @@ def summarize(match_entry, aln_entry, fmt):
                 continue
             e = al.split("\t")
             if lines == 0:
-                head = "#%s\t%s\t%s\t" % (e[2], e[3], mf[1])
+                head = "#%s\t%s\t%s\t" % (e[2], e[3], mf[1]) + (mf[3] + "\t" if report_fdr else "")      # SummarizeResults.cpp:91-116
             lines += 1
             if fmt in (1, 2):
                 t = ">" + "\t".join([e[1], e[3], e[4], e[5], e[6], e[8], e[9]] + (e[13:15] if len(e) == 15 else []))

@@ -370,6 +370,9 @@ static const AlpEntry kAlpTable[] = {
     // proteinaln2nucl: NucleotideMatrix(nucleotide.out, 1.0, 0.0), gap open 10, extend 2 (tests/golden/examples.json.gz: info.nucl_evalue.alp)
     {"nucleotide.out", 10, 2, {"0x1.4469d1f7ec6c4p-1", "0x1.af9f955180647p-2", "0x1.5f922abcb8de4p-1", "0x1.838e08750576p-3", "0x1.6cacd8a69e238p-1", "0x1.73f45a27d096ep+1",
                                "0x1.5f922abcb8de4p-1", "0x1.838e08750576p-3", "0x1.6cacd8a69e238p-1", "0x1.73f45a27d096ep+1", "0x1.6cd5a205f28f5p-1", "0x1.72ffa1ebd61p+1"}},
+    // the module's own defaults (Parameters.cpp: nucleotide gap open 5, extend 2), fitted by `oracle/_ref/ref_sets nuclalp <db> nucleotide.out 5 2`
+    {"nucleotide.out", 5, 2, {"0x1.3de995e742594p-1", "0x1.6837f664724b1p-2", "0x1.7d956af2b60d6p-1", "-0x1.6ba8cc62c7c7ep-1", "0x1.037654c94bd2ep+0", "-0x1.42e626a2af9a8p+1",
+                              "0x1.7d956af2b60d6p-1", "-0x1.6ba8cc62c7c7ep-1", "0x1.037654c94bd2ep+0", "-0x1.42e626a2af9a8p+1", "0x1.00d16215dfda5p+0", "-0x1.306383babbceap+1"}},
 };
 
 bool Evaluer::init(const std::string &matrixName, int gapOpen, int gapExtend, uint64_t dbRes, std::string &err) {

@@ -10,7 +10,7 @@
 //   lib/mmseqs/src/util/mergeresultsbyset.cpp:10-58       (mergeresultsbyset)
 //   src/util/CombineScore.cpp:12-113                      (combinescore)
 //   src/util/FilterMatchbyFdr.cpp:13-264                  (filtermatchbyfdr)
-//   src/util/SummarizeResults.cpp:13-197                  (summarizeresults, without a taxonomy DB)
+//   src/util/SummarizeResults.cpp:13-197                  (summarizeresults; taxonomy columns from the NCBI dump files next to the target set)
 // No kernels here: these steps move a few bytes per hit; what they gain on the MI355X path is that they can run on the
 // records in host memory without the DB round trips in between.
 #include "sp_sets.h"
@@ -254,6 +254,7 @@ bool proteinLineToNucl(const char *line, const NuclScorer &sc, const char *qNuc,
         if (*p >= '0' && *p <= '9') { cnt = (int) atou(p); while (*p >= '0' && *p <= '9') p++; }
         const char op = *p;
         if (op == 'M') {
+            if (qPos < 0 || tPos < 0 || qPos + (long) cnt * 3 > (long) qNucLen || tPos + (long) cnt * 3 > (long) tNucLen) { err = "proteinaln2nucl: an alignment runs past its nucleotide ORF (peptide and nucleotide DBs disagree)"; return false; }
             for (int b = 0; b < cnt * 3; b++) { const unsigned char a = (unsigned char) qNuc[qPos], c = (unsigned char) tNuc[tPos]; ids += (a == c); score += sc.score(a, c); qPos++; tPos++; }
         } else if (op == 'D') { tPos += cnt * 3; score -= sc.gapOpen + ((cnt - 1) * 3) * sc.gapExtend; }
         else if (op == 'I') { qPos += cnt * 3; score -= sc.gapOpen + ((cnt - 1) * 3) * sc.gapExtend; }
@@ -399,53 +400,77 @@ bool combineScore(const char *entry, uint32_t querySetSize, const SetLookup &mem
 // ------------------------------------------------------------------------------------------------------------------
 // f4  filtermatchbyfdr (FilterMatchbyFdr.cpp:49-215): score threshold at a false-discovery rate from target and control scores
 // ------------------------------------------------------------------------------------------------------------------
-void fdrThreshold(std::vector<double> P, std::vector<double> N, bool haveControl, double cutoff, bool reportFdr, FdrResult &r) {
-    std::sort(P.begin(), P.end(), [](double a, double b) { return a > b; });
+// The step in four pieces.  The floating-point expressions keep the reference's operand order (they decide which score
+// becomes the threshold); the cutoff is a FLOAT there (LocalParameters.h:57), so 0.05 is compared as 0.0500000007...
+namespace {
+struct RocCurve { std::vector<double> fp, tp; };      // per distinct target score, best first: control fraction / target fraction above it
+
+// (:95-118) one point per distinct target score s: tp = #target scores > s / #target, fp = (#control scores > s + 0.5) / (#control + 1); closes at (1, 1)
+RocCurve rocCurve(const std::vector<double> &target, const std::vector<double> &control, std::vector<double> &distinct) {
+    RocCurve c; size_t above = 0; double last = DBL_MAX;
+    for (size_t k = 0; k < target.size(); k++) {
+        if (!(target[k] < last)) continue;
+        last = target[k];
+        while (above < control.size() && target[k] < control[above]) above++;
+        distinct.push_back(target[k]);
+        c.tp.push_back(1.0 * k / target.size());
+        c.fp.push_back(1.0 * (above + 0.5) / (control.size() + 1));
+    }
+    c.fp.push_back(1.0); c.tp.push_back(1.0);
+    return c;
+}
+
+// (:120-138) greedy upper hull: from vertex v the next one is the LAST point of the steepest slope seen (ties move on: >=)
+void upperHull(const RocCurve &c, std::vector<size_t> &vertex, std::vector<double> &steep) {
+    for (size_t v = 0; v + 1 < c.fp.size();) {
+        size_t nxt = v + 1; double top = 0;
+        for (size_t w = v + 1; w < c.fp.size(); w++) { const double sl = 1.0 * (c.tp[w] - c.tp[v]) / (c.fp[w] - c.fp[v]); if (sl >= top) { top = sl; nxt = w; } }
+        vertex.push_back(nxt); steep.push_back(top); v = nxt;
+    }
+}
+}  // namespace
+
+void fdrThreshold(std::vector<double> P, std::vector<double> N, bool haveControl, double cutoffArg, bool reportFdr, FdrResult &r) {
+    const double cutoff = (double) (float) cutoffArg;
+    std::sort(P.begin(), P.end(), std::greater<double>());
     if (P.empty()) P.push_back(0);
     r = FdrResult();
+    r.threshold = P.back();
     if (!haveControl) {
-        if (reportFdr) { double s = DBL_MIN; for (double p : P) if (s < p) { r.uniqueScores.push_back(p); r.fdr.push_back(0.0); s = p; } }
-        r.threshold = P.back();
+        // (:201-212) every match is printed; with --report-fdr the table lists each score above DBL_MIN with FDR 0 (the reference declares
+        // its running score inside the loop, so nothing is merged); scores at or below DBL_MIN are looked up past the table there
+        if (reportFdr) for (double p : P) if (DBL_MIN < p) { r.uniqueScores.push_back(p); r.fdr.push_back(0.0); }
         return;
     }
-    std::sort(N.begin(), N.end(), [](double a, double b) { return a > b; });
-    std::vector<double> x, y;
-    double cur = DBL_MAX; size_t nc = 0;
-    for (size_t pc = 0; pc < P.size(); pc++) {
-        if (P[pc] < cur) {
-            cur = P[pc];
-            while (nc < N.size() && cur < N[nc]) nc++;
-            r.uniqueScores.push_back(cur);
-            y.push_back(1.0 * pc / P.size());
-            x.push_back(1.0 * (nc + 0.5) / (N.size() + 1));
-        }
+    std::sort(N.begin(), N.end(), std::greater<double>());
+    const RocCurve c = rocCurve(P, N, r.uniqueScores);
+    std::vector<size_t> vertex; std::vector<double> steep;
+    upperHull(c, vertex, steep);
+    // (:142-144) null proportion: mean of the last two hull slopes.  A hull of ONE segment (one distinct target score) makes the reference read in
+    // front of its vector; that segment's slope stands in twice here
+    const double pi0 = ((steep.size() >= 2 ? steep[steep.size() - 2] : steep.back()) + steep.back()) / 2;
+    // (:146-155) first hull vertex whose estimated FDR exceeds the cutoff -- searched only when the LAST vertex reaches it
+    size_t seg = 0;
+    if (c.fp[vertex.back()] * pi0 / c.tp[vertex.back()] >= cutoff) { double est = 0; while (est <= cutoff) { est = c.fp[vertex[seg]] * pi0 / c.tp[vertex[seg]]; seg++; } }
+    if (seg >= 2) {
+        // (:166-180) walk the curve from the vertex before, interpolating along the hull segment, until the FDR passes the cutoff
+        size_t at = vertex[seg - 2];
+        double all = c.tp[at], null = c.fp[at] * pi0, est = 0;
+        while (est <= cutoff) { at++; const double step = c.fp[at] - c.fp[at - 1]; all += step * steep[seg - 1]; null += step * pi0; est = null / all; }
+        r.threshold = r.uniqueScores[at];
     }
-    x.push_back(1.0); y.push_back(1.0);
-    std::vector<double> slopes; std::vector<size_t> hull;
-    for (size_t i = 0; i < x.size() - 1;) {
-        size_t jMax = i + 1; double best = 0;
-        for (size_t j = i + 1; j < x.size(); j++) { const double s = 1.0 * (y[j] - y[i]) / (x[j] - x[i]); if (s >= best) { jMax = j; best = s; } }
-        i = jMax; slopes.push_back(best); hull.push_back(jMax);
-    }
-    const double pi0 = (slopes.end()[-2] + slopes.end()[-1]) / 2;      // (a single-segment hull reads the element in front of the vector in the reference too)
-    size_t i = 0; double fdr = 0;
-    if (x[hull.back()] * pi0 / y[hull.back()] >= cutoff) while (fdr <= cutoff) { fdr = x[hull[i]] * pi0 / y[hull[i]]; i++; }
-    if (i < 2) r.threshold = P.back();
-    else {
-        size_t j = hull[i - 2];
-        double TPFP = y[j], FP = x[j] * pi0;
-        fdr = 0;
-        while (fdr <= cutoff) { j++; const double dx = x[j] - x[j - 1]; TPFP += dx * slopes[i - 1]; FP += dx * pi0; fdr = FP / TPFP; }
-        r.threshold = r.uniqueScores[j];
-    }
-    if (reportFdr) {
-        for (size_t j = 0; j < hull[0]; j++) r.fdr.push_back(0.0);
-        for (size_t h = 0; h + 1 < hull.size(); h++) {
-            double TPFP = y[hull[h]], FP = x[hull[h]] * pi0;
-            for (size_t j = hull[h]; j < hull[h + 1]; j++) {
-                if (std::isinf(slopes[h])) r.fdr.push_back(x[hull[h]] * pi0 / y[hull[h]]);
-                else { TPFP += (x[j] - x[j - 1]) * slopes[h]; FP += (x[j] - x[j - 1]) * pi0; r.fdr.push_back(FP / TPFP); }
-            }
+    if (!reportFdr) return;
+    // (:184-200) FDR of every distinct score: 0 in front of the first vertex, then accumulated segment by segment
+    r.fdr.assign(vertex[0], 0.0);
+    for (size_t h = 0; h + 1 < vertex.size(); h++) {
+        const size_t from = vertex[h], to = vertex[h + 1];
+        const bool vertical = std::isinf(steep[h]);
+        double all = c.tp[from], null = c.fp[from] * pi0;
+        for (size_t at = from; at < to; at++) {
+            if (vertical) { r.fdr.push_back(c.fp[from] * pi0 / c.tp[from]); continue; }
+            const double step = c.fp[at] - c.fp[at - 1];
+            all += step * steep[h]; null += step * pi0;
+            r.fdr.push_back(null / all);
         }
     }
 }
@@ -604,6 +629,34 @@ static bool forChunks(size_t n, W weight, int threads, std::vector<Out> &outs, F
 }
 static void flushChunks(std::vector<ChunkOut> &outs, DbWriter &w) { for (ChunkOut &o : outs) if (!o.keys.empty()) w.addBlock(o.keys, o.lengths, std::move(o.block)); }
 
+// DBReader::softlinkDb(in, out, flags) for the files next to a sequence DB (commons/DBReader.cpp:1093-1163): every listed file that exists
+// is linked under the output's name by its real path, replacing what is there (FileUtil::symlinkAbs, FileUtil.cpp:242-278).
+// SEQUENCE_ANCILLARY = headers, lookup, source and the taxonomy files (DBReader.h:43-47).
+static const char *const kSourceOnly[] = {".source", NULL};
+static const char *const kSequenceAncillary[] = {"_h", "_h.index", "_h.dbtype", ".lookup", ".source", "_mapping", "_names.dmp", "_nodes.dmp", "_merged.dmp", NULL};
+static bool linkAncillary(const std::string &in, const std::string &out, const char *const *suffixes, std::string &err) {
+    for (const char *const *sfx = suffixes; *sfx; sfx++) {
+        const std::string from = in + *sfx, to = out + *sfx;
+        struct stat st;
+        if (stat(from.c_str(), &st) != 0) continue;
+        char *real = realpath(from.c_str(), NULL);
+        if (!real) { err = "Could not get realpath of " + from; return false; }
+        std::string dir = to, base = to;
+        const size_t slash = to.rfind('/');
+        if (slash == std::string::npos) dir = "."; else { dir = to.substr(0, slash ? slash : 1); base = to.substr(slash + 1); }
+        char *realDir = realpath(dir.c_str(), NULL);
+        if (!realDir) { free(real); err = "Could not get realpath of " + to; return false; }
+        const std::string link = std::string(realDir) + "/" + base;
+        free(realDir);
+        if (link == real) { free(real); continue; }      // in == out
+        (void) unlink(link.c_str());
+        const int rc = symlink(real, link.c_str());
+        free(real);
+        if (rc != 0) { err = "Could not create symlink of " + from; return false; }
+    }
+    return true;
+}
+
 int runExtractOrfs(int argc, const char **argv) {
     Flags f; std::string err;
     if (!parseFlags(argc, argv, with({"--min-length", "--max-length", "--max-gaps", "--contig-start-mode", "--contig-end-mode", "--orf-start-mode", "--forward-frames",
@@ -694,7 +747,7 @@ int runExtractOrfs(int argc, const char **argv) {
     }
     lap("number");
     if (createLookup) { std::ofstream o(f.positional[1] + ".lookup", std::ios::binary); o.write(lookup.data(), (std::streamsize) lookup.size()); if (!o.good()) return fail("extractorfs: cannot write the lookup file"); }
-    { std::ifstream src(f.positional[0] + ".source", std::ios::binary); if (src.good()) { std::ofstream dst(f.positional[1] + ".source", std::ios::binary); dst << src.rdbuf(); } }
+    if (!linkAncillary(f.positional[0], f.positional[1], kSourceOnly, err)) return fail("extractorfs: " + err);      // softlinkDb(db1, db2, SOURCE), extractorfs.cpp:156
     {   std::string hdrErr; bool hdrOk = true;
         std::thread hdrThread([&]() { hdrOk = hdrW.close(hdrErr); });
         const bool seqOk = seqW.close(err);
@@ -724,8 +777,8 @@ int runTranslateNucs(int argc, const char **argv) {
         o.keys.push_back(in.entries[i].key); o.lengths.push_back(n + 1);
     }, err)) return fail("translatenucs: " + err);
     flushChunks(outs, w);
-    for (const char *ext : {".lookup", ".source"}) { std::ifstream src(f.positional[0] + ext, std::ios::binary); if (src.good()) { std::ofstream dst(f.positional[1] + ext, std::ios::binary); dst << src.rdbuf(); } }
     if (!w.close(err)) return fail("translatenucs: " + err);
+    if (!linkAncillary(f.positional[0], f.positional[1], kSequenceAncillary, err)) return fail("translatenucs: " + err);      // softlinkDb(db1, db2, SEQUENCE_ANCILLARY), translatenucs.cpp:103
     return 0;
 }
 
@@ -744,8 +797,8 @@ int runReverseSeqByCodon(int argc, const char **argv) {
         o.keys.push_back(in.entries[i].key); o.lengths.push_back(o.block.size() - at);
     }, err)) return fail("reverseseqbycodon: " + err);
     flushChunks(outs, w);
-    for (const char *ext : {".lookup", ".source"}) { std::ifstream src(f.positional[0] + ext, std::ios::binary); if (src.good()) { std::ofstream dst(f.positional[1] + ext, std::ios::binary); dst << src.rdbuf(); } }
     if (!w.close(err)) return fail("reverseseqbycodon: " + err);
+    if (!linkAncillary(f.positional[0], f.positional[1], kSequenceAncillary, err)) return fail("reverseseqbycodon: " + err);      // ReverseSeqByCodon.cpp:58
     return 0;
 }
 
@@ -898,30 +951,153 @@ int runFilterMatchByFdr(int argc, const char **argv) {
     return 0;
 }
 
+// The taxonomy columns of the report (SummarizeResults.cpp:17-22,118-120,156-180) need three lookups of NcbiTaxonomy: node by id,
+// names along the path to the root, rank tables.  This reads the three NCBI dump files the way taxonomy/NcbiTaxonomy.cpp:110-183,
+// 429-455 does; the LCA machinery of that class is not needed for a report and stays out of scope.
+struct TaxTable {
+    struct Node { int taxId, parent; std::string rank, name; bool named = false; };
+    std::vector<Node> nodes; std::vector<int> slot; int maxTaxId = 0;      // slot[taxId] = index into nodes, -1 = none (merged ids share a node)
+    static std::vector<std::string> fields(const std::string &line, size_t maxCol) {      // NcbiTaxonomy.cpp:92-107: pieces between "\t|\t"
+        std::vector<std::string> r; size_t prev = 0, pos = 0, n = 0;
+        do { pos = line.find("\t|\t", prev); if (pos == std::string::npos) pos = line.size(); r.push_back(line.substr(prev, pos - prev)); prev = pos + 3; n++; } while (pos < line.size() && prev < line.size() && n < maxCol);
+        return r;
+    }
+    bool exists(int id) const { return id >= 0 && id <= maxTaxId && slot[(size_t) id] != -1; }
+    const Node *node(int id) const { return (id == 0 || !exists(id)) ? nullptr : &nodes[(size_t) slot[(size_t) id]]; }
+    bool load(const std::string &prefix, std::string &err) {
+        std::string nodesFile = prefix + "_nodes.dmp", namesFile = prefix + "_names.dmp", mergedFile = prefix + "_merged.dmp";
+        struct stat st;
+        if (stat(namesFile.c_str(), &st) != 0 || stat(mergedFile.c_str(), &st) != 0) {      // openTaxonomy falls back to the working directory (:510-525)
+            if (stat("nodes.dmp", &st) == 0 && stat("names.dmp", &st) == 0 && stat("merged.dmp", &st) == 0) { nodesFile = "nodes.dmp"; namesFile = "names.dmp"; mergedFile = "merged.dmp"; }
+            else { err = "names.dmp, nodes.dmp, merged.dmp from NCBI taxdump could not be found"; return false; }
+        }
+        std::string line;
+        {   std::ifstream in(nodesFile);
+            if (!in.good()) { err = "File " + nodesFile + " not found"; return false; }
+            std::map<int, int> first;
+            while (std::getline(in, line)) {
+                const std::vector<std::string> c = fields(line, 3);
+                if (c.size() < 3) { err = nodesFile + ": malformed line"; return false; }
+                Node n; n.taxId = (int) strtol(c[0].c_str(), NULL, 10); n.parent = (int) strtol(c[1].c_str(), NULL, 10); n.rank = c[2];
+                if (n.taxId < 0) { err = nodesFile + ": negative taxon id"; return false; }
+                maxTaxId = std::max(maxTaxId, n.taxId);
+                first.emplace(n.taxId, (int) nodes.size());
+                nodes.push_back(n);
+            }
+            slot.assign((size_t) maxTaxId + 1, -1);
+            for (const auto &kv : first) slot[(size_t) kv.first] = kv.second;
+            for (const Node &n : nodes) if (!exists(n.parent)) { err = "Inconsistent nodes.dmp taxonomy file! Cannot find parent taxon with ID " + std::to_string(n.parent); return false; } }
+        {   std::ifstream in(mergedFile);
+            if (!in.good()) { err = "File " + mergedFile + " not found"; return false; }
+            while (std::getline(in, line)) {
+                const std::vector<std::string> c = fields(line, 2);
+                if (c.size() != 2) { err = mergedFile + ": invalid entry"; return false; }
+                const unsigned long oldId = strtoul(c[0].c_str(), NULL, 10), newId = strtoul(c[1].c_str(), NULL, 10);
+                if (oldId > (unsigned long) maxTaxId) continue;      // (the reference writes past its table for such a line)
+                if (!exists((int) oldId) && newId <= (unsigned long) maxTaxId && exists((int) newId)) slot[oldId] = slot[newId];
+            } }
+        {   std::ifstream in(namesFile);
+            if (!in.good()) { err = "File " + namesFile + " not found"; return false; }
+            while (std::getline(in, line)) {
+                if (line.find("scientific name") == std::string::npos) continue;
+                const std::vector<std::string> c = fields(line, 2);
+                if (c.size() != 2) { err = namesFile + ": invalid name entry"; return false; }
+                const int id = (int) strtol(c[0].c_str(), NULL, 10);
+                if (!exists(id)) { err = "loadNames: Taxon " + std::to_string(id) + " not present in nodes file"; return false; }
+                Node &n = nodes[(size_t) slot[(size_t) id]]; n.name = c[1]; n.named = true;
+            } }
+        return true;
+    }
+    // rank order and one-letter codes of taxonomy/NcbiTaxonomy.h:57-93
+    static int rankIndex(const std::string &rank) {
+        static const char *order[] = {"forma", "varietas", "subspecies", "species", "species subgroup", "species group", "subgenus", "genus", "subtribe", "tribe", "subfamily", "family",
+                                      "superfamily", "parvorder", "infraorder", "suborder", "order", "superorder", "infraclass", "subclass", "class", "superclass", "subphylum", "phylum",
+                                      "superphylum", "subkingdom", "kingdom", "superkingdom"};
+        for (size_t i = 0; i < sizeof(order) / sizeof(order[0]); i++) if (rank == order[i]) return (int) i + 1;
+        return -1;
+    }
+    static char shortRank(const std::string &rank) {
+        static const std::pair<const char *, char> code[] = {{"species", 's'}, {"genus", 'g'}, {"family", 'f'}, {"order", 'o'}, {"class", 'c'}, {"phylum", 'p'}, {"kingdom", 'k'}, {"superkingdom", 'd'}};
+        for (const auto &c : code) if (rank == c.first) return c.second;
+        return '-';
+    }
+    // AtRanks (NcbiTaxonomy.cpp:312-338): the name at each requested rank on the path to the root (the lowest node of a rank wins), "uc_<name>" for
+    // ranks below the node's own, "unknown" otherwise
+    std::string atRanks(const Node *n, const std::vector<std::string> &levels) const {
+        std::map<std::string, std::string> onPath;
+        for (const Node *p = n;; p = node(p->parent)) {
+            if (p->taxId == 1) { onPath.emplace(p->rank, p->name); break; }
+            if (p->rank != "no_rank" && p->rank != "no rank") onPath.emplace(p->rank, p->name);
+            if (p->parent == p->taxId) break;      // a root that is not taxon 1 (the reference never leaves this loop then)
+        }
+        const int base = rankIndex(n->rank); std::string out;
+        for (size_t i = 0; i < levels.size(); i++) {
+            if (i) out.push_back(';');
+            const auto it = onPath.find(levels[i]);
+            if (it != onPath.end()) out += it->second;
+            else if (rankIndex(levels[i]) < base) out += "uc_" + n->name;
+            else out += "unknown";
+        }
+        return out;
+    }
+    // taxLineage (NcbiTaxonomy.cpp:367-390): the nodes from below the root down to this one
+    std::string lineage(const Node *n, bool names) const {
+        std::vector<const Node *> path;
+        do { path.push_back(n); n = node(n->parent); } while (n->parent != n->taxId);
+        std::string out;
+        for (size_t i = path.size(); i-- > 0;) {
+            if (names) { out.push_back(shortRank(path[i]->rank)); out.push_back('_'); out += path[i]->name; } else out += std::to_string(path[i]->taxId);
+            if (i > 0) out.push_back(';');
+        }
+        return out;
+    }
+};
+
+struct SummaryOptions { int fmt = 1; bool reportFdr = false; const TaxTable *tax = nullptr; std::vector<std::string> ranks; int lineage = 0; };
+
 // one match entry joined with the alignment lines of its query set (SummarizeResults.cpp:66-180); fmt: 0 short, 1 long, 2 long + alignment
-static bool summarizeEntry(const char *match, const char *aln, int fmt, std::string &out, std::string &err) {
-    const char *e[20]; std::string cScore, tmp; char nb[24];
+static bool summarizeEntry(const char *match, const char *aln, const SummaryOptions &o, std::string &out, std::string &err) {
+    const char *e[20]; std::string cScore, fdr, tmp; char nb[24];
     for (const char *m = match; *m != '\0';) {
-        if (words(m, e, 20) < 2) { err = "summarizeresults: invalid match record"; return false; }
+        const size_t matchColumns = words(m, e, 20);
+        if (matchColumns < 2) { err = "summarizeresults: invalid match record"; return false; }
+        if (o.reportFdr && matchColumns < 4) { err = "summarizeresults: --report-fdr 1 needs the FDR column filtermatchbyfdr --report-fdr 1 writes"; return false; }
         m = skipLine(m);
         const unsigned long targetSet = atou(e[0]);
-        size_t lines = 0;
+        size_t lines = 0; int taxId = 0;
         for (const char *cur = aln; *cur != '\0';) {
             if (atou(cur) != targetSet) { cur = skipLine(cur); continue; }
-            if (lines == 0) cScore.assign(e[1], (size_t) (e[2] - e[1]));
+            if (lines == 0) { cScore.assign(e[1], (size_t) (e[2] - e[1])); if (o.reportFdr) fdr.assign(e[3], (size_t) (e[4] - e[3])); }
             const size_t columns = words(cur, e, 20);
             if (columns < 10) { err = "summarizeresults: invalid alignment result record"; return false; }
             cur = skipLine(cur);
-            if (lines == 0) { out.push_back('#'); out.append(e[2], (size_t) (e[3] - e[2] - 1)); out.push_back('\t'); out.append(e[3], (size_t) (e[4] - e[3] - 1)); out.push_back('\t'); out += cScore; }
+            if (lines == 0) {
+                out.push_back('#'); out.append(e[2], (size_t) (e[3] - e[2] - 1)); out.push_back('\t'); out.append(e[3], (size_t) (e[4] - e[3] - 1)); out.push_back('\t'); out += cScore;
+                if (o.reportFdr) { out += fdr; out.push_back('\t'); }
+                if (o.tax) {
+                    if (columns < 13) { err = "summarizeresults: the target set has a taxonomy but the alignment records carry no taxid column"; return false; }
+                    taxId = (int) strtol(e[12], NULL, 10);
+                }
+            }
             lines++;
-            if (fmt != 1 && fmt != 2) continue;
+            if (o.fmt != 1 && o.fmt != 2) continue;
             tmp.push_back('>'); tmp.append(e[1], (size_t) (e[2] - e[1] - 1));
             for (int c : {3, 4, 5, 6, 8, 9}) { tmp.push_back('\t'); tmp.append(e[c], (size_t) (e[c + 1] - e[c] - 1)); }
             if (columns == 15) { tmp.push_back('\t'); tmp.append(e[13], (size_t) (e[14] - e[13] - 1)); tmp.push_back('\t'); tmp.append(e[14], (size_t) (e[15] - e[14])); }
-            if (fmt == 2) { tmp.push_back('\n'); tmp.append(e[10], (size_t) (e[11] - e[10] - 1)); tmp.push_back('\n'); tmp.append(e[11], (size_t) (e[12] - e[11] - 1)); }
+            if (o.fmt == 2) { tmp.push_back('\n'); tmp.append(e[10], (size_t) (e[11] - e[10] - 1)); tmp.push_back('\n'); tmp.append(e[11], (size_t) (e[12] - e[11] - 1)); }
             tmp.push_back('\n');
         }
-        if (lines > 0) { char *x = u32toa((uint32_t) lines, nb); out.append(nb, (size_t) (x - nb)); out.push_back('\n'); out += tmp; }
+        if (lines > 0) {
+            char *x = u32toa((uint32_t) lines, nb); out.append(nb, (size_t) (x - nb));
+            const TaxTable::Node *n = o.tax ? o.tax->node(taxId) : nullptr;
+            if (n) {
+                if (!n->named) { err = "summarizeresults: taxon " + std::to_string(n->taxId) + " has no scientific name in names.dmp"; return false; }
+                out.push_back('\t'); out += std::to_string(n->taxId); out.push_back('\t'); out += n->rank; out.push_back('\t'); out += n->name;
+                if (!o.ranks.empty()) { out.push_back('\t'); out += o.tax->atRanks(n, o.ranks); }
+                if (o.lineage == 1 || o.lineage == 2) { out.push_back('\t'); out += o.tax->lineage(n, o.lineage == 1); }
+            }
+            out.push_back('\n'); out += tmp;
+        }
         tmp.clear();
     }
     return true;
@@ -930,25 +1106,30 @@ static bool summarizeEntry(const char *match, const char *aln, int fmt, std::str
 int runSummarizeResults(int argc, const char **argv) {
     Flags f; std::string err;
     if (!parseFlags(argc, argv, with({"--fmt", "--report-fdr", "--lca-ranks", "--tax-lineage", "--db-output"}), 4, f, err)) return fail("summarizeresults: " + err);
-    if (!uncompressedOnly(f, err) || !requireValue(f, "--report-fdr", {"0"}, err)) return fail("summarizeresults: " + err);
-    { struct stat st; if (stat((f.positional[0] + "_nodes.dmp").c_str(), &st) == 0) return fail("summarizeresults: target sets with a taxonomy DB are not supported by the MI355X path (no taxonomy report)"); }
+    if (!uncompressedOnly(f, err)) return fail("summarizeresults: " + err);
+    SummaryOptions o; o.fmt = (int) f.num("--fmt", 1); o.reportFdr = f.num("--report-fdr", 0) != 0; o.lineage = (int) f.num("--tax-lineage", 0);
+    {   const std::string ranks = f.str("--lca-ranks", "");      // NcbiTaxonomy::parseRanks: comma separated, every name a known rank
+        for (size_t from = 0; from < ranks.size();) { size_t to = ranks.find(',', from); if (to == std::string::npos) to = ranks.size(); o.ranks.push_back(ranks.substr(from, to - from)); from = to + 1; }
+        for (const std::string &r : o.ranks) if (TaxTable::rankIndex(r) == -1) return fail("summarizeresults: Invalid taxonomic rank " + r + " given"); }
+    TaxTable tax;
+    { struct stat st; if (stat((f.positional[0] + "_nodes.dmp").c_str(), &st) == 0) { if (!tax.load(f.positional[0], err)) return fail("summarizeresults: " + err); o.tax = &tax; } }
     Db match, aln;
     if (!loadDb(f.positional[1], match, err) || !loadDb(f.positional[2], aln, err)) return fail("summarizeresults: " + err);
     KeyMap aIdx; keyIndex(aln, aIdx);
-    const int fmt = (int) f.num("--fmt", 1); const bool dbOut = f.num("--db-output", 0) != 0;
+    const bool dbOut = f.num("--db-output", 0) != 0;
     DbWriter w; w.path = f.positional[3]; w.dbtype = 12;
     std::string out, flat;
     for (size_t i = 0; i < match.entries.size(); i++) {
         uint32_t a;
         if (!aIdx.find(match.entries[i].key, a)) continue;
         out.clear();
-        if (!summarizeEntry(match.ptr(i), aln.ptr(a), fmt, out, err)) return fail(err);
+        if (!summarizeEntry(match.ptr(i), aln.ptr(a), o, out, err)) return fail(err);
         if (dbOut) w.add(match.entries[i].key, out); else flat += out;
     }
     if (dbOut) { if (!w.close(err)) return fail("summarizeresults: " + err); return 0; }
     // --db-output 0 (the workflow's default): one flat text file, no index (SummarizeResults.cpp:188-191)
-    std::ofstream o(f.positional[3], std::ios::binary); o.write(flat.data(), (std::streamsize) flat.size());
-    if (!o.good()) return fail("summarizeresults: cannot write " + f.positional[3]);
+    std::ofstream o2(f.positional[3], std::ios::binary); o2.write(flat.data(), (std::streamsize) flat.size());
+    if (!o2.good()) return fail("summarizeresults: cannot write " + f.positional[3]);
     return 0;
 }
 

@@ -12,6 +12,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import sp_sets_oracle as so      # noqa: E402
 
 
+# host-only checks of the oracle itself; collected for the CPU suite and, with the `gpu` marker, for the driver's -m gpu run on the box
+@pytest.fixture(autouse=True, params=[pytest.param("cpu-suite"), pytest.param("gpu-suite", marks=pytest.mark.gpu)])
+def suite(request):
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def g():
     return load_golden("examples")
@@ -86,7 +92,8 @@ def test_fdr_and_summary(g):
         out, thr = so.fdr_filter({int(k): v for k, v in c["pos"].items()}, {int(k): v for k, v in c["neg"].items()}, c["fdr"], c["report"])
         assert thr == float.fromhex(c["threshold"]) and out == {int(k): v for k, v in c["out"].items()}
         nontrivial += thr > 0
-    assert nontrivial >= 4
+    assert nontrivial >= 8 and len(g["fdr_cases"]) >= 17
     match, aln = db(g, "match"), db(g, "aln")
     for fmt in (0, 1, 2):
         assert {k: so.summarize(v, aln[k], fmt) for k, v in match.items()} == db(g, "summary%d" % fmt)
+    assert {k: so.summarize(v, aln[k], 1, report_fdr=True) for k, v in db(g, "match_fdr").items()} == db(g, "summary_fdr")

@@ -1,13 +1,29 @@
 """The set-level module drop-ins (host-only, so they run without a GPU) on BASELINE.json
 configs[0] -- the reference's bundled examples -- against the DBs the reference code produced for the same inputs
-(tests/golden/examples.json.gz, made by tests/golden/make_examples.py through oracle/_ref/ref_sets).  Every output entry must be
-byte-identical."""
+(tests/golden/examples.json.gz, made by tests/golden/make_examples.py through oracle/_ref/ref_sets: the reference's own module
+translation units, and repeated through a binary of the reference when one is at hand).  Every output entry must be byte-identical.
+
+Host-only code, but part of the path the GPU box has to deliver: every test here is collected twice, once for the CPU suite and once with the
+`gpu` marker so that the driver's `-m gpu` run on the MI355X box executes it as well."""
 import os
 import struct
 
 import pytest
 
 from conftest import load_golden
+
+
+@pytest.fixture(autouse=True, params=[pytest.param("cpu-suite"), pytest.param("gpu-suite", marks=pytest.mark.gpu)])
+def suite(request):
+    return request.param
+
+
+ANCILLARY = ("_h", "_h.index", "_h.dbtype", ".lookup", ".source", "_mapping", "_names.dmp", "_nodes.dmp", "_merged.dmp")
+
+
+def links(prefix):
+    """suffix -> 'link' / 'file' of the sequence-DB side files next to <prefix>"""
+    return {s: ("link" if os.path.islink(prefix + s) else "file") for s in ANCILLARY if os.path.lexists(prefix + s)}
 
 
 def write_db(path, db):
@@ -42,6 +58,12 @@ def ex(tmp_path_factory):
         write_db(str(d / name), db)
     for name, text in list(g["lookup"].items()) + list(g["lookup_x"].items()):
         open(str(d / (name + ".lookup")), "w").write(text)
+    for name in ("q_nucl", "t_nucl"):      # createdb's .source: file number, file name
+        files = g["query_files"] if name == "q_nucl" else g["target_files"]
+        open(str(d / (name + ".source")), "w").write("".join("%d\t%s\n" % (i, f) for i, f in enumerate(files)))
+    for n, text in g["taxonomy"].items():      # a target set WITH a taxonomy: tx = t_nucl + the three NCBI dump files
+        open(str(d / ("tx_%s.dmp" % n)), "w").write(text)
+    write_db(str(d / "tx"), g["db"]["t_nucl"])
     return g, d
 
 
@@ -66,18 +88,28 @@ def test_extractorfs_translatenucs_reverseseqbycodon(ex):
     check(g, d, "o_q_nucl_orf", "q_nucl_orf")
     check(g, d, "o_q_nucl_orf_h", "q_nucl_orf_h")
     assert open(P("o_q_nucl_orf.lookup")).read() == g["lookup"]["q_nucl_orf"]
+    want = lambda name: {k: v for k, v in g["ancillary"][name].items() if k in ANCILLARY}      # noqa: E731
+    assert links(P("o_q_nucl_orf")) == want("q_nucl_orf")      # .source linked (extractorfs.cpp:156), lookup and headers written
     sa.module_host("extractorfs", [P("t_nucl"), P("o_t_nucl_orf"), "--min-length", "30", "--orf-start-mode", "0", "--create-lookup", "1"] + THREADS)
     check(g, d, "o_t_nucl_orf", "t_nucl_orf")
     check(g, d, "o_t_nucl_orf_h", "t_nucl_orf_h")
     assert open(P("o_t_nucl_orf.lookup")).read() == g["lookup"]["t_nucl_orf"]
     sa.module_host("translatenucs", [P("o_q_nucl_orf"), P("o_q"), "--translation-table", "1", "--add-orf-stop", "0"] + THREADS)
     check(g, d, "o_q", "q")
+    # DBReader::softlinkDb(in, out, SEQUENCE_ANCILLARY): headers, lookup and source of the ORF DB are linked under the peptide DB's name
+    assert links(P("o_q")) == want("q") and open(P("o_q_h.index")).read() == open(P("o_q_nucl_orf_h.index")).read()
+    assert os.path.realpath(P("o_q.lookup")) == os.path.realpath(P("o_q_nucl_orf.lookup"))
     sa.module_host("translatenucs", [P("o_t_nucl_orf"), P("o_t"), "--translation-table", "1", "--add-orf-stop", "0"] + THREADS)
     check(g, d, "o_t", "t")
     sa.module_host("reverseseqbycodon", [P("o_t_nucl_orf"), P("o_c_nucl_orf")] + THREADS)
     check(g, d, "o_c_nucl_orf", "c_nucl_orf")
+    assert links(P("o_c_nucl_orf")) == want("c_nucl_orf")
     sa.module_host("translatenucs", [P("o_c_nucl_orf"), P("o_c"), "--translation-table", "1", "--add-orf-stop", "0"] + THREADS)
     check(g, d, "o_c", "c")
+    assert links(P("o_c")) == want("c") and links(P("o_t")) == want("t")
+    # a second run replaces the links instead of failing on them
+    sa.module_host("reverseseqbycodon", [P("o_t_nucl_orf"), P("o_c_nucl_orf")] + THREADS)
+    assert links(P("o_c_nucl_orf")) == want("c_nucl_orf")
 
 
 def test_orf_and_translation_corners(ex):
@@ -118,6 +150,16 @@ def test_proteinaln2nucl_to_combinescore(ex, tag, T):
     check(g, d, "o_cScore" + tag, "cScore" + tag)
 
 
+def test_proteinaln2nucl_with_its_own_default_gap_costs(ex):
+    """a bare call: nucleotide gap open 5 / extend 2 (Parameters.cpp defaults), another row of the tabulated Gumbel parameters"""
+    import spacepharer_amd as sa
+    g, d = ex
+    P = lambda x: str(d / x)      # noqa: E731
+    sa.module_host("proteinaln2nucl", [P("q_nucl_orf"), P("t_nucl_orf"), P("q"), P("t"), P("prot_result"), P("o_nucl_result_default")] + THREADS)
+    check(g, d, "o_nucl_result_default", "nucl_result_default")
+    assert g["db"]["nucl_result_default"]["entries"] != g["db"]["nucl_result"]["entries"]
+
+
 def test_besthitperset_second_best_correction(ex):
     import spacepharer_amd as sa
     g, d = ex
@@ -133,14 +175,25 @@ def test_filtermatchbyfdr_and_summarizeresults(ex):
     for name, fdr, rep in (("match", "0.05", "0"), ("match_fdr", "0.05", "1"), ("match_all", "1", "0")):
         sa.module_host("filtermatchbyfdr", [P("cScore"), P("cScore_rev"), P("o_" + name), "--fdr", fdr, "--report-fdr", rep] + THREADS)
         check(g, d, "o_" + name, name)
-    for fmt in (0, 1, 2):
-        sa.module_host("summarizeresults", [P("t_nucl"), P("match"), P("aln"), P("o_summary%d" % fmt), "--fmt", str(fmt), "--report-fdr", "0", "--db-output", "1"] + THREADS)
-        check(g, d, "o_summary%d" % fmt, "summary%d" % fmt)
-    # the workflow's form: one flat report file, entries in match-DB order
-    sa.module_host("summarizeresults", [P("t_nucl"), P("match"), P("aln"), P("o_report.tsv"), "--fmt", "1", "--report-fdr", "0"] + THREADS)
-    exp = g["db"]["summary1"]["entries"]
-    assert open(P("o_report.tsv")).read() == "".join(exp[k] for k in sorted(exp, key=int))
-    assert not os.path.exists(P("o_report.tsv.index"))
+    variants = [("summary%d" % fmt, "t_nucl", "match", "aln", ["--fmt", str(fmt)]) for fmt in (0, 1, 2)]
+    variants.append(("summary_fdr", "t_nucl", "match_fdr", "aln", ["--fmt", "1", "--report-fdr", "1"]))
+    # a target set with a taxonomy (<targetDB>_nodes.dmp exists, SummarizeResults.cpp:17-21): taxon id, rank and name columns, a merged taxon id,
+    # a taxon that is not in the table, taxon 0; --lca-ranks and both --tax-lineage forms
+    variants += [("summary_tax", "tx", "match", "aln_tax", ["--fmt", "1"]), ("summary_tax_ranks", "tx", "match", "aln_tax", ["--fmt", "1", "--lca-ranks", "species,genus,family,superkingdom"]),
+                 ("summary_tax_lineage1", "tx", "match", "aln_tax", ["--fmt", "1", "--tax-lineage", "1"]),
+                 ("summary_tax_lineage2", "tx", "match", "aln_tax", ["--fmt", "1", "--tax-lineage", "2", "--lca-ranks", "order"])]
+    for name, tdb, match, aln, flags in variants:
+        sa.module_host("summarizeresults", [P(tdb), P(match), P(aln), P("o_" + name)] + flags + ["--db-output", "1"] + THREADS)
+        check(g, d, "o_" + name, name)
+        # the workflow's form (and the only one the reference binary offers): one flat report file, entries in match-DB order, no index
+        sa.module_host("summarizeresults", [P(tdb), P(match), P(aln), P("o_" + name + ".tsv")] + flags + THREADS)
+        assert open(P("o_" + name + ".tsv")).read() == g["report"][name], name
+        assert not os.path.exists(P("o_" + name + ".tsv.index"))
+    assert "\t40521\tspecies\tListeria phage A118\n" in g["report"]["summary_tax"] and "\t10710\tspecies\t" in g["report"]["summary_tax"]      # direct and merged id
+    with pytest.raises(sa.SpError):      # a match DB without the FDR column cannot be reported with it
+        sa.module_host("summarizeresults", [P("t_nucl"), P("match"), P("aln"), P("o_bad"), "--report-fdr", "1"] + THREADS)
+    with pytest.raises(sa.SpError):
+        sa.module_host("summarizeresults", [P("tx"), P("match"), P("aln_tax"), P("o_bad"), "--lca-ranks", "species,nonsense"] + THREADS)
 
 
 def test_unknown_flags_and_unsupported_values_fail_loudly(ex):
@@ -162,6 +215,7 @@ def test_filtermatchbyfdr_on_long_score_lists(tmp_path):
     import spacepharer_amd as sa
     g = load_golden("examples")
     nontrivial = 0
+    assert len(g["fdr_cases"]) >= 17
     for i, c in enumerate(g["fdr_cases"]):
         P = lambda x: str(tmp_path / ("%d_%s" % (i, x)))      # noqa: E731
         write_db(P("pos"), {"dbtype": 5, "entries": c["pos"]})
@@ -170,7 +224,7 @@ def test_filtermatchbyfdr_on_long_score_lists(tmp_path):
         got, dbtype = read_db(P("out"))
         assert dbtype == 12 and got == c["out"], i
         nontrivial += float.fromhex(c["threshold"]) > 0
-    assert nontrivial >= 4
+    assert nontrivial >= 8
 
 
 def test_threaded_drivers_write_the_bytes_a_single_thread_writes(tmp_path):
