@@ -4,9 +4,15 @@
 Runs only in the build container (needs /root/reference and `make -C oracle ref`).  The committed
 outputs (tests/golden/*.json.gz) are pure data: seeded synthetic inputs + what the reference computed.
 
+The harness mirrors the control loops around the reference classes (Prefiltering::runSplit, IndexBuilder::fillDatabase,
+Alignment::run).  When a binary of the reference is at hand (SP_REF_BINARY, default /tmp/ref_build/src/spacepharer -- the
+survey's cmake build; this script never builds one) every case is ALSO searched by the real `prefilter` and `align` modules
+with the workflow's flag lists on DB triples, and their result DBs must equal the harness' text entry
+for entry; `ref.cross_checked_with_reference_binary` records that it happened.
+
 usage: python tests/golden/make_golden.py
 """
-import gzip, json, os, random, subprocess, sys, tempfile
+import gzip, json, os, random, struct, subprocess, sys, tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -116,6 +122,60 @@ def make_long_target_case(seed, n_targets, n_queries, tmin, tmax, qmin, qmax):
     return T, Q
 
 
+REF_BINARY = os.environ.get("SP_REF_BINARY", "/tmp/ref_build/src/spacepharer")
+PREF_FLAGS = ("--sub-mat nucl:nucleotide.out,aa:VTML40.out --seed-sub-mat nucl:nucleotide.out,aa:VTML80.out -k 6 --k-score 2147483647 --alph-size nucl:5,aa:21 "
+              "--max-seq-len 65535 --split 0 --split-mode 2 --split-memory-limit 0 -c 0 --cov-mode 0 --comp-bias-corr 1 --diag-score 1 --exact-kmer-matching 0 "
+              "--mask 1 --mask-lower-case 0 --min-ungapped-score 15 --add-self-matches 0 --spaced-kmer-mode 1 --db-load-mode 0 --pca 1 --pcb 1.5 "
+              "--spaced-kmer-pattern 11011101 --threads 1 --compressed 0 -v 1 -s 5.7").split()
+ALN_FLAGS = ("--sub-mat nucl:nucleotide.out,aa:VTML40.out -a 1 --alignment-mode 2 --alignment-output-mode 0 --wrapped-scoring 0 -e 200 --min-seq-id 0 --min-aln-len 0 "
+             "--seq-id-mode 0 --alt-ali 0 -c 0 --cov-mode 0 --max-seq-len 65535 --comp-bias-corr 1 --max-rejected 2147483647 --max-accept 2147483647 "
+             "--add-self-matches 0 --db-load-mode 0 --pca 1 --pcb 1.5 --score-bias 0 --realign 0 --realign-score-bias -0.2 --realign-max-seqs 2147483647 "
+             "--gap-open nucl:10,aa:16 --gap-extend 2 --zdrop 40 --threads 1 --compressed 0 -v 1").split()
+
+
+def write_db(path, seqs):
+    off, idx = 0, []
+    with open(path, "wb") as f:
+        for k, s in enumerate(seqs):
+            b = s.encode() + b"\n\0"
+            f.write(b)
+            idx.append("%d\t%d\t%d\n" % (k, off, len(b)))
+            off += len(b)
+    open(path + ".index", "w").write("".join(idx))
+    open(path + ".dbtype", "wb").write(struct.pack("<i", 0))
+
+
+def read_db(path):
+    files = [path] if os.path.exists(path) else []
+    while not os.path.exists(path) and os.path.exists("%s.%d" % (path, len(files))):      # split data files <path>.0, <path>.1, ...
+        files.append("%s.%d" % (path, len(files)))
+    data = b"".join(open(p, "rb").read() for p in files)
+    out = {}
+    for line in open(path + ".index"):
+        k, o, l = (int(x) for x in line.split("\t"))
+        out[k] = data[o:o + l - 1].decode()
+    return out
+
+
+def cross_check(d, T, Q, ref, flags):
+    """the real modules on DB triples against the harness' text; False when there is no binary or the case forces what no flag can (--bin-size)"""
+    if not os.path.exists(REF_BINARY) or "--bin-size" in flags:
+        return False
+    max_seqs = flags[flags.index("--max-seqs") + 1] if "--max-seqs" in flags else "300"
+    q, t, pref, aln = (os.path.join(d, x) for x in ("qdb", "tdb", "pref", "aln"))
+    write_db(q, Q)
+    write_db(t, T)
+    subprocess.check_call([REF_BINARY, "prefilter", q, t, pref, "--max-seqs", max_seqs] + PREF_FLAGS, stdout=subprocess.DEVNULL)
+    subprocess.check_call([REF_BINARY, "align", q, t, pref, aln] + ALN_FLAGS, stdout=subprocess.DEVNULL)
+    got_pref, got_aln = read_db(pref), read_db(aln)
+    exp_pref = {x["id"]: x["pref"] for x in ref["queries"]}
+    exp_aln = {x["id"]: x["text"] for x in ref["aln"]}
+    for k in range(len(Q)):
+        assert got_pref.get(k, "") == exp_pref.get(k, ""), ("prefilter", k, got_pref.get(k, "")[:200], exp_pref.get(k, "")[:200])
+        assert got_aln.get(k, "") == exp_aln.get(k, ""), ("align", k, got_aln.get(k, "")[:200], exp_aln.get(k, "")[:200])
+    return True
+
+
 def main():
     if not os.path.exists(HARNESS):
         sys.exit("build the harness first: make -C oracle ref")
@@ -130,6 +190,8 @@ def main():
             open(qf, "w").write("\n".join(Q) + "\n")
             subprocess.check_call([HARNESS, M80, M40, tf, qf, of] + flags)
             ref = json.load(open(of))
+            ref["cross_checked_with_reference_binary"] = cross_check(d, T, Q, ref, flags)
+            print(name, "real prefilter + align modules equal the harness:", ref["cross_checked_with_reference_binary"])
         doc = {"case": name, "seed": seed, "targets": T, "queries": Q, "flags": flags, "ref": ref}
         out = os.path.join(HERE, name + ".json.gz")
         with gzip.GzipFile(out, "wb", mtime=0) as f:
