@@ -179,7 +179,7 @@ def _deliver(ctx, slot):
 
 def test_two_contexts_in_flight_deliver_the_single_context_bytes():
     """the configuration bench.py times: two search contexts on one GPU, each on its own host thread and HIP streams with its
-    own query batch, match_blocks_per_cu = 2, passes interleaving freely.  Every round of both contexts must deliver exactly
+    own query batch, match_blocks_per_cu = 3 (bench.py --match-blocks default), passes interleaving freely.  Every round of both contexts must deliver exactly
     the bytes (hit list, offsets, sp_alignment records, backtrace pool) the same batch gives when its context has the GPU to
     itself with default tuning."""
     import threading
@@ -198,7 +198,7 @@ def test_two_contexts_in_flight_deliver_the_single_context_bytes():
         ctxs.append(c); slots.append(s)
     assert ref[0] != ref[1] and len(ref[0][1]) > 8 * 60000 and len(ref[1][2]) > 60 * 60000
     for c in ctxs:
-        c.set_tuning("match_blocks_per_cu", 2)
+        c.set_tuning("match_blocks_per_cu", 3)      # what bench.py sets for its timed regions (--match-blocks)
     rounds, bad, errors = 12, [], []
     gate = threading.Barrier(2)
 

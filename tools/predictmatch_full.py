@@ -1,0 +1,169 @@
+"""BASELINE.json configs[4] at its stated size on one MI355X: 100 000 spacers (5 000 CRISPR arrays x 20) against a 10x replicated phage
+set of ~10^8 translated ORF residues AND against its codon-reversed control, the set-level chain, FDR filtering -- the path
+data/predictmatch.sh:27-125 walks.  (The 8-GPU form of the config shards the same target set; tests/test_gpu_predictmatch_full.py
+checks that 8 target shards reproduce the unsplit bytes.)
+
+Nucleotide route, as the workflow has it: synthetic coding-dense genomes (tools/predictmatch_e2e.py: make_data) -> `replicas` copies
+with distinct keys (each copy its own target set, like the config's replicated GenBank) -> extractorfs / translatenucs /
+reverseseqbycodon through the host module drop-ins on DB triples -> the DBs loaded as flat buffers (numpy; no Python string per ORF)
+-> per target set (targets, control): index on the device, ONE batch of all query peptides through prefilter + align, the chain
+proteinaln2nucl ... combinescore in memory (sp_ctx_set_scores) -> filtermatchbyfdr on the two score DBs.
+
+usage: python tools/predictmatch_full.py [unique_genomes] [genome_nt] [replicas] [arrays] [spacers_per_array]   -> one JSON line
+       defaults 900 x 20 000 nt x 10 replicas (~10^8 ORF residues), 5 000 x 20 spacers"""
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import predictmatch_e2e as pm      # noqa: E402
+
+
+def read_table(path, cols):
+    """integer columns of a tab separated text file (index: key, offset, length; lookup: key, name, set)"""
+    try:
+        import pandas as pd
+        df = pd.read_csv(path, sep="\t", header=None, usecols=cols, dtype=np.int64, engine="c")
+        return [df[c].to_numpy() for c in cols]
+    except ImportError:
+        a = np.loadtxt(path, dtype=np.int64, usecols=cols, delimiter="\t", ndmin=2)
+        return [a[:, i] for i in range(len(cols))]
+
+
+class Flat:
+    """a sequence DB as the C ABI takes it: residues back to back (entry terminators "\\n\\0" removed), offsets[n + 1]"""
+
+    def __init__(self, path):
+        key, off, length = read_table(path + ".index", [0, 1, 2])
+        assert (key == np.arange(len(key))).all(), path + ": keys are not 0..n-1"
+        assert (off[1:] == off[:-1] + length[:-1]).all() and off[0] == 0, path + ": entries are not contiguous in key order"
+        data = np.fromfile(path, dtype=np.uint8)
+        assert len(data) == int(off[-1] + length[-1])
+        self.n = len(key)
+        self.res = np.ascontiguousarray(data[(data != 10) & (data != 0)])
+        self.off = np.zeros(self.n + 1, dtype=np.uint64)
+        self.off[1:] = np.cumsum(length - 2).astype(np.uint64)
+        assert int(self.off[-1]) == len(self.res), path + ": a sequence holds a newline or NUL"
+
+    def ptr(self):
+        return C.cast(self.res.ctypes.data, C.c_char_p)
+
+    def offs(self):
+        return self.off.ctypes.data_as(C.POINTER(C.c_uint64))
+
+    def seq(self, i):
+        return self.res[int(self.off[i]):int(self.off[i + 1])].tobytes().decode()
+
+
+def u32(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def prepare(d, genomes, arrays, replicas, threads, times):
+    import spacepharer_amd as sa
+    P = lambda x: os.path.join(d, x)      # noqa: E731
+    th = ["--threads", str(threads), "--compressed", "0", "-v", "3"]
+    t0 = time.perf_counter()
+    pm.nucl_db(P("q_nucl"), arrays)
+    pm.nucl_db(P("t_nucl"), [[g] for g in genomes] * replicas)      # copy r of genome g: contig key = set = r * len(genomes) + g
+    t1 = time.perf_counter()
+    sa.module_host("extractorfs", [P("q_nucl"), P("q_nucl_orf"), "--min-length", "9", "--orf-start-mode", "1", "--create-lookup", "1"] + th)
+    sa.module_host("translatenucs", [P("q_nucl_orf"), P("q")] + th)
+    sa.module_host("extractorfs", [P("t_nucl"), P("t_nucl_orf"), "--min-length", "30", "--orf-start-mode", "0", "--create-lookup", "1"] + th)
+    sa.module_host("translatenucs", [P("t_nucl_orf"), P("t")] + th)
+    sa.module_host("reverseseqbycodon", [P("t_nucl_orf"), P("c_nucl_orf")] + th)
+    sa.module_host("translatenucs", [P("c_nucl_orf"), P("c")] + th)
+    t2 = time.perf_counter()
+    dbs = {}
+    for name in ("q", "t", "c"):
+        aa, nuc = Flat(P(name)), Flat(P(name + "_nucl_orf"))
+        assert aa.n == nuc.n
+        (sets,) = read_table(P(name + "_nucl_orf.lookup"), [2])      # reverseseqbycodon / translatenucs link the lookup of the ORF DB
+        assert len(sets) == aa.n
+        dbs[name] = {"aa": aa, "nucl": nuc, "set": sets.astype(np.uint32)}
+    t3 = time.perf_counter()
+    times.update(write_input_dbs_python_s=t1 - t0, six_host_modules_s=t2 - t1, load_dbs_numpy_s=t3 - t2)
+    return dbs
+
+
+def search_and_score(ctx, dbs, tname, times, keep=False):
+    """one search of ALL query peptides (one batch) against target set `tname` + the in-memory chain -> {query set: cScore entry}"""
+    q, t = dbs["q"], dbs[tname]
+    t0 = time.perf_counter()
+    ctx.set_targets_raw(t["aa"].ptr(), t["aa"].offs(), t["aa"].n)
+    t1 = time.perf_counter()
+    ctx.set_queries_raw(q["aa"].ptr(), q["aa"].offs(), q["aa"].n)
+    ctx.prefilter()
+    t2 = time.perf_counter()
+    aln, cig, n = ctx.align_hits_raw()
+    t3 = time.perf_counter()
+    qs, qsp = u32(q["set"])
+    ts, tsp = u32(t["set"])
+    score = ctx.set_scores_raw((q["nucl"].ptr(), q["nucl"].offs()), (t["nucl"].ptr(), t["nucl"].offs()), qsp, tsp, aln, cig, stage=0)
+    t4 = time.perf_counter()
+    times[tname] = {"stage_targets_s": t1 - t0, "prefilter_s": t2 - t1, "align_s": t3 - t2, "set_scores_s": t4 - t3, "alignments": n,
+                    "kernel_ms": {k: ctx.stat("ms_" + k) for k in ("match", "sw_forward")},
+                    "counters": {k: ctx.stat(k) for k in ("kmers", "db_matches", "diagonals", "hits")}}
+    return score, n
+
+
+def run(unique_genomes=900, genome_nt=20000, replicas=10, n_arrays=5000, per_array=20, threads=16, keep_dir=None, seed=2024):
+    import spacepharer_amd as sa
+    t_all = time.perf_counter()
+    genomes, arrays, truth = pm.make_data(unique_genomes, genome_nt, n_arrays, per_array, seed=seed)
+    times = {"make_data_python_s": time.perf_counter() - t_all}
+    tmp = None
+    if keep_dir is None:
+        tmp = tempfile.TemporaryDirectory()
+        keep_dir = tmp.name
+    P = lambda x: os.path.join(keep_dir, x)      # noqa: E731
+    dbs = prepare(keep_dir, genomes, arrays, replicas, threads, times)
+    ctx = sa.SearchContext()
+    t0 = time.perf_counter()
+    score, n_t = search_and_score(ctx, dbs, "t", times)
+    t1 = time.perf_counter()
+    score_rev, n_c = search_and_score(ctx, dbs, "c", times)
+    t2 = time.perf_counter()
+    pm.write_db(P("cScore"), [(k, v) for k, v in sorted(score.items())], 5)
+    pm.write_db(P("cScore_rev"), [(k, v) for k, v in sorted(score_rev.items())], 5)
+    sa.module_host("filtermatchbyfdr", [P("cScore"), P("cScore_rev"), P("match"), "--fdr", "0.05", "--report-fdr", "0", "--threads", str(threads), "--compressed", "0", "-v", "3"])
+    match = pm.read_db(P("match"))
+    t3 = time.perf_counter()
+    times.update(search_target_s=t1 - t0, search_control_s=t2 - t1, fdr_s=t3 - t2)
+    U = unique_genomes
+    found = other = 0
+    for a, entry in match.items():
+        for line in entry.splitlines():
+            g = int(line.split("\t")[0])
+            if truth[a] >= 0 and g % U == truth[a]:
+                found += 1
+            else:
+                other += 1
+    chain_s = times["six_host_modules_s"] + times["load_dbs_numpy_s"] + (t3 - t0)
+    n_sp = n_arrays * per_array
+    info = {"config": "BASELINE configs[4] on one MI355X: %d spacers vs %d genomes (%d unique x %d replicas) + codon-reversed control + FDR" % (n_sp, U * replicas, U, replicas),
+            "spacers": n_sp, "arrays": n_arrays, "query_peptides": dbs["q"]["aa"].n, "target_orfs": dbs["t"]["aa"].n, "target_residues": int(dbs["t"]["aa"].off[-1]),
+            "target_nt": genome_nt * U * replicas, "alignments_target": n_t, "alignments_control": n_c,
+            "seconds": {k: (round(v, 4) if not isinstance(v, dict) else v) for k, v in times.items()},
+            "chain_s_without_python_input_writing": round(chain_s, 4), "spacers_per_s_whole_chain": n_sp / chain_s,
+            "spacer_queries_per_s_two_searches_gpu_side": 2 * n_sp / sum(times[x][k] for x in ("t", "c") for k in ("prefilter_s", "align_s")),
+            "matches_reported": found + other, "true_matches_found": found, "real_arrays": sum(1 for g in truth if g >= 0), "planted_pairs": sum(1 for g in truth if g >= 0) * replicas,
+            "other_matches": other}
+    state = {"dbs": dbs, "score": score, "score_rev": score_rev, "match": match, "truth": truth, "ctx": ctx, "dir": keep_dir, "tmp": tmp, "unique": U, "replicas": replicas}
+    return info, state
+
+
+if __name__ == "__main__":
+    a = [int(x) for x in sys.argv[1:]]
+    info, st = run(*a)
+    st["ctx"].close()
+    print(json.dumps(info))
