@@ -266,6 +266,9 @@ def main():
                          "(1 = strictly one pass at a time)")
     ap.add_argument("--shard", default=None, choices=["queries", "targets"],
                     help="decomposition: target shards + RCCL all-gather (default at N > 1) or query partition with replicated index (default at N = 1)")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2], help="device-driven steps queued per context before the oldest is collected")
+    ap.add_argument("--host-driven", action="store_true", help="the round-2 step: the host learns the hit count between prefilter and align and the record count after align "
+                    "(sp_ctx_prefilter + sp_ctx_align_hits_begin / _end) instead of one device-driven step (sp_ctx_search_begin / _end)")
     ap.add_argument("--no-module-e2e", action="store_true", help="N = 1: skip the files-to-files timing of the module drop-ins (tools/module_e2e.py)")
     ap.add_argument("--shards", type=int, default=0, help="N > 1, target-sharded: S target shards x N / S query groups (all-gather within a group); 0 = N shards, every rank matches all queries (BASELINE configs[3])")
     ap.add_argument("--no-hybrid", action="store_true", help="N >= 4: skip the additional 2-shard x N/2-group measurement")
@@ -384,7 +387,14 @@ def main():
         slots = [[Slot(L, nq, caps[i], full) for _ in range(share[i])] for i in range(n_pipe)]
         ref_slot = [Slot(L, nq, caps[i], full) for i in range(n_pipe)]
 
+        device_driven = full and not shard_targets and not args.host_driven      # the whole step queued without a host round trip (sp_ctx_search_begin / _end)
+
         def step(c, slot):
+            if device_driven:      # one step at a time (reference digests, warm-up, breakdown): queue it, collect it
+                c.search_begin(slot.hits, slot.off, slot.cap, slot.rec, slot.cig, slot.cig_cap)
+                n, used = c.search_end()
+                slot.n, slot.used.value, slot.hits_ptr_ok = n, used, True
+                return n
             c.set_hit_sink(slot.hits, slot.off, slot.cap)
             search(c)
             n = slot.n = c.num_hits()
@@ -397,7 +407,8 @@ def main():
 
         def barrier():
             for c in ctxs:
-                c.align_hits_end()                         # the last pass's alignment records are in host memory
+                if not device_driven:
+                    c.align_hits_end()                     # the last pass's alignment records are in host memory
             if dist is not None and world > 1:
                 dist.barrier()
             if gpu_dev is not None:
@@ -426,6 +437,28 @@ def main():
 
         def run(i):
             c = ctxs[i]
+            if device_driven:
+                # two steps in flight per context: step j + 1 is queued before step j is collected, so the context's stream never waits for the
+                # host; every step is complete (hit list, records, backtraces in ITS page-locked buffers) when its search_end() returns
+                def collect(slot):
+                    n, used = c.search_end()
+                    slot.n, slot.used.value, slot.hits_ptr_ok = n, used, True
+                    acc[i][1] = n
+                    v = c.stat("ms_match")
+                    acc[i][0] += 0.0 if v != v else v
+                prev = None
+                for j in range(share[i]):
+                    s = slots[i][j]
+                    c.search_begin(s.hits, s.off, s.cap, s.rec, s.cig, s.cig_cap)
+                    if args.in_flight < 2:
+                        collect(s)
+                        continue
+                    if prev is not None:
+                        collect(prev)
+                    prev = s
+                if prev is not None:
+                    collect(prev)
+                return
             for j in range(share[i]):
                 acc[i][1] = step(c, slots[i][j])
                 v = c.stat("ms_match")
@@ -473,7 +506,8 @@ def main():
             stats = {k: v / 3 for k, v in stats.items()}
             ctx.set_timing(1)
         counters = {k: ctx.stat(k) for k in ("kmers", "db_matches", "diagonals", "diag_residues", "hits")}
-        out = dict(region_dt=region_dt, region_match=region_match, checked=checked, pairs=pairs, stats=stats, counters=counters, n_pipe=n_pipe, nq=nq,
+        out = dict(region_dt=region_dt, region_match=region_match, checked=checked, pairs=pairs, stats=stats, counters=counters, n_pipe=n_pipe, nq=nq, device_driven=device_driven,
+                   steps_repeated=sum(v for v in (c.stat("steps_repeated") for c in ctxs) if v == v),
                    t_index=t_index, batches=batches, xch=xch_region, q_slice=(q_from, q_to))
         for grp in slots + [ref_slot]:
             for s in grp:
@@ -530,6 +564,8 @@ def main():
                    "parallelism": ("target shards x%d%s, %s all-gather of candidates, selection + align by query slice" % (args.shards or world, (" x %d query groups" % (world // args.shards)) if args.shards and args.shards != world else "", "RCCL" if args.exchange == "rccl" else "gloo")) if sharded
                                   else ("query partition x%d, index replicated" % world),
                    "passes_in_flight_per_gpu": n_pipe, "distinct_query_batches": n_pipe,
+                   "step": ("device-driven: the whole step is queued without a host round trip (sp_ctx_search_begin / _end), two steps in flight per context; %d steps met a capacity and were repeated the synchronous way" % int(m["steps_repeated"]))
+                           if m["device_driven"] else "host-driven: the host learns the hit count between prefilter and align (sp_ctx_prefilter + sp_ctx_align_hits_begin / _end)",
                    "index_build_s": round(m["t_index"], 3)},
         "regions": regions,
         "results_checked": {"steps": m["checked"], "equal_to_single_context_result": True,

@@ -154,6 +154,17 @@ int sp_ctx_align_hits(sp_ctx *c, sp_alignment *results, char *cigars, uint64_t c
    run the next sp_ctx_prefilter(): the copy overlaps it. */
 int sp_ctx_align_hits_begin(sp_ctx *c, sp_alignment *results, char *cigars, uint64_t cigar_cap, uint64_t *cigar_used);
 int sp_ctx_align_hits_end(sp_ctx *c);
+/* A whole search step of the resident query batch -- sp_ctx_prefilter() + sp_ctx_align_hits() -- queued WITHOUT a host round trip (the
+   reference's prefilter + align module pair for one batch, lib/mmseqs/src/prefiltering/Prefiltering.cpp:717-872 +
+   lib/mmseqs/src/alignment/Alignment.cpp:255-549): the hit count stays on the device, every kernel of the align half reads it there, the hit
+   list (hits[n], offsets[n_queries + 1]), the records (results[i] belongs to hit i) and the packed backtraces travel on a copy stream into the
+   caller's page-locked buffers (sp_host_alloc; hits and results hold hit_cap entries, cigars cigar_cap bytes).  _begin returns as soon as the
+   step is queued; up to two steps may be in flight per context (the second one's kernels run while the first one's results travel); _end
+   waits for the OLDEST step and reports its counts.  Leave the buffers alone between _begin and _end; do not call sp_ctx_set_queries /
+   sp_ctx_set_targets or the synchronous entry points while a step is in flight.  A step that meets a capacity (more hits than earlier passes
+   delivered, a traceback that needs the host path) is repeated the synchronous way inside _end: the results are always complete. */
+int sp_ctx_search_begin(sp_ctx *c, sp_hit_packed *hits, uint32_t *offsets, uint64_t hit_cap, sp_alignment *results, char *cigars, uint64_t cigar_cap);
+int sp_ctx_search_end(sp_ctx *c, uint64_t *n_hits, uint64_t *cigar_used);
 /* rescorediagonal core: mode 1 = substitution score, 2 = score + start/end */
 int sp_ctx_rescore(sp_ctx *c, const uint32_t *query_idx, const uint32_t *target_idx, const int16_t *diagonal, uint64_t n,
                    int mode, sp_rescore *results);
@@ -216,7 +227,9 @@ int sp_ctx_sync(sp_ctx *c);
    event record between two kernels costs ~6 us of idle GPU), 2 = every stage.  Stages that are not timed report NaN. */
 int sp_ctx_set_timing(sp_ctx *c, int level);
 /* tuning knobs (never change a result).  "match_blocks_per_cu": resident blocks of the matching kernel per CU, 0 = as many as
-   fit (3).  Two leave LDS for the aligner of another context on the same GPU -- better when several passes are in flight. */
+   fit.  Fewer leave LDS for the aligner of another context on the same GPU -- better when several passes are in flight.
+   "match_small": footprint of the matching kernel, -1 by index density (default), 0 large, 1 small.  "match_heavy_threshold": similar
+   k-mers from which a query is started first, -1 by batch size (default), 0 no list. */
 int sp_ctx_set_tuning(sp_ctx *c, const char *name, int value);
 /* raw HIP stream the context launches on (hipStream_t), for callers that time with their own events */
 void *sp_ctx_stream(const sp_ctx *c);

@@ -103,6 +103,8 @@ def load_library():
     L.sp_ctx_align_hits.argtypes = [vp, C.POINTER(Alignment), C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.sp_ctx_align_hits_begin.argtypes = [vp, C.POINTER(Alignment), C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.sp_ctx_align_hits_end.argtypes = [vp]
+    L.sp_ctx_search_begin.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64]
+    L.sp_ctx_search_end.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.sp_ctx_rescore.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int16), C.c_uint64, C.c_int,
                                  C.POINTER(Rescore)]
     L.sp_ctx_set_targets_shard.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint64, C.c_uint64, C.c_uint64]
@@ -452,6 +454,17 @@ class SearchContext:
     def align_hits_end(self):
         _check(self.L.sp_ctx_align_hits_end(self.ctx))
         return getattr(self, "_aln", None), getattr(self, "_cig", None)
+
+    def search_begin(self, hits_ptr, offsets_ptr, hit_cap, records_ptr, cigars_ptr, cigar_cap):
+        """queue one whole step (prefilter + align of every hit + delivery into the caller's page-locked buffers: addresses) without a host
+        round trip; up to two steps in flight; search_end() collects the oldest"""
+        _check(self.L.sp_ctx_search_begin(self.ctx, hits_ptr, offsets_ptr, hit_cap, records_ptr, cigars_ptr, cigar_cap))
+
+    def search_end(self):
+        """-> (hits of the oldest step in flight, bytes of its backtrace pool); its results are complete in the buffers given to search_begin()"""
+        n, used = C.c_uint64(), C.c_uint64()
+        _check(self.L.sp_ctx_search_end(self.ctx, C.byref(n), C.byref(used)))
+        return int(n.value), int(used.value)
 
     def set_scores(self, q_nucl, t_nucl, q_set, t_set, aln, cig, stage=0, simple_best_hit=True):
         """predictmatch's chain after the search on the records in memory (sp_ctx_set_scores); q_nucl / t_nucl: lists of nucleotide

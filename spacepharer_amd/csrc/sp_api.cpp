@@ -57,6 +57,7 @@ struct sp_ctx {
     bool tablesUp = false, kmerTablesUp = false;
     sp::GateTable gate; bool gateValid = false; uint64_t gateSerial = 0;    // E-value tables of the resident query batch / target set
     std::vector<char> targetFirst;                         // first letter of every target (proteinaln2nucl's '*' test)
+    sp::StepOut stepOut[2]; uint64_t stepsBegun = 0, stepsEnded = 0;      // result buffers of the device-driven steps in flight (sp_ctx_search_begin / _end)
     sp::AlignHost alnHost;                                 // pinned staging, reused; declared last = released before the device context
 };
 
@@ -150,6 +151,7 @@ int sp_ctx_set_targets_shard(sp_ctx *c, const char *residues, const uint64_t *of
 }
 
 static int setTargets(sp_ctx *c, const char *residues, const uint64_t *offsets, const uint32_t *keys, uint64_t n, int flags, uint64_t from, uint64_t to) {
+    if (c && c->stepsBegun != c->stepsEnded) { g_err = "sp_ctx_set_targets: a search step is in flight (sp_ctx_search_end first)"; return SP_ERR_STATE; }
     if (c) c->gpu.makeCurrent();
     if (!c || !residues || !offsets) { g_err = "sp_ctx_set_targets: null argument"; return SP_ERR_ARG; }
     const bool noIndex = (flags & 1) != 0;
@@ -189,6 +191,7 @@ static int setTargets(sp_ctx *c, const char *residues, const uint64_t *offsets, 
 }
 
 int sp_ctx_set_queries(sp_ctx *c, const char *residues, const uint64_t *offsets, uint64_t n) {
+    if (c && c->stepsBegun != c->stepsEnded) { g_err = "sp_ctx_set_queries: a search step is in flight (sp_ctx_search_end first)"; return SP_ERR_STATE; }
     if (c) c->gpu.makeCurrent();
     if (!c || !residues || !offsets) { g_err = "sp_ctx_set_queries: null argument"; return SP_ERR_ARG; }
     if (offsets[n] >= (1ull << 32)) { g_err = "query batch larger than 4 GiB of residues"; return SP_ERR_ARG; }
@@ -467,6 +470,58 @@ int sp_ctx_align_hits_end(sp_ctx *c) {
     return SP_OK;
 }
 
+/* One whole search step (sp_ctx_prefilter + sp_ctx_align_hits) queued without a host round trip; see include/spacepharer_amd.h */
+int sp_ctx_search_begin(sp_ctx *c, sp_hit_packed *hits, uint32_t *offsets, uint64_t hit_cap, sp_alignment *results, char *cigars, uint64_t cigar_cap) {
+    if (c) c->gpu.makeCurrent();
+    if (!c || c->targets.n == 0) { g_err = "sp_ctx_search_begin: no target set"; return SP_ERR_STATE; }
+    if (c->indexEntries == 0) { g_err = "sp_ctx_search_begin: the target set has no k-mer index"; return SP_ERR_STATE; }
+    if (!hits || !offsets || !results || !cigars) { g_err = "sp_ctx_search_begin: result buffers missing"; return SP_ERR_ARG; }
+    std::string err;
+    if (!ensureEvaluers(c, true, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
+    buildGate(c);
+    sp::StepOut o; o.hits = reinterpret_cast<sp::GpuHit *>(hits); o.offsets = offsets; o.hitCap = hit_cap; o.records = reinterpret_cast<sp::AlnRec *>(results);
+    o.cigars = cigars; o.recordCap = hit_cap; o.cigarCap = cigar_cap;
+    if (!c->gpu.stepBegin(c->kmerThr, c->binSize, sp_ctx_max_seqs(c), c->par.min_ungapped_score, c->par.gap_open, c->par.gap_extend, c->gate, o, err)) { g_err = err; return SP_ERR_STATE; }
+    c->stepOut[c->stepsBegun++ & 1] = o;
+    return SP_OK;
+}
+
+int sp_ctx_search_end(sp_ctx *c, uint64_t *n_hits, uint64_t *cigar_used) {
+    if (c) c->gpu.makeCurrent();
+    if (!c || c->stepsBegun == c->stepsEnded) { g_err = "sp_ctx_search_end: no step in flight"; return SP_ERR_STATE; }
+    const sp::StepOut o = c->stepOut[c->stepsEnded++ & 1];
+    sp::StepResult r; std::string err;
+    if (!c->gpu.stepEnd(r, err)) { g_err = err; return SP_ERR_OVERFLOW; }
+    c->stats["steps_repeated"] += r.repeat ? 1.0 : 0.0;
+    if (r.repeat) {
+        // rare: the step met a capacity.  Let everything queued finish (a newer step keeps its results), then take this step the synchronous way
+        // into the same buffers; the context remembers the larger sizes.
+        if (getenv("SP_DEBUG")) fprintf(stderr, "[sp] search step repeated: %s\n", r.why.c_str());
+        if (!c->gpu.drain(err)) { g_err = err; return SP_ERR_DEVICE; }
+        c->gpu.setHitSink(o.hits, o.offsets, (size_t) o.hitCap);
+        if (!c->gpu.prefilter(c->kmerThr, c->binSize, sp_ctx_max_seqs(c), c->par.min_ungapped_score, err)) { c->gpu.setHitSink(nullptr, nullptr, 0); g_err = err; return SP_ERR_OVERFLOW; }
+        const uint64_t n = c->gpu.counters().hits;
+        if (n > o.hitCap) { c->gpu.setHitSink(nullptr, nullptr, 0); g_err = "sp_ctx_search_end: the pass delivers " + std::to_string(n) + " hits, the result buffers hold " + std::to_string(o.hitCap); return SP_ERR_OVERFLOW; }
+        sp::AlignDirect direct; direct.records = o.records; direct.cigars = o.cigars; direct.cigarCap = o.cigarCap;
+        uint64_t used = 0;
+        bool ok = c->gpu.align(nullptr, 0, c->par.gap_open, c->par.gap_extend, c->gate, c->alnHost, &direct, err);
+        int rc = ok ? finishDirectOrHost(c, direct, reinterpret_cast<sp_alignment *>(o.records), o.cigars, o.cigarCap, &used) : SP_ERR_DEVICE;
+        const sp::GpuHit *h = nullptr; const uint32_t *off = nullptr; size_t cnt = 0;
+        if (ok && rc == SP_OK && !c->gpu.hostHits(h, off, cnt, err)) { ok = false; rc = SP_ERR_DEVICE; }
+        c->gpu.setHitSink(nullptr, nullptr, 0);
+        if (!ok) g_err = err;
+        if (rc != SP_OK) return rc;
+        c->gpu.stepCapacityHint((size_t) (n + n / 8 + 4096));
+        r.hits = n; r.cigarUsed = used;
+    }
+    prefilterStats(c);
+    sp::KernelTimes kt = c->gpu.times();
+    c->stats["ms_sw_forward"] = kt.swForward; c->stats["ms_sw_reverse"] = kt.swReverse; c->stats["ms_traceback"] = kt.traceback; c->stats["ms_assemble"] = kt.assemble;
+    if (n_hits) *n_hits = r.hits;
+    if (cigar_used) *cigar_used = r.cigarUsed;
+    return SP_OK;
+}
+
 int sp_ctx_rescore(sp_ctx *c, const uint32_t *qidx, const uint32_t *tidx, const int16_t *diag, uint64_t n, int mode, sp_rescore *res) {
     if (c) c->gpu.makeCurrent();
     if (!c || c->targets.n == 0) { g_err = "sp_ctx_rescore: no target set"; return SP_ERR_STATE; }
@@ -559,6 +614,7 @@ int sp_ctx_sync(sp_ctx *c) { c->gpu.makeCurrent(); c->gpu.sync(); return SP_OK; 
 int sp_ctx_set_timing(sp_ctx *c, int level) { c->gpu.setTiming(level); return SP_OK; }
 int sp_ctx_set_tuning(sp_ctx *c, const char *name, int value) {
     if (c && name && !strcmp(name, "match_blocks_per_cu")) { c->gpu.setMatchBlocksPerCU(value); return SP_OK; }
+    if (c && name && c->gpu.setKnob(name, value)) return SP_OK;
     g_err = std::string("sp_ctx_set_tuning: unknown knob '") + (name ? name : "") + "'"; return SP_ERR_ARG;
 }
 int sp_ctx_diag_stream_read(sp_ctx *c, uint64_t bytes, int laneBytes, double *ms) {

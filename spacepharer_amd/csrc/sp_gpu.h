@@ -32,6 +32,10 @@ struct AlnRec { uint32_t dbKey; int32_t bitScore, rawScore; float seqId; double 
 // where align() may put finished records directly (host memory of the caller, ideally page-locked: sp_host_alloc)
 // async: return as soon as the copies are queued; the caller collects them with Gpu::waitAlignCopy()
 struct AlignDirect { void *records = nullptr; char *cigars = nullptr; uint64_t cigarCap = 0; uint64_t cigarUsed = 0; bool done = false; bool overflow = false; bool async = false; };
+// one device-driven search step (Gpu::stepBegin / stepEnd): where its results go (caller-owned, page-locked: sp_host_alloc) ...
+struct StepOut { GpuHit *hits = nullptr; uint32_t *offsets = nullptr; uint64_t hitCap = 0; AlnRec *records = nullptr; char *cigars = nullptr; uint64_t recordCap = 0, cigarCap = 0; };
+// ... and what the host learns when it collects the step
+struct StepResult { uint64_t hits = 0, pairs = 0, cigarUsed = 0; bool repeat = false; std::string why; };
 struct DiagRescore { int32_t score, startPos, endPos, diagonalLen, diagonal; uint32_t distToDiagonal; };
 
 // page-locked host memory for device<->host copies (pageable std::vector memory costs a staging copy per transfer)
@@ -119,6 +123,16 @@ public:
     // buffers (direct->done); when a pair needs the host-driven retry path, `out` is filled instead (direct->done stays false)
     bool align(const SwPair *hostPairs, size_t n, int gapOpen, int gapExtend, const GateTable &gate, AlignHost &out, AlignDirect *direct, std::string &err);
     bool waitAlignCopy(std::string &err);
+    // One whole search step of the resident queries -- prefilter, selection, align of every hit, record assembly, delivery of the hit list, the
+    // records and the packed backtraces into `out` -- queued WITHOUT a host round trip: the hit count stays on the device (kernels sized by a
+    // capacity read it themselves), results and counters travel on the copy stream.  stepBegin returns as soon as everything is queued; up to two
+    // steps may be in flight; stepEnd waits for the OLDEST one.  r.repeat: the step ran into a capacity (more hits than estimated, a traceback that
+    // needs the host path, backtraces beyond out.cigarCap): nothing is lost, the caller repeats the step through prefilter() + align().
+    bool stepBegin(int kmerThr, unsigned binSize, int maxHits, int minDiagScore, int gapOpen, int gapExtend, const GateTable &gate, const StepOut &out, std::string &err);
+    bool stepEnd(StepResult &r, std::string &err);
+    size_t stepsInFlight() const;
+    bool drain(std::string &err);      // both streams idle; uncollected steps keep their results (used before a step is repeated the synchronous way)
+    void stepCapacityHint(size_t pairs);
     uint32_t maxQueryLen() const;
     size_t alignRetries() const { return alignRetries_; }      // pairs of the last align() that went through the host-driven traceback
 
@@ -131,11 +145,15 @@ public:
     void sync();
     void setTiming(int level);
     void setMatchBlocksPerCU(int n);   // 0 = as many as fit
+    bool setKnob(const std::string &name, int value);      // "match_small", "match_heavy_threshold"; false: unknown
     void makeCurrent();            // HIP's current device is per host thread: every entry point that may run on another thread calls this     // 0 none, 1 k_match only (default), 2 every stage
     void *stream() const { return stream_; }
 
 private:
     bool prefetchHits(std::string &err);
+    // recordsLeft / hitsLeft: HIP events (or nullptr) the kernels that rewrite the record / hit buffers wait for on the device
+    bool queueAlign(size_t cap, const uint32_t *nDev, const SwPair *hostPairs, int gapOpen, int gapExtend, const GateTable &gate, bool assemble, bool prefetch, void *recordsLeft, std::string &err);
+    bool queueSelect(unsigned binSize, int maxHits, int minDiagScore, void *hitsLeft, std::string &err);
     bool matchAndScore(int kmerThr, bool withOrd, std::string &err);
     bool finishPrefilter(bool matched, std::string &err);
     struct Impl;

@@ -21,6 +21,7 @@
 
 namespace sp {
 
+
 #define HIP_OK(call)                                                                                   \
     do {                                                                                               \
         hipError_t e_ = (call);                                                                        \
@@ -1618,8 +1619,21 @@ struct SwDev {
 
 struct Gpu::Impl {
     hipStream_t stream = nullptr;
-    hipEvent_t ev[10] = {};
+    hipEvent_t ev[2][10] = {};                   // stage timing events; the device-driven steps alternate between the two sets
+    int evSet = 0;
     int numCU = 256;
+    // environment knobs (diagnostics / experiments), read once per context instead of once per pass
+    struct Knobs {
+        int matchSmall = -1, matchPerCU = 0, matchHeavy = -1, matchStatic = 4, matchDChunk = 4;
+        bool debug = false, prepSplit = false, swRows32 = false, swRows16 = false, swOldForward = false;
+        void read() {
+            auto num = [](const char *k, int d) { const char *e = getenv(k); return e ? atoi(e) : d; };
+            matchSmall = num("SP_MATCH_SMALL", -1); matchPerCU = num("SP_MATCH_PERCU", 0); matchHeavy = num("SP_MATCH_HEAVY", -1);
+            matchStatic = num("SP_MATCH_STATIC", 4); matchDChunk = std::max(1, num("SP_MATCH_DCHUNK", 4));
+            debug = getenv("SP_DEBUG") != nullptr; prepSplit = getenv("SP_PREP_SPLIT") != nullptr; swRows32 = getenv("SP_SW_ROWS32") != nullptr;
+            swRows16 = getenv("SP_SW_ROWS16") != nullptr; swOldForward = getenv("SP_SW_OLD_FORWARD") != nullptr;
+        }
+    } knob;
     // tables
     DevBuf<uint32_t> ext3; DevBuf<uint16_t> ext3cnt; int cntMin = 0; DevBuf<short> seedSub; DevBuf<double> seedBack; DevBuf<signed char> ungSub; DevBuf<signed char> alnSub;
     DevBuf<short> alnSub16; DevBuf<double> alnBack;
@@ -1668,13 +1682,25 @@ struct Gpu::Impl {
     uint32_t nCand = 0;
     SwState sw;
     SwDev swd;
+    // device-driven steps (stepBegin / stepEnd): the whole pass -- prefilter, selection, align, record assembly, delivery -- is queued without a
+    // host round trip; counts stay on the device, results and counters travel on the copy stream.  Up to two steps in flight.
+    struct StepSlot { hipEvent_t selected = nullptr, assembled = nullptr, hitsOnHost = nullptr, alnOnHost = nullptr; size_t cap = 0; StepOut out; };
+    StepSlot step[2];
+    uint64_t stepsBegun = 0, stepsEnded = 0;
+    bool drained = false;                        // every queued step has finished on the device and its results are in host memory (drain())
+    size_t stepCap = 0;                          // pairs the device buffers of a step are sized for (grows with what the steps deliver)
+    DevBuf<uint32_t> stepWords;                  // [0] hits of the pass, [1] pairs aligned = min(hits, capacity), [2] flags
+    uint32_t *stepMail = nullptr;                // page-locked: 2 x 64 words, one block per step in flight
 };
 
 Gpu::Gpu() : d_(new Impl) {}
 Gpu::~Gpu() {
     if (d_) {
+        if (d_->stream) (void) hipStreamSynchronize(d_->stream);
         if (d_->stream) (void) hipStreamDestroy(d_->stream);
-        for (hipEvent_t e : d_->ev) if (e) (void) hipEventDestroy(e);
+        for (auto &set : d_->ev) for (hipEvent_t e : set) if (e) (void) hipEventDestroy(e);
+        for (Impl::StepSlot &ss : d_->step) for (hipEvent_t e : {ss.selected, ss.assembled, ss.hitsOnHost, ss.alnOnHost}) if (e) (void) hipEventDestroy(e);
+        if (d_->stepMail) pinnedFree(d_->stepMail);
         if (d_->mailbox) pinnedFree(d_->mailbox);
         if (d_->copyStream) { (void) hipStreamSynchronize(d_->copyStream); (void) hipStreamDestroy(d_->copyStream); }
         if (d_->hitsOnHost) (void) hipEventDestroy(d_->hitsOnHost);
@@ -1695,11 +1721,19 @@ static hipError_t spinSync(hipStream_t s) {
 }
 
 // stage timing: an event record between two kernels opens a ~6 us bubble, so only the roofline kernel is bracketed by default
-#define SP_EV(i, level) do { if (d.timing >= (level)) HIP_OK(hipEventRecord(d.ev[i], d.stream)); } while (0)
+#define SP_EV(i, level) do { if (d.timing >= (level)) HIP_OK(hipEventRecord(d.ev[d.evSet][i], d.stream)); } while (0)
 static float evMs(int timing, int level, hipEvent_t a, hipEvent_t b) {
     float t = 0; if (timing < level || hipEventElapsedTime(&t, a, b) != hipSuccess) return __builtin_nanf(""); return t;
 }
 void Gpu::setMatchBlocksPerCU(int n) { d_->matchPerCU = n < 0 ? 0 : n; }
+// scheduling knobs of k_match (they change the order of the work, never a result): footprint -1 by index density / 0 large / 1 small;
+// similar k-mers from which a query is started first, -1 = by batch size, 0 = no list.  Initial values: SP_MATCH_SMALL / SP_MATCH_HEAVY.
+bool Gpu::setKnob(const std::string &name, int value) {
+    if (name == "match_small") { d_->knob.matchSmall = value < 0 ? -1 : (value ? 1 : 0); return true; }
+    if (name == "match_heavy_threshold") { d_->knob.matchHeavy = value < 0 ? -1 : value; return true; }
+    if (name == "step_capacity") { d_->stepCap = value < 0 ? 0 : (size_t) value; return true; }      // pairs the next device-driven step is sized for (0 = estimate again); tests
+    return false;
+}
 void Gpu::makeCurrent() { (void) hipSetDevice(d_->device); }
 void Gpu::setTiming(int level) { d_->timing = level < 0 ? 0 : (level > 2 ? 2 : level); }
 
@@ -1714,12 +1748,19 @@ __global__ void k_fill(FillArgs a) {
 
 // small results for the host: one kernel stores them straight into the page-locked mailbox (each hipMemcpyAsync of a few
 // bytes is a copy kernel of its own)
-struct PublishArgs { const void *src[3]; uint32_t words[3]; uint32_t at[3]; uint32_t *mailbox; };
+struct PublishArgs { const void *src[5]; uint32_t words[5]; uint32_t at[5]; uint32_t *mailbox; };
 __global__ void k_publish(PublishArgs a) {
-    for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < 5; r++) {
         const uint32_t *s = static_cast<const uint32_t *>(a.src[r]);
         for (uint32_t i = threadIdx.x; i < a.words[r]; i += blockDim.x) a.mailbox[a.at[r] + i] = s[i];
     }
+}
+
+// a device-driven step learns its pair count here: hits of the selection (the scan leaves the total behind the last query's offset), clipped to
+// the capacity the align buffers and the caller's result buffers were sized for; a clipped step is flagged and repeated by the host
+struct StepCountArgs { const uint32_t *total; uint32_t cap; uint32_t *words; };
+__global__ void k_step_counts(StepCountArgs a) {
+    if (threadIdx.x == 0) { const uint32_t n = *a.total; a.words[0] = n; a.words[1] = n < a.cap ? n : a.cap; a.words[2] = n > a.cap ? 1u : 0u; }
 }
 
 int Gpu::deviceCount() const { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
@@ -1745,7 +1786,9 @@ bool Gpu::init(int device, std::string &err) {
     HIP_OK(hipStreamCreateWithFlags(&d_->copyStream, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&d_->hitsOnHost, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&d_->alnOnHost, hipEventDisableTiming));
-    for (hipEvent_t &e : d_->ev) HIP_OK(hipEventCreate(&e));
+    for (auto &set : d_->ev) for (hipEvent_t &e : set) HIP_OK(hipEventCreate(&e));
+    for (Impl::StepSlot &ss : d_->step) for (hipEvent_t *e : {&ss.selected, &ss.assembled, &ss.hitsOnHost, &ss.alnOnHost}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    d_->knob.read();
     stream_ = d_->stream;
     return true;
 }
@@ -1870,14 +1913,14 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     // 45 vs 51 ms at 2 x 10^8 residues, because three blocks per CU stay resident instead of one).
     // footprint by index density (SP_MATCH_SMALL=0/1 overrides): sparse -> small, dense -> large; the sharded search always small
     // (its ordinal arrays push the large footprint to two blocks per CU)
-    const bool small = getenv("SP_MATCH_SMALL") ? atoi(getenv("SP_MATCH_SMALL")) != 0 : (withOrd || !d.denseIndex);
+    const bool small = d.knob.matchSmall >= 0 ? d.knob.matchSmall != 0 : (withOrd || !d.denseIndex);
     const void *fn = small ? (withOrd ? (const void *) k_match<256, true, true> : (const void *) k_match<256, false, true>)
                            : (withOrd ? (const void *) k_match<512, true, false> : (const void *) k_match<512, false, false>);
     int perCU = 2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, fn, 64 * kWavesPerBlock, 0) != hipSuccess || perCU < 1) perCU = 2;
     if (d.matchPerCU > 0) perCU = std::min(perCU, d.matchPerCU);
-    if (const char *e = getenv("SP_MATCH_PERCU")) perCU = std::max(1, atoi(e));
-    const bool dbg = getenv("SP_DEBUG") != nullptr;
+    if (d.knob.matchPerCU > 0) perCU = d.knob.matchPerCU;
+    const bool dbg = d.knob.debug;
     if (dbg) fprintf(stderr, "[sp] k_match footprint=%s ord=%d blocks/CU=%d\n", small ? "small" : "large", (int) withOrd, perCU);
     const uint32_t blocks = (uint32_t) std::min<size_t>((nq_ + kWavesPerBlock - 1) / kWavesPerBlock, (size_t) d.numCU * perCU);
     d.matchBlocks = blocks;
@@ -1895,10 +1938,10 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     // SP_MATCH_HEAVY: similar k-mers from which a query counts as heavy and is started first (0 = none)
     // (worth its 30 us per 60 000 queries only while a wave gets few queries: with more than ~30 per wave the heavy ones no
     // longer decide when the kernel ends)
-    const uint32_t heavyThr = getenv("SP_MATCH_HEAVY") ? (uint32_t) atoi(getenv("SP_MATCH_HEAVY")) : (nq_ <= (size_t) blocks * kWavesPerBlock * 32 ? 4000u : 0u);
+    const uint32_t heavyThr = d.knob.matchHeavy >= 0 ? (uint32_t) d.knob.matchHeavy : (nq_ <= (size_t) blocks * kWavesPerBlock * 32 ? 4000u : 0u);
     WeighArgs wa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, heavyThr ? heavyThr : 0xFFFFFFFFu, d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p};
     const unsigned weighBlocks = (unsigned) std::min<size_t>((nq_ + 31) / 32, (size_t) d.numCU * 8);
-    if (d.maxQLen <= 64 && !getenv("SP_PREP_SPLIT")) {
+    if (d.maxQLen <= 64 && !d.knob.prepSplit) {
         const uint32_t stride = std::max<uint32_t>(16u, (d.maxQLen + 7u) & ~7u);      // staging row per query (<= 64)
         Prep8Args p8{pa, wa, stride};
         hipLaunchKernelGGL(k_prep8, dim3(weighBlocks), dim3(256), (size_t) 32 * stride * 12, d.stream, p8);
@@ -1914,7 +1957,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.pbits.p, d.prank.p, d.prow.p, d.slots.p, d.ientries.p, d.spill.p, d.queue.p,
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
-                 (uint32_t) (getenv("SP_MATCH_STATIC") ? atoi(getenv("SP_MATCH_STATIC")) : 4), (uint32_t) (getenv("SP_MATCH_DCHUNK") ? std::max(1, atoi(getenv("SP_MATCH_DCHUNK"))) : 4),
+                 (uint32_t) d.knob.matchStatic, (uint32_t) d.knob.matchDChunk,
                  d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p, d.wavePartial.p};
     if (small) {
         if (withOrd) hipLaunchKernelGGL((k_match<256, true, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
@@ -1938,7 +1981,7 @@ bool Gpu::finishPrefilter(bool matched, std::string &err) {
     unsigned long long *c = d.mailbox; uint32_t *qv = reinterpret_cast<uint32_t *>(d.mailbox + 16); uint32_t &totalHits = *reinterpret_cast<uint32_t *>(d.mailbox + 24);
     totalHits = 0;
     {   // counters -> mailbox words 0..31, queue -> 32..39, the number of hits (the scan leaves it behind the last query's offset) -> 48
-        PublishArgs pa{{d.counters.p, d.queue.p, d.outOffset.p + nq_}, {32, 8, 1}, {0, 32, 48}, reinterpret_cast<uint32_t *>(d.mailbox)};
+        PublishArgs pa{{d.counters.p, d.queue.p, d.outOffset.p + nq_, nullptr, nullptr}, {32, 8, 1, 0, 0}, {0, 32, 48, 0, 0}, reinterpret_cast<uint32_t *>(d.mailbox)};
         hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, d.stream, pa);
     }
     HIP_OK(spinSync(d.stream));
@@ -1955,11 +1998,11 @@ bool Gpu::finishPrefilter(bool matched, std::string &err) {
     }
 #endif
     if (matched) {
-        times_.prep = evMs(d.timing, 2, d.ev[0], d.ev[1]);
-        times_.match = evMs(d.timing, 1, d.ev[1], d.ev[2]);
-        times_.score = evMs(d.timing, 2, d.ev[2], d.ev[3]);
+        times_.prep = evMs(d.timing, 2, d.ev[d.evSet][0], d.ev[d.evSet][1]);
+        times_.match = evMs(d.timing, 1, d.ev[d.evSet][1], d.ev[d.evSet][2]);
+        times_.score = evMs(d.timing, 2, d.ev[d.evSet][2], d.ev[d.evSet][3]);
     }
-    times_.select = evMs(d.timing, 2, d.ev[3], d.ev[4]);
+    times_.select = evMs(d.timing, 2, d.ev[d.evSet][3], d.ev[d.evSet][4]);
     if (counters_.overflowQueries) {
         // error path only: name the first offending query (k_match marks them in qDiagBase)
         std::vector<uint32_t> base(nq_); std::string which;
@@ -1974,23 +2017,136 @@ bool Gpu::finishPrefilter(bool matched, std::string &err) {
     return true;
 }
 
-bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore, std::string &err) {
+// selection of the scored diagonals + hits into query order (queued behind matchAndScore)
+bool Gpu::queueSelect(unsigned binSize, int maxHits, int minDiagScore, void *hitsLeft, std::string &err) {
     Impl &d = *d_;
-    if (nq_ == 0) return true;
-    maxHits_ = maxHits;
-    if (!matchAndScore(kmerThr, false, err)) return false;
-    const bool dbg = getenv("SP_DEBUG") != nullptr;
+    const bool dbg = d.knob.debug;
     // a query's selected hits are staged where its diagonal records sit (they are at most as many): no separate layout pass
     const size_t stageCap = std::max<size_t>(nq_ * (size_t) maxHits, d.diagCap);
     if (!d.outHits.ensure(nq_ * (size_t) maxHits, err) || !d.outStage.ensure(stageCap, err) || !d.outQuery.ensure(stageCap, err)) return false;
     SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.qDiagBase.p,
                   binSize - 1, maxHits, minDiagScore, d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.counters.p};
     hipLaunchKernelGGL(k_select, dim3(d.matchBlocks), dim3(64 * kWavesPerBlock), 0, d.stream, se);
+    if (hitsLeft) HIP_OK(hipStreamWaitEvent(d.stream, static_cast<hipEvent_t>(hitsLeft), 0));      // the previous step's hit list has left outOffset / outHits
     if (!d.scanCounts(d.outCount.p, (uint32_t) nq_, d.outOffset.p, err)) return false;
     hipLaunchKernelGGL(k_reorder_hits, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.outStage.p, d.outBase.p, d.outCount.p, d.outOffset.p, (uint32_t) nq_, d.outHits.p, d.outQuery.p);
     SP_DBG_SYNC("k_select");
     SP_EV(4, 2);
+    return true;
+}
+
+bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore, std::string &err) {
+    Impl &d = *d_;
+    if (nq_ == 0) return true;
+    if (d.stepsBegun != d.stepsEnded && !d.drained) { err = "prefilter: a device-driven step is in flight (collect it with stepEnd first)"; return false; }
+    maxHits_ = maxHits;
+    if (!matchAndScore(kmerThr, false, err)) return false;
+    if (!queueSelect(binSize, maxHits, minDiagScore, nullptr, err)) return false;
     return finishPrefilter(true, err);      // the hit list travels when somebody asks for it (hostHits) or underneath the align kernels (align)
+}
+
+// ---- device-driven steps ----------------------------------------------------------------------------------------------------------------
+// wait until everything queued on both streams is done (steps not yet collected keep their results and counters)
+bool Gpu::drain(std::string &err) {
+    Impl &d = *d_;
+    HIP_OK(hipStreamSynchronize(d.stream));
+    HIP_OK(hipStreamSynchronize(d.copyStream));
+    d.drained = true;
+    d.evSet = (int) (d.stepsEnded & 1) ^ 1;      // the event set no uncollected step reads its times from
+    return true;
+}
+size_t Gpu::stepsInFlight() const { return (size_t) (d_->stepsBegun - d_->stepsEnded); }
+void Gpu::stepCapacityHint(size_t pairs) { d_->stepCap = std::max(d_->stepCap, pairs); }
+
+bool Gpu::stepBegin(int kmerThr, unsigned binSize, int maxHits, int minDiagScore, int gapOpen, int gapExtend, const GateTable &gate, const StepOut &out, std::string &err) {
+    Impl &d = *d_;
+    SwDev &s = d.swd;
+    if (d.stepsBegun - d.stepsEnded >= 2) { err = "stepBegin: two steps are in flight, collect one with stepEnd first"; return false; }
+    if (nq_ == 0) { err = "stepBegin: no queries resident"; return false; }
+    if (!out.hits || !out.offsets || !out.records || !out.cigars) { err = "stepBegin: result buffers missing"; return false; }
+    if (!d.stepMail) { d.stepMail = static_cast<uint32_t *>(pinnedAlloc(2 * 64 * sizeof(uint32_t))); memset(d.stepMail, 0, 2 * 64 * sizeof(uint32_t)); }
+    const int slot = (int) (d.stepsBegun & 1);
+    Impl::StepSlot &ss = d.step[slot];
+    d.drained = false;
+    // capacity of this step: what earlier passes delivered plus a margin, bounded by the caller's buffers
+    if (d.stepCap == 0) d.stepCap = counters_.hits ? (size_t) counters_.hits + (size_t) counters_.hits / 8 + 4096 : nq_ * 4 + 4096;
+    const size_t cap = std::max<size_t>(1, std::min<size_t>({d.stepCap, (size_t) out.hitCap, (size_t) out.recordCap, (size_t) 0x7FFFFFF0u}));
+    ss.cap = cap; ss.out = out;
+    maxHits_ = maxHits;
+    if (!d.stepWords.ensure(4, err)) return false;
+    // the step in front: its hit list / records are still leaving buffers this one rewrites near its end -- the kernels that rewrite them wait
+    // for those copies on the device (k_reorder_hits, k_aln_assemble), everything before them runs underneath the copies
+    const bool behind = d.stepsBegun != d.stepsEnded;
+    const Impl::StepSlot &prev = d.step[slot ^ 1];
+    if (!behind) {
+        if (d.hitsInFlight) { (void) hipEventSynchronize(d.hitsOnHost); d.hitsInFlight = false; }
+        if (!waitAlignCopy(err)) return false;
+    }
+    d.evSet = slot;
+    if (!matchAndScore(kmerThr, false, err)) return false;
+    if (!queueSelect(binSize, maxHits, minDiagScore, behind ? prev.hitsOnHost : nullptr, err)) return false;
+    {   StepCountArgs ca{d.outOffset.p + nq_, (uint32_t) cap, d.stepWords.p};
+        hipLaunchKernelGGL(k_step_counts, dim3(1), dim3(64), 0, d.stream, ca); }
+    HIP_OK(hipEventRecord(ss.selected, d.stream));
+    // the hit list travels underneath the align kernels: offsets exactly, hit records up to the capacity
+    HIP_OK(hipStreamWaitEvent(d.copyStream, ss.selected, 0));
+    HIP_OK(hipMemcpyAsync(out.offsets, d.outOffset.p, (nq_ + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, d.copyStream));
+    HIP_OK(hipMemcpyAsync(out.hits, d.outHits.p, cap * sizeof(GpuHit), hipMemcpyDeviceToHost, d.copyStream));
+    HIP_OK(hipEventRecord(ss.hitsOnHost, d.copyStream));
+    if (!queueAlign(cap, d.stepWords.p + 1, nullptr, gapOpen, gapExtend, gate, true, false, behind ? prev.alnOnHost : nullptr, err)) return false;
+    // counters of the step -> its mailbox block (page-locked): prefilter counters [0, 32), work queues [32, 40), step words [40, 44), align counters [44, 52), backtrace bytes [52]
+    {   PublishArgs pa{{d.counters.p, d.queue.p, d.stepWords.p, s.counters.p, s.cigOff.p + cap}, {32, 8, 4, 8, 1}, {0, 32, 40, 44, 52}, d.stepMail + 64 * slot};
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, d.stream, pa); }
+    SP_EV(9, 2);
+    HIP_OK(hipEventRecord(ss.assembled, d.stream));
+    HIP_OK(hipStreamWaitEvent(d.copyStream, ss.assembled, 0));
+    HIP_OK(hipMemcpyAsync(out.records, s.rec.p, cap * sizeof(AlnRec), hipMemcpyDeviceToHost, d.copyStream));
+    const size_t cigBytes = (size_t) std::min<uint64_t>(out.cigarCap, (uint64_t) s.cig.n);
+    if (cigBytes) HIP_OK(hipMemcpyAsync(out.cigars, s.cig.p, cigBytes, hipMemcpyDeviceToHost, d.copyStream));
+    HIP_OK(hipEventRecord(ss.alnOnHost, d.copyStream));
+    HIP_OK(hipGetLastError());
+    d.stepsBegun++;
+    return true;
+}
+
+bool Gpu::stepEnd(StepResult &r, std::string &err) {
+    Impl &d = *d_;
+    r = StepResult();
+    if (d.stepsBegun == d.stepsEnded) { err = "stepEnd: no step in flight"; return false; }
+    const int slot = (int) (d.stepsEnded & 1);
+    Impl::StepSlot &ss = d.step[slot];
+    for (hipEvent_t e : {ss.hitsOnHost, ss.alnOnHost}) {      // short waits on the critical path: poll
+        for (;;) { const hipError_t q = hipEventQuery(e); if (q == hipSuccess) break; if (q != hipErrorNotReady) { err = std::string("stepEnd: ") + hipGetErrorString(q); d.stepsEnded++; return false; } __builtin_ia32_pause(); }
+    }
+    d.stepsEnded++;
+    const uint32_t *m = d.stepMail + 64 * slot;
+    const unsigned long long *c = reinterpret_cast<const unsigned long long *>(m);
+    counters_.kmers = c[0]; counters_.dbMatches = c[1]; counters_.overflowQueries = c[2]; counters_.diagResidues = c[3]; counters_.diagonals = c[5];
+    const uint32_t nHits = m[40], nPairs = m[41], clipped = m[42], needHost = m[44 + 2], cigTotal = m[52];
+    counters_.hits = nHits;
+    d.nCand = m[32 + 4];
+    d.sw.n = nPairs;
+    alignRetries_ = 0;
+    times_ = KernelTimes();
+    times_.prep = evMs(d.timing, 2, d.ev[slot][0], d.ev[slot][1]);
+    times_.match = evMs(d.timing, 1, d.ev[slot][1], d.ev[slot][2]);
+    times_.score = evMs(d.timing, 2, d.ev[slot][2], d.ev[slot][3]);
+    times_.select = evMs(d.timing, 2, d.ev[slot][3], d.ev[slot][4]);
+    times_.swForward = evMs(d.timing, 2, d.ev[slot][5], d.ev[slot][6]);
+    times_.swReverse = evMs(d.timing, 2, d.ev[slot][6], d.ev[slot][7]);
+    times_.traceback = evMs(d.timing, 2, d.ev[slot][7], d.ev[slot][8]);
+    times_.assemble = evMs(d.timing, 2, d.ev[slot][8], d.ev[slot][9]);
+    r.hits = nHits; r.pairs = nPairs; r.cigarUsed = cigTotal;
+    d.stepCap = std::max<size_t>(d.stepCap, (size_t) nHits + (size_t) nHits / 8 + 4096);
+    if (counters_.overflowQueries) {
+        err = std::to_string(counters_.overflowQueries) + " queries produced more index hits (limit 65535 per query), diagonals or candidates than the device buffers hold; "
+              "run sp_ctx_prefilter() on this batch for the list of such queries and search them against target shards (sp_ctx_set_targets_shard / sp_ctx_merge_candidates)";
+        return false;
+    }
+    if (clipped) { r.repeat = true; r.why = "more hits (" + std::to_string(nHits) + ") than the step was sized for (" + std::to_string(ss.cap) + ")"; }
+    else if (needHost) { r.repeat = true; r.why = std::to_string(needHost) + " alignments need the host-driven traceback"; }
+    else if (cigTotal > ss.out.cigarCap) { r.repeat = true; r.why = "backtraces (" + std::to_string(cigTotal) + " bytes) exceed the caller's buffer"; }
+    return true;
 }
 
 // sharded search, step 1: this shard's candidates (per query and target the best double-hit diagonal with score >= min)
@@ -1999,7 +2155,7 @@ bool Gpu::prefilterCandidates(int kmerThr, int minDiagScore, std::string &err) {
     d.nCand = 0;
     if (nq_ == 0) return true;
     if (!matchAndScore(kmerThr, true, err)) return false;
-    const bool dbg = getenv("SP_DEBUG") != nullptr;
+    const bool dbg = d.knob.debug;
     if (!d.cand.ensure(d.diagCap, err)) return false;
     CandArgs ca{d.diagRec.p, d.diagQuery.p, d.diagScore.p, d.diagOrd.p, d.queue.p + 1, (uint32_t) d.diagCap, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qoff.p, minDiagScore,
                 d.cand.p, d.queue.p + 4, (uint32_t) d.diagCap};
@@ -2033,7 +2189,7 @@ bool Gpu::mergeCandidates(const Candidate *src, size_t n, bool onDevice, size_t 
     if (n >= (1ull << 32)) { err = "mergeCandidates: more than 2^32 candidates"; return false; }
     qTo = std::min(qTo, nq_); qFrom = std::min(qFrom, qTo);
     maxHits_ = maxHits;
-    const bool dbg = getenv("SP_DEBUG") != nullptr;
+    const bool dbg = d.knob.debug;
     const size_t stageCap = std::max<size_t>(nq_ * (size_t) maxHits, n + 1);      // a query's hits are staged where its candidates sit in the grouped list
     if (!d.outHits.ensure(nq_ * (size_t) maxHits, err) || !d.outStage.ensure(stageCap, err) || !d.outQuery.ensure(stageCap, err)) return false;
     if (!d.candCnt.ensure(nq_ + 1, err) || !d.candFill.ensure(nq_ + 1, err) || !d.candOffset.ensure(nq_ + 2, err) || !d.candByQuery.ensure(n + 1, err)) return false;
@@ -2076,7 +2232,7 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
     if (!d.tplain.ensure((size_t) R + 1, err) || !d.tmasked.ensure((size_t) R + 1, err) || !d.ixCounters.ensure(4, err)) return false;
     HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_aa2num), seed.aa2num, 256, 0, hipMemcpyHostToDevice, d.stream));
     HIP_OK(hipMemsetAsync(d.ixCounters.p, 0, 4 * sizeof(unsigned long long), d.stream));
-    HIP_OK(hipEventRecord(d.ev[0], d.stream));
+    HIP_OK(hipEventRecord(d.ev[0][0], d.stream));
     if (R) { MapArgs ma{d.tascii.p, R, d.tplain.p, d.tmasked.p}; hipLaunchKernelGGL(k_map_residues, dim3((unsigned) std::min<uint64_t>((R + 255) / 256, 65536)), dim3(256), 0, d.stream, ma); }
     if (mask && to > from) {
         TantanModel tm; tantanModel(seed, tm);
@@ -2088,7 +2244,7 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
         ta.b2b = tm.b2b; ta.f2b = tm.f2b; ta.f2f0 = tm.f2f0; ta.probs = d.ttProbs.p; ta.scale = d.ttScale.p; ta.maskedCount = d.ixCounters.p;
         hipLaunchKernelGGL(k_tantan, dim3((unsigned) ((to - from + 63) / 64)), dim3(64), 0, d.stream, ta);
     }
-    HIP_OK(hipEventRecord(d.ev[1], d.stream));
+    HIP_OK(hipEventRecord(d.ev[0][1], d.stream));
     const size_t words = kTableSize / 64;
     d.denseIndex = false;
     if (!d.pbits.ensure(words, err) || !d.prank.ensure(words, err) || !d.prow.ensure(kTableSize / 8000, err) || !d.slots.ensure(1, err) || !d.ientries.ensure(1, err)) return false;
@@ -2151,14 +2307,14 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
             d.indexEntries = E; out.indexEntries = E; out.indexSlots = nSlots;
         }
     }
-    HIP_OK(hipEventRecord(d.ev[2], d.stream));
+    HIP_OK(hipEventRecord(d.ev[0][2], d.stream));
     unsigned long long ctr[4];
     HIP_OK(hipMemcpyAsync(ctr, d.ixCounters.p, sizeof(ctr), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipStreamSynchronize(d.stream));
     HIP_OK(hipGetLastError());
     out.maskedResidues = ctr[0];
-    (void) hipEventElapsedTime(&out.msMask, d.ev[0], d.ev[1]);
-    (void) hipEventElapsedTime(&out.msIndex, d.ev[1], d.ev[2]);
+    (void) hipEventElapsedTime(&out.msMask, d.ev[0][0], d.ev[0][1]);
+    (void) hipEventElapsedTime(&out.msIndex, d.ev[0][1], d.ev[0][2]);
     return true;
 }
 

@@ -43,11 +43,11 @@ def test_dense_unsplit_equals_union_of_eight_sparse_shards():
     ctx.prefilter()                                                                     # idempotent
     h2, off2, n2 = _hits_np(ctx)
     assert n2 == n and np.array_equal(h2, h) and np.array_equal(off2, off)
-    os.environ["SP_MATCH_SMALL"] = "1"                                                  # the footprint meant for sparse indices (256 hits in LDS,
+    ctx.set_tuning("match_small", 1)                                                    # the footprint meant for sparse indices (256 hits in LDS,
     try:                                                                                # 8 192-bucket pre-filter): slower here, same hits
         ctx.prefilter()
     finally:
-        os.environ.pop("SP_MATCH_SMALL", None)
+        ctx.set_tuning("match_small", -1)
     h2, off2, n2 = _hits_np(ctx)
     assert n2 == n and np.array_equal(h2, h) and np.array_equal(off2, off)
     aln, cig, na = ctx.align_hits_raw()

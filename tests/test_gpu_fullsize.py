@@ -104,11 +104,11 @@ def test_work_order_and_timing_level_do_not_change_results(full):
         h2 = np.ctypeslib.as_array(C.cast(hits, C.POINTER(C.c_int32)), shape=(max(1, n), 3))[:n]
         return n == full["n"] and np.array_equal(h2, h) and np.array_equal(np.ctypeslib.as_array(offs).astype(np.int64), off)
     try:
-        for thr in ("0", "1500", "20000"):
-            os.environ["SP_MATCH_HEAVY"] = thr
+        for thr in (0, 1500, 20000):
+            ctx.set_tuning("match_heavy_threshold", thr)
             assert same(), thr
     finally:
-        os.environ.pop("SP_MATCH_HEAVY", None)
+        ctx.set_tuning("match_heavy_threshold", -1)
     try:
         ctx.set_timing(0); assert same(); assert ctx.stat("ms_match") != ctx.stat("ms_match")          # NaN
         ctx.set_timing(2); assert same(); assert ctx.stat("ms_match") > 0 and ctx.stat("ms_select") > 0
@@ -178,50 +178,76 @@ def _deliver(ctx, slot):
 
 
 def test_two_contexts_in_flight_deliver_the_single_context_bytes():
-    """the configuration bench.py times: two search contexts on one GPU, each on its own host thread and HIP streams with its
-    own query batch, match_blocks_per_cu = 3 (bench.py --match-blocks default), passes interleaving freely.  Every round of both contexts must deliver exactly
-    the bytes (hit list, offsets, sp_alignment records, backtrace pool) the same batch gives when its context has the GPU to
-    itself with default tuning."""
+    """the configuration bench.py times: two search contexts on one GPU, each on its own host thread and HIP streams with its own query batch,
+    the bench's match_blocks_per_cu, every step queued device-driven (sp_ctx_search_begin / _end) with TWO steps in flight per context, into its
+    own page-locked buffers.  Every step of both contexts must deliver exactly the bytes (hit list, offsets, sp_alignment records, backtrace
+    pool) the same batch gives through the synchronous path when its context has the GPU to itself with default tuning.  Then the same with the
+    host-driven step (bench.py --host-driven)."""
+    import argparse
     import threading
     import bench
     import spacepharer_amd as sa
     L = sa.load_library()
+    match_blocks = 3      # bench.py --match-blocks default
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'ap.add_argument("--match-blocks", type=int, default=%d' % match_blocks in src
     batches = [bench.make_workload(10000, 50000, 200, 12345, qs) for qs in (None, 12345 + 104729)]
     ctxs, slots, ref = [], [], []
+    rounds = 12
     for tres, toff, qres, qoff in batches:
         c = sa.SearchContext()
         c.set_targets_raw(tres.tobytes(), bench.u64p(toff), len(toff) - 1)
         c.set_queries_raw(qres.tobytes(), bench.u64p(qoff), len(qoff) - 1)
         c.prefilter()
-        s = bench.Slot(L, len(qoff) - 1, int(c.num_hits() * 1.05) + 1024, True)
-        ref.append(_deliver(c, s))                # alone on the GPU
-        ctxs.append(c); slots.append(s)
+        ss = [bench.Slot(L, len(qoff) - 1, int(c.num_hits() * 1.05) + 1024, True) for _ in range(3)]
+        ref.append(_deliver(c, ss[0]))                # alone on the GPU, synchronous path
+        ctxs.append(c); slots.append(ss)
     assert ref[0] != ref[1] and len(ref[0][1]) > 8 * 60000 and len(ref[1][2]) > 60 * 60000
     for c in ctxs:
-        c.set_tuning("match_blocks_per_cu", 3)      # what bench.py sets for its timed regions (--match-blocks)
-    rounds, bad, errors = 12, [], []
-    gate = threading.Barrier(2)
+        c.set_tuning("match_blocks_per_cu", match_blocks)
 
-    def run(i):
-        try:
-            gate.wait()
-            for r in range(rounds):
-                got = _deliver(ctxs[i], slots[i])
-                for part, (g, e) in enumerate(zip(got, ref[i])):
-                    if g != e:
-                        bad.append((i, r, part))
-        except Exception as e:      # noqa: BLE001
-            errors.append(repr(e))
+    def got(s, n, used):
+        return (C.string_at(s.off, 4 * (s.nq + 1)), C.string_at(s.hits, 8 * n), bench_mod().record_fields(s.rec, n), C.string_at(s.cig, used))
 
-    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    assert not errors, errors
-    assert not bad, bad[:10]
-    for s in slots:
-        s.free()
+    for device_driven in (True, False):
+        bad, errors = [], []
+        gate = threading.Barrier(2)
+
+        def run(i):
+            try:
+                c, ss = ctxs[i], slots[i]
+                gate.wait()
+                if not device_driven:
+                    for r in range(rounds):
+                        for part, (g, e) in enumerate(zip(_deliver(c, ss[0]), ref[i])):
+                            if g != e:
+                                bad.append((i, r, part))
+                    return
+                prev = None
+                for r in range(rounds + 1):
+                    if r < rounds:
+                        s = ss[r % 3]
+                        c.search_begin(s.hits, s.off, s.cap, s.rec, s.cig, s.cig_cap)
+                    if prev is not None:
+                        n, used = c.search_end()
+                        for part, (g, e) in enumerate(zip(got(prev, n, used), ref[i])):
+                            if g != e:
+                                bad.append((i, r - 1, part))
+                    prev = ss[r % 3] if r < rounds else None
+            except Exception as e:      # noqa: BLE001
+                errors.append(repr(e))
+
+        th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, (device_driven, errors)
+        assert not bad, (device_driven, bad[:10])
+    assert all(c.stat("steps_repeated") == 0 for c in ctxs)
+    for ss in slots:
+        for s in ss:
+            s.free()
     for c in ctxs:
         c.close()
 

@@ -39,17 +39,16 @@ def test_prefilter_matches_reference_golden(name):
     # double-hit diagonals found over all queries (QueryMatcher::match output sizes)
     assert ctx.stat("diagonals") == sum(len(q["diag"]) for q in r["queries"])
     # k_match has two footprints and picks by the index' density: the other one must find the same
-    import os
     try:
-        for small in ("0", "1"):
-            os.environ["SP_MATCH_SMALL"] = small
+        for small in (0, 1):
+            ctx.set_tuning("match_small", small)
             ctx.prefilter()
             got = ctx.hits()
             for q in r["queries"]:
                 assert [list(h) for h in got[q["id"]]] == q["hits"], (name, q["id"], small)
             assert ctx.stat("diagonals") == sum(len(q["diag"]) for q in r["queries"])
     finally:
-        os.environ.pop("SP_MATCH_SMALL", None)
+        ctx.set_tuning("match_small", -1)
     ctx.close()
 
 
