@@ -635,10 +635,12 @@ def main():
             pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "module_e2e.py"), "10000", "100000"], capture_output=True, text=True, timeout=1200)
             doc = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])["module_e2e"]
             out["module_e2e"] = {"what": "spacer-queries/s files-to-files on the bench targets (1e7 residues): module argv in, alignment DB on disk out; 'process' = fresh processes of "
-                                         "spacepharer_amd/spacepharer-amd per module call (process start + HIP runtime start-up + tables included), 'warm' = repeated call inside one process, 'served' = client processes of the same binary forwarding to a resident `spacepharer-amd serve` (runtime, tables and target set stay up)",
+                                         "spacepharer_amd/spacepharer-amd per module call (process start + HIP runtime start-up + tables included), 'warm' = repeated call inside one process, 'served' = client processes of the same binary forwarding to a resident `spacepharer-amd serve` (runtime, tables and target set stay up), 'auto_server' = the same fresh client processes with SP_SERVER=auto and nothing set up: the first one starts the server (first = the pair of calls that pays for it, next = the pairs after it; the server leaves when idle)",
                                  "runs": [{"spacers": r["spacers"], "mode": r["mode"], "threads": r["threads"], "process_s": r["process_total_s"], "process_spacer_queries_per_s": r["process_spacer_queries_per_s"],
                                            "in_process_s": [x["total_s"] for x in r["runs"]], "warm_spacer_queries_per_s": r["warm_spacer_queries_per_s"],
-                                           "served_s": r["served_total_s"], "served_spacer_queries_per_s": r["served_spacer_queries_per_s"], "aln_db_bytes": r["aln_db_bytes"],
+                                           "served_s": r["served_total_s"], "served_spacer_queries_per_s": r["served_spacer_queries_per_s"],
+                                           "auto_server_s": r["auto_server_total_s"], "auto_server_first_spacer_queries_per_s": r["auto_server_first_spacer_queries_per_s"],
+                                           "auto_server_next_spacer_queries_per_s": r["auto_server_next_spacer_queries_per_s"], "aln_db_bytes": r["aln_db_bytes"],
                                            "aln_db_crc": r["aln_db_crc"]} for r in doc]}
         except Exception as e:      # noqa: BLE001
             out["module_e2e"] = {"error": repr(e)[:300]}

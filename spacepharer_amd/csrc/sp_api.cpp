@@ -688,3 +688,5 @@ int sp_filtermatchbyfdr_run(int argc, const char **argv) { return sp::sets::runF
 int sp_summarizeresults_run(int argc, const char **argv) { return sp::sets::runSummarizeResults(argc, argv); }
 
 }  // extern "C"
+
+namespace sp { AlignParams alignParamsOf(const sp_ctx *c) { return AlignParams{c->subName, c->par.gap_open, c->par.gap_extend, c->par.evalue}; } }

@@ -144,10 +144,24 @@ inline void partRange(const std::vector<uint64_t> &lengths, const Part &p, size_
     to = from + per[(size_t) p.rank];
 }
 
+// Buffers a module call formats its output into, kept (with their capacity) from call to call on the calling thread.  A fresh process does not
+// care; a resident server would otherwise first-touch the same tens of megabytes again in every call, and page faults of several threads of one
+// process serialise (on the virtualised MI355X boxes: 30 of the 75 ms of a served 100 000-spacer `prefilter` call).
+struct BufferPool {
+    std::vector<std::string> strings; std::vector<std::vector<DbEntry>> entryLists;
+    static BufferPool &mine() { static thread_local BufferPool p; return p; }
+    std::string takeString() { if (strings.empty()) return std::string(); std::string s = std::move(strings.back()); strings.pop_back(); s.clear(); return s; }
+    void give(std::string &&s) { if (s.capacity() >= (1u << 16) && strings.size() < 256) { s.clear(); strings.push_back(std::move(s)); } }
+    std::vector<DbEntry> takeEntries() { if (entryLists.empty()) return {}; std::vector<DbEntry> v = std::move(entryLists.back()); entryLists.pop_back(); v.clear(); return v; }
+    void give(std::vector<DbEntry> &&v) { if (v.capacity() >= 4096 && entryLists.size() < 8) { v.clear(); entryLists.push_back(std::move(v)); } }
+};
+
 struct DbWriter {
     std::string path; int dbtype;
     Part part = currentPart();
-    std::vector<char> data; std::vector<DbEntry> entries;
+    std::vector<char> data; std::vector<DbEntry> entries = BufferPool::mine().takeEntries();
+    // strings for addBlock(), one per chunk, from the calling thread's pool (call before the workers start)
+    static std::vector<std::string> pooledBlocks(size_t n) { std::vector<std::string> v(n); for (std::string &s : v) s = BufferPool::mine().takeString(); return v; }
     void add(uint32_t key, const std::string &payload) {
         DbEntry e; e.key = key; e.offset = blockBytes + data.size(); e.length = payload.size() + 1;
         data.insert(data.end(), payload.begin(), payload.end());
@@ -189,7 +203,7 @@ struct DbWriter {
         {   // index text: formatted by a few threads over contiguous ranges, written with one call
             const size_t n = entries.size();
             const size_t T = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, (size_t) defaultThreads()), n / 65536 + 1));
-            std::vector<std::string> texts(T);
+            std::vector<std::string> texts = pooledBlocks(T);
             auto fmt = [&](size_t t) {
                 std::string &text = texts[t]; const size_t from = n * t / T, to = n * (t + 1) / T;
                 text.reserve((to - from) * 24);
@@ -205,12 +219,20 @@ struct DbWriter {
             };
             if (T == 1) fmt(0);
             else { std::vector<std::thread> pool; for (size_t t = 0; t < T; t++) pool.emplace_back(fmt, t); for (auto &th : pool) th.join(); }
-            std::string all; size_t total = 0; for (auto &t : texts) total += t.size();
+            std::string all = BufferPool::mine().takeString(); size_t total = 0; for (auto &t : texts) total += t.size();
             all.reserve(total); for (auto &t : texts) all += t;
-            if (!writeFile(indexPath, all.data(), all.size())) { err = "cannot write " + indexPath; return false; }
+            const bool wrote = writeFile(indexPath, all.data(), all.size());
+            BufferPool &pool = BufferPool::mine();
+            for (std::string &t : texts) pool.give(std::move(t));
+            pool.give(std::move(all));
+            if (!wrote) { err = "cannot write " + indexPath; return false; }
         }
         // .dbtype is written LAST so that a crashed step is re-run by the workflow scripts (DBWriter.cpp:243)
         { const int32_t v = dbtype; if (!writeFile(typePath, (const char *) &v, 4)) { err = "cannot write " + typePath; return false; } }
+        {   BufferPool &pool = BufferPool::mine();      // everything is on disk: the buffers go back to the pool with their capacity
+            for (std::string &b : blocks) pool.give(std::move(b));
+            blocks.clear();
+            pool.give(std::move(entries)); }
         return true;
     }
 };

@@ -6,8 +6,11 @@
 // `spacepharer-amd serve <socket>` keeps ONE process with the HIP runtime up and the last target sets resident in HBM and runs
 // module calls for clients: with SP_SERVER=<socket> in the environment `spacepharer-amd <module> <args...>` forwards its argv
 // (and working directory) there and exits with the module's status.  A module call then costs what it costs in a warm process
-// -- a fresh process pays ~0.2 s of runtime start-up, tables and first-touch page mapping before its first kernel, more than the
-// whole search of 10^5 spacers takes.  Without a reachable server the call runs in this process as before.
+// -- a fresh process pays ~0.12 s of runtime start-up and tables before its first kernel, more than the whole search of 10^5 spacers
+// takes.  Without a reachable server the call runs in this process as before.  SP_SERVER=auto[:<idle seconds>] uses a per-user
+// server on a default socket and STARTS it when nobody answers (it leaves by itself after 120 s without a call): the workflow
+// scripts' back-to-back module processes (blastp.sh:33,41 for targets and again for the control set) then pay the start-up once,
+// and `align` finds the hits its `prefilter` left resident (sp_modules.cpp: PrefilterMemo).
 #include <cerrno>
 #include <csignal>
 #include <cstdint>
@@ -15,8 +18,16 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <algorithm>
+#include <exception>
+#include <fcntl.h>
+#include <malloc.h>
+#include <poll.h>
 #include <sys/socket.h>
+#include <sys/stat.h>
+#include <sys/time.h>
 #include <sys/un.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <vector>
 
@@ -60,18 +71,50 @@ static int forward(int fd, int argc, const char **argv) {
     return rc;
 }
 
-static int serve(const char *path) {
+// default socket of the per-user resident server (SP_SERVER=auto)
+static std::string defaultSocket() {
+    const char *dir = getenv("XDG_RUNTIME_DIR");
+    struct stat st;
+    if (dir && *dir && stat(dir, &st) == 0 && S_ISDIR(st.st_mode)) return std::string(dir) + "/spacepharer-amd.sock";
+    return "/tmp/spacepharer-amd-" + std::to_string((long) getuid()) + ".sock";
+}
+
+// idleSeconds > 0: leave when no client has called for that long (the auto-started server)
+static int serve(const char *path, int idleSeconds) {
     signal(SIGPIPE, SIG_IGN);
-    if (sp_init(0) != SP_OK) { fprintf(stderr, "%s\n", sp_last_error()); return 1; }
-    if (!getenv("SP_CONTEXT_CACHE")) setenv("SP_CONTEXT_CACHE", "4", 1);
+    // A module call formats tens of megabytes into fresh buffers.  glibc hands every large request straight to mmap and returns it on free, so
+    // a resident process would first-touch the same pages again in every call -- and a first touch is slow on a virtualised box (a third
+    // of a served call went there).  Keep freed memory in the heap instead: the next call finds it mapped.
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 64 << 20);
+    // the socket first, the runtime second: clients that connect while the HIP runtime and the tables come up simply wait in the backlog
+    {   struct stat st;      // a leftover SOCKET nobody answers on is replaced; anything else at that path is not ours to remove
+        if (lstat(path, &st) == 0) {
+            if (!S_ISSOCK(st.st_mode)) { fprintf(stderr, "spacepharer-amd serve: %s exists and is not a socket\n", path); return 1; }
+            const int probe = connectTo(path);
+            if (probe >= 0) { close(probe); fprintf(stderr, "spacepharer-amd serve: another server answers on %s\n", path); return 0; }
+            unlink(path);
+        } }
     const int ls = socket(AF_UNIX, SOCK_STREAM, 0);
     sockaddr_un a; memset(&a, 0, sizeof(a)); a.sun_family = AF_UNIX; strncpy(a.sun_path, path, sizeof(a.sun_path) - 1);
-    unlink(path);
-    if (ls < 0 || bind(ls, (sockaddr *) &a, sizeof(a)) != 0 || listen(ls, 64) != 0) { fprintf(stderr, "spacepharer-amd serve: cannot listen on %s: %s\n", path, strerror(errno)); return 1; }
+    const mode_t old = umask(077);      // the server runs module calls (chdir, DB writes) as this user for whoever may connect: owner only
+    const bool bound = ls >= 0 && bind(ls, (sockaddr *) &a, sizeof(a)) == 0 && listen(ls, 64) == 0;
+    umask(old);
+    if (!bound) { fprintf(stderr, "spacepharer-amd serve: cannot listen on %s: %s\n", path, strerror(errno)); return 1; }
+    if (sp_init(0) != SP_OK) { fprintf(stderr, "%s\n", sp_last_error()); close(ls); unlink(path); return 1; }
+    if (!getenv("SP_CONTEXT_CACHE")) setenv("SP_CONTEXT_CACHE", "4", 1);
     fprintf(stderr, "spacepharer-amd: serving on %s\n", path);
     for (;;) {      // one call at a time: a module call owns the GPU while it runs
+        if (idleSeconds > 0) {
+            pollfd pf{ls, POLLIN, 0};
+            const int pr = poll(&pf, 1, idleSeconds * 1000);
+            if (pr == 0) break;                       // idle: leave, the next client starts a new one
+            if (pr < 0) { if (errno == EINTR) continue; break; }
+        }
         const int fd = accept(ls, nullptr, nullptr);
         if (fd < 0) { if (errno == EINTR) continue; break; }
+        { timeval tv{30, 0}; setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv)); }      // a client that connects and stalls does not hold the server
         std::string cwd; uint32_t argc = 0; std::vector<std::string> args;
         bool ok = recvStr(fd, cwd) && recvAll(fd, &argc, 4) && argc >= 1 && argc < 4096;
         for (uint32_t i = 0; i < argc && ok; i++) { std::string s; ok = recvStr(fd, s); args.push_back(s); }
@@ -84,8 +127,8 @@ static int serve(const char *path) {
             if (!cwd.empty() && chdir(cwd.c_str()) != 0) msg = "cannot enter " + cwd;
             else {
                 std::vector<const char *> av; for (size_t i = 1; i < args.size(); i++) av.push_back(args[i].c_str());
-                rc = m->run((int) av.size(), av.data());
-                if (rc != 0) msg = sp_last_error();
+                try { rc = m->run((int) av.size(), av.data()); if (rc != 0) msg = sp_last_error(); }
+                catch (const std::exception &e) { rc = 1; msg = std::string(args[0]) + ": " + e.what(); }      // (bad_alloc on a huge DB: the call fails, the server stays)
             }
         }
         sendAll(fd, &rc, 4); sendStr(fd, msg);
@@ -96,16 +139,55 @@ static int serve(const char *path) {
     return 0;
 }
 
+// SP_SERVER=auto: connect to this user's resident server, starting it first when nobody answers.  The client process never touches the GPU, so
+// the server is a plain child of it: detached (own session, stdio closed), this binary again with `serve <socket> --idle <seconds>`.
+static int connectOrStart(const std::string &path, const char *self, int idleSeconds) {
+    int fd = connectTo(path.c_str());
+    if (fd >= 0) return fd;
+    const pid_t pid = fork();
+    if (pid < 0) return -1;
+    if (pid == 0) {
+        if (setsid() < 0) _exit(1);
+        const int nul = open("/dev/null", O_RDWR);
+        const char *log = getenv("SP_SERVER_LOG");
+        const int err = log ? open(log, O_WRONLY | O_CREAT | O_APPEND, 0600) : nul;
+        if (nul >= 0) { dup2(nul, 0); dup2(nul, 1); }
+        if (err >= 0) dup2(err, 2);
+        const std::string idle = std::to_string(idleSeconds);
+        char exe[4096]; const ssize_t n = readlink("/proc/self/exe", exe, sizeof(exe) - 1);
+        if (n > 0) { exe[n] = 0; execl(exe, exe, "serve", path.c_str(), "--idle", idle.c_str(), (char *) nullptr); }
+        execlp(self, self, "serve", path.c_str(), "--idle", idle.c_str(), (char *) nullptr);
+        _exit(1);
+    }
+    for (int waited = 0; waited < 20000; waited += 2) {      // the socket appears within milliseconds; requests wait in its backlog while the runtime starts
+        fd = connectTo(path.c_str());
+        if (fd >= 0) return fd;
+        int st; if (waitpid(pid, &st, WNOHANG) == pid) break;      // the server could not start (no device, socket path not writable)
+        usleep(2000);
+    }
+    return connectTo(path.c_str());
+}
+
 int main(int argc, const char **argv) {
     if (argc < 2) {
         fprintf(stderr, "usage: %s <module> <args>   with module one of:", argv[0]);
         for (const Module &m : kModules) fprintf(stderr, " %s", m.name);
-        fprintf(stderr, "\n       %s serve <socket>          run module calls for clients that set SP_SERVER=<socket>\n", argv[0]);
+        fprintf(stderr, "\n       %s serve <socket> [--idle <seconds>]   run module calls for clients that set SP_SERVER=<socket>\n"
+                        "       SP_SERVER=auto[:<idle seconds>] %s <module> <args>   forward to this user's resident server, starting it when nobody answers\n", argv[0], argv[0]);
         return 1;
     }
-    if (!strcmp(argv[1], "serve")) { if (argc != 3) { fprintf(stderr, "usage: %s serve <socket>\n", argv[0]); return 1; } return serve(argv[2]); }
+    if (!strcmp(argv[1], "serve")) {
+        if (argc != 3 && !(argc == 5 && !strcmp(argv[3], "--idle"))) { fprintf(stderr, "usage: %s serve <socket> [--idle <seconds>]\n", argv[0]); return 1; }
+        return serve(argv[2], argc == 5 ? atoi(argv[4]) : 0);
+    }
     if (const char *srv = getenv("SP_SERVER")) {
-        if (!strcmp(argv[1], "shutdown") || findModule(argv[1])) { const int fd = connectTo(srv); if (fd >= 0) return forward(fd, argc - 1, argv + 1); }
+        const bool known = !strcmp(argv[1], "shutdown") || findModule(argv[1]);
+        if (known && !strncmp(srv, "auto", 4) && (srv[4] == 0 || srv[4] == ':')) {
+            const std::string path = defaultSocket();
+            const Module *m = findModule(argv[1]);
+            const int fd = (m && m->device) ? connectOrStart(path, argv[0], srv[4] == ':' ? std::max(1, atoi(srv + 5)) : 120) : connectTo(path.c_str());      // host-only steps and `shutdown` never start one
+            if (fd >= 0) return forward(fd, argc - 1, argv + 1);
+        } else if (known) { const int fd = connectTo(srv); if (fd >= 0) return forward(fd, argc - 1, argv + 1); }
         if (!strcmp(argv[1], "shutdown")) return 0;
     }
     const Module *m = findModule(argv[1]);

@@ -65,6 +65,17 @@ static std::string fileIdentity(const std::string &path) {
     for (const char *ext : {"", ".0", ".index", ".dbtype"}) if (stat((path + ext).c_str(), &st) == 0) id += std::to_string((long long) st.st_size) + ":" + std::to_string((long long) st.st_mtim.tv_sec) + "." + std::to_string((long long) st.st_mtim.tv_nsec) + ";";
     char real[4096]; return std::string(realpath(path.c_str(), real) ? real : path.c_str()) + "|" + id;
 }
+// Serving (`spacepharer-amd serve`): what the last `prefilter` call left behind.  The context it used still holds the query batch, the hit list and
+// the targets in HBM; when the next call is `align` on exactly that result DB (same query / target / result files by path, size and mtime -- what
+// blastp.sh:33,41 issues back to back) the hits are aligned where they are: no DB is read or parsed again, nothing is uploaded.  Any other use of the
+// context forgets the memo.
+struct PrefilterMemo { sp_ctx *c = nullptr; std::string query, target, result; std::vector<uint32_t> qkeys, tkeys; };
+static PrefilterMemo g_memo;
+static void forgetPrefilter(const sp_ctx *c) { if (!c || g_memo.c == c) g_memo = PrefilterMemo(); }
+static void rememberPrefilter(sp_ctx *c, const std::string &q, const std::string &t, const std::string &r, const std::vector<uint32_t> &qkeys, const std::vector<uint32_t> &tkeys) {
+    g_memo.c = c; g_memo.query = fileIdentity(q); g_memo.target = fileIdentity(t); g_memo.result = fileIdentity(r); g_memo.qkeys = qkeys; g_memo.tkeys = tkeys;
+}
+
 // a context for (params, target DB): from the cache when serving, else a fresh one.  what = "index" (searchable) or "residues"
 static bool acquireCtx(const sp_search_params &p, const std::string &targetPath, const char *what, Ctx &ctx, std::string &err) {
     const size_t cap = ctxCacheSize();
@@ -74,7 +85,7 @@ static bool acquireCtx(const sp_search_params &p, const std::string &targetPath,
               std::to_string(p.min_ungapped_score) + "|" + std::to_string(p.mask) + "|" + std::to_string(p.gap_open) + "|" + std::to_string(p.gap_extend) + "|" + std::to_string(p.evalue) + "|" +
               std::to_string(p.threads) + "|" + fileIdentity(targetPath);
         std::lock_guard<std::mutex> lk(g_ctxMutex);
-        for (CachedCtx &e : g_ctxCache) if (e.key == key) { e.stamp = ++g_ctxStamp; ctx.c = e.c; ctx.cached = true; ctx.targetsStaged = true; return true; }
+        for (CachedCtx &e : g_ctxCache) if (e.key == key) { e.stamp = ++g_ctxStamp; ctx.c = e.c; ctx.cached = true; ctx.targetsStaged = true; forgetPrefilter(e.c); return true; }
     }
     ctx.c = sp_ctx_create(&p);
     if (!ctx.c) { err = sp_last_error(); return false; }
@@ -82,6 +93,7 @@ static bool acquireCtx(const sp_search_params &p, const std::string &targetPath,
         std::lock_guard<std::mutex> lk(g_ctxMutex);
         if (g_ctxCache.size() >= cap) {      // evict the least recently used
             size_t lru = 0; for (size_t i = 1; i < g_ctxCache.size(); i++) if (g_ctxCache[i].stamp < g_ctxCache[lru].stamp) lru = i;
+            forgetPrefilter(g_ctxCache[lru].c);
             sp_ctx_destroy(g_ctxCache[lru].c); g_ctxCache.erase(g_ctxCache.begin() + (long) lru);
         }
         g_ctxCache.push_back({key, ctx.c, ++g_ctxStamp});
@@ -94,10 +106,12 @@ static void dropCtx(Ctx &ctx) {
     if (!ctx.cached || !ctx.c) return;
     std::lock_guard<std::mutex> lk(g_ctxMutex);
     for (size_t i = 0; i < g_ctxCache.size(); i++) if (g_ctxCache[i].c == ctx.c) { g_ctxCache.erase(g_ctxCache.begin() + (long) i); break; }
+    forgetPrefilter(ctx.c);
     sp_ctx_destroy(ctx.c); ctx.c = nullptr; ctx.cached = false;
 }
 void releaseCachedContexts() {
     std::lock_guard<std::mutex> lk(g_ctxMutex);
+    forgetPrefilter(nullptr);
     for (CachedCtx &e : g_ctxCache) sp_ctx_destroy(e.c);
     g_ctxCache.clear();
 }
@@ -300,23 +314,43 @@ int runPrefilterModule(int argc, const char **argv) {
     const size_t batch = 1u << 20;
     size_t qFrom = 0, nq = qkeys.size();
     { std::vector<uint64_t> lens(qkeys.size()); for (size_t i = 0; i < lens.size(); i++) lens[i] = qoff[i + 1] - qoff[i] + 2; partRange(lens, w.part, qFrom, nq); }   // this GPU's queries
-    std::string payload; char buf[64];
-    // hits of the context's current batch -> one entry per query key (QueryMatcher::prefilterHitToBuffer, QueryMatcher.h:114-126)
+    // hits of the context's current batch -> one entry per query key (QueryMatcher::prefilterHitToBuffer, QueryMatcher.h:114-126), read from the
+    // device's own packed records in place and formatted on --threads workers over contiguous query ranges (the blocks go to the writer in order)
+    const int fmtThreads = (int) f.num("--threads", 0) > 0 ? (int) f.num("--threads", 0) : defaultThreads();
     auto writeBatch = [&](sp_ctx *c, const std::vector<uint32_t> &keys) -> bool {
-        std::vector<sp_hit> hits(std::max<uint64_t>(1, sp_ctx_num_hits(c))); std::vector<uint64_t> ho(keys.size() + 1);
-        if (sp_ctx_get_hits_compact(c, hits.data(), ho.data()) != SP_OK) return false;
-        for (size_t q = 0; q < keys.size(); q++) {
-            payload.clear();
-            for (uint64_t h = ho[q]; h < ho[q + 1]; h++) {
-                char *e = u32toa(tkeys[hits[h].seq_id], buf); *e++ = '\t';
-                e = i32toa(hits[h].score, e); *e++ = '\t';
-                e = i32toa((int32_t) hits[h].diagonal, e); *e++ = '\n';
-                payload.append(buf, e - buf);
+        const sp_hit_packed *hits = nullptr; const uint32_t *ho = nullptr; uint64_t nHits = 0;
+        if (sp_ctx_hits_view(c, &hits, &ho, &nHits) != SP_OK) return false;
+        laps.lap("  hit list on the host");
+        const size_t nChunks = numChunks(keys.size(), fmtThreads);
+        std::vector<std::string> blocks = DbWriter::pooledBlocks(nChunks);
+        static thread_local std::vector<std::vector<uint32_t>> keyPool; static thread_local std::vector<std::vector<uint64_t>> lenPool;      // (kept with their capacity, like the blocks)
+        std::vector<std::vector<uint32_t>> &bKeys = keyPool; std::vector<std::vector<uint64_t>> &bLens = lenPool;      // the CALLING thread's pools: the workers below see them through these references
+        bKeys.resize(std::max(bKeys.size(), nChunks)); bLens.resize(std::max(bLens.size(), nChunks));
+        for (size_t ci = 0; ci < nChunks; ci++) { bKeys[ci].clear(); bLens[ci].clear(); }
+        parallelChunks(keys.size(), fmtThreads, [&](size_t ci, size_t from, size_t to) {
+            // (the chunk's buffers as LOCALS of the worker: the headers of neighbouring std::strings / vectors share cache lines, and every append
+            // of one thread would pull the line out of its neighbour's cache -- 0.5 us per hit line on a two-socket host instead of 0.1)
+            std::string block = std::move(blocks[ci]); std::vector<uint32_t> ck = std::move(bKeys[ci]); std::vector<uint64_t> cl = std::move(bLens[ci]); char buf[64];
+            block.reserve((size_t) (ho[to] - ho[from]) * 20 + (to - from));
+            ck.reserve(to - from); cl.reserve(to - from);
+            for (size_t q = from; q < to; q++) {
+                const size_t before = block.size();
+                for (uint32_t h = ho[q]; h < ho[q + 1]; h++) {
+                    char *e = u32toa(tkeys[hits[h].seq_id], buf); *e++ = '\t';
+                    e = i32toa((int32_t) hits[h].score, e); *e++ = '\t';
+                    e = i32toa((int32_t) hits[h].diagonal, e); *e++ = '\n';
+                    block.append(buf, (size_t) (e - buf));
+                }
+                block.push_back('\0');      // every query key gets an entry, empty ones too
+                ck.push_back(keys[q]); cl.push_back(block.size() - before);
             }
-            w.add(keys[q], payload);     // every query key gets an entry, empty ones too
-        }
+            blocks[ci] = std::move(block); bKeys[ci] = std::move(ck); bLens[ci] = std::move(cl);
+        });
+        laps.lap("  format (threads)");
+        for (size_t ci = 0; ci < nChunks; ci++) w.addBlock(bKeys[ci], bLens[ci], std::move(blocks[ci]));
         return true;
     };
+    bool oneBatch = false;
     for (size_t b0 = qFrom; b0 < nq; b0 += batch) {
         const size_t b1 = std::min(nq, b0 + batch);
         std::vector<uint64_t> off(qoff.begin() + b0, qoff.begin() + b1 + 1);
@@ -343,10 +377,13 @@ int runPrefilterModule(int argc, const char **argv) {
         if (rc != SP_OK) return fail(std::string("prefilter: ") + sp_last_error());
         laps.lap("queries -> device, search");
         if (!writeBatch(ctx.c, keys)) return fail(std::string("prefilter: ") + sp_last_error());
+        oneBatch = b0 == 0 && b1 == qkeys.size();
     }
     laps.lap("format hits");
     if (!w.close(err)) return fail("prefilter: " + err);
     laps.lap("write DB");
+    // serving: the context still holds this batch and its hits -- an `align` call on exactly this result DB need not read it back
+    if (ctx.cached && oneBatch && w.part.count <= 1) rememberPrefilter(ctx.c, f.positional[0], f.positional[1], f.positional[2], qkeys, tkeys);
     return 0;
 }
 
@@ -356,28 +393,46 @@ int runPrefilterModule(int argc, const char **argv) {
 struct Triples { std::vector<uint32_t> q, t; std::vector<int16_t> d; std::vector<uint64_t> perQuery; /* offsets per result entry */ std::vector<uint32_t> entryQuery; std::vector<uint32_t> entryKey; };
 
 static bool collectTriples(const Db &res, const KeyMap &qIndex, const KeyMap &tIndex, Triples &tr, std::string &err) {
-    tr.perQuery.assign(1, 0);
-    tr.q.reserve(res.dataSize() / 12); tr.t.reserve(res.dataSize() / 12); tr.d.reserve(res.dataSize() / 12);
     size_t eFrom = 0, eTo = res.entries.size();
     { std::vector<uint64_t> lens(res.entries.size()); for (size_t i = 0; i < lens.size(); i++) lens[i] = res.entries[i].length; partRange(lens, currentPart(), eFrom, eTo); }   // this GPU's entries
-    for (size_t i = eFrom; i < eTo; i++) {
-        const uint32_t key = res.entries[i].key;
-        const char *p = res.ptr(i);
-        uint32_t qi = 0xFFFFFFFFu;
-        if (*p != '\0' && !qIndex.find(key, qi)) { err = "query " + std::to_string(key) + " of the result DB is not in the query DB"; return false; }
-        while (*p != '\0') {
-            char *e; unsigned long tk = strtoul(p, &e, 10);
-            long score = 0, diag = 0; int cols = 1;
-            if (*e == '\t') { score = strtol(e + 1, &e, 10); cols++; }
-            if (*e == '\t') { diag = strtol(e + 1, &e, 10); cols++; }
-            (void) score;
-            uint32_t ti = 0;
-            if (!tIndex.find((uint32_t) tk, ti)) { err = "target " + std::to_string(tk) + " of the result DB is not in the target DB"; return false; }
-            tr.q.push_back(qi); tr.t.push_back(ti); tr.d.push_back(cols == 3 ? (int16_t) diag : 0);
-            while (*e != '\n' && *e != '\0') e++;
-            p = (*e == '\n') ? e + 1 : e;
+    // entry ranges are parsed on a few threads (740 000 lines of a 100 000-spacer result DB: 30 ms on one), the pieces are joined in entry order
+    const int threads = defaultThreads();
+    const size_t n = eTo - eFrom, nChunks = numChunks(n, threads);
+    std::vector<Triples> part(nChunks); std::vector<std::string> errs(nChunks);
+    parallelChunks(n, threads, [&](size_t ci, size_t from, size_t to) {
+        Triples p; std::string e;      // worker-local, moved into the shared slots at the end
+        size_t bytes = 0; for (size_t i = eFrom + from; i < eFrom + to; i++) bytes += res.entries[i].length;
+        p.q.reserve(bytes / 12); p.t.reserve(bytes / 12); p.d.reserve(bytes / 12); p.perQuery.reserve(to - from + 1); p.entryQuery.reserve(to - from); p.entryKey.reserve(to - from);
+        p.perQuery.push_back(0);
+        for (size_t i = eFrom + from; i < eFrom + to && e.empty(); i++) {
+            const uint32_t key = res.entries[i].key;
+            const char *c = res.ptr(i);
+            uint32_t qi = 0xFFFFFFFFu;
+            if (*c != '\0' && !qIndex.find(key, qi)) { e = "query " + std::to_string(key) + " of the result DB is not in the query DB"; break; }
+            while (*c != '\0') {
+                char *end; unsigned long tk = strtoul(c, &end, 10);
+                long score = 0, diag = 0; int cols = 1;
+                if (*end == '\t') { score = strtol(end + 1, &end, 10); cols++; }
+                if (*end == '\t') { diag = strtol(end + 1, &end, 10); cols++; }
+                (void) score;
+                uint32_t ti = 0;
+                if (!tIndex.find((uint32_t) tk, ti)) { e = "target " + std::to_string(tk) + " of the result DB is not in the target DB"; break; }
+                p.q.push_back(qi); p.t.push_back(ti); p.d.push_back(cols == 3 ? (int16_t) diag : 0);
+                while (*end != '\n' && *end != '\0') end++;
+                c = (*end == '\n') ? end + 1 : end;
+            }
+            p.perQuery.push_back(p.q.size()); p.entryQuery.push_back(qi); p.entryKey.push_back(key);
         }
-        tr.perQuery.push_back(tr.q.size()); tr.entryQuery.push_back(qi); tr.entryKey.push_back(key);
+        part[ci] = std::move(p); errs[ci] = std::move(e);
+    });
+    for (const std::string &e : errs) if (!e.empty()) { err = e; return false; }
+    size_t total = 0; for (const Triples &p : part) total += p.q.size();
+    tr.perQuery.assign(1, 0); tr.q.reserve(total); tr.t.reserve(total); tr.d.reserve(total); tr.perQuery.reserve(n + 1); tr.entryQuery.reserve(n); tr.entryKey.reserve(n);
+    for (const Triples &p : part) {
+        const uint64_t base = tr.q.size();
+        tr.q.insert(tr.q.end(), p.q.begin(), p.q.end()); tr.t.insert(tr.t.end(), p.t.begin(), p.t.end()); tr.d.insert(tr.d.end(), p.d.begin(), p.d.end());
+        for (size_t k = 1; k < p.perQuery.size(); k++) tr.perQuery.push_back(base + p.perQuery[k]);
+        tr.entryQuery.insert(tr.entryQuery.end(), p.entryQuery.begin(), p.entryQuery.end()); tr.entryKey.insert(tr.entryKey.end(), p.entryKey.begin(), p.entryKey.end());
     }
     return true;
 }
@@ -422,29 +477,56 @@ int runAlignModule(int argc, const char **argv) {
     { const int rc = fanOut("align", argc, argv, f.positional[3]); if (rc >= 0) return rc; }
     Laps laps("align");
     Ctx ctx; Db qdb, tdb, rdb; std::vector<uint32_t> qkeys, tkeys; std::vector<char> qres; std::vector<uint64_t> qoff;
-    if (!openSearch(f, "align", true, ctx, qdb, tdb, qkeys, tkeys, qres, qoff, err)) return fail("align: " + err);
-    laps.lap("read DBs, context, device");
-    if (!rdb.load(f.positional[2], err)) return fail("align: " + err);
-    KeyMap qIndex, tIndex; qIndex.build(qkeys); tIndex.build(tkeys);
     Triples tr;
-    if (!collectTriples(rdb, qIndex, tIndex, tr, err)) return fail("align: " + err);
-    laps.lap("read + parse result DB");
+    std::vector<sp_alignment> res; std::vector<char> cig; uint64_t used = 0;
     const double minSeqId = f.real("--min-seq-id", 0.0); const long minAlnLen = f.num("--min-aln-len", 0);
     const long maxAccept = f.num("--max-accept", INT_MAX), maxRejected = f.num("--max-rejected", INT_MAX);
-    std::vector<sp_alignment> res(std::max<size_t>(1, tr.q.size()));
-    std::vector<char> cig(64 * (tr.q.size() + 16)); uint64_t used = 0;
-    int rc = sp_ctx_align(ctx.c, tr.q.data(), tr.t.data(), tr.q.size(), res.data(), cig.data(), cig.size(), &used);
-    if (rc == SP_ERR_OVERFLOW && used > cig.size()) { cig.resize(used + 16); rc = sp_ctx_align(ctx.c, tr.q.data(), tr.t.data(), tr.q.size(), res.data(), cig.data(), cig.size(), &used); }
-    if (rc != SP_OK) return fail(std::string("align: ") + sp_last_error());
-    laps.lap("align on the device");
+    // serving, and this is the result DB the last `prefilter` call wrote from a context that still holds the batch: align its hits where they are
+    bool resident = false;
+    if (g_memo.c && currentPart().count <= 1 && g_memo.result == fileIdentity(f.positional[2]) && g_memo.query == fileIdentity(f.positional[0]) && g_memo.target == fileIdentity(f.positional[1])) {
+        const AlignParams ap = alignParamsOf(g_memo.c);
+        resident = ap.subMat == aaPart(f.str("--sub-mat", "VTML40.out")) && ap.gapOpen == (int) strtol(aaPart(f.str("--gap-open", "11")).c_str(), NULL, 10) &&
+                   ap.gapExtend == (int) strtol(aaPart(f.str("--gap-extend", "1")).c_str(), NULL, 10) && ap.evalue == f.real("-e", 0.001);
+    }
+    if (resident) {
+        sp_ctx *c = g_memo.c;
+        const sp_hit_packed *hits = nullptr; const uint32_t *ho = nullptr; uint64_t nHits = 0;
+        if (sp_ctx_hits_view(c, &hits, &ho, &nHits) != SP_OK) return fail(std::string("align: ") + sp_last_error());
+        res.resize(std::max<uint64_t>(1, nHits)); cig.resize(64 * ((size_t) nHits + 16));
+        int rc = sp_ctx_align_hits(c, res.data(), cig.data(), cig.size(), &used);
+        if (rc == SP_ERR_OVERFLOW && used > cig.size()) { cig.resize(used + 16); rc = sp_ctx_align_hits(c, res.data(), cig.data(), cig.size(), &used); }
+        if (rc != SP_OK) return fail(std::string("align: ") + sp_last_error());
+        // entries in the order the ordinary path takes them -- the result DB's data order (Db::load), which is the batch order the prefilter call
+        // wrote -- with the records of query q at the offsets of its hits
+        tr.entryKey = g_memo.qkeys;
+        tr.perQuery.assign(ho, ho + g_memo.qkeys.size() + 1);
+        laps.lap("align on the device (resident hits)");
+    } else {
+        if (!openSearch(f, "align", true, ctx, qdb, tdb, qkeys, tkeys, qres, qoff, err)) return fail("align: " + err);
+        laps.lap("read DBs, context, device");
+        if (!rdb.load(f.positional[2], err)) return fail("align: " + err);
+        KeyMap qIndex, tIndex; qIndex.build(qkeys); tIndex.build(tkeys);
+        if (!collectTriples(rdb, qIndex, tIndex, tr, err)) return fail("align: " + err);
+        laps.lap("read + parse result DB");
+        res.resize(std::max<size_t>(1, tr.q.size())); cig.resize(64 * (tr.q.size() + 16));
+        int rc = sp_ctx_align(ctx.c, tr.q.data(), tr.t.data(), tr.q.size(), res.data(), cig.data(), cig.size(), &used);
+        if (rc == SP_ERR_OVERFLOW && used > cig.size()) { cig.resize(used + 16); rc = sp_ctx_align(ctx.c, tr.q.data(), tr.t.data(), tr.q.size(), res.data(), cig.data(), cig.size(), &used); }
+        if (rc != SP_OK) return fail(std::string("align: ") + sp_last_error());
+        laps.lap("align on the device");
+    }
     DbWriter w; w.path = f.positional[3]; w.dbtype = 5;       // DBTYPE_ALIGNMENT_RES
     // entries are formatted by --threads workers over contiguous ranges and appended in order
-    const size_t nEntries = tr.perQuery.size() - 1;
+    const size_t nEntries = tr.entryKey.size();
     const int threads = (int) f.num("--threads", 0) > 0 ? (int) f.num("--threads", 0) : defaultThreads();
     const size_t nChunks = numChunks(nEntries, threads);
-    std::vector<std::string> blocks(nChunks); std::vector<std::vector<uint32_t>> bKeys(nChunks); std::vector<std::vector<uint64_t>> bLens(nChunks);
+    std::vector<std::string> blocks = DbWriter::pooledBlocks(nChunks);
+        static thread_local std::vector<std::vector<uint32_t>> keyPool; static thread_local std::vector<std::vector<uint64_t>> lenPool;      // (kept with their capacity, like the blocks)
+        std::vector<std::vector<uint32_t>> &bKeys = keyPool; std::vector<std::vector<uint64_t>> &bLens = lenPool;      // the CALLING thread's pools: the workers below see them through these references
+        bKeys.resize(std::max(bKeys.size(), nChunks)); bLens.resize(std::max(bLens.size(), nChunks));
+        for (size_t ci = 0; ci < nChunks; ci++) { bKeys[ci].clear(); bLens[ci].clear(); }
     parallelChunks(nEntries, threads, [&](size_t ci, size_t from, size_t to) {
-        std::string &block = blocks[ci];
+        std::string block = std::move(blocks[ci]); std::vector<uint32_t> ck = std::move(bKeys[ci]); std::vector<uint64_t> cl = std::move(bLens[ci]);      // worker-local: no shared cache lines
+        ck.reserve(to - from); cl.reserve(to - from);
         std::vector<uint64_t> ok;
         for (size_t e = from; e < to; e++) {
             ok.clear();
@@ -458,8 +540,9 @@ int runAlignModule(int argc, const char **argv) {
             const size_t before = block.size();
             for (uint64_t i : ok) appendAlnLine(block, res[i], cig.data() + res[i].cigar_offset, true);
             block.push_back('\0');
-            bKeys[ci].push_back(tr.entryKey[e]); bLens[ci].push_back(block.size() - before);
+            ck.push_back(tr.entryKey[e]); cl.push_back(block.size() - before);
         }
+        blocks[ci] = std::move(block); bKeys[ci] = std::move(ck); bLens[ci] = std::move(cl);
     });
     for (size_t ci = 0; ci < nChunks; ci++) w.addBlock(bKeys[ci], bLens[ci], std::move(blocks[ci]));
     laps.lap("format records");
@@ -558,10 +641,15 @@ int runSearchModule(int argc, const char **argv) {
         laps.lap("align on the device");
         const size_t nEntries = keys.size();
         const size_t nChunks = numChunks(nEntries, threads);
-        std::vector<std::string> blocks(nChunks); std::vector<std::vector<uint32_t>> bKeys(nChunks); std::vector<std::vector<uint64_t>> bLens(nChunks);
+        std::vector<std::string> blocks = DbWriter::pooledBlocks(nChunks);
+        static thread_local std::vector<std::vector<uint32_t>> keyPool; static thread_local std::vector<std::vector<uint64_t>> lenPool;      // (kept with their capacity, like the blocks)
+        std::vector<std::vector<uint32_t>> &bKeys = keyPool; std::vector<std::vector<uint64_t>> &bLens = lenPool;      // the CALLING thread's pools: the workers below see them through these references
+        bKeys.resize(std::max(bKeys.size(), nChunks)); bLens.resize(std::max(bLens.size(), nChunks));
+        for (size_t ci = 0; ci < nChunks; ci++) { bKeys[ci].clear(); bLens[ci].clear(); }
         parallelChunks(nEntries, threads, [&](size_t ci, size_t from, size_t to) {
-            std::string &block = blocks[ci];
+            std::string block = std::move(blocks[ci]); std::vector<uint32_t> ck = std::move(bKeys[ci]); std::vector<uint64_t> cl = std::move(bLens[ci]);      // worker-local: no shared cache lines
             block.reserve((size_t) ((to - from) * 40 + (ho[to] - ho[from]) * 64));
+            ck.reserve(to - from); cl.reserve(to - from);
             std::vector<uint64_t> ok;
             for (size_t e = from; e < to; e++) {
                 ok.clear();
@@ -575,8 +663,9 @@ int runSearchModule(int argc, const char **argv) {
                 const size_t before = block.size();
                 for (uint64_t i : ok) appendAlnLine(block, res[i], cig + res[i].cigar_offset, true);
                 block.push_back('\0');
-                bKeys[ci].push_back(keys[e]); bLens[ci].push_back(block.size() - before);
+                ck.push_back(keys[e]); cl.push_back(block.size() - before);
             }
+            blocks[ci] = std::move(block); bKeys[ci] = std::move(ck); bLens[ci] = std::move(cl);
         });
         for (size_t ci = 0; ci < nChunks; ci++) w.addBlock(bKeys[ci], bLens[ci], std::move(blocks[ci]));
         laps.lap("format records");

@@ -621,7 +621,9 @@ static bool forChunks(size_t n, W weight, int threads, std::vector<Out> &outs, F
     const size_t C = cut.size() - 1;
     outs.clear(); outs.resize(C);
     std::atomic<size_t> next{0};
-    auto work = [&]() { for (;;) { const size_t c = next.fetch_add(1); if (c >= C) break; Out &o = outs[c]; for (size_t i = cut[c]; i < cut[c + 1] && o.err.empty(); i++) fn(i, o); } };
+    // (a chunk's output is built in a LOCAL of the worker and moved into its slot at the end: the headers of neighbouring strings / vectors in
+    // `outs` share cache lines, and every append of one thread would pull the line out of its neighbour's cache)
+    auto work = [&]() { for (;;) { const size_t c = next.fetch_add(1); if (c >= C) break; Out o = std::move(outs[c]); for (size_t i = cut[c]; i < cut[c + 1] && o.err.empty(); i++) fn(i, o); outs[c] = std::move(o); } };
     if (C <= 1 || T == 1) work();
     else { std::vector<std::thread> pool; for (size_t t = 1; t < std::min(T, C); t++) pool.emplace_back(work); work(); for (auto &th : pool) th.join(); }
     for (const Out &o : outs) if (!o.err.empty()) { err = o.err; return false; }

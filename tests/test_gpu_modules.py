@@ -318,6 +318,83 @@ def test_module_calls_through_a_resident_server(tmp_path):
             srv.kill()
 
 
+def test_auto_started_server_and_align_on_resident_hits(tmp_path):
+    """SP_SERVER=auto: the first module process finds no server on the per-user socket, starts one (detached, idle time-out) and forwards; `align`
+    on the result DB the server's `prefilter` just wrote aligns the hits that are still resident (no DB read back) -- same bytes as fresh
+    processes; a result DB that changed on disk, other align parameters or another query DB take the ordinary path; shuffled / sparse query keys;
+    the server leaves by itself when idle; a stale socket file is replaced, a regular file at the socket path is left alone."""
+    import random
+    import subprocess
+    import time
+    g = load_golden("spacer")
+    r = g["ref"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "spacepharer_amd", "spacepharer-amd")
+    rnd = random.Random(5)
+    qkeys = rnd.sample(range(10, 10 * len(g["queries"])), len(g["queries"]))      # sparse, shuffled keys: the index is sorted by key, the data is not
+    write_seq_db(str(tmp_path / "qdb"), g["queries"], keys=qkeys)
+    write_seq_db(str(tmp_path / "qdb2"), g["queries"][::-1], keys=qkeys)
+    write_seq_db(str(tmp_path / "tdb"), g["targets"])
+    pf = (PREF_FLAGS % r["maxSeqs"]).split()
+    af = ALN_FLAGS.split()
+    direct = dict(os.environ)
+    direct.pop("SP_SERVER", None)
+
+    def pair(env, tag, qdb="qdb", aflags=af):
+        for mod, args in (("prefilter", [qdb, "tdb", "pref" + tag] + pf), ("align", [qdb, "tdb", "pref" + tag, "aln" + tag] + aflags)):
+            p = subprocess.run([exe, mod] + args, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0, (mod, p.stderr)
+        return open(str(tmp_path / ("aln" + tag)), "rb").read(), open(str(tmp_path / ("aln" + tag + ".index"))).read()
+
+    ref = pair(direct, "_ref")
+    expect = {qkeys[a["id"]]: a["text"] for a in r["aln"]}
+    got, _ = read_db(str(tmp_path / "aln_ref"))
+    assert all(got[k] == v for k, v in expect.items()) and len(got) == len(qkeys)
+    rt = tmp_path / "rt"
+    rt.mkdir()
+    sock = str(rt / "spacepharer-amd.sock")
+    open(sock, "w").write("not a socket")      # something else at the path: the server refuses, the clients run the modules themselves
+    env = dict(os.environ, SP_SERVER="auto:4", XDG_RUNTIME_DIR=str(rt), SP_SERVER_LOG=str(tmp_path / "server.log"), SP_MODULE_TIMES="1")
+    assert pair(env, "_nosrv") == ref and open(sock).read() == "not a socket"
+    os.remove(sock)
+    assert pair(env, "_a") == ref                       # starts the server, prefilter + align through it
+    assert os.path.exists(sock) and (os.stat(sock).st_mode & 0o077) == 0
+    log = open(str(tmp_path / "server.log")).read()
+    assert "resident hits" in log                        # the align call used what prefilter left in HBM
+    assert pair(env, "_b") == ref
+    # the ordinary path behind the same server: another E-value threshold (not what the context aligns with) ...
+    af2 = ALN_FLAGS.replace("-e 200", "-e 0.5").split()
+    assert "-e 0.5" in " ".join(af2)
+    n_res = open(str(tmp_path / "server.log")).read().count("resident hits")
+    other = pair(env, "_c", aflags=af2)
+    assert other == pair(direct, "_c_ref", aflags=af2) and other != ref
+    assert open(str(tmp_path / "server.log")).read().count("resident hits") == n_res
+    # ... a result DB somebody rewrote after the prefilter call ...
+    p = subprocess.run([exe, "prefilter", "qdb", "tdb", "pref_d"] + pf, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    data = open(str(tmp_path / "pref_d"), "rb").read()
+    time.sleep(0.02)
+    open(str(tmp_path / "pref_d"), "wb").write(data)
+    p = subprocess.run([exe, "align", "qdb", "tdb", "pref_d", "aln_d"] + af, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and open(str(tmp_path / "aln_d"), "rb").read() == ref[0]
+    assert open(str(tmp_path / "server.log")).read().count("resident hits") == n_res
+    # ... and another query DB under the memo's result name
+    assert pair(env, "_e", qdb="qdb2") == pair(direct, "_e_ref", qdb="qdb2")
+    # idle: the server leaves and takes its socket with it; the next call starts a new one
+    for _ in range(200):
+        if not os.path.exists(sock):
+            break
+        time.sleep(0.1)
+    assert not os.path.exists(sock)
+    assert pair(env, "_f") == ref and os.path.exists(sock)
+    subprocess.run([exe, "shutdown"], env=env, capture_output=True, timeout=60)
+    for _ in range(100):
+        if not os.path.exists(sock):
+            break
+        time.sleep(0.1)
+    assert not os.path.exists(sock)
+
+
 def test_modules_take_a_query_beyond_the_hit_stream_limit_through_target_shards(tmp_path):
     """a query with more than 65 535 index hits (tests/test_gpu_sharded.py builds the same case): the in-memory call refuses its batch,
     the module drop-ins search the batch without it and take it through target shards -- every entry equals the oracle's / the

@@ -1,5 +1,4 @@
-# GPU box: wall-clock laps (SP_MODULE_TIMES=1) of fresh `spacepharer-amd` processes on the bench workload: prefilter, align (what
-# blastp.sh:33,41 issues) and the fused search.  SPACERS=100000 by default.
+# GPU box: wall-clock laps (SP_MODULE_TIMES=1, from the server's log) of prefilter + align client processes against the auto-started server
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
 import os, sys, subprocess, tempfile, time
@@ -15,18 +14,16 @@ write_seq_db(d + "/q", Q); write_seq_db(d + "/t", T)
 th = str(bench.host_info()["cores_for_cpu_baseline"])
 pf = (PREF_FLAGS % 300).replace("--threads 8", "--threads " + th).split()
 af = ALN_FLAGS.replace("--threads 8", "--threads " + th).split()
-sf = pf + ["-a", "1", "--alignment-mode", "2", "-e", "200", "--gap-open", "nucl:10,aa:16", "--gap-extend", "2"]
-env = dict(os.environ, SP_MODULE_TIMES="1")
+env = dict(os.environ, SP_MODULE_TIMES="1", SP_SERVER="auto:20", XDG_RUNTIME_DIR=d, SP_SERVER_LOG=d + "/server.log")
 exe = "spacepharer_amd/spacepharer-amd"
-for rep in range(2):
+for rep in range(3):
+    mark = os.path.getsize(d + "/server.log") if os.path.exists(d + "/server.log") else 0
     t0 = time.perf_counter()
     p1 = subprocess.run([exe, "prefilter", d + "/q", d + "/t", d + "/pref%d" % rep] + pf, env=env, capture_output=True, text=True)
     t1 = time.perf_counter()
     p2 = subprocess.run([exe, "align", d + "/q", d + "/t", d + "/pref%d" % rep, d + "/aln%d" % rep] + af, env=env, capture_output=True, text=True)
     t2 = time.perf_counter()
-    print("== %d spacers: prefilter process %.3f s (rc %d), align process %.3f s (rc %d), both %.3f s" % (n, t1 - t0, p1.returncode, t2 - t1, p2.returncode, t2 - t0))
-    print(p1.stderr[-1200:]); print(p2.stderr[-1200:])
-t0 = time.perf_counter()
-p = subprocess.run([exe, "search", d + "/q", d + "/t", d + "/alnf", d] + sf, env=env, capture_output=True, text=True)
-print("== fused search process %.3f s rc=%d" % (time.perf_counter() - t0, p.returncode)); print(p.stderr[-1500:])
+    print("== %d spacers, pair %d: prefilter client %.3f s (rc %d), align client %.3f s (rc %d), both %.3f s" % (n, rep, t1 - t0, p1.returncode, t2 - t1, p2.returncode, t2 - t0))
+    print(open(d + "/server.log").read()[mark:])
+subprocess.run([exe, "shutdown"], env=env)
 PY
