@@ -22,6 +22,7 @@
 
 #include "ref_par.h"
 
+#include <omp.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -117,6 +118,7 @@ int main(int argc, char **argv) {
     }
     if (i != argc) { fprintf(stderr, "ref_sets: flag without a value\n"); return 2; }
     par.scoringMatrixFile = MultiParam<char *>("blosum62.out", subMat.c_str());
+    omp_set_num_threads(std::max(1, par.threads));      // the modules' OpenMP regions index their readers / writers by thread (Parameters::parseParameters does this, Parameters.cpp:2111-2121)
     const Command command = {module.c_str(), it->second.first, NULL, 0, "", "", "", "", 0, {}};
     return it->second.first(0, NULL, command);
 }
