@@ -49,6 +49,7 @@ int sp_init(int device_mask);              /* bit i = use HIP device i; 0 = devi
 void sp_shutdown(void);
 const char *sp_last_error(void);
 int sp_device_count(void);
+int sp_device_memory(uint64_t *free_bytes, uint64_t *total_bytes);   /* HBM of the current device (hipMemGetInfo) */
 const char *sp_version(void);
 
 /* ---- (1) module drop-ins ---- */

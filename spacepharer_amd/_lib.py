@@ -83,6 +83,7 @@ def load_library():
     L.sp_last_error.restype = C.c_char_p
     L.sp_version.restype = C.c_char_p
     L.sp_default_params.argtypes = [C.POINTER(SearchParams)]
+    L.sp_device_memory.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.sp_ctx_create.restype = vp
     L.sp_ctx_create.argtypes = [C.POINTER(SearchParams)]
     L.sp_ctx_destroy.argtypes = [vp]

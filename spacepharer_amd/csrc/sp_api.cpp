@@ -76,6 +76,13 @@ static uint64_t ext3Digest(const std::vector<uint32_t> &packed, int16_t *scoreHe
 extern "C" {
 
 const char *sp_last_error(void) { return g_err.c_str(); }
+int sp_device_memory(uint64_t *free_bytes, uint64_t *total_bytes) {
+    size_t f = 0, t = 0;
+    if (!sp::deviceMemory(f, t)) { g_err = "sp_device_memory: hipMemGetInfo failed (no device initialised?)"; return SP_ERR_DEVICE; }
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return SP_OK;
+}
 const char *sp_version(void) { return "spacepharer_amd 0.1 (gfx950)"; }
 
 int sp_init(int device_mask) {

@@ -39,6 +39,7 @@ struct StepResult { uint64_t hits = 0, pairs = 0, cigarUsed = 0; bool repeat = f
 struct DiagRescore { int32_t score, startPos, endPos, diagonalLen, diagonal; uint32_t distToDiagonal; };
 
 // page-locked host memory for device<->host copies (pageable std::vector memory costs a staging copy per transfer)
+bool deviceMemory(size_t &freeBytes, size_t &totalBytes);      // hipMemGetInfo of the current device
 void *pinnedAlloc(size_t bytes, bool coherent = false);      // coherent: kernels store into it while the host polls (mailboxes); else DMA destinations the CPU reads cached
 void pinnedFree(void *p);
 template <typename T>

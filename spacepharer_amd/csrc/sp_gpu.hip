@@ -423,6 +423,7 @@ struct MatchArgs {
     const uint64_t *slots;          // per OCCUPIED slot (rank order): the entry itself (seqId | pos << 32) when the list has one
                                     // entry, else bit 63 | len << 32 | offset into ientries
     const uint64_t *ientries;       // seqId | pos << 32, lists concatenated in k-mer order
+    const uint64_t *buckets;        // large footprint only: 4 words per k-mer SLOT (20^6 of them, 2 GB): offset | length << 32 (0 = no list), entries 0..2 of the list
     uint64_t *spill;                // per-wave scratch: kSpillCap+1 keys (+ bitmap) each
     uint32_t *queue;                // work counter
     DiagRec *diagRec; uint32_t *diagQuery; uint32_t diagCap; uint32_t *diagCursor;
@@ -483,7 +484,7 @@ __device__ void markKept(const uint64_t *keys, uint32_t M, uint32_t *bits, int l
 template <int kHitCap, bool kOrd, bool kSmall>
 __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) void k_match(MatchArgs a) {
     constexpr int kSuper = kSmall ? 512 : 1024;         // similar k-mers per enumeration super-round
-    constexpr int kOccRegs = kSmall ? 2 : 4;            // occupied slots per lane and batch in the fetch phase (64 x kOccRegs slot words in flight per wave)
+    constexpr int kOccRegs = 2;                          // occupied slots per lane and batch in the fetch phase: 64 x 2 slot words (small footprint) or 32-byte buckets (large) in flight per wave
     constexpr int kATile = kSmall ? 128 : 256;          // a's per tile of row A (a window of a spacer peptide has 20-60)
     static_assert(kHitCap == (kSmall ? 256 : 512), "hit buffer and footprint go together");
     __shared__ uint16_t s_occOrd[kWavesPerBlock][kOrd ? kSuper : 1];
@@ -567,12 +568,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
         const int myThr = lane < L ? (int) a.qthr[qo + lane] : -1;
         SP_T(0);
 
+        // the exact pre-filter of the tail (below) works on two bitmaps of hashed target ids, "seen" and "seen again".  The large footprint (dense
+        // index: 2 000+ hits per query, most of them spilled to HBM) marks them WHILE the hits are emitted -- the occupied-slot list whose LDS they
+        // share is not used on that path -- so the tail reads the spilled hits once (to sift them) instead of twice (mark, then sift).
+        uint32_t *seen = occList, *again = occList + kSuper / 2;     // 2 x kSuper / 2 words: 16 384 (large) or 8 192 (small) buckets each
+        constexpr int kBktShift = kSuper == 1024 ? 18 : 19;
+        constexpr uint32_t kMul0 = 2654435761u;                       // the first round's multiplier
+        if constexpr (!kSmall) { for (uint32_t t = lane * 4; t < (uint32_t) kSuper; t += 256) *reinterpret_cast<uint4 *>(occList + t) = make_uint4(0u, 0u, 0u, 0u); waveSync(); }
         auto emit = [&](uint64_t ent, uint32_t h, uint32_t ord, int win) {
             const uint32_t seqId = (uint32_t) ent;
             const uint32_t diag = (uint32_t) (win - (int) (uint32_t) ((ent >> 32) & 0xFFFF)) & 0xFFFFu;
             const uint64_t key = ((uint64_t) seqId << 32) | ((uint64_t) (h & 0xFFFFu) << 16) | diag;
             if (h < (uint32_t) kHitCap) { keys[h] = key; if (kOrd) ordL[h] = ord; }
             else if (h < (uint32_t) kSpillCap) { spillKeys[h] = key; if (kOrd) spillOrd[h] = ord; }
+            if constexpr (!kSmall) {
+                if (h < (uint32_t) kSpillCap) { const uint32_t bkt = (seqId * kMul0) >> kBktShift, bit = 1u << (bkt & 31u); if (atomicOr(&seen[bkt >> 5], bit) & bit) atomicOr(&again[bkt >> 5], bit); }
+            }
         };
         // Multi-entry lists are rare while the index is sparse (3 % of the occupied slots at phage scale) but walking them
         // right away costs every batch of slots another dependent memory round trip: their slot words are parked in LDS
@@ -589,7 +600,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
                 if (t < defN) { sw[r] = defSlot[t]; mt[r] = defMeta[t]; if (kOrd) od[r] = defOrd[t]; ln[r] = (uint32_t) (sw[r] >> 32) & 0x7FFFFFFFu; }
                 lenMax = ln[r] > lenMax ? ln[r] : lenMax;
             }
-            for (uint32_t e0 = 0; e0 < lenMax; e0 += 4) {
+            for (uint32_t e0 = kSmall ? 0u : 3u; e0 < lenMax; e0 += 4) {      // (bucket layout: the first three entries of a list were emitted with its bucket)
                 uint64_t ent[4][kDeferCap / 64];
 #pragma unroll
                 for (int u = 0; u < 4; u++)
@@ -742,6 +753,78 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
                         }
                     }
                     SP_T(3);
+                    if constexpr (!kSmall) {
+                        // Dense index (the large footprint): a DIRECT table of 32-byte buckets, one per k-mer slot -- {offset | length << 32, entries 0..2 of the
+                        // list} -- read with the slot number itself.  At 2 x 10^8 residues 95 % of the slots are occupied and lists average three entries: the
+                        // occupancy probe (a quarter of the L2 misses there: the 8 MB bit table does not fit one XCD's L2), the rank lookup, the compaction of
+                        // the occupied slots and the second random line per list (slot word -> entry array) all go; only the tail of a longer list is walked.
+#pragma unroll
+                        for (int g = 0; g < kSuper / 64; g += kOccRegs) {
+                            if (s0 + 64u * (uint32_t) g >= tileK) break;                   // (uniform: the rounds beyond the list hold nothing)
+                            uint64_t hdR[kOccRegs], e0R[kOccRegs], e1R[kOccRegs], e2R[kOccRegs]; uint32_t lenR[kOccRegs], hR[kOccRegs], ordR[kOccRegs];
+#pragma unroll
+                            for (int r = 0; r < kOccRegs; r++) {
+                                hdR[r] = 0ull; e0R[r] = 0ull; e1R[r] = 0ull; e2R[r] = 0ull; lenR[r] = 0u; ordR[r] = 0u;
+                                const uint32_t km = kmerR[g + r];
+                                if (km != 0xFFFFFFFFu) {
+                                    const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(a.buckets + 4ull * km);
+                                    const ulonglong2 v0 = bp[0], v1 = bp[1];
+                                    hdR[r] = v0.x; e0R[r] = v0.y; e1R[r] = v1.x; e2R[r] = v1.y;
+                                    lenR[r] = (uint32_t) (hdR[r] >> 32);
+                                    if (kOrd) ordR[r] = qK0 + kBase + s0 + 64u * (uint32_t) (g + r) + (uint32_t) lane;
+                                }
+                            }
+                            uint32_t lenLong = 0, run = M;
+#pragma unroll
+                            for (int r = 0; r < kOccRegs; r++) {
+                                hR[r] = run;
+                                if (s0 + 64u * (uint32_t) (g + r) >= tileK) continue;      // (uniform)
+                                const uint32_t incl = waveInclusiveScan(lenR[r], lane);
+                                hR[r] = run + incl - lenR[r];
+                                run += lane63(incl);
+                                if (lenR[r] > 3u && lenR[r] > lenLong) lenLong = lenR[r];
+                            }
+                            uint32_t nLong = 0;
+#pragma unroll
+                            for (int r = 0; r < kOccRegs; r++) {
+                                if (lenR[r] >= 1u) emit(e0R[r], hR[r], ordR[r], i);
+                                if (lenR[r] >= 2u) emit(e1R[r], hR[r] + 1u, ordR[r], i);
+                                if (lenR[r] >= 3u) emit(e2R[r], hR[r] + 2u, ordR[r], i);
+                                nLong += (uint32_t) __popcll(__ballot(lenR[r] > 3u));
+                            }
+                            // tails of lists longer than three entries: parked (their stream positions are assigned) and fetched together, kDeferCap lists
+                            // at a time -- walking the ~20 long lists of a batch on the spot costs as many dependent round trips as the longest of them has steps
+                            if (nLong > 0 && nLong <= (uint32_t) kDeferCap && defN + nLong > (uint32_t) kDeferCap) flushDeferred();
+                            if (nLong > (uint32_t) kDeferCap) {
+                                for (uint32_t e0 = 3; e0 < lenLong; e0 += kWalkStep) {      // (never with two buckets per lane: a batch has 128 lists)
+                                    uint64_t ent[kWalkStep][kOccRegs];
+#pragma unroll
+                                    for (int u = 0; u < kWalkStep; u++)
+#pragma unroll
+                                        for (int r = 0; r < kOccRegs; r++) ent[u][r] = (e0 + u < lenR[r]) ? a.ientries[(uint32_t) hdR[r] + e0 + u] : 0ull;
+#pragma unroll
+                                    for (int u = 0; u < kWalkStep; u++)
+#pragma unroll
+                                        for (int r = 0; r < kOccRegs; r++) if (e0 + u < lenR[r]) emit(ent[u][r], hR[r] + e0 + u, ordR[r], i);
+                                }
+                            } else if (nLong > 0) {
+#pragma unroll
+                                for (int r = 0; r < kOccRegs; r++) {
+                                    const bool longList = lenR[r] > 3u && hR[r] < (uint32_t) kSpillCap;
+                                    const uint64_t m = __ballot(longList);
+                                    if (longList) {
+                                        const uint32_t at = defN + lanePrefixCount(m);
+                                        defSlot[at] = (1ull << 63) | hdR[r]; defMeta[at] = hR[r] | ((uint32_t) i << 16); if (kOrd) defOrd[at] = ordR[r];
+                                    }
+                                    defN += (uint32_t) __popcll(m);
+                                }
+                            }
+                            M = run;
+                        }
+                        waveSync();
+                        SP_T(5);
+                        continue;
+                    }
                     uint64_t prR[kSuper / 64];
 #pragma unroll
                     for (int r = 0; r < kSuper / 64; r++) prR[r] = (kmerR[r] != 0xFFFFFFFFu) ? a.pbits[kmerR[r] >> 6] : 0ull;
@@ -846,13 +929,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
             // hash, so while the survivors do not fit the register path it runs again on them with another hash: on a dense
             // index (2 000 - 60 000 hits per query) the chance collisions fall geometrically (2 200 -> 300 -> 120 -> the true
             // double hits) and nothing is ever sorted in HBM.
-            uint32_t *seen = occList, *again = occList + kSuper / 2;     // 2 x 512 words; the enumeration arrays are free now
-            constexpr int kBktShift = kSuper == 1024 ? 18 : 19;      // two bitmaps of kSuper / 2 words in the (then idle) occupied-slot list: 16 384 or 8 192 buckets each
             // (hits beyond the LDS buffer live in the per-wave HBM scratch; the survivors usually fit LDS again)
 #pragma nounroll
             for (int round = 0; round < 6; round++) {
-                const uint32_t mul = uni(2654435761u + (uint32_t) round * 0x3C6EF372u);      // odd multipliers, a different one per round
-                for (uint32_t t = lane * 4; t < (uint32_t) kSuper; t += 256) *reinterpret_cast<uint4 *>(occList + t) = make_uint4(0u, 0u, 0u, 0u);
+                const uint32_t mul = uni(kMul0 + (uint32_t) round * 0x3C6EF372u);      // odd multipliers, a different one per round
+                const bool marked = !kSmall && round == 0;      // (large footprint: the first round's bitmaps were filled while the hits were emitted)
+                if (!marked) { for (uint32_t t = lane * 4; t < (uint32_t) kSuper; t += 256) *reinterpret_cast<uint4 *>(occList + t) = make_uint4(0u, 0u, 0u, 0u); }
                 waveSync();
                 // hits beyond the LDS buffer come from the per-wave HBM scratch: those chunks are read kTailKeys keys per lane at a
                 // time (independent loads; one load per step would pay the memory latency 35 times for 2 200 hits)
@@ -861,15 +943,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
                     if (atomicOr(&seen[bkt >> 5], bit) & bit) atomicOr(&again[bkt >> 5], bit);
                 };
                 const uint32_t mLds = M < (uint32_t) kHitCap ? M : (uint32_t) kHitCap;
-                for (uint32_t t = lane; t < mLds; t += 64) mark(keys[t]);
-                for (uint32_t base = (uint32_t) kHitCap; base < M; base += 64u * kTailKeys) {
-                    uint64_t k4[kTailKeys];
+                if (!marked) {
+                    for (uint32_t t = lane; t < mLds; t += 64) mark(keys[t]);
+                    for (uint32_t base = (uint32_t) kHitCap; base < M; base += 64u * kTailKeys) {
+                        uint64_t k4[kTailKeys];
 #pragma unroll
-                    for (int u = 0; u < kTailKeys; u++) { const uint32_t t = base + 64u * u + lane; k4[u] = t < M ? spillKeys[t] : 0ull; }
+                        for (int u = 0; u < kTailKeys; u++) { const uint32_t t = base + 64u * u + lane; k4[u] = t < M ? spillKeys[t] : 0ull; }
 #pragma unroll
-                    for (int u = 0; u < kTailKeys; u++) if (base + 64u * u + lane < M) mark(k4[u]);
+                        for (int u = 0; u < kTailKeys; u++) if (base + 64u * u + lane < M) mark(k4[u]);
+                    }
+                    waveSync();
                 }
-                waveSync();
                 uint32_t wr = 0;
                 auto sift = [&](uint64_t k, bool valid) {
                     const uint32_t bkt = ((uint32_t) (k >> 32) * mul) >> kBktShift;
@@ -1603,6 +1687,10 @@ struct DevBuf {
         return true;
     }
     void release() { if (p) (void) hipFree(p); p = nullptr; n = 0; }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }      // (a context that goes away gives its device memory back: a long-lived process creates and destroys many)
 };
 
 struct SwDev {
@@ -1639,6 +1727,7 @@ struct Gpu::Impl {
     DevBuf<short> alnSub16; DevBuf<double> alnBack;
     int ungMinAbs = 0, alnMinAbs = 0;
     // targets
+    DevBuf<uint64_t> buckets; bool bucketsValid = false; size_t indexSlots = 0;      // large-footprint layout of the slot table, derived from slots / ientries on first use
     DevBuf<uint64_t> pbits; DevBuf<uint16_t> prank; DevBuf<uint32_t> prow; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff; DevBuf<uint32_t> tkeys;
     size_t nTargets = 0; size_t indexEntries = 0;
     // index construction scratch (kept for the next target set)
@@ -1954,7 +2043,12 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
         SP_DBG_SYNC("k_weigh");
     }
     SP_EV(1, 1);
-    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.pbits.p, d.prank.p, d.prow.p, d.slots.p, d.ientries.p, d.spill.p, d.queue.p,
+    if (!small && !d.bucketsValid) {      // (once per target set, on the first pass with the large footprint)
+        if (!d.buckets.ensure(4 * (size_t) kSlots, err)) return false;
+        hipLaunchKernelGGL(k_idx_buckets, dim3((unsigned) ((kSlots + 255) / 256)), dim3(256), 0, d.stream, d.pbits.p, d.prank.p, d.prow.p, d.slots.p, d.ientries.p, d.buckets.p);
+        d.bucketsValid = true;
+    }
+    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.pbits.p, d.prank.p, d.prow.p, d.slots.p, d.ientries.p, small ? nullptr : d.buckets.p, d.spill.p, d.queue.p,
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
                  (uint32_t) d.knob.matchStatic, (uint32_t) d.knob.matchDChunk,
@@ -2225,7 +2319,7 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
     const size_t n = ts.n;
     to = std::min(to, n); from = std::min(from, to);
     const uint64_t R = ts.offsets[n];
-    d.nTargets = n; d.indexEntries = 0;
+    d.nTargets = n; d.indexEntries = 0; d.indexSlots = 0; d.bucketsValid = false;
     out = TargetBuild();
     if (!upload(d.tascii, ascii, (size_t) R, d.stream, err) || !upload(d.toff, ts.offsets.data(), n + 1, d.stream, err) ||
         !upload(d.tkeys, ts.keys.data(), n, d.stream, err)) return false;
@@ -2304,7 +2398,7 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
             hipLaunchKernelGGL(k_idx_ranks, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, d.ixBefore.p, (uint32_t) words, d.prank.p, d.prow.p);
             HIP_OK(hipGetLastError());
             d.denseIndex = (uint64_t) E * 2 >= (uint64_t) nSlots * 3;
-            d.indexEntries = E; out.indexEntries = E; out.indexSlots = nSlots;
+            d.indexEntries = E; d.indexSlots = nSlots; out.indexEntries = E; out.indexSlots = nSlots;
         }
     }
     HIP_OK(hipEventRecord(d.ev[0][2], d.stream));
@@ -2360,6 +2454,7 @@ void *pinnedAlloc(size_t bytes, bool coherent) {
     if (hipHostMalloc(&p, bytes ? bytes : 1, coherent ? hipHostMallocDefault : hipHostMallocNonCoherent) != hipSuccess) { fprintf(stderr, "spacepharer_amd: hipHostMalloc(%zu) failed\n", bytes); abort(); }
     return p;
 }
+bool deviceMemory(size_t &freeBytes, size_t &totalBytes) { return hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess; }
 void pinnedFree(void *p) { if (p) (void) hipHostFree(p); }
 
 bool Gpu::waitAlignCopy(std::string &err) {
@@ -2372,6 +2467,9 @@ bool Gpu::waitAlignCopy(std::string &err) {
 void Gpu::setHitSink(GpuHit *hits, uint32_t *offsets, size_t capHits) {
     Impl &d = *d_;
     if (d.hitsInFlight) { (void) hipEventSynchronize(d.hitsOnHost); }      // a copy into the previous destination is still running
+    // the last pass's hit list may already sit in the OLD destination: forget that copy, so that hostHits() after a switch copies again (into the
+    // new buffers, or the internal staging) instead of handing out the new pointers with the old count
+    d.hitsInFlight = false; d.sinkUsed = false; d.sinkN = 0;
     d.sinkHits = hits; d.sinkOff = offsets; d.sinkCap = (hits && offsets) ? capHits : 0;
 }
 

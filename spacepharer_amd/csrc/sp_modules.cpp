@@ -88,6 +88,10 @@ static bool acquireCtx(const sp_search_params &p, const std::string &targetPath,
         for (CachedCtx &e : g_ctxCache) if (e.key == key) { e.stamp = ++g_ctxStamp; ctx.c = e.c; ctx.cached = true; ctx.targetsStaged = true; forgetPrefilter(e.c); return true; }
     }
     ctx.c = sp_ctx_create(&p);
+    if (!ctx.c && cap) {      // serving: the resident target sets may be what fills the device -- let go of them and try once more
+        releaseCachedContexts();
+        ctx.c = sp_ctx_create(&p);
+    }
     if (!ctx.c) { err = sp_last_error(); return false; }
     if (cap) {
         std::lock_guard<std::mutex> lk(g_ctxMutex);
@@ -307,7 +311,18 @@ int runPrefilterModule(int argc, const char **argv) {
     laps.lap("context (matrices, tables)");
     std::vector<char> tres, qres; std::vector<uint64_t> toff, qoff; std::vector<uint32_t> tkeys, qkeys;
     flatten(tdb, tres, toff, tkeys);
-    if (!ctx.targetsStaged && sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) { const std::string e = sp_last_error(); dropCtx(ctx); return fail("prefilter: " + e); }
+    if (!ctx.targetsStaged && sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) {
+        // serving: cached target sets of earlier calls may be what fills the device; a fresh process would have succeeded, so drop them all and stage again
+        std::string e = sp_last_error();
+        const bool retry = ctx.cached;
+        dropCtx(ctx);
+        if (retry) {
+            releaseCachedContexts();
+            if (!acquireCtx(p, f.positional[1], "index", ctx, err)) return fail("prefilter: " + err);
+            if (sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) == SP_OK) e.clear(); else { e = sp_last_error(); dropCtx(ctx); }
+        }
+        if (!e.empty()) return fail("prefilter: " + e);
+    }
     laps.lap("targets -> device, index");
     flatten(qdb, qres, qoff, qkeys);
     DbWriter w; w.path = f.positional[2]; w.dbtype = 7;      // DBTYPE_PREFILTER_RES

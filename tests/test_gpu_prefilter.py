@@ -127,3 +127,32 @@ def test_empty_batches_and_no_hit_batches():
     aln, cig, n = ctx.align_hits_raw()
     assert n == ctx.num_hits()
     ctx.close()
+
+
+def test_a_destroyed_context_gives_its_device_memory_back():
+    """contexts come and go in a long-lived process (the resident server, this test session): HBM in use must return to where it was"""
+    import ctypes as C
+    import spacepharer_amd as sa
+    L = sa.load_library()
+    g = load_golden("small")
+
+    def free_bytes():
+        f, t = C.c_uint64(), C.c_uint64()
+        assert L.sp_device_memory(C.byref(f), C.byref(t)) == 0
+        return int(f.value)
+
+    def cycle():
+        ctx = sa.SearchContext()
+        ctx.set_targets(g["targets"])
+        ctx.set_queries(g["queries"])
+        ctx.prefilter()
+        ctx.align_hits_raw()
+        ctx.set_tuning("match_small", 0)      # the large footprint and its 2 GB direct table
+        ctx.prefilter()
+        ctx.close()
+
+    cycle()                                  # (the first context also brings up what stays for the process: code objects, the runtime's pools)
+    before = free_bytes()
+    for _ in range(5):
+        cycle()
+    assert before - free_bytes() < (1 << 30), (before, free_bytes())
