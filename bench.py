@@ -329,11 +329,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
-    def measure(shard_targets, spacers, steps, regions, warmup, want_breakdown, shards=0):
+    def measure(shard_targets, spacers, steps, regions, warmup, want_breakdown, shards=0, partition=False):
         """one decomposition on this rank: set-up, reference digests, `regions` timed K-step regions with digest checks.
         shards (target-sharded mode): S target shards x world / S query groups -- group g = rank // S searches query slice g against the
         S shards and all-gathers within the group; 0 / world = every rank is a shard and matches all queries (BASELINE configs[3])."""
         n_pipe = 1 if shard_targets else max(1, min(args.pipeline, steps))
+        # partition (N > 1, index replicated): the SAME job as the sharded one -- `spacers` spacers against the whole target set -- cut by QUERY: rank r
+        # searches slice r of every batch against the full index in its own HBM and the per-rank hit lists are all-gathered (RCCL) after every step
         S = (shards or world) if shard_targets else 1
         G = world // S if shard_targets else 1
         sub = None
@@ -346,10 +348,19 @@ def main():
         for b in range(n_pipe):
             if shard_targets:
                 qs = None                                         # the SAME spacers on every rank
+            elif partition:
+                qs = None if b == 0 else 12345 + 104729 * b       # the same batches on every rank, each rank keeps its slice
             else:
                 qs = None if (rank == 0 and b == 0) else 12345 + 7919 * rank + 104729 * b
             batches.append(make_workload(spacers, args.targets, args.target_len, 12345, qs))
         tres, toff = batches[0][0], batches[0][1]
+        if partition and world > 1:
+            for b in range(n_pipe):
+                tr, to, qr, qo = batches[b]
+                p_from, p_cnt = decompose_by_residues(np.diff(qo).astype(np.int64) + 2, rank, world)
+                lo, hi = int(qo[p_from]), int(qo[p_from + p_cnt])
+                batches[b] = (tr, to, qr[lo:hi].copy(), (qo[p_from:p_from + p_cnt + 1] - qo[p_from]).astype(qo.dtype))
+            assert len({len(bb[3]) for bb in batches}) == 1, "the slices of the batches differ in size"
         if shard_targets and G > 1:      # this rank's group holds query slice g of every batch only
             for b in range(n_pipe):
                 tr, to, qr, qo = batches[b]
@@ -395,6 +406,32 @@ def main():
         ref_slot = [Slot(L, nq, caps[i], full) for i in range(n_pipe)]
 
         device_driven = full and not shard_targets and not args.host_driven      # the whole step queued without a host round trip (sp_ctx_search_begin / _end)
+
+        def exchange_hits(slot):
+            """query partition: the step's hit list of every rank, all-gathered (counts, then the padded 8-byte records): what the host-side steps
+            behind the search (besthitperset ... FDR) need in one place; RCCL HBM -> xGMI -> HBM, gloo through host memory in the tests"""
+            if not (partition and world > 1):
+                return
+            t0 = time.perf_counter()
+            dev = gpu_dev if gpu_dev is not None else torch.device("cpu")
+            n = torch.tensor([slot.n], dtype=torch.int64, device=dev)
+            ns = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(ns, n)
+            max_n = max(1, max(int(x.item()) for x in ns))
+            mine = torch.from_numpy(np.frombuffer(C.string_at(slot.hits, 8 * slot.n), dtype=np.uint8).reshape(-1, 8).copy()) if slot.n else torch.zeros((0, 8), dtype=torch.uint8)
+            pad = torch.zeros((max_n, 8), dtype=torch.uint8, device=dev)
+            if slot.n:
+                pad[:slot.n] = mine.to(dev)
+            if dev.type != "cpu" and hasattr(dist, "all_gather_into_tensor"):
+                out = torch.empty((world * max_n, 8), dtype=torch.uint8, device=dev)
+                dist.all_gather_into_tensor(out, pad)
+                torch.cuda.synchronize(dev)
+            else:
+                parts = [torch.empty_like(pad) for _ in range(world)]
+                dist.all_gather(parts, pad)
+            xch["s"] += time.perf_counter() - t0
+            xch["bytes"] += world * max_n * 8
+            xch["n"] += 1
 
         def step(c, slot):
             if device_driven:      # one step at a time (reference digests, warm-up, breakdown): queue it, collect it
@@ -450,6 +487,7 @@ def main():
                 def collect(slot):
                     n, used = c.search_end()
                     slot.n, slot.used.value, slot.hits_ptr_ok = n, used, True
+                    done[id(slot)].set()      # (the exchange thread takes the steps in a fixed order, the same on every rank)
                     acc[i][1] = n
                     v = c.stat("ms_match")
                     acc[i][0] += 0.0 if v != v else v
@@ -478,10 +516,20 @@ def main():
             xch.update(s=0.0, bytes=0, n=0)
             barrier()
             t0 = time.perf_counter()
-            if n_pipe == 1:
+            done = {id(sl): threading.Event() for grp in slots for sl in grp}
+
+            def exchanger():      # collectives from ONE host thread per rank, steps in the order (round, context)
+                for j in range(max(share)):
+                    for i2 in range(n_pipe):
+                        if j < share[i2]:
+                            done[id(slots[i2][j])].wait()
+                            exchange_hits(slots[i2][j])
+            threads = [threading.Thread(target=run, args=(i,)) for i in range(n_pipe)]
+            if partition and world > 1 and device_driven:
+                threads.append(threading.Thread(target=exchanger))
+            if len(threads) == 1:
                 run(0)
             else:
-                threads = [threading.Thread(target=run, args=(i,)) for i in range(n_pipe)]
                 for th in threads:
                     th.start()
                 for th in threads:
@@ -524,9 +572,11 @@ def main():
         return out
 
     m = measure(sharded, n_spacers, args.steps, args.regions, args.warmup, True, shards=args.shards)
-    rep = hyb = None
+    rep = hyb = qpart = None
     if world > 1 and sharded and not args.no_replica:
         rep = measure(False, 10000, max(4, args.steps // 2), max(1, min(3, args.regions)), args.warmup, False)
+        # the same 100 000-spacer job cut by QUERY (index replicated, hit lists all-gathered after every step): strong scaling like the sharded line
+        qpart = measure(False, n_spacers, max(4, args.steps // 2), max(1, min(3, args.regions)), args.warmup, False, partition=True)
     if world >= 4 and world % 2 == 0 and sharded and not args.shards and not args.no_hybrid:
         # the same job with TWO target shards x world / 2 query groups: the enumeration of the similar k-mers is replicated twice, not world times
         hyb = measure(True, n_spacers, max(4, args.steps // 2), max(1, min(3, args.regions)), args.warmup, False, shards=2)
@@ -606,6 +656,28 @@ def main():
         out["hybrid"] = {"value": n_spacers * max(4, args.steps // 2) / hdt, "unit": "spacer-queries/s", "scaling": "strong", "ms_per_step": hdt / max(4, args.steps // 2) * 1e3,
                          "regions": hregions, "results_checked": hyb["checked"],
                          "parallelism": "2 target shards x %d query groups: RCCL all-gather of the candidates within each pair of ranks" % (world // 2)}
+    if qpart is not None:
+        k2 = max(4, args.steps // 2)
+        qdt, qregions = region_summary(qpart, n_spacers * k2)
+        x = qpart["xch"]
+        out["query_partition"] = {"value": n_spacers * k2 / qdt, "unit": "spacer-queries/s", "scaling": "strong", "ms_per_step": qdt / k2 * 1e3, "regions": qregions,
+                                  "results_checked": qpart["checked"], "allgather_bytes_per_step": x["bytes"] / max(1, x["n"]), "exchange_ms_per_step": 1e3 * x["s"] / max(1, x["n"]),
+                                  "parallelism": "the same job cut by query: every rank holds the full index (it fits HBM a hundred times over) and searches 1/%d of the spacers of a step, "
+                                                 "device-driven steps, %s all-gather of the hit lists after every step" % (world, "RCCL" if args.exchange == "rccl" else "gloo")}
+    if world > 1 and sharded:
+        # the headline at N > 1: the best of the decompositions of the SAME job (100 000 spacers against the whole target set, strong scaling); all of them stay in the line
+        cands = {"target_shards": out["value"]}
+        if hyb is not None:
+            cands["hybrid"] = out["hybrid"]["value"]
+        if qpart is not None:
+            cands["query_partition"] = out["query_partition"]["value"]
+        best = max(cands, key=cands.get)
+        out["decompositions"] = {"spacer_queries_per_s": cands, "value_from": best,
+                                 "target_shards_ms_per_step": out["ms_per_step"]}
+        if best != "target_shards":
+            out["value"] = cands[best]
+            out["ms_per_step"] = out[best]["ms_per_step"]
+            out["config"]["parallelism"] = out[best]["parallelism"] + " (the best of the decompositions measured in this run: see 'decompositions'; BASELINE configs[3]'s target shards + candidate all-gather: %.0f spacer-queries/s)" % cands["target_shards"]
     if rep is not None:
         rdt, rregions = region_summary(rep, 10000 * world * max(4, args.steps // 2))
         out["replica"] = {"value": 10000 * world * max(4, args.steps // 2) / rdt, "unit": "spacer-queries/s", "scaling": "weak",

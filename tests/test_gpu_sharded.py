@@ -134,7 +134,14 @@ def test_bench_self_launches_the_target_sharded_run_with_several_ranks(ranks):
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                   # rank 0 alone prints the line
     out = json.loads(lines[0])
-    assert out["n_gpus"] == ranks and out["scaling"] == "strong" and "target shards x%d" % ranks in out["config"]["parallelism"]
+    assert out["n_gpus"] == ranks and out["scaling"] == "strong"
+    # the headline is the best decomposition of the same job; all of them are in the line
+    dec = out["decompositions"]
+    assert set(dec["spacer_queries_per_s"]) >= {"target_shards", "query_partition"} and dec["value_from"] in dec["spacer_queries_per_s"]
+    assert out["value"] == max(dec["spacer_queries_per_s"].values())
+    assert ("target shards x%d" % ranks) in out["config"]["parallelism"] or "target shards" in out["config"]["parallelism"]
+    qp = out["query_partition"]
+    assert qp["scaling"] == "strong" and qp["results_checked"] > 0 and qp["allgather_bytes_per_step"] > 0 and qp["exchange_ms_per_step"] > 0
     assert out["exchange"]["ranks"] == ranks and out["exchange"]["allgather_bytes_per_step"] > 0 and out["exchange"]["exchange_ms_per_step"] > 0
     assert out["config"]["pairs_aligned_per_step"] == one["config"]["pairs_aligned_per_step"]
     assert out["results_checked"]["steps"] == 6
@@ -206,5 +213,7 @@ def test_bench_two_shards_times_two_query_groups_on_four_ranks():
                        capture_output=True, text=True, timeout=1800, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-    assert "target shards x4" in out["config"]["parallelism"] and out["hybrid"]["value"] > 0 and out["hybrid"]["results_checked"] > 0
+    assert out["hybrid"]["value"] > 0 and out["hybrid"]["results_checked"] > 0
+    dec = out["decompositions"]["spacer_queries_per_s"]      # four shards and 2 x 2, the better one is the headline
+    assert set(dec) == {"target_shards", "hybrid"} and out["value"] == max(dec.values()) and "target shards" in out["config"]["parallelism"]
     assert out["config"]["pairs_aligned_per_step"] == one["config"]["pairs_aligned_per_step"]
