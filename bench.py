@@ -4,9 +4,12 @@
 A "step" is one pass of the hot path over one resident batch of synthetic spacer peptides:
     k_prep -> k_match -> k_score -> k_select -> SW forward -> E-value gate -> SW reverse + traceback -> record assembly
 with the target index / residues / similar-k-mer tables and the query batches already resident in HBM; both results (the
-prefilter hit list and the alignment records + backtraces) are delivered to host memory -- the hit list travels on a copy
-stream while the align kernels run, the alignment records while the NEXT step's prefilter runs (sp_ctx_align_hits_begin /
-_end); the last step's records are collected before the closing barrier, so all K steps complete inside the timed region.
+prefilter hit list and the alignment records + backtraces) are delivered to host memory.  By default the step is
+DEVICE-DRIVEN (sp_ctx_search_begin / _end): every count stays in HBM, all kernels of the step and the four result copies are
+queued without the host learning anything in between, two steps per context may be in flight (--in-flight), and a step whose
+outputs outgrow the capacities is repeated the ordinary way inside _end ("steps_repeated" in the line; 0 on this workload).
+--host-driven times the round-2 sequence instead (sp_ctx_prefilter, sp_ctx_align_hits_begin / _end: the host reads the hit
+count between the two halves).  All K steps complete inside the timed region.
 Every step delivers into its OWN page-locked buffers; after the clock has stopped every delivered result (hit list,
 offsets, alignment records, backtraces) is digested and must equal the digest of the same batch searched by one context
 alone -- a wrong byte anywhere fails the run.
@@ -19,13 +22,15 @@ spacers): the matching kernel is latency-bound, the Smith-Waterman kernel VALU-b
 better than one.  The K-step region is repeated --regions times (default 5); `value` is the median region, the spread is
 reported next to it.
 
-N > 1 (BASELINE.json configs[3]): 100 000 spacers (600 000 peptides) against the same phages SHARDED BY TARGET RANGE over the
-N GPUs: rank g indexes range g, all ranks match all queries against their shard, the per-shard candidates are all-gathered
-over RCCL/xGMI (HBM -> xGMI -> HBM) and each rank finishes (selection on the union + align) its slice of the queries --
-strong scaling, value = spacers / max time over ranks.  The same run then also measures the query partition (every rank
-holds the full index and searches its own 10 000 spacers, no data-path collective; key "replica", weak scaling) and, at N >= 4,
-the same job as 2 target shards x N / 2 query groups (key "hybrid": the similar-k-mer enumeration is replicated per SHARD, so two shards
-replicate it twice instead of N times; --shards S chooses any split).
+N > 1 (BASELINE.json configs[3]): the same 100 000 spacers (600 000 peptides) against the same phages, strong scaling, value =
+spacers / max time over ranks.  The job is measured under every decomposition the path offers and `value` is the best of them
+(`parallelism` names it, `decompositions` holds all): "target shards" (rank g indexes target range g, all ranks match all queries
+against their shard, the per-shard candidates are all-gathered over RCCL/xGMI, each rank finishes -- selection on the union +
+align -- its slice of the queries), "hybrid" at N >= 4 (2 target shards x N / 2 query groups; --shards S chooses any split: the
+similar-k-mer enumeration is replicated per SHARD), and "query partition" (every rank holds the full index and searches 1/N of
+the spacers; the hit lists and alignment records are all-gathered so that every rank ends with the whole result, the exchange
+of one batch running beside the search of the next).  Key "replica" is the weak-scaling side figure (every rank its own 10 000
+spacers, no collective).
 `python bench.py --gpus N` starts the N ranks itself (child processes, started before anything touches the GPU); under
 torchrun it uses the ranks it is given.
 """
