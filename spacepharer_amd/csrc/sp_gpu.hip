@@ -86,6 +86,15 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
     return uni(v);
 }
 
+// LDS byte address of a __shared__ object, and one 16-byte-per-lane LDS-DMA: lane l's 16 bytes at gsrc land at ldsDst + 16 l (ldsDst wave-uniform, in an
+// SGPR).  The request is invisible to the compiler's wait bookkeeping: the reader waits with its own s_waitcnt vmcnt(0) (memory operations retire in order,
+// so the compiler's own counted waits only become stricter).  M0 is saved and restored inside the statement.
+__device__ __forceinline__ uint32_t ldsAddr(const void *p) { return (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) void *) p; }
+__device__ __forceinline__ void ldsDma16(const void *gsrc, uint32_t ldsDst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(ldsDst) : "memory");
+}
+
 __device__ __forceinline__ uint64_t laneMaskLt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
 // number of set bits of a wave mask below this lane: v_mbcnt_lo + v_mbcnt_hi on the mask's scalar halves (popcount(m & laneMaskLt) builds the lane mask first: 4 instructions)
 __device__ __forceinline__ uint32_t lanePrefixCount(uint64_t m) { return (uint32_t) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)); }
@@ -400,6 +409,7 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kSpillCap = 65535;     // hits per query in the per-wave HBM scratch (16-bit stream index)
 constexpr int kBTile = 512;
+constexpr int kBStage = 256;         // partners of row B staged in LDS by the small footprint of k_match (one 16-byte LDS-DMA per lane); later ones are read in place
 constexpr uint32_t kMaxKmerResult = 262144u * 32u;   // KmerGenerator.h:45
 constexpr int kWavesPerBlock = 4;
 constexpr uint32_t kDiagChunk = 64;   // diagonal records reserved per atomic in k_match
@@ -482,7 +492,7 @@ __device__ void markKept(const uint64_t *keys, uint32_t M, uint32_t *bits, int l
 // the second super-round of a window above 512 k-mers costs); with two search contexts per GPU it is 6 % faster per step.  A dense index
 // (2 200 hits per query) needs the large one: its pre-filter bitmaps and hit buffer are sized by kSuper / kHitCap.
 template <int kHitCap, bool kOrd, bool kSmall>
-__global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) void k_match(MatchArgs a) {
+__global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOrd ? 2 : 3)) void k_match(MatchArgs a) {
     constexpr int kSuper = kSmall ? 512 : 1024;         // similar k-mers per enumeration super-round
     constexpr int kOccRegs = 2;                          // occupied slots per lane and batch in the fetch phase: 64 x 2 slot words (small footprint) or 32-byte buckets (large) in flight per wave
     constexpr int kATile = kSmall ? 128 : 256;          // a's per tile of row A (a window of a spacer peptide has 20-60)
@@ -492,8 +502,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
     __shared__ uint64_t s_keys[kWavesPerBlock][kHitCap];
     __shared__ uint32_t s_aStart[kWavesPerBlock][kATile + 1];
     __shared__ uint16_t s_aIdx[kWavesPerBlock][kATile];
-    __shared__ uint16_t s_bIdx[kWavesPerBlock][kBTile];
-    __shared__ uint16_t s_cntB[kWavesPerBlock][kCntW];
+    // small footprint: the rows a window starts from -- the head of row A, the head of row B and the count row -- arrive by LDS-DMA (global_load_lds,
+    // no registers in between), requested while the PREVIOUS window's slots are still being fetched; the large footprint keeps the partner indices only
+    __shared__ uint16_t s_bIdx[kWavesPerBlock][kSmall ? 1 : kBTile];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stA[kWavesPerBlock][kSmall ? kATile : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stB[kWavesPerBlock][kSmall ? kBStage : 4];
+    __shared__ __attribute__((aligned(16))) uint16_t s_cntB[kWavesPerBlock][kCntW];
     __shared__ uint32_t s_bits[kWavesPerBlock][kHitCap / 32];
     __shared__ uint32_t s_occ[kWavesPerBlock][kSuper];
     __shared__ unsigned long long s_hflag[kWavesPerBlock][kSuper / 64];
@@ -507,6 +521,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
     uint32_t *aStart = s_aStart[w];
     uint16_t *aIdx = s_aIdx[w];
     uint16_t *bIdx = s_bIdx[w];
+    uint32_t *stA = s_stA[w], *stB = s_stB[w];
     uint16_t *cntB = s_cntB[w];
     uint32_t *bitsL = s_bits[w];
     uint32_t *occList = s_occ[w];
@@ -541,31 +556,62 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
     const uint32_t nHeavy = uni(a.heavyCount[myList * kHeavyStride]);
     const uint32_t *heavyList = a.heavyList + (size_t) myList * a.nq;
     uint32_t hNext = (uint32_t) w * listBlocks + blockIdx.x / (uint32_t) kHeavyLists;
-    for (uint32_t qc = 0, qcEnd = 0;;) {
-        uint32_t qi;
-        if (hNext < nHeavy) { qi = uni(heavyList[hNext]); hNext += listBlocks * kWavesPerBlock; }
-        else {
-            if (qc == qcEnd) {
-                if (sNext < staticEnd) { qc = sNext; sNext += nWavesTot * kQueryChunk; qcEnd = qc + kQueryChunk; }
-                else { qc = staticEnd + popQueue(a.queue, lane) * a.dynChunk; qcEnd = qc + a.dynChunk; }
-                if (qc >= a.nq) break;
-            }
-            qi = qc++;
-            if (qi >= a.nq) break;
-            if (uni((uint32_t) a.heavyFlag[qi])) continue;
+    // Work arrives in CHUNKS of consecutive queries (one heavy query, kQueryChunk dealt ones or dynChunk popped ones): one round trip brings the
+    // offsets and the heavy flags of the whole chunk into lanes, and the residues / thresholds of a query (one lane per position, packed) are requested
+    // while the query before it is still being matched -- the wave never waits for a header in the middle of a chunk.
+    uint32_t c0 = 0, offL = 0; uint64_t todo = 0ull; int nxt = -1, pkN = -256;
+    auto header = [&](int c) -> int {
+        const uint32_t o = (uint32_t) __builtin_amdgcn_readlane((int) offL, c), Lc = (uint32_t) __builtin_amdgcn_readlane((int) offL, c + 1) - o;
+        return (uint32_t) lane < Lc ? ((int) a.qres[o + lane] | ((int) a.qthr[o + lane] << 8)) : -256;      // residue | threshold << 8; beyond the query: threshold -1
+    };
+    // rows staged in LDS (small footprint): which (row A, row B) pair they are, or are on their way to be
+    uint32_t stagedA = 0xFFFFFFFFu, stagedB = 0xFFFFFFFFu;
+    const uint32_t stALds = uni(ldsAddr(stA)), stBLds = uni(ldsAddr(stB)), cntLds = uni(ldsAddr(cntB));
+    auto stage = [&](uint32_t ia, uint32_t ib) {
+        const uint32_t *rowA = a.ext3 + (size_t) ia * 8000u, *rowB = a.ext3 + (size_t) ib * 8000u;
+        const uint16_t *cntRow = a.ext3cnt + (size_t) ib * kCntW;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every read of the staging area issued so far has returned
+        if (lane < kATile / 4) ldsDma16(rowA + 4 * lane, stALds);
+        if (lane < kBStage / 4) ldsDma16(rowB + 4 * lane, stBLds);
+        if (lane < kCntW / 8) ldsDma16(cntRow + 8 * lane, cntLds);
+        stagedA = ia; stagedB = ib;
+    };
+    for (;;) {
+        if (nxt < 0) {
+            uint32_t nC; bool heavyChunk = false;
+            if (hNext < nHeavy) { c0 = uni(heavyList[hNext]); nC = 1; hNext += listBlocks * kWavesPerBlock; heavyChunk = true; }
+            else if (sNext < staticEnd) { c0 = sNext; sNext += nWavesTot * kQueryChunk; nC = kQueryChunk; }
+            else { c0 = staticEnd + popQueue(a.queue, lane) * a.dynChunk; nC = a.dynChunk; if (c0 >= a.nq) break; }
+            if (c0 + nC > a.nq) nC = a.nq - c0;
+            offL = (uint32_t) lane <= nC ? a.qoff[c0 + lane] : 0u;
+            const uint32_t flag = (!heavyChunk && (uint32_t) lane < nC) ? (uint32_t) a.heavyFlag[c0 + lane] : (lane == 0 && heavyChunk ? 0u : 1u);
+            todo = __ballot(flag == 0u);                  // (the heavy queries of a dealt chunk were served first, from the lists)
+            if (todo == 0ull) continue;
+            nxt = __builtin_ctzll(todo); todo &= todo - 1ull;
+            pkN = header(nxt);
         }
-        const uint32_t qo = uni(a.qoff[qi]);
-        const int L = (int) (uni(a.qoff[qi + 1]) - qo);
+        const int cur = nxt;
+        const uint32_t qi = c0 + (uint32_t) cur;
+        const uint32_t qo = (uint32_t) __builtin_amdgcn_readlane((int) offL, cur);
+        const int L = (int) ((uint32_t) __builtin_amdgcn_readlane((int) offL, cur + 1) - qo);
         const uint8_t *q = a.qres + qo;
         const int nScan = L - kSpan;        // windows 0 .. L-9 ; the last window (L-8) is never scanned
         uint32_t M = 0;
         uint32_t qK0 = 0;                   // similar k-mers of the windows before the current one
         bool overflow = false;
-        // the wave is bound by chains of dependent memory round trips, so: residues and thresholds of the first 64
-        // positions are fetched once per query into lanes (readlane per window), and all loads of a window's
-        // prologue (row A tile, head of row B, count-table row) are issued together
-        const int myRes = lane < L ? (int) q[lane] : 0;
-        const int myThr = lane < L ? (int) a.qthr[qo + lane] : -1;
+        // residues and thresholds of the first 64 positions live in lanes (readlane per window)
+        const int myPk = pkN;
+        nxt = todo ? __builtin_ctzll(todo) : -1;
+        if (nxt >= 0) { todo &= todo - 1ull; pkN = header(nxt); }
+        // the windows whose 8 positions lie inside the first 64 (all of them for a spacer peptide) and that have a threshold
+        const int nLaneWin = nScan < 65 - kSpan ? nScan : 65 - kSpan;
+        uint64_t wm = __ballot(lane < nLaneWin && (myPk >> 8) >= 0);
+        int iLong = 65 - kSpan;             // (queries longer than 64: the remaining windows fetch their positions one by one)
+        auto rowsOf = [&](int pk, int i, uint32_t &ia, uint32_t &ib) {
+            auto r = [&](int x) { return (uint32_t) __builtin_amdgcn_readlane(pk, x) & 0xFFu; };
+            ia = r(i) + 20u * r(i + 1) + 400u * r(i + 3);
+            ib = r(i + 4) + 20u * r(i + 5) + 400u * r(i + 7);
+        };
         SP_T(0);
 
         // the exact pre-filter of the tail (below) works on two bitmaps of hashed target ids, "seen" and "seen again".  The large footprint (dense
@@ -614,43 +660,71 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
             defN = 0;
             waveSync();
         };
-        for (int i = 0; i < nScan; i++) {
-            int thr; uint32_t ia, ib;
-            if (i + kSpan <= 64) {
-                thr = __builtin_amdgcn_readlane(myThr, i);
-                ia = (uint32_t) __builtin_amdgcn_readlane(myRes, i) + 20u * (uint32_t) __builtin_amdgcn_readlane(myRes, i + 1) + 400u * (uint32_t) __builtin_amdgcn_readlane(myRes, i + 3);
-                ib = (uint32_t) __builtin_amdgcn_readlane(myRes, i + 4) + 20u * (uint32_t) __builtin_amdgcn_readlane(myRes, i + 5) + 400u * (uint32_t) __builtin_amdgcn_readlane(myRes, i + 7);
-            } else {
+        for (;;) {
+            int i, thr; uint32_t ia, ib;
+            if (wm) {
+                i = __builtin_ctzll(wm); wm &= wm - 1ull;
+                thr = __builtin_amdgcn_readlane(myPk, i) >> 8;
+                rowsOf(myPk, i, ia, ib);
+            } else if (iLong < nScan) {
+                i = iLong++;
                 thr = (int) uni((uint32_t) (int) a.qthr[qo + i]);
+                if (thr < 0) continue;
                 ia = uni(q[i] + 20u * q[i + 1] + 400u * q[i + 3]);
                 ib = uni(q[i + 4] + 20u * q[i + 5] + 400u * q[i + 7]);
-            }
-            if (thr < 0) continue;
+            } else break;
             const uint32_t *rowA = a.ext3 + (size_t) ia * 8000u;
             const uint32_t *rowB = a.ext3 + (size_t) ib * 8000u;
-            const uint16_t *cntRow = a.ext3cnt + (size_t) ib * kCntW;
-            // ---- one batch of independent loads
-            uint32_t vA0[kATile / 64];
+            // Small footprint: the rows of the NEXT window (of this query, or the first one of the next query of the chunk) are requested as soon as this
+            // window has no more use for the staging area -- after its last mapping phase -- and land while its slots are fetched: a window starts from LDS.
+            bool requested = false;
+            auto requestNext = [&]() {
+                if constexpr (kSmall) {
+                    if (requested) return;
+                    requested = true;
+                    uint32_t na, nb;
+                    if (wm) { rowsOf(myPk, __builtin_ctzll(wm), na, nb); stage(na, nb); }
+                    else if (iLong >= nScan && nxt >= 0) {
+                        const int Ln = (int) ((uint32_t) __builtin_amdgcn_readlane((int) offL, nxt + 1) - (uint32_t) __builtin_amdgcn_readlane((int) offL, nxt));
+                        const int nl = Ln - kSpan < 65 - kSpan ? Ln - kSpan : 65 - kSpan;
+                        const uint64_t wn = __ballot(lane < nl && (pkN >> 8) >= 0);
+                        if (wn) { rowsOf(pkN, __builtin_ctzll(wn), na, nb); stage(na, nb); }
+                    }
+                }
+            };
+            int sA0, sB0; uint32_t vA0[kATile / 64];
+            if constexpr (kSmall) {
+                if (stagedA != ia || stagedB != ib) stage(ia, ib);      // (the first window of a chunk, windows beyond position 64)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA of this wave has landed
+                waveSync();
+                sB0 = (int) uni((uint32_t) extScore(stB[0]));
+                sA0 = (int) uni((uint32_t) extScore(stA[0]));
 #pragma unroll
-            for (int j = 0; j < kATile / 64; j++) vA0[j] = rowA[j * 64 + lane];
-            const uint32_t vB0 = rowB[lane], vB1 = rowB[64 + lane];
-            uint16_t cw[kCntW / 64];
+                for (int j = 0; j < kATile / 64; j++) vA0[j] = 0u;
+            } else {
+                // ---- one batch of independent loads
+                const uint16_t *cntRow = a.ext3cnt + (size_t) ib * kCntW;
 #pragma unroll
-            for (int j = 0; j < kCntW / 64; j++) cw[j] = cntRow[j * 64 + lane];
-            const int sB0 = (int) uni((uint32_t) extScore(vB0));
-            const int sA0 = (int) uni((uint32_t) extScore(vA0[0]));
+                for (int j = 0; j < kATile / 64; j++) vA0[j] = rowA[j * 64 + lane];
+                const uint32_t vB0 = rowB[lane], vB1 = rowB[64 + lane];
+                uint16_t cw[kCntW / 64];
+#pragma unroll
+                for (int j = 0; j < kCntW / 64; j++) cw[j] = cntRow[j * 64 + lane];
+                sB0 = (int) uni((uint32_t) extScore(vB0));
+                sA0 = (int) uni((uint32_t) extScore(vA0[0]));
+                // "how many b reach cutoff c": precomputed per-row count table
+#pragma unroll
+                for (int j = 0; j < kCntW / 64; j++) cntB[j * 64 + lane] = cw[j];
+                bIdx[lane] = (uint16_t) extIndex(vB0); bIdx[64 + lane] = (uint16_t) extIndex(vB1);
+            }
             const int cutoff1 = (short) (thr - sB0);
-            if (sA0 < cutoff1) continue;
+            if (sA0 < cutoff1) { requestNext(); continue; }
             const int minCut2 = (short) (thr - sA0);
             SP_T(1);
-            // "how many b reach cutoff c": precomputed per-row count table
-#pragma unroll
-            for (int j = 0; j < kCntW / 64; j++) cntB[j * 64 + lane] = cw[j];
-            bIdx[lane] = (uint16_t) extIndex(vB0); bIdx[64 + lane] = (uint16_t) extIndex(vB1);
             waveSync();
             int cAt = minCut2 - a.cntMin; cAt = cAt < 0 ? 0 : (cAt >= kCntW ? kCntW - 1 : cAt);
             const uint32_t nBmax = uni((uint32_t) cntB[cAt]);
-            for (uint32_t p = 128 + lane; p < nBmax && p < (uint32_t) kBTile; p += 64) bIdx[p] = (uint16_t) extIndex(rowB[p]);
+            if constexpr (!kSmall) { for (uint32_t p = 128 + lane; p < nBmax && p < (uint32_t) kBTile; p += 64) bIdx[p] = (uint16_t) extIndex(rowB[p]); }
             waveSync();
             // ---- tiles of row A, flattened (a, b) enumeration in the reference's list order
             uint32_t kBase = 0;
@@ -661,7 +735,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
 #pragma unroll
                 for (int j = 0; j < kATile / 64; j++) { nbR[j] = 0; aStR[j] = 0; }
 #pragma unroll
-                for (int j = 0; j < kATile / 64; j++) { const uint32_t ai = a0 + j * 64 + lane; vA[j] = a0 == 0 ? vA0[j] : (ai < 8000u ? rowA[ai] : 0u); }
+                for (int j = 0; j < kATile / 64; j++) { const uint32_t ai = a0 + j * 64 + lane; vA[j] = a0 == 0 ? (kSmall ? stA[j * 64 + lane] : vA0[j]) : (ai < 8000u ? rowA[ai] : 0u); }
 #pragma unroll
                 for (int j = 0; j < kATile / 64; j++) {
                     const uint32_t ai = a0 + j * 64 + lane;
@@ -729,21 +803,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
                         }
 #pragma unroll
                         for (int r = 0; r < kMapGroup; r++) bbG[r] = aStart[aiG[r]];
+                        constexpr uint32_t kBLds = kSmall ? kBStage : kBTile;      // partners whose index is in LDS
                         uint32_t far = 0;
 #pragma unroll
                         for (int r = 0; r < kMapGroup; r++) {
                             const uint32_t k = s0 + 64u * (uint32_t) (g + r) + (uint32_t) lane;
                             bbG[r] = k - bbG[r];
-                            far |= (k < tileK && bbG[r] >= (uint32_t) kBTile) ? 1u : 0u;
+                            far |= (k < tileK && bbG[r] >= kBLds) ? 1u : 0u;
                         }
                         uint32_t biG[kMapGroup], a3G[kMapGroup];
 #pragma unroll
-                        for (int r = 0; r < kMapGroup; r++) { biG[r] = bIdx[bbG[r] < (uint32_t) kBTile ? bbG[r] : 0u]; a3G[r] = aIdx[aiG[r]]; }
+                        for (int r = 0; r < kMapGroup; r++) {
+                            if constexpr (kSmall) biG[r] = extIndex(stB[bbG[r] < kBLds ? bbG[r] : 0u]); else biG[r] = bIdx[bbG[r] < kBLds ? bbG[r] : 0u];
+                            a3G[r] = aIdx[aiG[r]];
+                        }
                         if (__ballot(far != 0u) != 0ull) {
 #pragma unroll
                             for (int r = 0; r < kMapGroup; r++) {
                                 const uint32_t k = s0 + 64u * (uint32_t) (g + r) + (uint32_t) lane;
-                                if (k < tileK && bbG[r] >= (uint32_t) kBTile) biG[r] = extIndex(rowB[bbG[r]]);
+                                if (k < tileK && bbG[r] >= kBLds) biG[r] = extIndex(rowB[bbG[r]]);
                             }
                         }
 #pragma unroll
@@ -753,6 +831,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
                         }
                     }
                     SP_T(3);
+                    if (lastTile && s0 + (uint32_t) kSuper >= tileK) requestNext();      // (the staging area is free from here on)
                     if constexpr (!kSmall) {
                         // Dense index (the large footprint): a DIRECT table of 32-byte buckets, one per k-mer slot -- {offset | length << 32, entries 0..2 of the
                         // list} -- read with the slot number itself.  At 2 x 10^8 residues 95 % of the slots are occupied and lists average three entries: the
@@ -914,6 +993,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : 1) v
                 kBase += tileK;
                 waveSync();
             }
+            requestNext();
             kmersTotal += kBase;
             qK0 += kBase;
         }
