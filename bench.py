@@ -273,6 +273,7 @@ def main():
     ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the reference CPU baseline (one process each); 0 = all usable cores")
     ap.add_argument("--match-blocks", type=int, default=3, help="k_match blocks per CU while several search contexts share the GPU (0 = all that fit); "
                     "the small footprint fits four, three leave room for the other context's aligner")
+    ap.add_argument("--tune", action="append", default=[], metavar="NAME=VALUE", help="sp_ctx_set_tuning(name, value) on every search context of the timed region (experiments)")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="search contexts per GPU, each on its own HIP streams and host thread with its own query batch, taking the steps in turn "
                          "(1 = strictly one pass at a time)")
@@ -475,6 +476,8 @@ def main():
         if n_pipe > 1:
             for c in ctxs:
                 c.set_tuning("match_blocks_per_cu", args.match_blocks)     # leaves LDS / registers for the other context's aligner on every CU
+                for kv in args.tune:
+                    c.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
         for i, c in enumerate(ctxs):
             for _ in range(warmup):
                 step(c, slots[i][0])

@@ -583,26 +583,27 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
             else if (sNext < staticEnd) { c0 = sNext; sNext += nWavesTot * kQueryChunk; nC = kQueryChunk; }
             else { c0 = staticEnd + popQueue(a.queue, lane) * a.dynChunk; nC = a.dynChunk; if (c0 >= a.nq) break; }
             if (c0 + nC > a.nq) nC = a.nq - c0;
-            offL = (uint32_t) lane <= nC ? a.qoff[c0 + lane] : 0u;
+            if constexpr (kSmall) offL = (uint32_t) lane <= nC ? a.qoff[c0 + lane] : 0u;
             const uint32_t flag = (!heavyChunk && (uint32_t) lane < nC) ? (uint32_t) a.heavyFlag[c0 + lane] : (lane == 0 && heavyChunk ? 0u : 1u);
             todo = __ballot(flag == 0u);                  // (the heavy queries of a dealt chunk were served first, from the lists)
             if (todo == 0ull) continue;
             nxt = __builtin_ctzll(todo); todo &= todo - 1ull;
-            pkN = header(nxt);
+            if constexpr (kSmall) pkN = header(nxt);
         }
         const int cur = nxt;
         const uint32_t qi = c0 + (uint32_t) cur;
-        const uint32_t qo = (uint32_t) __builtin_amdgcn_readlane((int) offL, cur);
-        const int L = (int) ((uint32_t) __builtin_amdgcn_readlane((int) offL, cur + 1) - qo);
+        const uint32_t qo = kSmall ? (uint32_t) __builtin_amdgcn_readlane((int) offL, cur) : uni(a.qoff[qi]);
+        const int L = (int) ((kSmall ? (uint32_t) __builtin_amdgcn_readlane((int) offL, cur + 1) : uni(a.qoff[qi + 1])) - qo);
         const uint8_t *q = a.qres + qo;
         const int nScan = L - kSpan;        // windows 0 .. L-9 ; the last window (L-8) is never scanned
         uint32_t M = 0;
         uint32_t qK0 = 0;                   // similar k-mers of the windows before the current one
         bool overflow = false;
         // residues and thresholds of the first 64 positions live in lanes (readlane per window)
-        const int myPk = pkN;
+        // (the large footprint has no register to spare for the header of the query after this one: it fetches its own)
+        const int myPk = kSmall ? pkN : (lane < L ? ((int) q[lane] | ((int) a.qthr[qo + lane] << 8)) : -256);
         nxt = todo ? __builtin_ctzll(todo) : -1;
-        if (nxt >= 0) { todo &= todo - 1ull; pkN = header(nxt); }
+        if (nxt >= 0) { todo &= todo - 1ull; if constexpr (kSmall) pkN = header(nxt); }
         // the windows whose 8 positions lie inside the first 64 (all of them for a spacer peptide) and that have a threshold
         const int nLaneWin = nScan < 65 - kSpan ? nScan : 65 - kSpan;
         uint64_t wm = __ballot(lane < nLaneWin && (myPk >> 8) >= 0);
@@ -1258,8 +1259,9 @@ __global__ void k_score(ScoreArgs a) {
 // (score desc, seqId & (BINSIZE-1) asc, stream position asc); the first maxHits with score >= threshold survive;
 // output is sorted by (final score desc, seqId asc).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kSelCap = 1024;
-constexpr int kSelChunk = 16;     // queries per work-queue pop
+constexpr int kSelCap = 256;
+constexpr int kSelChunk = 64;     // queries per chunk: one per lane
+constexpr int kSelLane = 4;       // diagonals up to which a query is selected inside its lane
 
 struct SelectArgs {
     uint32_t nq; const DiagRec *diagRec; const uint16_t *diagScore; const uint32_t *qDiagBase; const uint32_t *qDiagCnt;
@@ -1270,6 +1272,7 @@ struct SelectArgs {
     uint32_t binMask; int maxHits; int minDiagScore;
     GpuHit *outHits; uint32_t *outQuery; uint32_t *outCount; uint32_t *outBase;   // compact output: each query owns [outBase, outBase+outCount)
     unsigned long long *counters;   // [4] += hits
+    uint32_t chunkQ;                // queries per chunk (<= kSelChunk): 64 while most queries are finished inside a lane, 16 when most need the whole wave (dense index)
 };
 
 __device__ __forceinline__ void selectOne(const SelectArgs &a, const uint32_t qi, const uint32_t obase, uint32_t *hist, uint64_t *keys, uint64_t *scratch, const int lane) {
@@ -1428,26 +1431,48 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_select(SelectArgs a) {
     // No atomics: chunks are dealt round-robin to the waves (the work per chunk is even) and every query's output range is
     // known beforehand (the place of its diagonal records); two contended counters cost more than the kernel's work.
     const uint32_t nWaves = gridDim.x * kWavesPerBlock;
-    for (uint32_t chunk = blockIdx.x * kWavesPerBlock + w; (uint64_t) chunk * kSelChunk < a.nq; chunk += nWaves) {
-        const uint32_t qi = chunk * kSelChunk + lane;
-        const bool mine = lane < kSelChunk && qi < a.nq;
+    static_assert(kSelChunk == 64, "one query per lane");
+    for (uint32_t chunk = blockIdx.x * kWavesPerBlock + w; (uint64_t) chunk * a.chunkQ < a.nq; chunk += nWaves) {
+        const uint32_t qi = chunk * a.chunkQ + lane;
+        const bool mine = (uint32_t) lane < a.chunkQ && qi < a.nq;
+        // everything a query's selection starts from in ONE round trip, the records of the small ones in a second: this kernel usually runs beside another
+        // context's k_match with a single wave per SIMD, where only the number of dependent round trips counts
         const uint32_t D = mine ? a.qDiagCnt[qi] : 0;
-        const uint32_t myBase = mine ? a.wantOff[qi] : 0;
-        const bool fast = (D == 1) && a.maxHits > 1;
+        const uint32_t myBase = mine ? a.wantOff[qi] : 0;       // (= the place of its diagonal records)
+        const uint32_t o0 = mine ? a.qoff[qi] : 0, o1 = mine ? a.qoff[qi + 1] : 0;
+        const int bias = mine ? a.qbias[qi] : 0;
+        const int qL = (int) (o1 - o0);
+        const int maxC = (qL >= 32768) ? 255 : 255 - bias, truncAt = 255 - bias;
+        // up to kSelLane diagonals: the whole selection of the query in its lane (the statement of selectSmall; D == 1 needs none of its conditions)
+        const bool fast = mine && D >= 1 && D < (uint32_t) a.maxHits && (D == 1 || (D <= (uint32_t) kSelLane && a.minDiagScore < 255 - bias));
         if (fast) {
-            const uint32_t b = a.qDiagBase[qi];
-            const int qL = (int) (a.qoff[qi + 1] - a.qoff[qi]);
-            const int bias = a.qbias[qi];
-            const int maxC = (qL >= 32768) ? 255 : 255 - bias;
-            const int ex = a.diagScore[b];
-            const int c = min(ex, maxC);
+            DiagRec r[kSelLane]; int ex[kSelLane];
+#pragma unroll
+            for (int u = 0; u < kSelLane; u++) { r[u] = DiagRec{0xFFFFFFFFu, 0, 0}; ex[u] = 0; }
+#pragma unroll
+            for (int u = 0; u < kSelLane; u++) if ((uint32_t) u < D) { r[u] = a.diagRec[myBase + u]; ex[u] = (int) a.diagScore[myBase + u]; }
+            int c[kSelLane]; bool best[kSelLane]; uint64_t key[kSelLane]; int score[kSelLane];
+#pragma unroll
+            for (int u = 0; u < kSelLane; u++) c[u] = min(ex[u], maxC);
+#pragma unroll
+            for (int u = 0; u < kSelLane; u++) {
+                best[u] = (uint32_t) u < D && c[u] >= a.minDiagScore;
+#pragma unroll
+                for (int v = 0; v < kSelLane; v++) if (v != u && (uint32_t) v < D && r[v].seqId == r[u].seqId && ((v < u && c[v] >= c[u]) || (v > u && c[v] > c[u]))) best[u] = false;
+                score[u] = (c[u] >= truncAt) ? ex[u] : c[u];
+                if (score[u] > 65535) score[u] = 65535;
+                key[u] = ((uint64_t) (65535 - score[u]) << 32) | r[u].seqId;
+            }
             uint32_t cnt = 0;
-            if (c >= a.minDiagScore) {
-                const DiagRec r = a.diagRec[b];
-                const int score = (c >= 255 - bias) ? ex : c;
-                GpuHit h; h.seqId = r.seqId; h.score = (uint16_t) (score > 65535 ? 65535 : score); h.diag = r.diag;
-                a.outHits[myBase] = h; a.outQuery[myBase] = qi;
-                cnt = 1;
+#pragma unroll
+            for (int u = 0; u < kSelLane; u++) {
+                if (!best[u]) continue;
+                uint32_t rank = 0;
+#pragma unroll
+                for (int v = 0; v < kSelLane; v++) if (v != u && best[v] && key[v] < key[u]) rank++;
+                GpuHit h; h.seqId = r[u].seqId; h.score = (uint16_t) score[u]; h.diag = r[u].diag;
+                a.outHits[(size_t) myBase + rank] = h; a.outQuery[(size_t) myBase + rank] = qi;
+                cnt++;
             }
             a.outBase[qi] = myBase; a.outCount[qi] = cnt;
         } else if (mine && D == 0) { a.outCount[qi] = 0; a.outBase[qi] = 0; }
@@ -1457,9 +1482,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_select(SelectArgs a) {
             slow &= slow - 1;
             const uint32_t dq = (uint32_t) __builtin_amdgcn_readlane((int) D, bit);
             const uint32_t ob = (uint32_t) __builtin_amdgcn_readlane((int) myBase, bit);
-            const int qbias = (int) uni((uint32_t) a.qbias[chunk * kSelChunk + (uint32_t) bit]);
-            if (dq <= 64u && dq < (uint32_t) a.maxHits && a.minDiagScore < 255 - qbias) selectSmall(a, chunk * kSelChunk + (uint32_t) bit, dq, ob, lane);
-            else selectOne(a, chunk * kSelChunk + (uint32_t) bit, ob, s_hist[w], s_keys[w], scratch, lane);
+            const int qbias = __builtin_amdgcn_readlane(bias, bit);
+            if (dq <= 64u && dq < (uint32_t) a.maxHits && a.minDiagScore < 255 - qbias) selectSmall(a, chunk * a.chunkQ + (uint32_t) bit, dq, ob, lane);
+            else selectOne(a, chunk * a.chunkQ + (uint32_t) bit, ob, s_hist[w], s_keys[w], scratch, lane);
         }
     }
 }
@@ -2199,7 +2224,7 @@ bool Gpu::queueSelect(unsigned binSize, int maxHits, int minDiagScore, void *hit
     const size_t stageCap = std::max<size_t>(nq_ * (size_t) maxHits, d.diagCap);
     if (!d.outHits.ensure(nq_ * (size_t) maxHits, err) || !d.outStage.ensure(stageCap, err) || !d.outQuery.ensure(stageCap, err)) return false;
     SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.qDiagBase.p,
-                  binSize - 1, maxHits, minDiagScore, d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.counters.p};
+                  binSize - 1, maxHits, minDiagScore, d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.counters.p, d.denseIndex ? 16u : (uint32_t) kSelChunk};
     hipLaunchKernelGGL(k_select, dim3(d.matchBlocks), dim3(64 * kWavesPerBlock), 0, d.stream, se);
     if (hitsLeft) HIP_OK(hipStreamWaitEvent(d.stream, static_cast<hipEvent_t>(hitsLeft), 0));      // the previous step's hit list has left outOffset / outHits
     if (!d.scanCounts(d.outCount.p, (uint32_t) nq_, d.outOffset.p, err)) return false;

@@ -40,11 +40,13 @@ def test_match_and_sw_kernels_keep_their_occupancy(tmp_path):
 
     match = kernel("k_matchILi512ELb0ELb0")                   # k_match<512, false, false>: the unsharded search on a dense index (large footprint)
     assert match["Occupancy [waves/SIMD]"] >= 3, match
-    assert match["VGPRs"] <= 168 and match.get("VGPRs Spill", 0) == 0, match
+    # (up to 8 spilled registers: four wave-constant pointers parked in the kernel's first instructions and fetched back in a query's tail -- none inside the window loop)
+    assert match["VGPRs"] <= 168 and match.get("VGPRs Spill", 0) <= 8, match
     assert match["LDS Size [bytes/block]"] * 3 <= 160 * 1024, match
     small = kernel("k_matchILi256ELb0ELb1")                   # k_match<256, false, true>: sparse index -- four waves per SIMD, or three and room for an aligner
     assert small["Occupancy [waves/SIMD]"] >= 4 and small["VGPRs"] <= 128 and small.get("VGPRs Spill", 0) <= 4, small
     assert small["LDS Size [bytes/block]"] * 4 <= 160 * 1024, small
+    assert small["LDS Size [bytes/block]"] * 3 + 2 * 25 * 1024 <= 160 * 1024, small      # three blocks per CU leave two blocks of the forward aligner their LDS
     shard = kernel("k_matchILi256ELb1ELb1")                   # k_match<256, true, true>: the target-sharded search (ordinals recorded): three blocks per CU
     assert shard["Occupancy [waves/SIMD]"] >= 3 and shard["LDS Size [bytes/block]"] * 3 <= 160 * 1024, shard
     for gl in (10, 12, 16, 32):                               # the packed Smith-Waterman kernels: eight waves per SIMD
