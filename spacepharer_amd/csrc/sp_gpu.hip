@@ -1822,7 +1822,7 @@ struct Gpu::Impl {
         void read() {
             auto num = [](const char *k, int d) { const char *e = getenv(k); return e ? atoi(e) : d; };
             matchSmall = num("SP_MATCH_SMALL", -1); matchPerCU = num("SP_MATCH_PERCU", 0); matchHeavy = num("SP_MATCH_HEAVY", -1);
-            matchStatic = num("SP_MATCH_STATIC", 4); matchDChunk = std::max(1, num("SP_MATCH_DCHUNK", 4));
+            matchStatic = num("SP_MATCH_STATIC", 4); matchDChunk = std::min(32, std::max(1, num("SP_MATCH_DCHUNK", 4)));      // (a chunk's offsets live in the lanes of a wave)
             debug = getenv("SP_DEBUG") != nullptr; prepSplit = getenv("SP_PREP_SPLIT") != nullptr; swRows32 = getenv("SP_SW_ROWS32") != nullptr;
             swRows16 = getenv("SP_SW_ROWS16") != nullptr; swOldForward = getenv("SP_SW_OLD_FORWARD") != nullptr;
         }
