@@ -214,6 +214,7 @@ __global__ void k_prep(PrepArgs a) {
 // of the work depends on this, never a result.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kCntW = 320;         // width of a row of the count table: cutoffs cntMin .. cntMin + 319
+constexpr int kHeavyEstW = 64;     // slack values the per-window estimate of the similar k-mers is tabulated for (k_heavy_calib)
 constexpr int kHeavyLists = 16;    // the heavy queries are collected in 16 lists with counters on separate cache lines (a block appends with one
                                    // atomic, and a thousand blocks finishing together on ONE counter would queue up for ~12 ns each)
 constexpr int kHeavyStride = 32;   // words between two counters
@@ -221,6 +222,7 @@ struct WeighArgs {
     const uint8_t *qres; const uint32_t *qoff; uint32_t nq; const short *qthr;
     const uint32_t *ext3; const uint16_t *ext3cnt; int cntMin; uint32_t heavyThr;
     uint32_t *heavyList; uint8_t *heavyFlag; uint32_t *heavyCount;
+    const uint32_t *est;            // k_prep8 only: similar k-mers of a window by the slack of its best pair (k_heavy_calib); nullptr = count exactly
 };
 __global__ __launch_bounds__(256) void k_weigh(WeighArgs a) {
     // 8 lanes per query share the score values of a window (the loads of one lane would be a long dependent chain); a block
@@ -277,7 +279,10 @@ __global__ __launch_bounds__(256) void k_weigh(WeighArgs a) {
 // residues / bias values / thresholds staged in LDS, so the chains of dependent global round trips of the one-lane-per-query
 // kernels (store bias -> load it back per window, threshold -> table heads -> count rows) shrink to three.  Same
 // arithmetic, in the same order, as k_prep; same counts as k_weigh.
-struct Prep8Args { PrepArgs p; WeighArgs w; uint32_t stride; };
+// (+ the per-query part of the Smith-Waterman set-up -- composition bias of the align matrix and profile bias, k_sw_prep8 in sp_gpu_sw.inc -- when sw.sub16 is
+// set: it needs the same staged residues, and as a launch of its own it cost the step 35-80 us beside another context's k_match)
+struct SwBiasArgs { const short *sub16; const double *back; int matMinAbs; signed char *qcomp; int *qbias; };
+struct Prep8Args { PrepArgs p; WeighArgs w; uint32_t stride; SwBiasArgs sw; };
 __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
     const PrepArgs &a = a8.p; const WeighArgs &wa = a8.w;
     __shared__ short s_seed[kAlph * kAlph]; __shared__ double s_back[kAlph]; __shared__ signed char s_ung[kAlph * kAlph];
@@ -291,8 +296,11 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
     uint8_t *const s_qA = reinterpret_cast<uint8_t *>(s_tA + 32 * S);           // [32][S]
     signed char *const s_cA = reinterpret_cast<signed char *>(s_qA + 32 * S);   // [32][S]
     __shared__ uint32_t s_list[1024]; __shared__ uint32_t s_n, s_base;
-    for (int x = threadIdx.x; x < kAlph * kAlph; x += blockDim.x) { s_seed[x] = a.seedSub[x]; s_ung[x] = a.ungSub[x]; }
-    if (threadIdx.x < kAlph) s_back[threadIdx.x] = a.seedBack[threadIdx.x];
+    __shared__ short s_sw[kAlph * kAlph]; __shared__ double s_swBack[kAlph]; __shared__ uint32_t s_est[kHeavyEstW];
+    if (a8.w.est && threadIdx.x < kHeavyEstW) s_est[threadIdx.x] = a8.w.est[threadIdx.x];
+    const SwBiasArgs &sw = a8.sw;
+    for (int x = threadIdx.x; x < kAlph * kAlph; x += blockDim.x) { s_seed[x] = a.seedSub[x]; s_ung[x] = a.ungSub[x]; if (sw.sub16) s_sw[x] = sw.sub16[x]; }
+    if (threadIdx.x < kAlph) { s_back[threadIdx.x] = a.seedBack[threadIdx.x]; if (sw.sub16) s_swBack[threadIdx.x] = sw.back[threadIdx.x]; }
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     const uint32_t per = (a.nq + gridDim.x - 1) / gridDim.x, qFrom = blockIdx.x * per, qTo = min(a.nq, qFrom + per);
@@ -325,6 +333,26 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
 #pragma unroll
         for (int d = 1; d < 8; d <<= 1) { const int ob = __shfl_xor(aaBias, d, 8); aaBias = ob < aaBias ? ob : aaBias; }
         if (have && sub == 0) a.qbias[qi] = a.ungMinAbs + abs(aaBias > 0 ? 0 : aaBias);
+        if (sw.sub16) {      // SmithWaterman::ssw_init (StripedSmithWaterman.cpp:689-743): the statement of k_sw_prep8
+            int cb = 0;
+            for (int i = sub; i < L; i += 8) {
+                const int minPos = max(0, i - 20), maxPos = min(L, i + 20);
+                const short *row = s_sw + s_qA[slot * S + (i)] * kAlph;
+                int sum = 0;
+                for (int j = minPos; j < maxPos; j++) sum += row[s_qA[slot * S + (j)]];
+                sum -= row[s_qA[slot * S + (i)]];
+                float d = (float) sum;
+                d = (float) ((double) d / (-1.0 * (double) (float) (maxPos - minPos)));
+                for (int x = 0; x < kAlph; x++) d = (float) ((double) d + s_swBack[x] * (double) (float) row[x]);
+                const signed char c = (signed char) ((d < 0.0) ? (double) d - 0.5 : (double) d + 0.5);
+                sw.qcomp[o + i] = c;
+                cb = (cb < c) ? cb : c;
+            }
+#pragma unroll
+            for (int dd = 1; dd < 8; dd <<= 1) { const int ob = __shfl_xor(cb, dd, 8); cb = ob < cb ? ob : cb; }
+            if (cb > 0) cb = 0;
+            if (have && sub == 0) sw.qbias[qi] = sw.matMinAbs + abs(cb);
+        }
         __syncthreads();
         // k-mer thresholds per window (QueryMatcher.cpp:205-219)
         for (int i = sub; i < L; i += 8) {
@@ -349,7 +377,31 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
             a.qself[qi] = mx;
         }
         __syncthreads();
-        // similar k-mers the query will generate (see k_weigh); the best scores of all windows' rows are fetched together
+        // similar k-mers the query will generate (see k_weigh).  Estimated from the slack of every window's best pair over its threshold -- the best pair is
+        // the k-mer itself, its score the sum of six diagonal entries -- when the calibration table is there: no table row is read, this kernel's chains
+        // of dependent round trips (heads of two rows per window, then their count rows) shrink to the residues alone.
+        const bool weighEst = wa.heavyThr != 0xFFFFFFFFu && wa.est != nullptr;
+        if (weighEst) {
+            uint32_t Ke = 0;
+            for (int i = sub; i < L - 8; i += 8) {
+                const int thr = s_tA[slot * S + (i)];
+                if (thr < 0) continue;
+                const uint8_t *q = s_qA + slot * S;
+                int self = 0;
+                const int pp[6] = {0, 1, 3, 4, 5, 7};
+#pragma unroll
+                for (int p = 0; p < 6; p++) self += s_seed[q[i + pp[p]] * kAlph + q[i + pp[p]]];
+                const int slack = self - thr;
+                if (slack >= 0) Ke += s_est[slack < kHeavyEstW ? slack : kHeavyEstW - 1];
+            }
+#pragma unroll
+            for (int d = 1; d < 8; d <<= 1) Ke += (uint32_t) __shfl_xor((int) Ke, d, 8);
+            const bool heavyE = have && sub == 0 && Ke >= wa.heavyThr;
+            if (have && sub == 0) wa.heavyFlag[qi] = heavyE ? 1 : 0;
+            if (heavyE) { const uint32_t at = atomicAdd(&s_n, 1u); if (at < 1024u) s_list[at] = qi; else wa.heavyFlag[qi] = 0; }
+            __syncthreads();
+            continue;
+        }
         const bool weigh = wa.heavyThr != 0xFFFFFFFFu;        // off for large batches (see matchAndScore)
         for (int i = sub; i < (weigh ? L - 8 : 0); i += 8) {
             const uint8_t *q = s_qA + slot * S;
@@ -1817,7 +1869,7 @@ struct Gpu::Impl {
     int numCU = 256;
     // environment knobs (diagnostics / experiments), read once per context instead of once per pass
     struct Knobs {
-        int matchSmall = -1, matchPerCU = 0, matchHeavy = -1, matchStatic = 4, matchDChunk = 4;
+        int matchSmall = -1, matchPerCU = 0, matchHeavy = -1, matchStatic = 4, matchDChunk = 4, weighExact = 0;
         bool debug = false, prepSplit = false, swRows32 = false, swRows16 = false, swOldForward = false;
         void read() {
             auto num = [](const char *k, int d) { const char *e = getenv(k); return e ? atoi(e) : d; };
@@ -1828,9 +1880,10 @@ struct Gpu::Impl {
         }
     } knob;
     // tables
-    DevBuf<uint32_t> ext3; DevBuf<uint16_t> ext3cnt; int cntMin = 0; DevBuf<short> seedSub; DevBuf<double> seedBack; DevBuf<signed char> ungSub; DevBuf<signed char> alnSub;
+    DevBuf<uint32_t> ext3; DevBuf<uint16_t> ext3cnt; DevBuf<uint32_t> heavyEst; int cntMin = 0; DevBuf<short> seedSub; DevBuf<double> seedBack; DevBuf<signed char> ungSub; DevBuf<signed char> alnSub;
     DevBuf<short> alnSub16; DevBuf<double> alnBack;
     int ungMinAbs = 0, alnMinAbs = 0;
+    bool swBiasFresh = false;        // k_prep8 of the current pass left the Smith-Waterman bias of the resident queries in swd.qcomp / swd.qbias
     // targets
     DevBuf<uint64_t> buckets; bool bucketsValid = false; size_t indexSlots = 0;      // large-footprint layout of the slot table, derived from slots / ientries on first use
     DevBuf<uint64_t> pbits; DevBuf<uint16_t> prank; DevBuf<uint32_t> prow; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff; DevBuf<uint32_t> tkeys;
@@ -1923,6 +1976,7 @@ void Gpu::setMatchBlocksPerCU(int n) { d_->matchPerCU = n < 0 ? 0 : n; }
 // scheduling knobs of k_match (they change the order of the work, never a result): footprint -1 by index density / 0 large / 1 small;
 // similar k-mers from which a query is started first, -1 = by batch size, 0 = no list.  Initial values: SP_MATCH_SMALL / SP_MATCH_HEAVY.
 bool Gpu::setKnob(const std::string &name, int value) {
+    if (name == "match_weigh_exact") { d_->knob.weighExact = value ? 1 : 0; return true; }      // the heavy-query list from exact counts (table rows read) instead of the calibrated estimate
     if (name == "match_small") { d_->knob.matchSmall = value < 0 ? -1 : (value ? 1 : 0); return true; }
     if (name == "match_heavy_threshold") { d_->knob.matchHeavy = value < 0 ? -1 : value; return true; }
     if (name == "step_capacity") { d_->stepCap = value < 0 ? 0 : (size_t) value; return true; }      // pairs the next device-driven step is sized for (0 = estimate again); tests
@@ -2052,6 +2106,14 @@ bool Gpu::uploadTables(const SubMat &seed, const SubMat &ung, const SubMat &aln,
         HIP_OK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tempBytes, k1.p, k2.p, v1.p, v2.p, (int) N2, 0, 23, d.stream));
         hipLaunchKernelGGL(k_ext3_pack, dim3((unsigned) (N2 / 256)), dim3(256), 0, d.stream, k2.p, v2.p, hi, d.ext3.p);
         hipLaunchKernelGGL(k_ext3_count, dim3(8000), dim3(kCntW), 0, d.stream, d.ext3.p, lo, d.ext3cnt.p);
+        {   // similar k-mers of a window by the slack of its best pair (the order k_match takes the queries in; see k_heavy_calib)
+            if (!d.heavyEst.ensure(kHeavyEstW, err)) return false;
+            HeavyCalibArgs ha{d.ext3.p, d.ext3cnt.p, lo, {}, d.heavyEst.p};
+            double tot = 0, run = 0;
+            for (int i = 0; i < 20; i++) tot += seed.pBack[i];
+            for (int i = 0; i < 20; i++) { run += seed.pBack[i]; ha.cum[i] = tot > 0 ? (float) (run / tot) : (float) (i + 1) / 20.0f; }
+            hipLaunchKernelGGL(k_heavy_calib, dim3(kHeavyEstW), dim3(256), 0, d.stream, ha);
+        }
         HIP_OK(hipGetLastError());
         HIP_OK(hipStreamSynchronize(d.stream));
         for (DevBuf<uint32_t> *b : {&k1, &k2, &v1, &v2}) { (void) hipFree(b->p); b->p = nullptr; }
@@ -2084,7 +2146,7 @@ bool Gpu::uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std:
     nq_ = nq;
     d.qTotal = off[nq];
     d.hQoff.assign(off, off + nq + 1);
-    d.maxQLen = 0;
+    d.maxQLen = 0; d.swBiasFresh = false;
     for (size_t i = 0; i < nq; i++) d.maxQLen = std::max(d.maxQLen, off[i + 1] - off[i]);
     if (!upload(d.qres, res, d.qTotal, d.stream, err)) return false;
     if (!upload(d.qoff, off, nq + 1, d.stream, err)) return false;
@@ -2133,14 +2195,19 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     // (worth its 30 us per 60 000 queries only while a wave gets few queries: with more than ~30 per wave the heavy ones no
     // longer decide when the kernel ends)
     const uint32_t heavyThr = d.knob.matchHeavy >= 0 ? (uint32_t) d.knob.matchHeavy : (nq_ <= (size_t) blocks * kWavesPerBlock * 32 ? 4000u : 0u);
-    WeighArgs wa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, heavyThr ? heavyThr : 0xFFFFFFFFu, d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p};
+    WeighArgs wa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, heavyThr ? heavyThr : 0xFFFFFFFFu, d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p, d.knob.weighExact ? nullptr : d.heavyEst.p};
     const unsigned weighBlocks = (unsigned) std::min<size_t>((nq_ + 31) / 32, (size_t) d.numCU * 8);
     if (d.maxQLen <= 64 && !d.knob.prepSplit) {
         const uint32_t stride = std::max<uint32_t>(16u, (d.maxQLen + 7u) & ~7u);      // staging row per query (<= 64)
-        Prep8Args p8{pa, wa, stride};
+        // the Smith-Waterman bias of the same queries rides along when the align matrix is resident (queueAlign() then skips its own launch)
+        SwDev &sd = d.swd;
+        const bool withSw = d.alnSub16.p && d.alnBack.p && sd.qcomp.ensure(d.qTotal + 1, err) && sd.qbias.ensure(nq_ + 1, err);
+        Prep8Args p8{pa, wa, stride, withSw ? SwBiasArgs{d.alnSub16.p, d.alnBack.p, d.alnMinAbs, sd.qcomp.p, sd.qbias.p} : SwBiasArgs{nullptr, nullptr, 0, nullptr, nullptr}};
+        d.swBiasFresh = withSw;
         hipLaunchKernelGGL(k_prep8, dim3(weighBlocks), dim3(256), (size_t) 32 * stride * 12, d.stream, p8);
         SP_DBG_SYNC("k_prep8");
     } else {
+        d.swBiasFresh = false;
         hipLaunchKernelGGL(k_prep, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, pa);
         SP_DBG_SYNC("k_prep");
         if (heavyThr) hipLaunchKernelGGL(k_weigh, dim3(weighBlocks), dim3(256), 0, d.stream, wa);

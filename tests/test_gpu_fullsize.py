@@ -262,5 +262,11 @@ def test_bench_checks_every_delivered_result(tmp_path):
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["results_checked"]["steps"] == 12 and out["results_checked"]["equal_to_single_context_result"] is True
-    assert out["config"]["distinct_query_batches"] == 2 and out["regions"]["n"] == 2
+    assert out["regions"]["n"] == 2
     assert out["regions"]["min"] <= out["value"] <= out["regions"]["max"]
+    # no mode asked for: both step modes are measured, the better one is the value
+    modes = out["step_modes"]
+    assert set(modes) == {"device-driven x2", "host-driven x4", "value_from"}
+    assert out["config"]["distinct_query_batches"] == (2 if modes["value_from"] == "device-driven x2" else 4)
+    assert abs(out["value"] - max(modes[k]["spacer_queries_per_s"] for k in ("device-driven x2", "host-driven x4"))) < 1e-6 * out["value"]
+    assert abs(out["value"] - modes[modes["value_from"]]["spacer_queries_per_s"]) < 1e-6 * out["value"]
