@@ -1856,7 +1856,7 @@ struct SwDev {
     DevBuf<uint64_t> dirOff, rowOff, btOff; DevBuf<uint32_t> dirCap, rowCap, btCap;
     DevBuf<signed char> dirPool; DevBuf<int> rowPool; DevBuf<char> btPool; DevBuf<SwFull> full;
     DevBuf<uint16_t> diag; DevBuf<DiagRescore> resc;
-    DevBuf<uint32_t> passList, redoList, counters; DevBuf<unsigned long long> cursors; DevBuf<uint8_t> gatePass; DevBuf<uint16_t> gateSlot;
+    DevBuf<uint32_t> passList, redoList, wordPass, counters; DevBuf<unsigned long long> cursors; DevBuf<uint8_t> gatePass; DevBuf<uint16_t> gateSlot;
     size_t preparedFor = (size_t) -1; const void *preparedPtr = nullptr;
     DevBuf<double> evalTab; DevBuf<int32_t> bitTab; uint64_t gateVersion = 0;
     DevBuf<uint32_t> cigLen, cigOff; DevBuf<AlnRec> rec; DevBuf<char> cig;
