@@ -885,6 +885,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
                     }
                     SP_T(3);
                     if (lastTile && s0 + (uint32_t) kSuper >= tileK) requestNext();      // (the staging area is free from here on)
+#if defined(SP_ABLATE) && SP_ABLATE >= 3
+                    { uint32_t acc = 0;
+#pragma unroll
+                      for (int r = 0; r < kSuper / 64; r++) acc ^= kmerR[r];
+                      if (acc == 0x12345u) a.counters[7] = 1; }      // (keeps the mapping alive)
+                    continue;
+#endif
                     if constexpr (!kSmall) {
                         // Dense index (the large footprint): a DIRECT table of 32-byte buckets, one per k-mer slot -- {offset | length << 32, entries 0..2 of the
                         // list} -- read with the slot number itself.  At 2 x 10^8 residues 95 % of the slots are occupied and lists average three entries: the
@@ -977,6 +984,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
                     }
                     waveSync();
                     SP_T(4);
+#if defined(SP_ABLATE) && SP_ABLATE >= 2
+                    if (nOcc == 0x7FFFFFFFu) a.counters[7] = 1;
+                    continue;
+#endif
                     for (uint32_t ob = 0; ob < nOcc; ob += 64u * kOccRegs) {
                         uint64_t slotR[kOccRegs]; uint32_t lenR[kOccRegs], hR[kOccRegs], ordR[kOccRegs], rankR[kOccRegs];
 #pragma unroll
@@ -1051,6 +1062,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
             qK0 += kBase;
         }
         if (defN) flushDeferred();
+#if defined(SP_ABLATE) && SP_ABLATE >= 1
+        M = 0;
+#endif
         matchesTotal += M;
         if (M > (uint32_t) kSpillCap) { overflow = true; M = 0; }
         uint32_t D = 0, dbase = 0;
