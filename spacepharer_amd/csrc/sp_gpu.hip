@@ -51,6 +51,7 @@ __device__ __forceinline__ void waveSync() {
 #define SP_DPP_ROW_BCAST15 0x142
 #define SP_DPP_ROW_BCAST31 0x143
 #define SP_DPP_WAVE_SHR1 0x138
+#define SP_DPP_WAVE_SHL1 0x130
 
 __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, int lane) {
     (void) lane;
@@ -611,7 +612,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
     // Work arrives in CHUNKS of consecutive queries (one heavy query, kQueryChunk dealt ones or dynChunk popped ones): one round trip brings the
     // offsets and the heavy flags of the whole chunk into lanes, and the residues / thresholds of a query (one lane per position, packed) are requested
     // while the query before it is still being matched -- the wave never waits for a header in the middle of a chunk.
-    uint32_t c0 = 0, offL = 0; uint64_t todo = 0ull; int nxt = -1, pkN = -256;
+    uint32_t c0 = 0, offL = 0; uint64_t todo = 0ull; int nxt = -1, pkN = -256, wN = -1; bool wNValid = false;
+    auto windowWords = [&](int pk) -> int {
+        const int res = pk & 0xFF;
+        const int r1 = __builtin_amdgcn_update_dpp(0, res, SP_DPP_WAVE_SHL1, 0xF, 0xF, false);      // residue of lane + 1
+        const int r2 = __builtin_amdgcn_update_dpp(0, r1, SP_DPP_WAVE_SHL1, 0xF, 0xF, false);
+        const int r3 = __builtin_amdgcn_update_dpp(0, r2, SP_DPP_WAVE_SHL1, 0xF, 0xF, false);       // ... of lane + 3
+        return (res + 20 * r1 + 400 * r3) | ((pk >> 8) << 16);      // (threshold -1: negative word; positions whose window leaves the query are never asked)
+    };
     auto header = [&](int c) -> int {
         const uint32_t o = (uint32_t) __builtin_amdgcn_readlane((int) offL, c), Lc = (uint32_t) __builtin_amdgcn_readlane((int) offL, c + 1) - o;
         return (uint32_t) lane < Lc ? ((int) a.qres[o + lane] | ((int) a.qthr[o + lane] << 8)) : -256;      // residue | threshold << 8; beyond the query: threshold -1
@@ -619,14 +627,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
     // rows staged in LDS (small footprint): which (row A, row B) pair they are, or are on their way to be
     uint32_t stagedA = 0xFFFFFFFFu, stagedB = 0xFFFFFFFFu;
     const uint32_t stALds = uni(ldsAddr(stA)), stBLds = uni(ldsAddr(stB)), cntLds = uni(ldsAddr(cntB));
+    // one statement: the three requests with scalar row bases and a lane offset, exec narrowed inside (32 lanes bring the head of row A, 64 the partners of
+    // row B, 40 the count row), M0 and exec restored.  Called from wave-uniform code only (all lanes on).
+    const uint32_t dmaOff = (uint32_t) lane * 16u;
     auto stage = [&](uint32_t ia, uint32_t ib) {
-        const uint32_t *rowA = a.ext3 + (size_t) ia * 8000u, *rowB = a.ext3 + (size_t) ib * 8000u;
-        const uint16_t *cntRow = a.ext3cnt + (size_t) ib * kCntW;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every read of the staging area issued so far has returned
-        if (lane < kATile / 4) ldsDma16(rowA + 4 * lane, stALds);
-        if (lane < kBStage / 4) ldsDma16(rowB + 4 * lane, stBLds);
-        if (lane < kCntW / 8) ldsDma16(cntRow + 8 * lane, cntLds);
+      if constexpr (kSmall) {
+        const uint64_t bA = (uint64_t) (uintptr_t) a.ext3 + (uint64_t) ia * 32000ull, bB = (uint64_t) (uintptr_t) a.ext3 + (uint64_t) ib * 32000ull;
+        const uint64_t bC = (uint64_t) (uintptr_t) a.ext3cnt + (uint64_t) ib * (uint64_t) (kCntW * 2);
+        static_assert(kATile / 4 == 32 && kBStage / 4 == 64 && kCntW / 8 == 40, "lane counts of the three requests");
+        uint32_t keepM0; uint64_t keepExec;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"                      // every read of the staging area issued so far has returned
+                     "s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\t"
+                     "s_mov_b32 m0, %6\n\ts_mov_b32 exec_hi, 0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                     "s_mov_b32 m0, %7\n\ts_mov_b32 exec_hi, -1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+                     "s_mov_b32 m0, %8\n\ts_mov_b32 exec_hi, 0xff\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                     "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keepM0), "=&s"(keepExec) : "v"(dmaOff), "s"(bA), "s"(bB), "s"(bC), "s"(stALds), "s"(stBLds), "s"(cntLds) : "memory");
         stagedA = ia; stagedB = ib;
+      }
     };
     for (;;) {
         if (nxt < 0) {
@@ -654,16 +672,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
         // residues and thresholds of the first 64 positions live in lanes (readlane per window)
         // (the large footprint has no register to spare for the header of the query after this one: it fetches its own)
         const int myPk = kSmall ? pkN : (lane < L ? ((int) q[lane] | ((int) a.qthr[qo + lane] << 8)) : -256);
+        // per position: number of the 3-mer (i, i+1, i+3) | threshold << 16 -- a window reads its two rows' numbers with two readlanes (the b half of window
+        // i is the a half of position i + 4); built once per query from the residues in the lanes (wave_shl DPP)
+        const int myW = (kSmall && wNValid) ? wN : windowWords(myPk);
+        wNValid = false;
         nxt = todo ? __builtin_ctzll(todo) : -1;
         if (nxt >= 0) { todo &= todo - 1ull; if constexpr (kSmall) pkN = header(nxt); }
         // the windows whose 8 positions lie inside the first 64 (all of them for a spacer peptide) and that have a threshold
         const int nLaneWin = nScan < 65 - kSpan ? nScan : 65 - kSpan;
-        uint64_t wm = __ballot(lane < nLaneWin && (myPk >> 8) >= 0);
+        uint64_t wm = __ballot(lane < nLaneWin && myW >= 0);
         int iLong = 65 - kSpan;             // (queries longer than 64: the remaining windows fetch their positions one by one)
-        auto rowsOf = [&](int pk, int i, uint32_t &ia, uint32_t &ib) {
-            auto r = [&](int x) { return (uint32_t) __builtin_amdgcn_readlane(pk, x) & 0xFFu; };
-            ia = r(i) + 20u * r(i + 1) + 400u * r(i + 3);
-            ib = r(i + 4) + 20u * r(i + 5) + 400u * r(i + 7);
+        auto rowsOf = [&](int w, int i, uint32_t &ia, uint32_t &ib) {
+            ia = (uint32_t) __builtin_amdgcn_readlane(w, i) & 0xFFFFu;
+            ib = (uint32_t) __builtin_amdgcn_readlane(w, i + 4) & 0xFFFFu;
         };
         SP_T(0);
 
@@ -717,8 +738,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
             int i, thr; uint32_t ia, ib;
             if (wm) {
                 i = __builtin_ctzll(wm); wm &= wm - 1ull;
-                thr = __builtin_amdgcn_readlane(myPk, i) >> 8;
-                rowsOf(myPk, i, ia, ib);
+                { const int v = __builtin_amdgcn_readlane(myW, i); thr = v >> 16; ia = (uint32_t) v & 0xFFFFu; ib = (uint32_t) __builtin_amdgcn_readlane(myW, i + 4) & 0xFFFFu; }
             } else if (iLong < nScan) {
                 i = iLong++;
                 thr = (int) uni((uint32_t) (int) a.qthr[qo + i]);
@@ -736,12 +756,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
                     if (requested) return;
                     requested = true;
                     uint32_t na, nb;
-                    if (wm) { rowsOf(myPk, __builtin_ctzll(wm), na, nb); stage(na, nb); }
+                    if (wm) { rowsOf(myW, __builtin_ctzll(wm), na, nb); stage(na, nb); }
                     else if (iLong >= nScan && nxt >= 0) {
                         const int Ln = (int) ((uint32_t) __builtin_amdgcn_readlane((int) offL, nxt + 1) - (uint32_t) __builtin_amdgcn_readlane((int) offL, nxt));
                         const int nl = Ln - kSpan < 65 - kSpan ? Ln - kSpan : 65 - kSpan;
-                        const uint64_t wn = __ballot(lane < nl && (pkN >> 8) >= 0);
-                        if (wn) { rowsOf(pkN, __builtin_ctzll(wn), na, nb); stage(na, nb); }
+                        wN = windowWords(pkN); wNValid = true;
+                        const uint64_t wn = __ballot(lane < nl && wN >= 0);
+                        if (wn) { rowsOf(wN, __builtin_ctzll(wn), na, nb); stage(na, nb); }
                     }
                 }
             };
