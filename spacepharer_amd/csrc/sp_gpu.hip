@@ -2012,6 +2012,8 @@ void Gpu::setMatchBlocksPerCU(int n) { d_->matchPerCU = n < 0 ? 0 : n; }
 // similar k-mers from which a query is started first, -1 = by batch size, 0 = no list.  Initial values: SP_MATCH_SMALL / SP_MATCH_HEAVY.
 bool Gpu::setKnob(const std::string &name, int value) {
     if (name == "match_weigh_exact") { d_->knob.weighExact = value ? 1 : 0; return true; }      // the heavy-query list from exact counts (table rows read) instead of the calibrated estimate
+    if (name == "match_chunk") { d_->knob.matchDChunk = std::min(32, std::max(1, value)); return true; }      // queries per pop of the dynamically dealt part
+    if (name == "match_static") { d_->knob.matchStatic = std::min(8, std::max(0, value)); return true; }      // eighths of the queries dealt round-robin without atomics
     if (name == "match_small") { d_->knob.matchSmall = value < 0 ? -1 : (value ? 1 : 0); return true; }
     if (name == "match_heavy_threshold") { d_->knob.matchHeavy = value < 0 ? -1 : value; return true; }
     if (name == "step_capacity") { d_->stepCap = value < 0 ? 0 : (size_t) value; return true; }      // pairs the next device-driven step is sized for (0 = estimate again); tests

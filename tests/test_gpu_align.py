@@ -171,6 +171,47 @@ def test_packed_sw_kernel_byte_overflow_and_ragged_groups(heavy_lengths, short_r
     o.close()
 
 
+def test_more_sixteen_bit_pairs_than_the_word_kernels_grid_holds():
+    """k_sw_word is a small grid (two blocks per CU, 16 pairs per block and trip) that WALKS the redo list: with more 16-bit pairs than one trip of
+    the grid covers (2 x 256 CUs x 16 = 8 192) every block takes several; the same pairs through one call each way must agree, and a sample against the oracle"""
+    import random
+    from oracle_lib import Alp, Oracle
+    import spacepharer_amd as sa
+    g = load_golden("spacer")["ref"]
+    rnd = random.Random(99)
+    Q = ["".join(rnd.choice("WCHMYPNDFQRE") for _ in range(32)) for _ in range(48)]      # perfect matches score 250-290 (diverse: little composition bias): most leave the 8-bit pass
+    T = []
+    for q in Q:
+        for _ in range(5):
+            T.append("".join(rnd.choice("ACDEFGHIKLMNPQRSTVWY") for _ in range(rnd.randint(0, 20))) + q + "".join(rnd.choice("ACDEFGHIKLMNPQRSTVWY") for _ in range(rnd.randint(0, 20))))
+    ctx = sa.SearchContext()
+    ctx.set_targets(T)
+    ctx.set_queries(Q)
+    own = [(qi, 5 * qi + k) for qi in range(len(Q)) for k in range(5)]      # 240 pairs that overflow the 8-bit pass
+    pairs = (own * 60)[:13000]                                                # ... 13 000 of them in one call, plus ordinary ones in between
+    pairs += [(rnd.randrange(len(Q)), rnd.randrange(len(T))) for _ in range(1500)]
+    rnd.shuffle(pairs)
+    got = ctx.align(pairs)
+    first = {}
+    n_word = 0
+    for pr, (res, cig) in zip(pairs, got):
+        key = (res.raw_score, res.bit_score, res.q_start, res.q_end, res.db_start, res.db_end, res.aln_len, res.passed, cig)
+        assert first.setdefault(pr, key) == key, pr                          # the same pair: the same record wherever it stood in the list
+        n_word += res.raw_score >= 255
+    assert n_word > 8192 + 256, n_word
+    o = Oracle()
+    o.set_targets(T)
+    o.set_alp(Alp.from_ref(g["alpGapped"]), Alp.from_ref(g["alpGapless"]))
+    for (qi, ti) in own[:40] + pairs[:60]:
+        e = o.align(Q[qi], ti)
+        k = first[(qi, ti)]
+        assert (k[0], k[1], k[3], k[5], k[7]) == (e.rawScore, e.score, e.qEndPos, e.dbEndPos, e.passed), (qi, ti)
+        if e.passed:
+            assert (k[2], k[4], k[6], k[8]) == (e.qStartPos, e.dbStartPos, e.alnLength, e.backtrace.decode()), (qi, ti)
+    ctx.close()
+    o.close()
+
+
 def test_align_hits_begin_end_equals_blocking_call():
     """the split call (results still travelling when _begin returns; the next prefilter may be queued meanwhile) delivers
     the same bytes as the blocking one"""

@@ -129,6 +129,31 @@ def test_empty_batches_and_no_hit_batches():
     ctx.close()
 
 
+def test_the_order_the_queries_are_matched_in_never_changes_a_result():
+    """k_match starts with the queries k_prep8 weighs as heavy -- by the calibrated estimate (default), by exact counts (match_weigh_exact) or not at
+    all (match_heavy_threshold 0) -- and deals the rest in chunks: the hit list must be the same bytes whichever way"""
+    import ctypes as C
+    import zlib
+    import numpy as np
+    import bench
+    import spacepharer_amd as sa
+    tres, toff, qres, qoff = bench.make_workload(1500, 6000, 200, 777)
+    crcs = {}
+    for name, knobs in (("estimate", {}), ("exact", {"match_weigh_exact": 1}), ("none", {"match_heavy_threshold": 0}), ("all heavy", {"match_heavy_threshold": 1}),
+                        ("chunks of 1", {"match_chunk": 1}), ("chunks of 7, all dynamic", {"match_chunk": 7, "match_static": 0})):
+        ctx = sa.SearchContext()
+        ctx.set_targets_raw(tres.tobytes(), bench.u64p(toff), len(toff) - 1)
+        ctx.set_queries_raw(qres.tobytes(), bench.u64p(qoff), len(qoff) - 1)
+        for k, v in knobs.items():
+            ctx.set_tuning(k, v)
+        ctx.prefilter()
+        hp, op, n = ctx.hits_view()
+        crcs[name] = (n, zlib.crc32(C.string_at(hp, 8 * n), zlib.crc32(C.string_at(op, 4 * len(qoff)))))
+        ctx.close()
+    assert crcs["estimate"][0] > 1000
+    assert len(set(crcs.values())) == 1, crcs
+
+
 def test_a_destroyed_context_gives_its_device_memory_back():
     """contexts come and go in a long-lived process (the resident server, this test session): HBM in use must return to where it was"""
     import ctypes as C
