@@ -230,7 +230,10 @@ int sp_ctx_set_timing(sp_ctx *c, int level);
 /* tuning knobs (never change a result).  "match_blocks_per_cu": resident blocks of the matching kernel per CU, 0 = as many as
    fit.  Fewer leave LDS for the aligner of another context on the same GPU -- better when several passes are in flight.
    "match_small": footprint of the matching kernel, -1 by index density (default), 0 large, 1 small.  "match_heavy_threshold": similar
-   k-mers from which a query is started first, -1 by batch size (default), 0 no list. */
+   k-mers from which a query is started first, -1 by batch size (default), 0 no list.  "match_weigh_exact": 1 = those k-mers counted exactly
+   (two table rows read per window) instead of estimated from the window's slack over its threshold (default).  "match_chunk" (1..32) /
+   "match_static" (0..8): queries per pop of the dynamically dealt part / eighths of the batch dealt round-robin.  "step_capacity": pairs the
+   next sp_ctx_search_begin() is sized for (0 = estimate again). */
 int sp_ctx_set_tuning(sp_ctx *c, const char *name, int value);
 /* raw HIP stream the context launches on (hipStream_t), for callers that time with their own events */
 void *sp_ctx_stream(const sp_ctx *c);
