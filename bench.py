@@ -31,7 +31,8 @@ against their shard, the per-shard candidates are all-gathered over RCCL/xGMI, e
 align -- its slice of the queries), "hybrid" at N >= 4 (2 target shards x N / 2 query groups; --shards S chooses any split: the
 similar-k-mer enumeration is replicated per SHARD), and "query partition" (every rank holds the full index and searches 1/N of
 the spacers; the hit lists and alignment records are all-gathered so that every rank ends with the whole result, the exchange
-of one batch running beside the search of the next).  Key "replica" is the weak-scaling side figure (every rank its own 10 000
+of one batch running beside the search of the next; measured with host-driven steps in four contexts per rank first and with
+device-driven steps in two, the better one counts: "query_partition.step_modes").  Key "replica" is the weak-scaling side figure (every rank its own 10 000
 spacers, no collective).
 `python bench.py --gpus N` starts the N ranks itself (child processes, started before anything touches the GPU); under
 torchrun it uses the ranks it is given.
@@ -485,6 +486,7 @@ def main():
         for i, c in enumerate(ctxs):
             for _ in range(warmup):
                 step(c, slots[i][0])
+                exchange_hits(slots[i][0])      # (query partition at N > 1: the collective is part of the step -- its first calls set up connections / channels)
         barrier()
         import threading
         for c in ctxs:
@@ -518,6 +520,7 @@ def main():
                 return
             for j in range(share[i]):
                 acc[i][1] = step(c, slots[i][j])
+                done[id(slots[i][j])].set()           # (host-driven: the hit list is in host memory when step() returns)
                 v = c.stat("ms_match")
                 acc[i][0] += 0.0 if v != v else v
 
@@ -537,7 +540,7 @@ def main():
                             done[id(slots[i2][j])].wait()
                             exchange_hits(slots[i2][j])
             threads = [threading.Thread(target=run, args=(i,)) for i in range(n_pipe)]
-            if partition and world > 1 and device_driven:
+            if partition and world > 1:
                 threads.append(threading.Thread(target=exchanger))
             if len(threads) == 1:
                 run(0)
@@ -585,6 +588,10 @@ def main():
 
     dual = world == 1 and not sharded and full and args.pipeline is None and not args.host_driven
     alt = None
+    qpart_h = None
+    if world > 1 and sharded and full and not args.no_replica and args.pipeline is None and not args.host_driven:
+        # N > 1: the query partition with host-driven steps in four contexts per rank, measured before anything else for the same reason as at N = 1
+        qpart_h = measure(False, n_spacers, max(4, args.steps // 2), max(1, min(3, args.regions)), args.warmup, False, partition=True, pipeline=4, host_driven=True)
     if dual:
         # N = 1, no mode asked for: the step is measured both ways -- device-driven (two contexts, two steps in flight each) and host-driven with four
         # contexts, whose idle moments between prefilter and align the other contexts fill -- and `value` is the better of the two; both stay in the line.
@@ -702,10 +709,18 @@ def main():
         k2 = max(4, args.steps // 2)
         qdt, qregions = region_summary(qpart, n_spacers * k2)
         x = qpart["xch"]
-        out["query_partition"] = {"value": n_spacers * k2 / qdt, "unit": "spacer-queries/s", "scaling": "strong", "ms_per_step": qdt / k2 * 1e3, "regions": qregions,
+        modes = {"device-driven x2": n_spacers * k2 / qdt}
+        step_kind = "device-driven steps, two contexts per rank"
+        if qpart_h is not None:
+            hdt2, hregions2 = region_summary(qpart_h, n_spacers * k2)
+            modes["host-driven x4"] = n_spacers * k2 / hdt2
+            if hdt2 < qdt:
+                qdt, qregions, qpart, x = hdt2, hregions2, qpart_h, qpart_h["xch"]
+                step_kind = "host-driven steps, four contexts per rank"
+        out["query_partition"] = {"value": n_spacers * k2 / qdt, "unit": "spacer-queries/s", "scaling": "strong", "ms_per_step": qdt / k2 * 1e3, "regions": qregions, "step_modes": modes,
                                   "results_checked": qpart["checked"], "allgather_bytes_per_step": x["bytes"] / max(1, x["n"]), "exchange_ms_per_step": 1e3 * x["s"] / max(1, x["n"]),
                                   "parallelism": "the same job cut by query: every rank holds the full index (it fits HBM a hundred times over) and searches 1/%d of the spacers of a step, "
-                                                 "device-driven steps, %s all-gather of the hit lists after every step" % (world, "RCCL" if args.exchange == "rccl" else "gloo")}
+                                                 "%s, %s all-gather of the hit lists after every step" % (world, step_kind, "RCCL" if args.exchange == "rccl" else "gloo")}
     if world > 1 and sharded:
         # the headline at N > 1: the best of the decompositions of the SAME job (100 000 spacers against the whole target set, strong scaling); all of them stay in the line
         cands = {"target_shards": out["value"]}

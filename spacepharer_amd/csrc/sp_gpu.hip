@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <sched.h>
 #include <string>
 
 #include "sp_gpu.h"
@@ -1994,11 +1995,17 @@ Gpu::~Gpu() {
 
 // The two host waits of a search step (hit count after the prefilter, record count after the alignment) are short and
 // sit on the critical path: poll the stream instead of sleeping on an interrupt (tens of microseconds to wake up).
+// Short waits on the critical path are polled; a poll that has not succeeded after a few hundred tries gives the core away between tries (several contexts per
+// process, several processes per node: more pollers than the process may have CPUs -- cgroup quotas -- would otherwise starve the threads they wait for).
+static inline void pollPause(unsigned &tries) {
+    if (++tries < 256u) __builtin_ia32_pause(); else sched_yield();
+}
 static hipError_t spinSync(hipStream_t s) {
+    unsigned tries = 0;
     for (;;) {
         const hipError_t e = hipStreamQuery(s);
         if (e != hipErrorNotReady) return e;
-        __builtin_ia32_pause();
+        pollPause(tries);
     }
 }
 
@@ -2419,7 +2426,8 @@ bool Gpu::stepEnd(StepResult &r, std::string &err) {
     const int slot = (int) (d.stepsEnded & 1);
     Impl::StepSlot &ss = d.step[slot];
     for (hipEvent_t e : {ss.hitsOnHost, ss.alnOnHost}) {      // short waits on the critical path: poll
-        for (;;) { const hipError_t q = hipEventQuery(e); if (q == hipSuccess) break; if (q != hipErrorNotReady) { err = std::string("stepEnd: ") + hipGetErrorString(q); d.stepsEnded++; return false; } __builtin_ia32_pause(); }
+        unsigned tries = 0;
+        for (;;) { const hipError_t q = hipEventQuery(e); if (q == hipSuccess) break; if (q != hipErrorNotReady) { err = std::string("stepEnd: ") + hipGetErrorString(q); d.stepsEnded++; return false; } pollPause(tries); }
     }
     d.stepsEnded++;
     const uint32_t *m = d.stepMail + 64 * slot;

@@ -142,6 +142,7 @@ def test_bench_self_launches_the_target_sharded_run_with_several_ranks(ranks):
     assert ("target shards x%d" % ranks) in out["config"]["parallelism"] or "target shards" in out["config"]["parallelism"]
     qp = out["query_partition"]
     assert qp["scaling"] == "strong" and qp["results_checked"] > 0 and qp["allgather_bytes_per_step"] > 0 and qp["exchange_ms_per_step"] > 0
+    assert set(qp["step_modes"]) == {"device-driven x2", "host-driven x4"} and abs(qp["value"] - max(qp["step_modes"].values())) < 1e-6 * qp["value"]      # both step modes, the better one counts
     assert out["exchange"]["ranks"] == ranks and out["exchange"]["allgather_bytes_per_step"] > 0 and out["exchange"]["exchange_ms_per_step"] > 0
     assert out["config"]["pairs_aligned_per_step"] == one["config"]["pairs_aligned_per_step"]
     assert out["results_checked"]["steps"] == 6
