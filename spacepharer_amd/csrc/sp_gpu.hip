@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256) void k_weigh(WeighArgs a) {
 // set: it needs the same staged residues, and as a launch of its own it cost the step 35-80 us beside another context's k_match)
 struct SwBiasArgs { const short *sub16; const double *back; int matMinAbs; signed char *qcomp; int *qbias; };
 struct Prep8Args { PrepArgs p; WeighArgs w; uint32_t stride; SwBiasArgs sw; };
+template <bool kExactWeigh>      // (the exact weights' loops cost the kernel 40 registers: the estimating variant fits two waves per SIMD beside a matching kernel)
 __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
     const PrepArgs &a = a8.p; const WeighArgs &wa = a8.w;
     __shared__ short s_seed[kAlph * kAlph]; __shared__ double s_back[kAlph]; __shared__ signed char s_ung[kAlph * kAlph];
@@ -320,10 +321,12 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
             const int minPos = max(0, i - 20), maxPos = min(L, i + 20);
             const short *row = s_seed + s_qA[slot * S + (i)] * kAlph;
             int sum = 0;
+#pragma unroll 2
             for (int j = minPos; j < maxPos; j++) sum += row[s_qA[slot * S + (j)]];
             sum -= row[s_qA[slot * S + (i)]];
             float d = (float) sum;
             d = (float) ((double) d / (-1.0 * (double) (float) (maxPos - minPos)));
+#pragma unroll 1
             for (int x = 0; x < kAlph; x++) d = (float) ((double) d + s_back[x] * (double) (float) row[x]);
             a.biasf[o + i] = d; s_bA[slot * S + (i)] = d;
             float c = d;
@@ -341,10 +344,12 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
                 const int minPos = max(0, i - 20), maxPos = min(L, i + 20);
                 const short *row = s_sw + s_qA[slot * S + (i)] * kAlph;
                 int sum = 0;
-                for (int j = minPos; j < maxPos; j++) sum += row[s_qA[slot * S + (j)]];
+    #pragma unroll 2
+            for (int j = minPos; j < maxPos; j++) sum += row[s_qA[slot * S + (j)]];
                 sum -= row[s_qA[slot * S + (i)]];
                 float d = (float) sum;
                 d = (float) ((double) d / (-1.0 * (double) (float) (maxPos - minPos)));
+#pragma unroll 1
                 for (int x = 0; x < kAlph; x++) d = (float) ((double) d + s_swBack[x] * (double) (float) row[x]);
                 const signed char c = (signed char) ((d < 0.0) ? (double) d - 0.5 : (double) d + 0.5);
                 sw.qcomp[o + i] = c;
@@ -375,6 +380,7 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
         // self score on diagonal 0 (QueryMatcher::rescoreHits, prefiltering/QueryMatcher.cpp:489-494)
         if (have && sub == 0) {
             int mx = 0, sc = 0;
+#pragma unroll 2
             for (int i = 0; i < L; i++) { sc += s_ung[s_qA[slot * S + (i)] * kAlph + s_qA[slot * S + (i)]] + s_cA[slot * S + (i)]; sc = sc < 0 ? 0 : sc; mx = sc > mx ? sc : mx; }
             a.qself[qi] = mx;
         }
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
         // similar k-mers the query will generate (see k_weigh).  Estimated from the slack of every window's best pair over its threshold -- the best pair is
         // the k-mer itself, its score the sum of six diagonal entries -- when the calibration table is there: no table row is read, this kernel's chains
         // of dependent round trips (heads of two rows per window, then their count rows) shrink to the residues alone.
-        const bool weighEst = wa.heavyThr != 0xFFFFFFFFu && wa.est != nullptr;
+        const bool weighEst = !kExactWeigh && wa.heavyThr != 0xFFFFFFFFu && wa.est != nullptr;
         if (weighEst) {
             uint32_t Ke = 0;
             for (int i = sub; i < L - 8; i += 8) {
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
             __syncthreads();
             continue;
         }
-        const bool weigh = wa.heavyThr != 0xFFFFFFFFu;        // off for large batches (see matchAndScore)
+        const bool weigh = kExactWeigh && wa.heavyThr != 0xFFFFFFFFu;        // off for large batches (see matchAndScore)
         for (int i = sub; i < (weigh ? L - 8 : 0); i += 8) {
             const uint8_t *q = s_qA + slot * S;
             const uint32_t ia = q[i] + 20u * q[i + 1] + 400u * q[i + 3], ib = q[i + 4] + 20u * q[i + 5] + 400u * q[i + 7];
@@ -2248,7 +2254,8 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
         const bool withSw = d.alnSub16.p && d.alnBack.p && sd.qcomp.ensure(d.qTotal + 1, err) && sd.qbias.ensure(nq_ + 1, err);
         Prep8Args p8{pa, wa, stride, withSw ? SwBiasArgs{d.alnSub16.p, d.alnBack.p, d.alnMinAbs, sd.qcomp.p, sd.qbias.p} : SwBiasArgs{nullptr, nullptr, 0, nullptr, nullptr}};
         d.swBiasFresh = withSw;
-        hipLaunchKernelGGL(k_prep8, dim3(weighBlocks), dim3(256), (size_t) 32 * stride * 12, d.stream, p8);
+        if (p8.w.est || !heavyThr) hipLaunchKernelGGL(k_prep8<false>, dim3(weighBlocks), dim3(256), (size_t) 32 * stride * 12, d.stream, p8);
+        else hipLaunchKernelGGL(k_prep8<true>, dim3(weighBlocks), dim3(256), (size_t) 32 * stride * 12, d.stream, p8);
         SP_DBG_SYNC("k_prep8");
     } else {
         d.swBiasFresh = false;
