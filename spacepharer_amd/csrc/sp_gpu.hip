@@ -860,6 +860,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
                     }
                     waveSync();
                     const unsigned long long myW = lane < kSuper / 64 ? hflag[lane] : 0ull;
+#if defined(SP_ABLATE) && SP_ABLATE >= 4
+                    if (myW == 0x123456789abcull) a.counters[7] = 1;      // (keeps the head flags alive; no mapping rounds)
+                    if (lastTile && s0 + (uint32_t) kSuper >= tileK) requestNext();
+                    continue;
+#endif
                     uint32_t carry = 0;
                     uint32_t kmerR[kSuper / 64];
                     // The rounds are mapped in groups of kMapGroup WITHOUT per-round branches: three dependent LDS lookups per round

@@ -1,7 +1,7 @@
 # GPU box: instruction accounting of k_match by ablation (developer builds -DSP_ABLATE=1..3: no tail / no slot batch / no probe either).
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-for lib in libspacepharer_amd.so libspacepharer_amd_ab1.so libspacepharer_amd_ab2.so libspacepharer_amd_ab3.so; do
+for lib in ${LIBS:-libspacepharer_amd.so libspacepharer_amd_ab1.so libspacepharer_amd_ab2.so libspacepharer_amd_ab3.so libspacepharer_amd_ab4.so}; do
   rm -rf /tmp/ab_$lib
   SP_LIB_NAME=$lib timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY --output-format csv -d /tmp/ab_$lib -o p -- python3 $R/tools/pmc_workload.py > /dev/null 2>&1
   python3 - "$lib" <<'PY'
