@@ -88,14 +88,10 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v) {
     return uni(v);
 }
 
-// LDS byte address of a __shared__ object, and one 16-byte-per-lane LDS-DMA: lane l's 16 bytes at gsrc land at ldsDst + 16 l (ldsDst wave-uniform, in an
-// SGPR).  The request is invisible to the compiler's wait bookkeeping: the reader waits with its own s_waitcnt vmcnt(0) (memory operations retire in order,
-// so the compiler's own counted waits only become stricter).  M0 is saved and restored inside the statement.
+// LDS byte address of a __shared__ object (the destination base of an LDS-DMA, `global_load_lds_dwordx4`: lane l's 16 bytes land at base + 16 l, base wave-uniform
+// in M0).  Such requests are invisible to the compiler's wait bookkeeping: the reader waits with its own s_waitcnt vmcnt(0) (memory operations retire in
+// order, so the compiler's own counted waits only become stricter).  See `stage` in k_match.
 __device__ __forceinline__ uint32_t ldsAddr(const void *p) { return (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) void *) p; }
-__device__ __forceinline__ void ldsDma16(const void *gsrc, uint32_t ldsDst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(ldsDst) : "memory");
-}
 
 __device__ __forceinline__ uint64_t laneMaskLt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
 // number of set bits of a wave mask below this lane: v_mbcnt_lo + v_mbcnt_hi on the mask's scalar halves (popcount(m & laneMaskLt) builds the lane mask first: 4 instructions)
