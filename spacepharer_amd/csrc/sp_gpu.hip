@@ -1984,15 +1984,38 @@ struct Gpu::Impl {
 };
 
 Gpu::Gpu() : d_(new Impl) {}
+// Stream pairs (search stream, copy stream) are created once per process and device, in order, and handed from context to context: the HIP runtime
+// multiplexes streams onto 4 hardware queues in the order they are created, and how the streams of several contexts pair up on those queues is worth
+// 10 % of the throughput of four contexts.  A pool keeps the pairing of the first contexts of a process for every later one -- a resident
+// server, a bench that measures several configurations -- instead of leaving it to what was created and destroyed before.
+struct StreamPair { hipStream_t main = nullptr, copy = nullptr; bool busy = false; };
+static std::mutex g_streamPoolMutex;
+static std::map<int, std::vector<StreamPair>> g_streamPool;
+static bool takeStreams(int device, hipStream_t &mainS, hipStream_t &copyS) {
+    std::lock_guard<std::mutex> lock(g_streamPoolMutex);
+    std::vector<StreamPair> &pool = g_streamPool[device];
+    for (StreamPair &p : pool) if (!p.busy) { p.busy = true; mainS = p.main; copyS = p.copy; return true; }
+    StreamPair p;
+    if (hipStreamCreateWithFlags(&p.main, hipStreamNonBlocking) != hipSuccess) return false;
+    if (hipStreamCreateWithFlags(&p.copy, hipStreamNonBlocking) != hipSuccess) { (void) hipStreamDestroy(p.main); return false; }
+    p.busy = true; pool.push_back(p);
+    mainS = p.main; copyS = p.copy;
+    return true;
+}
+static void giveStreams(int device, hipStream_t mainS) {
+    std::lock_guard<std::mutex> lock(g_streamPoolMutex);
+    for (StreamPair &p : g_streamPool[device]) if (p.main == mainS) p.busy = false;
+}
+
 Gpu::~Gpu() {
     if (d_) {
         if (d_->stream) (void) hipStreamSynchronize(d_->stream);
-        if (d_->stream) (void) hipStreamDestroy(d_->stream);
         for (auto &set : d_->ev) for (hipEvent_t e : set) if (e) (void) hipEventDestroy(e);
         for (Impl::StepSlot &ss : d_->step) for (hipEvent_t e : {ss.selected, ss.assembled, ss.hitsOnHost, ss.alnOnHost}) if (e) (void) hipEventDestroy(e);
         if (d_->stepMail) pinnedFree(d_->stepMail);
         if (d_->mailbox) pinnedFree(d_->mailbox);
-        if (d_->copyStream) { (void) hipStreamSynchronize(d_->copyStream); (void) hipStreamDestroy(d_->copyStream); }
+        if (d_->copyStream) (void) hipStreamSynchronize(d_->copyStream);
+        if (d_->stream) giveStreams(d_->device, d_->stream);      // (idle now: the next context of this device takes the pair)
         if (d_->hitsOnHost) (void) hipEventDestroy(d_->hitsOnHost);
         if (d_->alnOnHost) (void) hipEventDestroy(d_->alnOnHost);
         d_->hitStage = PinVec<GpuHit>(); d_->hitOffStage = PinVec<uint32_t>();
@@ -2081,8 +2104,7 @@ bool Gpu::init(int device, std::string &err) {
         }
         name_ = it->second.first; d_->numCU = it->second.second;
     }
-    HIP_OK(hipStreamCreateWithFlags(&d_->stream, hipStreamNonBlocking));
-    HIP_OK(hipStreamCreateWithFlags(&d_->copyStream, hipStreamNonBlocking));
+    if (!takeStreams(d_->device, d_->stream, d_->copyStream)) { err = "hipStreamCreate failed"; return false; }
     HIP_OK(hipEventCreateWithFlags(&d_->hitsOnHost, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&d_->alnOnHost, hipEventDisableTiming));
     for (auto &set : d_->ev) for (hipEvent_t &e : set) HIP_OK(hipEventCreate(&e));
