@@ -239,7 +239,7 @@ static void prefilterStats(sp_ctx *c) {
     sp::KernelTimes kt = c->gpu.times();
     c->stats["kmers"] = (double) pc.kmers; c->stats["db_matches"] = (double) pc.dbMatches; c->stats["diagonals"] = (double) pc.diagonals;
     c->stats["diag_residues"] = (double) pc.diagResidues; c->stats["hits"] = (double) pc.hits;
-    c->stats["ms_prep"] = kt.prep; c->stats["ms_match"] = kt.match; c->stats["ms_score"] = kt.score; c->stats["ms_select"] = kt.select;
+    c->stats["ms_prep"] = kt.prep; c->stats["ms_match"] = kt.match; c->stats["ms_match_active"] = kt.matchActive; c->stats["ms_score"] = kt.score; c->stats["ms_select"] = kt.select;
 }
 
 int sp_ctx_prefilter_candidates(sp_ctx *c) {

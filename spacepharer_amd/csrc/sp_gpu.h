@@ -71,6 +71,8 @@ struct PrefilterCounters {       // the K, M, D, H terms of the roofline formula
 
 struct KernelTimes {             // HIP-event time of the last prefilter()/align() call, milliseconds
     float prep = 0, match = 0, score = 0, select = 0, swForward = 0, swReverse = 0, traceback = 0, assemble = 0;
+    float matchActive = 0;       // k_match from the start of its first wave to the end of its last (the kernel's own wall clock): what a profiler reports as its duration;
+                                 // the event time above also holds the wait for the first wave slots when other contexts' kernels fill the CUs
 };
 
 class Gpu {

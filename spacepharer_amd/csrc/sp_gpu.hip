@@ -597,6 +597,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
         for (uint32_t t = dChunkUsed + lane; t < dChunkCap; t += 64) if ((uint64_t) dChunkBase + t < a.diagCap) a.diagQuery[dChunkBase + t] = 0xFFFFFFFFu;
     };
     SP_T_DECL
+    if (threadIdx.x == 0) atomicMax(&a.counters[6], ~(unsigned long long) wall_clock64());      // (max of the complement = the earliest start; counters are zeroed per pass)
 
     // one atomic pops kQueryChunk queries: a single counter word serialises at ~12 ns per atomic (60 000 pops = 0.7 ms)
     // hybrid work distribution: the first staticEighths / 8 of the queries are dealt round-robin (no atomics), the rest are
@@ -1247,6 +1248,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
         SP_T(7);
     }
     SP_T_FLUSH(a.counters);
+    if (lane == 0) atomicMax(&a.counters[7], (unsigned long long) wall_clock64());
     markUnused();
     if (lane == 0) { unsigned long long *wp = a.wavePartial + (size_t) waveGlobal * 4; wp[0] = kmersTotal; wp[1] = matchesTotal; wp[2] = diagTotal; }
 }
@@ -1926,6 +1928,8 @@ struct Gpu::Impl {
     DevBuf<uint32_t> ext3; DevBuf<uint16_t> ext3cnt; DevBuf<uint32_t> heavyEst; int cntMin = 0; DevBuf<short> seedSub; DevBuf<double> seedBack; DevBuf<signed char> ungSub; DevBuf<signed char> alnSub;
     DevBuf<short> alnSub16; DevBuf<double> alnBack;
     int ungMinAbs = 0, alnMinAbs = 0;
+    unsigned long long matchSpan[2] = {0, 0};      // wall clock at k_match's first wave start / last wave end of the last pass
+    int wallKHz = 100000;            // rate of the device's constant wall clock (wall_clock64)
     bool swBiasFresh = false;        // k_prep8 of the current pass left the Smith-Waterman bias of the resident queries in swd.qcomp / swd.qbias
     // targets
     DevBuf<uint64_t> buckets; bool bucketsValid = false; size_t indexSlots = 0;      // large-footprint layout of the slot table, derived from slots / ientries on first use
@@ -2105,6 +2109,7 @@ bool Gpu::init(int device, std::string &err) {
         name_ = it->second.first; d_->numCU = it->second.second;
     }
     if (!takeStreams(d_->device, d_->stream, d_->copyStream)) { err = "hipStreamCreate failed"; return false; }
+    { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, d_->device) == hipSuccess && khz > 0) d_->wallKHz = khz; }
     HIP_OK(hipEventCreateWithFlags(&d_->hitsOnHost, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&d_->alnOnHost, hipEventDisableTiming));
     for (auto &set : d_->ev) for (hipEvent_t &e : set) HIP_OK(hipEventCreate(&e));
@@ -2325,7 +2330,7 @@ bool Gpu::finishPrefilter(bool matched, std::string &err) {
         hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, d.stream, pa);
     }
     HIP_OK(spinSync(d.stream));
-    if (matched) { counters_.kmers = c[0]; counters_.dbMatches = c[1]; counters_.diagResidues = c[3]; counters_.diagonals = c[5]; }
+    if (matched) { counters_.kmers = c[0]; counters_.dbMatches = c[1]; counters_.diagResidues = c[3]; counters_.diagonals = c[5]; d.matchSpan[0] = ~c[6]; d.matchSpan[1] = c[7]; }
     counters_.overflowQueries = c[2]; counters_.hits = totalHits;
     d.hitsInFlight = false;
     d.nCand = qv[4];
@@ -2340,6 +2345,7 @@ bool Gpu::finishPrefilter(bool matched, std::string &err) {
     if (matched) {
         times_.prep = evMs(d.timing, 2, d.ev[d.evSet][0], d.ev[d.evSet][1]);
         times_.match = evMs(d.timing, 1, d.ev[d.evSet][1], d.ev[d.evSet][2]);
+        times_.matchActive = d.matchSpan[1] > d.matchSpan[0] ? (float) ((double) (d.matchSpan[1] - d.matchSpan[0]) / (double) d.wallKHz) : 0.f;
         times_.score = evMs(d.timing, 2, d.ev[d.evSet][2], d.ev[d.evSet][3]);
     }
     times_.select = evMs(d.timing, 2, d.ev[d.evSet][3], d.ev[d.evSet][4]);
@@ -2463,6 +2469,7 @@ bool Gpu::stepEnd(StepResult &r, std::string &err) {
     const uint32_t *m = d.stepMail + 64 * slot;
     const unsigned long long *c = reinterpret_cast<const unsigned long long *>(m);
     counters_.kmers = c[0]; counters_.dbMatches = c[1]; counters_.overflowQueries = c[2]; counters_.diagResidues = c[3]; counters_.diagonals = c[5];
+    d.matchSpan[0] = ~c[6]; d.matchSpan[1] = c[7];
     const uint32_t nHits = m[40], nPairs = m[41], clipped = m[42], needHost = m[44 + 2], cigTotal = m[52];
     counters_.hits = nHits;
     d.nCand = m[32 + 4];
@@ -2471,6 +2478,7 @@ bool Gpu::stepEnd(StepResult &r, std::string &err) {
     times_ = KernelTimes();
     times_.prep = evMs(d.timing, 2, d.ev[slot][0], d.ev[slot][1]);
     times_.match = evMs(d.timing, 1, d.ev[slot][1], d.ev[slot][2]);
+    times_.matchActive = d.matchSpan[1] > d.matchSpan[0] ? (float) ((double) (d.matchSpan[1] - d.matchSpan[0]) / (double) d.wallKHz) : 0.f;
     times_.score = evMs(d.timing, 2, d.ev[slot][2], d.ev[slot][3]);
     times_.select = evMs(d.timing, 2, d.ev[slot][3], d.ev[slot][4]);
     times_.swForward = evMs(d.timing, 2, d.ev[slot][5], d.ev[slot][6]);
