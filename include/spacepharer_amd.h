@@ -219,7 +219,8 @@ uint64_t sp_ctx_overflow_queries(const sp_ctx *c, uint32_t *out, uint64_t cap);
 
 /* counters / timings of the last call, by name: "kmers", "db_matches", "diagonals", "diag_residues",
    "hits", "index_entries", "masked_residues", "target_residues", "kmer_thr", "bin_size",
-   "ms_prep", "ms_match", "ms_score", "ms_select", "ms_sw_forward", "ms_sw_reverse", "ms_traceback", "ms_assemble",
+   "ms_prep", "ms_match", "ms_match_active" (the matching kernel from its first wave's start to its last wave's end, by the device wall clock),
+   "ms_score", "ms_select", "ms_sw_forward", "ms_sw_reverse", "ms_traceback", "ms_assemble",
    "ms_index_build", "ms_upload" */
 double sp_ctx_stat(const sp_ctx *c, const char *name);
 /* wait for everything queued on the context's stream */
