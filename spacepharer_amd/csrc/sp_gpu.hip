@@ -630,6 +630,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
     };
     // rows staged in LDS (small footprint): which (row A, row B) pair they are, or are on their way to be
     uint32_t stagedA = 0xFFFFFFFFu, stagedB = 0xFFFFFFFFu;
+    bool stagedLanded = false;      // the staged rows are known to be in LDS (a wait went by since they were requested)
     const uint32_t stALds = uni(ldsAddr(stA)), stBLds = uni(ldsAddr(stB)), cntLds = uni(ldsAddr(cntB));
     // one statement: the three requests with scalar row bases and a lane offset, exec narrowed inside (32 lanes bring the head of row A, 64 the partners of
     // row B, 40 the count row), M0 and exec restored.  Called from wave-uniform code only (all lanes on).
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
                      "s_mov_b32 m0, %8\n\ts_mov_b32 exec_hi, 0xff\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
                      "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
                      : "=&s"(keepM0), "=&s"(keepExec) : "v"(dmaOff), "s"(bA), "s"(bB), "s"(bC), "s"(stALds), "s"(stBLds), "s"(cntLds) : "memory");
-        stagedA = ia; stagedB = ib;
+        stagedA = ia; stagedB = ib; stagedLanded = false;
       }
     };
     for (;;) {
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
             int sA0, sB0; uint32_t vA0[kATile / 64];
             if constexpr (kSmall) {
                 if (stagedA != ia || stagedB != ib) stage(ia, ib);      // (the first window of a chunk, windows beyond position 64)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA of this wave has landed
+                if (!stagedLanded) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stagedLanded = true; }      // the LDS-DMA of this wave has landed
                 waveSync();
                 sB0 = (int) uni((uint32_t) extScore(stB[0]));
                 sA0 = (int) uni((uint32_t) extScore(stA[0]));
@@ -1092,6 +1093,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
             qK0 += kBase;
         }
         if (defN) flushDeferred();
+        // The rows of the NEXT query's first window were requested during this query's last window; everything requested since has been waited for (memory
+        // operations retire in order), so this wait costs nothing -- and it must stand HERE: the same wait at the next window's start would also wait for the
+        // record stores of this query's tail, issued a few hundred cycles before it (gfx9 counts stores in vmcnt), a full write latency per query.
+        if constexpr (kSmall) { if (!stagedLanded) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stagedLanded = true; } }
 #if defined(SP_ABLATE) && SP_ABLATE >= 1
         M = 0;
 #endif
