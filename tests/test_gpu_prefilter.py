@@ -154,6 +154,23 @@ def test_the_order_the_queries_are_matched_in_never_changes_a_result():
     assert len(set(crcs.values())) == 1, crcs
 
 
+def test_the_matching_kernel_times_itself():
+    """sp_ctx_stat("ms_match_active"): k_match from its first wave's start to its last wave's end by the device wall clock -- inside the HIP-event time of the
+    same launch (the events also hold launch latency), and not much shorter when the context has the GPU to itself"""
+    import bench
+    import spacepharer_amd as sa
+    tres, toff, qres, qoff = bench.make_workload(3000, 20000, 200, 31)
+    ctx = sa.SearchContext()
+    ctx.set_targets_raw(tres.tobytes(), bench.u64p(toff), len(toff) - 1)
+    ctx.set_queries_raw(qres.tobytes(), bench.u64p(qoff), len(qoff) - 1)
+    ctx.set_timing(1)
+    for _ in range(3):
+        ctx.prefilter()
+    ev, act = ctx.stat("ms_match"), ctx.stat("ms_match_active")
+    assert 0.02 < act <= ev * 1.02 and act > 0.6 * ev, (ev, act)
+    ctx.close()
+
+
 def test_a_destroyed_context_gives_its_device_memory_back():
     """contexts come and go in a long-lived process (the resident server, this test session): HBM in use must return to where it was"""
     import ctypes as C
