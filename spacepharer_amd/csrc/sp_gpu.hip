@@ -1258,6 +1258,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
     if (lane == 0) { unsigned long long *wp = a.wavePartial + (size_t) waveGlobal * 4; wp[0] = kmersTotal; wp[1] = matchesTotal; wp[2] = diagTotal; }
 }
 
+#include "sp_gpu_match_grp.inc"
+
 // ---------------------------------------------------------------------------------------------------------------
 // K_score: one lane per double-hit diagonal -- ungapped local score along the diagonal of the MASKED target
 //   UngappedAlignment::scalarDiagonalScoring / computeSingelSequenceScores / computeLongScore
@@ -1919,11 +1921,11 @@ struct Gpu::Impl {
     int numCU = 256;
     // environment knobs (diagnostics / experiments), read once per context instead of once per pass
     struct Knobs {
-        int matchSmall = -1, matchPerCU = 0, matchHeavy = -1, matchStatic = 4, matchDChunk = 4, weighExact = 0;
+        int matchSmall = -1, matchPerCU = 0, matchHeavy = -1, matchStatic = 4, matchDChunk = 4, weighExact = 0, matchGroup = 1;
         bool debug = false, prepSplit = false, swRows32 = false, swRows16 = false, swOldForward = false;
         void read() {
             auto num = [](const char *k, int d) { const char *e = getenv(k); return e ? atoi(e) : d; };
-            matchSmall = num("SP_MATCH_SMALL", -1); matchPerCU = num("SP_MATCH_PERCU", 0); matchHeavy = num("SP_MATCH_HEAVY", -1);
+            matchSmall = num("SP_MATCH_SMALL", -1); matchGroup = num("SP_MATCH_GROUP", 1); weighExact = num("SP_MATCH_WEIGH_EXACT", 0) ? 1 : 0; matchPerCU = num("SP_MATCH_PERCU", 0); matchHeavy = num("SP_MATCH_HEAVY", -1);
             matchStatic = num("SP_MATCH_STATIC", 4); matchDChunk = std::min(32, std::max(1, num("SP_MATCH_DCHUNK", 4)));      // (a chunk's offsets live in the lanes of a wave)
             debug = getenv("SP_DEBUG") != nullptr; prepSplit = getenv("SP_PREP_SPLIT") != nullptr; swRows32 = getenv("SP_SW_ROWS32") != nullptr;
             swRows16 = getenv("SP_SW_ROWS16") != nullptr; swOldForward = getenv("SP_SW_OLD_FORWARD") != nullptr;
@@ -2061,6 +2063,7 @@ bool Gpu::setKnob(const std::string &name, int value) {
     if (name == "match_chunk") { d_->knob.matchDChunk = std::min(32, std::max(1, value)); return true; }      // queries per pop of the dynamically dealt part
     if (name == "match_static") { d_->knob.matchStatic = std::min(8, std::max(0, value)); return true; }      // eighths of the queries dealt round-robin without atomics
     if (name == "match_small") { d_->knob.matchSmall = value < 0 ? -1 : (value ? 1 : 0); return true; }
+    if (name == "match_group") { d_->knob.matchGroup = value ? 1 : 0; return true; }      // k_match_grp (queries matched four at a time) where its preconditions hold; 0: always k_match
     if (name == "match_heavy_threshold") { d_->knob.matchHeavy = value < 0 ? -1 : value; return true; }
     if (name == "step_capacity") { d_->stepCap = value < 0 ? 0 : (size_t) value; return true; }      // pairs the next device-driven step is sized for (0 = estimate again); tests
     return false;
@@ -2253,14 +2256,17 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     // footprint by index density (SP_MATCH_SMALL=0/1 overrides): sparse -> small, dense -> large; the sharded search always small
     // (its ordinal arrays push the large footprint to two blocks per CU)
     const bool small = d.knob.matchSmall >= 0 ? d.knob.matchSmall != 0 : (withOrd || !d.denseIndex);
-    const void *fn = small ? (withOrd ? (const void *) k_match<256, true, true> : (const void *) k_match<256, false, true>)
+    // short queries against a sparse index, unsharded: the grouped kernel (sp_gpu_match_grp.inc) -- same records, four queries per pass of a wave
+    const bool grouped = small && !withOrd && d.knob.matchGroup != 0 && d.maxQLen <= 64 && d.nTargets < ((size_t) 1 << 30);
+    const void *fn = grouped ? (const void *) k_match_grp :
+                     small ? (withOrd ? (const void *) k_match<256, true, true> : (const void *) k_match<256, false, true>)
                            : (withOrd ? (const void *) k_match<512, true, false> : (const void *) k_match<512, false, false>);
     int perCU = 2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, fn, 64 * kWavesPerBlock, 0) != hipSuccess || perCU < 1) perCU = 2;
     if (d.matchPerCU > 0) perCU = std::min(perCU, d.matchPerCU);
     if (d.knob.matchPerCU > 0) perCU = d.knob.matchPerCU;
     const bool dbg = d.knob.debug;
-    if (dbg) fprintf(stderr, "[sp] k_match footprint=%s ord=%d blocks/CU=%d\n", small ? "small" : "large", (int) withOrd, perCU);
+    if (dbg) fprintf(stderr, "[sp] k_match footprint=%s ord=%d blocks/CU=%d\n", grouped ? "grouped" : (small ? "small" : "large"), (int) withOrd, perCU);
     const uint32_t blocks = (uint32_t) std::min<size_t>((nq_ + kWavesPerBlock - 1) / kWavesPerBlock, (size_t) d.numCU * perCU);
     d.matchBlocks = blocks;
     if (!d.spill.ensure((size_t) blocks * kWavesPerBlock * kSpillWordsPerWave, err)) return false;
@@ -2309,7 +2315,8 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
                  (uint32_t) d.knob.matchStatic, (uint32_t) d.knob.matchDChunk,
                  d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p, d.wavePartial.p};
-    if (small) {
+    if (grouped) hipLaunchKernelGGL(k_match_grp, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+    else if (small) {
         if (withOrd) hipLaunchKernelGGL((k_match<256, true, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
         else hipLaunchKernelGGL((k_match<256, false, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     } else if (withOrd) hipLaunchKernelGGL((k_match<512, true, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
