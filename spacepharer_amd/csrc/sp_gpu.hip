@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
     __shared__ uint32_t s_defOrd[kWavesPerBlock][kOrd ? kDeferCap : 1];
 
     const int lane = laneId();
-    const int w = (int) (threadIdx.x >> 6);
+    const int w = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));      // (wave-uniform, and the compiler should know: the work distribution below derives from it)
     uint64_t *keys = s_keys[w];
     uint32_t *aStart = s_aStart[w];
     uint16_t *aIdx = s_aIdx[w];
@@ -2346,6 +2346,9 @@ bool Gpu::finishPrefilter(bool matched, std::string &err) {
     counters_.overflowQueries = c[2]; counters_.hits = totalHits;
     d.hitsInFlight = false;
     d.nCand = qv[4];
+#ifdef SP_GRP_STATS
+    if (matched) fprintf(stderr, "[sp] grp stats: groups %llu hits %llu rounds %llu survivors %llu passes %llu passHits %llu sorts %llu sortHits %llu\n", c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15]);
+#endif
 #ifdef SP_PHASE_TIMERS
     if (matched) {
         unsigned long long tot = 0; for (int ph = 0; ph < 8; ph++) tot += c[8 + ph];
