@@ -78,7 +78,14 @@ __device__ __forceinline__ uint32_t lane63(uint32_t v) { return (uint32_t) __bui
 // work-queue pop without a divergent `if (lane == 0)`: every lane issues the add (0 for all but lane 0); the
 // compiler's atomic optimiser folds it into one atomic per wave and lane 0 receives the old counter value
 __device__ __forceinline__ uint32_t popQueue(uint32_t *queue, int lane) {
-    const uint32_t v = atomicAdd(queue, lane == 0 ? 1u : 0u);
+    uint32_t v = 0;
+    if (lane == 0) v = atomicAdd(queue, 1u);
+    return uni(v);
+}
+// the same for an amount: lane 0 adds, everybody gets the old value (called from wave-uniform code)
+__device__ __forceinline__ uint32_t waveAtomicAdd(uint32_t *p, uint32_t amount, int lane) {
+    uint32_t v = 0;
+    if (lane == 0) v = atomicAdd(p, amount);
     return uni(v);
 }
 
@@ -2347,7 +2354,8 @@ bool Gpu::finishPrefilter(bool matched, std::string &err) {
     d.hitsInFlight = false;
     d.nCand = qv[4];
 #ifdef SP_GRP_STATS
-    if (matched) fprintf(stderr, "[sp] grp stats: groups %llu hits %llu rounds %llu survivors %llu passes %llu passHits %llu sorts %llu sortHits %llu\n", c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15]);
+    if (matched) fprintf(stderr, "[sp] grp stats: groups %llu hits %llu rounds %llu survivors %llu passes %llu passHits %llu | waves %llu mean busy %.1f us of span %.1f us\n", c[8], c[9], c[10], c[11], c[12], c[13], c[15],
+                         c[15] ? (double) c[14] / (double) c[15] / (double) d.wallKHz * 1e3 : 0.0, (double) (c[7] - ~c[6]) / (double) d.wallKHz * 1e3);
 #endif
 #ifdef SP_PHASE_TIMERS
     if (matched) {

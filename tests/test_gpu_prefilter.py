@@ -39,16 +39,20 @@ def test_prefilter_matches_reference_golden(name):
     # double-hit diagonals found over all queries (QueryMatcher::match output sizes)
     assert ctx.stat("diagonals") == sum(len(q["diag"]) for q in r["queries"])
     # k_match has two footprints and picks by the index' density: the other one must find the same
+    # ... and for short queries against a sparse index there are two kernels: k_match_grp (four queries per pass of a wave, the default where its
+    # preconditions hold) and k_match itself (match_group 0)
     try:
-        for small in (0, 1):
+        for small, group in ((0, 1), (1, 1), (1, 0)):
             ctx.set_tuning("match_small", small)
+            ctx.set_tuning("match_group", group)
             ctx.prefilter()
             got = ctx.hits()
             for q in r["queries"]:
-                assert [list(h) for h in got[q["id"]]] == q["hits"], (name, q["id"], small)
+                assert [list(h) for h in got[q["id"]]] == q["hits"], (name, q["id"], small, group)
             assert ctx.stat("diagonals") == sum(len(q["diag"]) for q in r["queries"])
     finally:
         ctx.set_tuning("match_small", -1)
+        ctx.set_tuning("match_group", 1)
     ctx.close()
 
 
@@ -140,7 +144,9 @@ def test_the_order_the_queries_are_matched_in_never_changes_a_result():
     tres, toff, qres, qoff = bench.make_workload(1500, 6000, 200, 777)
     crcs = {}
     for name, knobs in (("estimate", {}), ("exact", {"match_weigh_exact": 1}), ("none", {"match_heavy_threshold": 0}), ("all heavy", {"match_heavy_threshold": 1}),
-                        ("chunks of 1", {"match_chunk": 1}), ("chunks of 7, all dynamic", {"match_chunk": 7, "match_static": 0})):
+                        ("chunks of 1", {"match_chunk": 1}), ("chunks of 7, all dynamic", {"match_chunk": 7, "match_static": 0}),
+                        ("one query at a time", {"match_group": 0}), ("one query at a time, exact weights", {"match_group": 0, "match_weigh_exact": 1}),
+                        ("one query at a time, chunks of 5", {"match_group": 0, "match_chunk": 5, "match_static": 2})):
         ctx = sa.SearchContext()
         ctx.set_targets_raw(tres.tobytes(), bench.u64p(toff), len(toff) - 1)
         ctx.set_queries_raw(qres.tobytes(), bench.u64p(qoff), len(qoff) - 1)
