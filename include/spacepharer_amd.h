@@ -166,7 +166,9 @@ int sp_ctx_align_hits_end(sp_ctx *c);
    delivered, a traceback that needs the host path) is repeated the synchronous way inside _end: the results are always complete. */
 int sp_ctx_search_begin(sp_ctx *c, sp_hit_packed *hits, uint32_t *offsets, uint64_t hit_cap, sp_alignment *results, char *cigars, uint64_t cigar_cap);
 int sp_ctx_search_end(sp_ctx *c, uint64_t *n_hits, uint64_t *cigar_used);
-/* rescorediagonal core: mode 1 = substitution score, 2 = score + start/end */
+/* rescorediagonal core (alignment/DistanceCalculator.h:93-295): mode 0 = equal letters on the diagonal (the module's default), 1 = ungapped local score,
+ * 2 = score + start/end, 3 = the whole diagonal (start/end = its first / last column, a '*' at either end skipped), 4 = the longest stretch with at most five
+ * mismatches in any 20 columns.  evalue / bit_score are those of `score` (modes 1-4; the module ignores them in mode 0). */
 int sp_ctx_rescore(sp_ctx *c, const uint32_t *query_idx, const uint32_t *target_idx, const int16_t *diagonal, uint64_t n,
                    int mode, sp_rescore *results);
 

@@ -1202,7 +1202,7 @@ size_t spo_alignment_text(spo_aln *res, size_t n, char *buf, size_t cap) {
 }
 
 /* ------------------------------------------------------------------------------------------------
- * a20  DistanceCalculator::computeUngappedAlignment (alignment/DistanceCalculator.h:93-201) on ASCII
+ * a20  DistanceCalculator::computeUngappedAlignment (alignment/DistanceCalculator.h:93-295, all five rescore modes) on ASCII
  *      residues with the 123x123 char matrix of SubstitutionMatrix::createAsciiSubMat
  * ---------------------------------------------------------------------------------------------- */
 static void by_diagonal(const spo_ctx *c, const char *q, unsigned qLen, const char *t, unsigned tLen, int diagonal, int mode, spo_local *res) {
@@ -1214,10 +1214,43 @@ static void by_diagonal(const spo_ctx *c, const char *q, unsigned qLen, const ch
     else if (diagonal < 0 && minDist < tLen) { len = (tLen - minDist) < qLen ? (tLen - minDist) : qLen; s1 = q; s2 = t + minDist; }
     else return;
     res->diagonalLen = (int) len;
+#define SPO_PAIR(pos) ((int) (signed char) c->aln.sub[c->aln.aa2num[(unsigned char) s1[pos] > 122 ? 'X' : (unsigned char) s1[pos]]][c->aln.aa2num[(unsigned char) s2[pos] > 122 ? 'X' : (unsigned char) s2[pos]]])
+    if (mode == 0) {       /* RESCORE_MODE_HAMMING: computeInverseHammingDistance (:275-295) -- equal letters, bytes compared as they are */
+        unsigned same = 0;
+        for (unsigned pos = 0; pos < len; pos++) same += (s1[pos] == s2[pos]);
+        res->score = (int) same;
+        return;
+    }
+    if (mode == 3 || mode == 4) {
+        unsigned first = (s1[0] == '*' || s2[0] == '*') ? 1u : 0u, last = len - 1;
+        if (last > 0 && (s1[len - 1] == '*' || s2[len - 1] == '*')) last--;
+        if (mode == 3) {   /* RESCORE_MODE_GLOBAL_ALIGNMENT: computeGlobalSubstitutionStartEndDistance (:203-220) */
+            long long sum = 0;
+            for (unsigned pos = first; pos <= last && last != 0xFFFFFFFFu; pos++) sum += SPO_PAIR(pos);
+            if (sum < 0) sum = 0;
+            res->score = (int) sum; res->startPos = (int) first; res->endPos = (int) last;
+            return;
+        }
+        /* RESCORE_MODE_WINDOW_QUALITY_ALIGNMENT: computeWindowQualitySubstitutionStartEndDistance (:222-272), windowSize 20, historyErrors 5 */
+        unsigned long long window = 0, windowMask = 1ull << 19;
+        unsigned currErrors = 0, maxLength = 0, currLength = 0, maxEndPos = 0, maxStartPos = 0, startPos = first;
+        int maxScore = 0;
+        for (unsigned pos = first; pos <= last && last != 0xFFFFFFFFu; pos++) {
+            int currMatch = s1[pos] == s2[pos];
+            if (window & windowMask) currErrors -= 1;
+            window <<= 1;
+            if (!currMatch) { window |= 1ull; currErrors += 1; }
+            currLength += 1;
+            if (pos >= 19 && currErrors > 5) { startPos = pos - 20 + 2; currLength = 19; }
+            if (currLength > maxLength) { maxStartPos = startPos; maxEndPos = pos; maxLength = currLength; }
+        }
+        for (unsigned pos = maxStartPos; pos < maxEndPos; pos++) maxScore += SPO_PAIR(pos);
+        res->score = maxScore; res->startPos = (int) maxStartPos; res->endPos = (int) maxEndPos;
+        return;
+    }
     int maxScore = 0, maxEnd = 0, maxStart = 0, minPos = -1, score = 0;
     for (unsigned pos = 0; pos < len; pos++) {
-        unsigned char a = (unsigned char) s1[pos], b = (unsigned char) s2[pos];
-        int curr = (signed char) c->aln.sub[c->aln.aa2num[a > 122 ? 'X' : a]][c->aln.aa2num[b > 122 ? 'X' : b]];
+        int curr = SPO_PAIR(pos);
         score = curr + score;
         int isMin = (score <= 0);
         score = isMin ? 0 : score;
@@ -1237,12 +1270,12 @@ void spo_rescore_diagonal(const spo_ctx *c, const char *q, int qLen, const char 
     for (unsigned d = 1; d <= 1 + (unsigned) tLen / 32768; d++) {
         int real = (int) (-(int64_t) d * 65536 + diag);
         spo_local tmp; by_diagonal(c, q, (unsigned) qLen, t, (unsigned) tLen, real, mode, &tmp);
-        if (tmp.score > max.score) { max = tmp; have = 1; }
+        if ((unsigned) tmp.score > (unsigned) max.score) { max = tmp; have = 1; }      /* LocalAlignment::score is unsigned (DistanceCalculator.h:45) */
     }
     for (unsigned d = 0; d <= (unsigned) qLen / 65536; d++) {
         int real = (int) (d * 65536 + diag);
         spo_local tmp; by_diagonal(c, q, (unsigned) qLen, t, (unsigned) tLen, real, mode, &tmp);
-        if (tmp.score > max.score) { max = tmp; have = 1; }
+        if ((unsigned) tmp.score > (unsigned) max.score) { max = tmp; have = 1; }      /* LocalAlignment::score is unsigned (DistanceCalculator.h:45) */
     }
     (void) have;
     *out = max;

@@ -130,7 +130,7 @@ size_t spo_alignment_text(spo_aln *res, size_t n, char *buf, size_t cap);
 /* ---- rescorediagonal (DistanceCalculator.h:93-201), ASCII sequences ---- */
 typedef struct { int score, startPos, endPos, diagonalLen, diagonal; unsigned distToDiagonal; } spo_local;
 void spo_rescore_diagonal(const spo_ctx *c, const char *q, int qLen, const char *t, int tLen, uint16_t diag,
-                          int mode /*1 substitution, 2 alignment*/, spo_local *out);
+                          int mode /*0 hamming, 1 substitution, 2 alignment, 3 global, 4 window quality*/, spo_local *out);
 
 uint64_t spo_fnv1a(const void *p, size_t n, uint64_t h);
 

@@ -537,7 +537,7 @@ int sp_ctx_rescore(sp_ctx *c, const uint32_t *qidx, const uint32_t *tidx, const 
     std::vector<sp::SwPair> pairs(n); std::vector<uint16_t> d(n);
     for (uint64_t i = 0; i < n; i++) { pairs[i].query = qidx[i]; pairs[i].target = tidx[i]; d[i] = (uint16_t) diag[i]; }
     std::vector<sp::DiagRescore> out;
-    if (!c->gpu.rescoreDiagonals(pairs.data(), d.data(), (size_t) n, mode, out, err)) { g_err = err; return SP_ERR_DEVICE; }
+    if (!c->gpu.rescoreDiagonals(pairs.data(), d.data(), (size_t) n, mode, c->qascii.data(), out, err)) { g_err = err; return SP_ERR_DEVICE; }
     for (uint64_t i = 0; i < n; i++) {
         const uint32_t qL = c->qoff[qidx[i] + 1] - c->qoff[qidx[i]];
         res[i].score = out[i].score; res[i].start_pos = out[i].startPos; res[i].end_pos = out[i].endPos; res[i].diagonal_len = out[i].diagonalLen;

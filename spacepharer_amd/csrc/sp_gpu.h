@@ -140,7 +140,8 @@ public:
     size_t alignRetries() const { return alignRetries_; }      // pairs of the last align() that went through the host-driven traceback
 
     // rescorediagonal: ungapped score on one diagonal of the UNMASKED residues, align matrix, no composition bias
-    bool rescoreDiagonals(const SwPair *pairs, const uint16_t *diags, size_t n, int mode, std::vector<DiagRescore> &out, std::string &err);
+    // (modes 0, 3 and 4 compare letters: queryLetters = the resident queries' ASCII, concatenated like their residues)
+    bool rescoreDiagonals(const SwPair *pairs, const uint16_t *diags, size_t n, int mode, const char *queryLetters, std::vector<DiagRescore> &out, std::string &err);
 
     // profiling aid: streaming read of `bytes` with laneBytes (4/8/16) per lane, to calibrate the FETCH_SIZE counter
     bool diagStreamRead(uint64_t bytes, int laneBytes, double &ms, std::string &err);

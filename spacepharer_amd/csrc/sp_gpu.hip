@@ -7,6 +7,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1914,7 +1915,7 @@ struct SwDev {
     DevBuf<signed char> qcomp; DevBuf<int> qbias;
     DevBuf<uint64_t> dirOff, rowOff, btOff; DevBuf<uint32_t> dirCap, rowCap, btCap;
     DevBuf<signed char> dirPool; DevBuf<int> rowPool; DevBuf<char> btPool; DevBuf<SwFull> full;
-    DevBuf<uint16_t> diag; DevBuf<DiagRescore> resc;
+    DevBuf<uint16_t> diag; DevBuf<DiagRescore> resc; DevBuf<char> qletters;
     DevBuf<uint32_t> passList, redoList, wordPass, counters; DevBuf<unsigned long long> cursors; DevBuf<uint8_t> gatePass; DevBuf<uint16_t> gateSlot;
     size_t preparedFor = (size_t) -1; const void *preparedPtr = nullptr;
     DevBuf<double> evalTab; DevBuf<int32_t> bitTab; uint64_t gateVersion = 0;
@@ -1928,12 +1929,12 @@ struct Gpu::Impl {
     int numCU = 256;
     // environment knobs (diagnostics / experiments), read once per context instead of once per pass
     struct Knobs {
-        int matchSmall = -1, matchPerCU = 0, matchHeavy = -1, matchStatic = 4, matchDChunk = 4, weighExact = 0, matchGroup = 1;
+        int matchSmall = -1, matchPerCU = 0, matchHeavy = -1, matchStatic = 4, matchDChunk = 4, weighExact = -1, matchGroup = 1;
         bool debug = false, prepSplit = false, swRows32 = false, swRows16 = false, swOldForward = false;
         void read() {
             auto num = [](const char *k, int d) { const char *e = getenv(k); return e ? atoi(e) : d; };
-            matchSmall = num("SP_MATCH_SMALL", -1); matchGroup = num("SP_MATCH_GROUP", 1); weighExact = num("SP_MATCH_WEIGH_EXACT", 0) ? 1 : 0; matchPerCU = num("SP_MATCH_PERCU", 0); matchHeavy = num("SP_MATCH_HEAVY", -1);
-            matchStatic = num("SP_MATCH_STATIC", 4); matchDChunk = std::min(32, std::max(1, num("SP_MATCH_DCHUNK", 4)));      // (a chunk's offsets live in the lanes of a wave)
+            matchSmall = num("SP_MATCH_SMALL", -1); matchGroup = num("SP_MATCH_GROUP", 1); { const int we = num("SP_MATCH_WEIGH_EXACT", -1); weighExact = we < 0 ? -1 : (we ? 1 : 0); } matchPerCU = num("SP_MATCH_PERCU", 0); matchHeavy = num("SP_MATCH_HEAVY", -1);
+            matchStatic = std::min(8, std::max(0, num("SP_MATCH_STATIC", 4))); matchDChunk = std::min(32, std::max(1, num("SP_MATCH_DCHUNK", 4)));      // (a chunk's offsets live in the lanes of a wave)
             debug = getenv("SP_DEBUG") != nullptr; prepSplit = getenv("SP_PREP_SPLIT") != nullptr; swRows32 = getenv("SP_SW_ROWS32") != nullptr;
             swRows16 = getenv("SP_SW_ROWS16") != nullptr; swOldForward = getenv("SP_SW_OLD_FORWARD") != nullptr;
         }
@@ -1966,6 +1967,7 @@ struct Gpu::Impl {
     DevBuf<unsigned char> scanTemp; DevBuf<uint32_t> selWant, selWantOff;
     unsigned long long *mailbox = nullptr;       // page-locked landing area for counters
     int device = 0;
+    bool searcher = false;                       // counted in g_searchers: this context holds a query batch
     int matchPerCU = 0;                          // resident k_match blocks per CU (0 = what the occupancy calculator says)
     int timing = 1;                              // 0: no HIP events in the pipeline, 1: around k_match only (each record costs ~6 us of idle GPU), 2: every stage
     // the hit list starts travelling to the host on its own stream as soon as a prefilter pass is complete, so that the copy
@@ -2001,6 +2003,9 @@ struct Gpu::Impl {
     uint32_t *stepMail = nullptr;                // page-locked: 2 x 64 words, one block per step in flight
 };
 
+// contexts per device that hold a query batch (see matchAndScore: how the heavy queries are found)
+static std::atomic<int> g_searchers[64];
+
 Gpu::Gpu() : d_(new Impl) {}
 // Stream pairs (search stream, copy stream) are created once per process and device, in order, and handed from context to context: the HIP runtime
 // multiplexes streams onto 4 hardware queues in the order they are created, and how the streams of several contexts pair up on those queues is worth
@@ -2027,6 +2032,7 @@ static void giveStreams(int device, hipStream_t mainS) {
 
 Gpu::~Gpu() {
     if (d_) {
+        if (d_->searcher) g_searchers[d_->device & 63].fetch_sub(1, std::memory_order_relaxed);
         if (d_->stream) (void) hipStreamSynchronize(d_->stream);
         for (auto &set : d_->ev) for (hipEvent_t e : set) if (e) (void) hipEventDestroy(e);
         for (Impl::StepSlot &ss : d_->step) for (hipEvent_t e : {ss.selected, ss.assembled, ss.hitsOnHost, ss.alnOnHost}) if (e) (void) hipEventDestroy(e);
@@ -2066,7 +2072,7 @@ void Gpu::setMatchBlocksPerCU(int n) { d_->matchPerCU = n < 0 ? 0 : n; }
 // scheduling knobs of k_match (they change the order of the work, never a result): footprint -1 by index density / 0 large / 1 small;
 // similar k-mers from which a query is started first, -1 = by batch size, 0 = no list.  Initial values: SP_MATCH_SMALL / SP_MATCH_HEAVY.
 bool Gpu::setKnob(const std::string &name, int value) {
-    if (name == "match_weigh_exact") { d_->knob.weighExact = value ? 1 : 0; return true; }      // the heavy-query list from exact counts (table rows read) instead of the calibrated estimate
+    if (name == "match_weigh_exact") { d_->knob.weighExact = value < 0 ? -1 : (value ? 1 : 0); return true; }      // the heavy-query list from exact counts (table rows read) or from the calibrated estimate; -1: exact while this is the only searching context of the device
     if (name == "match_chunk") { d_->knob.matchDChunk = std::min(32, std::max(1, value)); return true; }      // queries per pop of the dynamically dealt part
     if (name == "match_static") { d_->knob.matchStatic = std::min(8, std::max(0, value)); return true; }      // eighths of the queries dealt round-robin without atomics
     if (name == "match_small") { d_->knob.matchSmall = value < 0 ? -1 : (value ? 1 : 0); return true; }
@@ -2236,6 +2242,7 @@ bool Gpu::uploadTables(const SubMat &seed, const SubMat &ung, const SubMat &aln,
 
 bool Gpu::uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std::string &err) {
     Impl &d = *d_;
+    if (!d.searcher) { d.searcher = true; g_searchers[d.device & 63].fetch_add(1, std::memory_order_relaxed); }
     nq_ = nq;
     d.qTotal = off[nq];
     d.hQoff.assign(off, off + nq + 1);
@@ -2291,7 +2298,10 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     // (worth its 30 us per 60 000 queries only while a wave gets few queries: with more than ~30 per wave the heavy ones no
     // longer decide when the kernel ends)
     const uint32_t heavyThr = d.knob.matchHeavy >= 0 ? (uint32_t) d.knob.matchHeavy : (nq_ <= (size_t) blocks * kWavesPerBlock * 32 ? 4000u : 0u);
-    WeighArgs wa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, heavyThr ? heavyThr : 0xFFFFFFFFu, d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p, d.knob.weighExact ? nullptr : d.heavyEst.p};
+    // exact weights order the heavy queries better (k_match alone 0.43 instead of 0.47 ms on the bench workload) and cost k_prep8 two table rows per window -- 20 us alone, a
+    // multiple beside other contexts' matching kernels, where the estimate wins: exact while this context is the only one searching on its device
+    const bool weighExact = d.knob.weighExact > 0 || (d.knob.weighExact < 0 && g_searchers[d.device & 63].load(std::memory_order_relaxed) <= 1);
+    WeighArgs wa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, heavyThr ? heavyThr : 0xFFFFFFFFu, d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p, weighExact ? nullptr : d.heavyEst.p};
     const unsigned weighBlocks = (unsigned) std::min<size_t>((nq_ + 31) / 32, (size_t) d.numCU * 8);
     if (d.maxQLen <= 64 && !d.knob.prepSplit) {
         const uint32_t stride = std::max<uint32_t>(16u, (d.maxQLen + 7u) & ~7u);      // staging row per query (<= 64)
@@ -2439,7 +2449,9 @@ bool Gpu::stepBegin(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     d.drained = false;
     // capacity of this step: what earlier passes delivered plus a margin, bounded by the caller's buffers
     if (d.stepCap == 0) d.stepCap = counters_.hits ? (size_t) counters_.hits + (size_t) counters_.hits / 8 + 4096 : nq_ * 4 + 4096;
-    const size_t cap = std::max<size_t>(1, std::min<size_t>({d.stepCap, (size_t) out.hitCap, (size_t) out.recordCap, (size_t) 0x7FFFFFF0u}));
+    // (... and by what the selection can deliver at all: nq x maxHits is what queueSelect() sizes the hit buffer for -- a small batch with a generous caller buffer
+    // would otherwise copy past it)
+    const size_t cap = std::max<size_t>(1, std::min<size_t>({d.stepCap, (size_t) out.hitCap, (size_t) out.recordCap, (size_t) 0x7FFFFFF0u, nq_ * (size_t) std::max(1, maxHits)}));
     ss.cap = cap; ss.out = out;
     maxHits_ = maxHits;
     if (!d.stepWords.ensure(4, err)) return false;
@@ -2526,6 +2538,7 @@ bool Gpu::prefilterCandidates(int kmerThr, int minDiagScore, std::string &err) {
     Impl &d = *d_;
     d.nCand = 0;
     if (nq_ == 0) return true;
+    if (d.stepsBegun != d.stepsEnded && !d.drained) { err = "prefilterCandidates: a device-driven step is in flight (collect it with stepEnd first)"; return false; }
     if (!matchAndScore(kmerThr, true, err)) return false;
     const bool dbg = d.knob.debug;
     if (!d.cand.ensure(d.diagCap, err)) return false;
@@ -2556,6 +2569,7 @@ bool Gpu::downloadCandidates(Candidate *out, std::string &err) {
 bool Gpu::mergeCandidates(const Candidate *src, size_t n, bool onDevice, size_t qFrom, size_t qTo, unsigned binSize, int maxHits, int minDiagScore, std::string &err) {
     Impl &d = *d_;
     if (nq_ == 0) return true;
+    if (d.stepsBegun != d.stepsEnded && !d.drained) { err = "mergeCandidates: a device-driven step is in flight (collect it with stepEnd first)"; return false; }
     if (!d.qbias.p || !d.queue.p) { err = "mergeCandidates: run prefilterCandidates() on this query batch first"; return false; }
     if (d.hitsInFlight) { (void) hipEventSynchronize(d.hitsOnHost); d.hitsInFlight = false; }
     if (n >= (1ull << 32)) { err = "mergeCandidates: more than 2^32 candidates"; return false; }

@@ -730,12 +730,14 @@ int runSearchModule(int argc, const char **argv) {
 int runRescoreDiagonalModule(int argc, const char **argv) {
     Flags f; std::string err;
     if (!parseFlags(argc, argv, kRescoreFlags, 4, f, err)) return fail("rescorediagonal: " + err);
-    if (!requireValue(f, "--rescore-mode", {"1", "2"}, err) || !requireValue(f, "--wrapped-scoring", {"0"}, err) || !requireValue(f, "--filter-hits", {"0"}, err) ||
+    // (--filter-hits 1 reads its score-per-column threshold from a table the reference generates at build time -- CovSeqidQscPercMinDiag.lib.h, rescorediagonal.cpp:9-10,98-103 --
+    // which is not in its source tree: refused, like wrapped scoring, which is for nucleotide DBs)
+    if (!requireValue(f, "--rescore-mode", {"0", "1", "2", "3", "4"}, err) || !requireValue(f, "--wrapped-scoring", {"0"}, err) || !requireValue(f, "--filter-hits", {"0"}, err) ||
         !requireValue(f, "--compressed", {"0"}, err) || !requireValue(f, "--add-self-matches", {"0"}, err) || !requireValue(f, "-c", {"0", "0.0", "0.000"}, err) ||
         !requireValue(f, "--seq-id-mode", {"0"}, err))
         return fail("rescorediagonal: " + err);
-    const int mode = (int) f.num("--rescore-mode", 0);
-    if (mode != 1 && mode != 2) return fail("rescorediagonal: only --rescore-mode 1 and 2 are implemented");
+    const int mode = (int) f.num("--rescore-mode", 0);      // RESCORE_MODE_HAMMING is the module's default (commons/Parameters.cpp:2256)
+    const bool alnFormat = mode >= 2;                        // modes 2, 3, 4 write alignment records (rescorediagonal.cpp:390-394), 0 and 1 prefilter-format lines
     { const int rc = fanOut("rescorediagonal", argc, argv, f.positional[3]); if (rc >= 0) return rc; }
     Ctx ctx; Db qdb, tdb, rdb; std::vector<uint32_t> qkeys, tkeys; std::vector<char> qres; std::vector<uint64_t> qoff;
     if (!openSearch(f, "rescorediagonal", false, ctx, qdb, tdb, qkeys, tkeys, qres, qoff, err)) return fail("rescorediagonal: " + err);
@@ -749,7 +751,7 @@ int runRescoreDiagonalModule(int argc, const char **argv) {
     const bool addBt = f.num("-a", 0) == 1; const bool sortRes = f.num("--sort-results", 0) > 0;
     // target ASCII for the identity count of mode 2 (rescorediagonal.cpp:283-290 compares letters case-insensitively)
     std::vector<char> tres; std::vector<uint64_t> toff; std::vector<uint32_t> tk2; flatten(tdb, tres, toff, tk2);
-    DbWriter w; w.path = f.positional[3]; w.dbtype = (mode == 2) ? 5 : (rdb.type() > 0 ? rdb.type() : 7);
+    DbWriter w; w.path = f.positional[3]; w.dbtype = alnFormat ? 5 : (rdb.type() > 0 ? rdb.type() : 7);
     std::string payload; char buf[64];
     for (size_t e = 0; e + 1 < tr.perQuery.size(); e++) {
         std::vector<std::pair<sp_alignment, std::string>> alns;
@@ -759,10 +761,12 @@ int runRescoreDiagonalModule(int argc, const char **argv) {
             const uint32_t qi = tr.q[i], ti = tr.t[i];
             const int qLen = (int) (qoff[qi + 1] - qoff[qi]), dbLen = (int) (toff[ti + 1] - toff[ti]);
             double seqId = 0; int alnLen = 0;
-            const bool hasEvalue = r.evalue <= evalThr;
+            // mode 0 has no E-value (it stays 0.0 and always passes -e >= 0): the score is the identity count, the aligned length the diagonal's (rescorediagonal.cpp:243-252)
+            const bool hasEvalue = (mode == 0 ? 0.0 : r.evalue) <= evalThr;
             sp_alignment a; memset(&a, 0, sizeof(a));
             std::string bt;
-            if (mode == 2) {
+            if (mode == 0) { alnLen = r.diagonal_len; seqId = (double) ((float) r.score / (float) r.diagonal_len); }
+            if (alnFormat) {
                 alnLen = (r.end_pos - r.start_pos) + 1;
                 int qs, qe, ts, te;
                 if (r.diagonal >= 0) { qs = r.start_pos + (int) r.dist_to_diagonal; qe = r.end_pos + (int) r.dist_to_diagonal; ts = r.start_pos; te = r.end_pos; }
@@ -778,11 +782,11 @@ int runRescoreDiagonalModule(int argc, const char **argv) {
             }
             const bool hasSeqId = seqId >= (seqIdThr - 1.1920929e-07), hasAlnLen = alnLen >= alnLenThr;
             if (!(hasAlnLen && hasSeqId && hasEvalue)) continue;
-            if (mode == 2) alns.push_back({a, bt});
-            else shorts.push_back({tkeys[ti], r.bit_score, r.diagonal});
+            if (alnFormat) alns.push_back({a, bt});
+            else shorts.push_back({tkeys[ti], mode == 0 ? (int) (100 * seqId) : r.bit_score, r.diagonal});      // (hit.prefScore = 100 * seqId: a double truncated to int, :357-358)
         }
         payload.clear();
-        if (mode == 2) {
+        if (alnFormat) {
             if (sortRes) std::sort(alns.begin(), alns.end(), [](const std::pair<sp_alignment, std::string> &x, const std::pair<sp_alignment, std::string> &y) { return alnLess(x.first, y.first); });
             for (auto &x : alns) {
                 // the reference prints the run-length string itself here (resultToBuffer(..., compress=false))

@@ -67,6 +67,13 @@ def test_rescorediagonal_matches_reference_golden(name):
         assert (b.score, b.start_pos, b.end_pos, b.diagonal_len, b.dist_to_diagonal, b.diagonal) == (s2, st, en, dlen, dist, diag)
         assert b.evalue == float.fromhex(ev)
         assert b.bit_score == bits
+    # --rescore-mode 0 (the module's default: equal letters), 3 (global) and 4 (window quality): letters compared as they are, '*' at the ends skipped
+    exp3 = [three for a in r["aln"] for three in a["rescoreModes"]]
+    assert len(exp3) == len(triples)
+    for k, mode in enumerate((0, 3, 4)):
+        got = ctx.rescore(triples, mode)
+        for x, three in zip(got, exp3):
+            assert [x.score, x.start_pos, x.end_pos, x.diagonal_len, x.dist_to_diagonal, x.diagonal] == three[k], (mode, three)
     ctx.close()
 
 

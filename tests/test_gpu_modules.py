@@ -213,6 +213,37 @@ def test_rescorediagonal_module_alignment_format(tmp_path):
             assert n > 10
 
 
+def test_rescorediagonal_module_with_the_reference_defaults_and_the_other_modes(tmp_path):
+    """a bare `rescorediagonal q t pref out` -- RESCORE_MODE_HAMMING, -e 0.001, no coverage / identity / length thresholds (commons/Parameters.cpp:2219-2260) -- writes
+    prefilter-format lines whose score is 100 x the fraction of equal letters on the diagonal (rescorediagonal.cpp:243-252, 354-360); --rescore-mode 3 (global) and 4
+    (window quality) write alignment records like mode 2 (DistanceCalculator.h:203-272)"""
+    import spacepharer_amd as sa
+    for name in ("small", "longt", "spacer"):
+        g = load_golden(name)
+        r = g["ref"]
+        q, t, pref = (str(tmp_path / (name + x)) for x in ("qdb", "tdb", "pref"))
+        write_seq_db(q, g["queries"])
+        write_seq_db(t, g["targets"])
+        sa.module_prefilter([q, t, pref] + (PREF_FLAGS % r["maxSeqs"]).split())
+        out = str(tmp_path / (name + "resc0"))
+        sa.module_rescorediagonal([q, t, pref, out])
+        got, dbtype = read_db(out)
+        assert dbtype == 7
+        n = 0
+        for a in r["aln"]:
+            assert got[a["id"]] == a["rescore0"], (name, a["id"])
+            n += a["rescore0"].count("\n")
+        assert n > 10
+        for mode in (3, 4):
+            out = str(tmp_path / (name + "resc%d" % mode))
+            sa.module_rescorediagonal([q, t, pref, out, "--sub-mat", "nucl:nucleotide.out,aa:VTML40.out", "--rescore-mode", str(mode), "-a", "1", "-e", "200", "-c", "0",
+                                       "--min-seq-id", "0", "--threads", "4", "--compressed", "0", "-v", "3"])
+            got, dbtype = read_db(out)
+            assert dbtype == 5
+            for a in r["aln"]:
+                assert got[a["id"]] == a["rescore%d" % mode], (name, mode, a["id"])
+
+
 def test_modules_with_sparse_keys_and_shuffled_entries(tmp_path):
     """DB keys are not positions: target keys sparse (the sorted-list branch of the key lookup), query keys neither dense nor monotone, the
     query entries shuffled in the data file, the index sorted by key as DBWriter leaves it.  Results are keyed by query key and name

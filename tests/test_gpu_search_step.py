@@ -100,3 +100,34 @@ def test_steps_equal_the_synchronous_path(case):
     for b in bufs:
         b.free()
     ctx.close()
+
+
+def test_a_small_batch_with_a_generous_caller_buffer():
+    """a few queries, a small --max-seqs and room for many more hits than the selection can ever deliver: the step's capacity is bounded by queries x max-seqs (what the
+    device hit buffer holds), not by the caller's buffers -- the copies stay inside the device allocation and the results are those of the synchronous path; the other
+    synchronous entry points refuse to run underneath a step as well"""
+    import spacepharer_amd as sa
+    L = sa.load_library()
+    g = load_golden("family")
+    T, Q = g["targets"], g["queries"][:8]
+    ctx = sa.SearchContext(max_seqs=3)
+    ctx.set_targets(T)
+    ctx.set_queries(Q)
+    ref, n = sync_result(ctx, len(Q))
+    assert 0 < n <= 24
+    big = [Bufs(L, len(Q), 100000) for _ in range(2)]
+    for rounds in range(3):
+        big[0].begin(ctx)
+        big[1].begin(ctx)
+        assert big[0].result(*ctx.search_end()) == ref
+        assert big[1].result(*ctx.search_end()) == ref
+    assert ctx.stat("steps_repeated") == 0
+    big[0].begin(ctx)
+    with pytest.raises(sa.SpError):
+        ctx.rescore([(0, 0, 0)], 1)
+    with pytest.raises(sa.SpError):
+        ctx.prefilter_candidates()
+    assert big[0].result(*ctx.search_end()) == ref
+    for b in big:
+        b.free()
+    ctx.close()

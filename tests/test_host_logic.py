@@ -42,8 +42,10 @@ def test_modules_reject_bad_command_lines(lib):
     assert rc != 0 and "unsupported value" in err
     rc, err = run("sp_align_run", ["q", "t", "r", "o", "--alt-ali", "3"])
     assert rc != 0 and "unsupported value" in err
-    rc, err = run("sp_rescorediagonal_run", ["q", "t", "r", "o", "--rescore-mode", "0"])
-    assert rc != 0
+    rc, err = run("sp_rescorediagonal_run", ["q", "t", "r", "o", "--rescore-mode", "5"])
+    assert rc != 0 and "unsupported value" in err
+    rc, err = run("sp_rescorediagonal_run", ["q", "t", "r", "o", "--filter-hits", "1"])
+    assert rc != 0 and "unsupported value" in err
     rc, err = run("sp_prefilter_run", ["/nonexistent/q", "/nonexistent/t", "/tmp/o"])
     assert rc != 0 and "cannot open" in err
 

@@ -196,3 +196,8 @@ def test_rescorediagonal(name):
             assert (r2.score, r2.startPos, r2.endPos, r2.diagonalLen, r2.distToDiagonal, r2.diagonal) == (s2, st, en, dlen, dist, diag)
             assert lib().spo_evalue(o.ctx, 0, float(s2), float(len(q))) == float.fromhex(ev)
             assert int(lib().spo_bitscore(o.ctx, 0, float(s2)) + 0.5) == bits
+        # the other three modes (hamming, global, window quality): DistanceCalculator.h:122-175, 203-295
+        for three, hit in zip(a["rescoreModes"], qh["hits"]):
+            for mode, exp in zip((0, 3, 4), three):
+                r = o.rescore(q, hit[0], hit[2], mode)
+                assert [r.score, r.startPos, r.endPos, r.diagonalLen, r.distToDiagonal, r.diagonal] == exp, (a["id"], hit, mode)
