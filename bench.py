@@ -285,6 +285,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2], help="device-driven steps queued per context before the oldest is collected")
     ap.add_argument("--host-driven", action="store_true", help="the round-2 step: the host learns the hit count between prefilter and align and the record count after align "
                     "(sp_ctx_prefilter + sp_ctx_align_hits_begin / _end) instead of one device-driven step (sp_ctx_search_begin / _end)")
+    ap.add_argument("--unshared", action="store_true", help="every search context of a GPU stages its own copy of the target set and tables (the round-3 configuration; default: one staged set, shared)")
     ap.add_argument("--no-module-e2e", action="store_true", help="N = 1: skip the files-to-files timing of the module drop-ins (tools/module_e2e.py)")
     ap.add_argument("--shards", type=int, default=0, help="N > 1, target-sharded: S target shards x N / S query groups (all-gather within a group); 0 = N shards, every rank matches all queries (BASELINE configs[3])")
     ap.add_argument("--no-hybrid", action="store_true", help="N >= 4: skip the additional 2-shard x N/2-group measurement")
@@ -345,6 +346,7 @@ def main():
         pipeline = (args.pipeline or 2) if pipeline is None else pipeline
         host_driven = args.host_driven if host_driven is None else host_driven
         n_pipe = 1 if shard_targets else max(1, min(pipeline, steps))
+        unshared = args.unshared
         # partition (N > 1, index replicated): the SAME job as the sharded one -- `spacers` spacers against the whole target set -- cut by QUERY: rank r
         # searches slice r of every batch against the full index in its own HBM and the per-rank hit lists are all-gathered (RCCL) after every step
         S = (shards or world) if shard_targets else 1
@@ -386,11 +388,16 @@ def main():
             c = sa.SearchContext(device_mask=1 << local_rank)
             if shard_targets:
                 t_from, t_cnt = decompose_by_residues(np.diff(toff).astype(np.int64) + 2, rank % S, S)
-                c.set_targets_shard_raw(tres.tobytes(), u64p(toff), len(toff) - 1, t_from, t_from + t_cnt)
+                if b == 0 or unshared:
+                    c.set_targets_shard_raw(tres.tobytes(), u64p(toff), len(toff) - 1, t_from, t_from + t_cnt)
+                else:
+                    c.share_targets(ctxs[0])
                 q_from, q_cnt = decompose_by_residues(np.diff(batches[b][3]).astype(np.int64) + 2, rank % S, S)
                 q_to = q_from + q_cnt
-            else:
+            elif b == 0 or unshared:
                 c.set_targets_raw(tres.tobytes(), u64p(toff), len(toff) - 1)
+            else:
+                c.share_targets(ctxs[0])      # ONE staged target set, several search contexts (streams, queries, result buffers of their own)
             if b == 0:
                 t_index = time.perf_counter() - t0
             c.set_queries_raw(batches[b][2].tobytes(), u64p(batches[b][3]), nq)

@@ -122,6 +122,11 @@ void sp_ctx_destroy(sp_ctx *c);
 int sp_ctx_set_targets(sp_ctx *c, const char *residues, const uint64_t *offsets, const uint32_t *keys, uint64_t n);
 /* flags: bit 0 = do not build / stage the k-mer index (align and rescorediagonal only need the residues) */
 int sp_ctx_set_targets_ex(sp_ctx *c, const char *residues, const uint64_t *offsets, const uint32_t *keys, uint64_t n, int flags);
+/* c searches the target set `from` has staged: device tables and target set are shared between the contexts (same device, same matrices / sensitivity / masking), not
+ * copied or rebuilt.  Several search contexts -- one per host thread, each with its own queries, streams and result buffers -- then hold ONE copy of the similar-k-mer
+ * tables, the residues and the index.  The reference shares these the same way between its OpenMP threads (one IndexTable / SequenceLookup / ScoreMatrix per process,
+ * prefiltering/Prefiltering.cpp:499-537; a QueryMatcher per thread, :716-740). */
+int sp_ctx_share_targets(sp_ctx *c, sp_ctx *from);
 /* query batch: ASCII residues concatenated, offsets[n+1]; uploaded once, stays resident until replaced */
 int sp_ctx_set_queries(sp_ctx *c, const char *residues, const uint64_t *offsets, uint64_t n);
 

@@ -109,6 +109,7 @@ def load_library():
     L.sp_ctx_rescore.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int16), C.c_uint64, C.c_int,
                                  C.POINTER(Rescore)]
     L.sp_ctx_set_targets_shard.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint64, C.c_uint64, C.c_uint64]
+    L.sp_ctx_share_targets.argtypes = [vp, vp]
     L.sp_ctx_prefilter_candidates.argtypes = [vp]
     L.sp_ctx_num_candidates.restype = C.c_uint64
     L.sp_ctx_overflow_queries.restype = C.c_uint64
@@ -258,6 +259,10 @@ class SearchContext:
         self.n_targets = n
 
     # ---- target-sharded search: this context indexes targets [shard_from, shard_to) of the full set
+    def share_targets(self, other):
+        """search the target set `other` has staged (device tables and set shared, not copied)"""
+        _check(self.L.sp_ctx_share_targets(self.ctx, other.ctx))
+
     def set_targets_shard(self, seqs, shard_from, shard_to, keys=None):
         buf, offs = _concat(seqs)
         karr = (C.c_uint32 * len(seqs))(*keys) if keys is not None else None

@@ -197,6 +197,30 @@ static int setTargets(sp_ctx *c, const char *residues, const uint64_t *offsets, 
     return SP_OK;
 }
 
+/* c searches the target set `from` has staged: the device tables (256 MB of similar 3-mers, the matrices) and the set itself (residues, masked residues, k-mer index) are
+ * SHARED between the two contexts, not copied or rebuilt -- four contexts of one process keep one copy in HBM and in the caches.  Both contexts must sit on the same device
+ * and have been created with the same matrices, sensitivity and masking.  sp_ctx_set_targets on either context later gives that context a set of its own again. */
+int sp_ctx_share_targets(sp_ctx *c, sp_ctx *from) {
+    if (!c || !from) { g_err = "sp_ctx_share_targets: null argument"; return SP_ERR_ARG; }
+    if (c == from) return SP_OK;
+    if (c->stepsBegun != c->stepsEnded) { g_err = "sp_ctx_share_targets: a search step is in flight (sp_ctx_search_end first)"; return SP_ERR_STATE; }
+    if (from->targets.n == 0 || !from->tablesUp) { g_err = "sp_ctx_share_targets: the other context has no target set"; return SP_ERR_STATE; }
+    if (c->seedName != from->seedName || c->subName != from->subName || c->kmerThr != from->kmerThr || (c->par.mask != 0) != (from->par.mask != 0)) {
+        g_err = "sp_ctx_share_targets: the contexts differ in matrices, sensitivity or masking"; return SP_ERR_ARG;
+    }
+    c->gpu.makeCurrent();
+    std::string err;
+    if (!c->gpu.shareFrom(from->gpu, err)) { g_err = err; return SP_ERR_DEVICE; }
+    c->targets = from->targets; c->targetFirst = from->targetFirst; c->indexEntries = from->indexEntries;
+    c->tablesUp = from->tablesUp; c->kmerTablesUp = from->kmerTablesUp;
+    c->binSize = c->par.bin_size ? c->par.bin_size : from->binSize;
+    for (const char *k : {"ms_mask_gpu", "ms_index_gpu", "index_slots", "index_entries", "masked_residues", "target_residues"}) { auto it = from->stats.find(k); if (it != from->stats.end()) c->stats[k] = it->second; }
+    c->stats["ms_ext_table"] = 0; c->stats["ms_index_build"] = 0; c->stats["ms_upload"] = 0; c->stats["bin_size"] = c->binSize;
+    c->haveGapped = c->haveGapless = false;
+    c->gateRows.clear(); c->evalRows.clear(); c->bitRow.clear(); c->gateValid = false;
+    return SP_OK;
+}
+
 int sp_ctx_set_queries(sp_ctx *c, const char *residues, const uint64_t *offsets, uint64_t n) {
     if (c && c->stepsBegun != c->stepsEnded) { g_err = "sp_ctx_set_queries: a search step is in flight (sp_ctx_search_end first)"; return SP_ERR_STATE; }
     if (c) c->gpu.makeCurrent();

@@ -94,6 +94,8 @@ public:
     // test hook: (k-mer, seqId, pos) triples of the resident index in table order, and the masked residue classes
     bool downloadIndex(std::vector<uint32_t> &kmers, std::vector<uint64_t> &entries, std::string &err);
     bool downloadMasked(std::vector<uint8_t> &masked, std::string &err);
+    // use the tables and the target set another context of the same device has staged (shared, not copied)
+    bool shareFrom(const Gpu &other, std::string &err);
     // queries: numeric residues (seed-matrix numbering) concatenated; off has nq+1 entries
     bool uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std::string &err);
     size_t numQueries() const { return nq_; }

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <sched.h>
 #include <string>
@@ -1939,17 +1940,27 @@ struct Gpu::Impl {
             swRows16 = getenv("SP_SW_ROWS16") != nullptr; swOldForward = getenv("SP_SW_OLD_FORWARD") != nullptr;
         }
     } knob;
-    // tables
-    DevBuf<uint32_t> ext3; DevBuf<uint16_t> ext3cnt; DevBuf<uint32_t> heavyEst; int cntMin = 0; DevBuf<short> seedSub; DevBuf<double> seedBack; DevBuf<signed char> ungSub; DevBuf<signed char> alnSub;
-    DevBuf<short> alnSub16; DevBuf<double> alnBack;
-    int ungMinAbs = 0, alnMinAbs = 0;
+    // What several search contexts of one device can SHARE (Gpu::shareFrom): the matrices and similar-k-mer tables, and the staged target set.  Both are written once,
+    // by the context that builds them, and only read by the kernels; four contexts of one process (bench.py, a resident server) hold ONE copy -- 256 MB of similar
+    // 3-mers, the index, the residues -- instead of four, in HBM and in the 256 MB Infinity Cache.
+    struct Tables {
+        DevBuf<uint32_t> ext3; DevBuf<uint16_t> ext3cnt; DevBuf<uint32_t> heavyEst; int cntMin = 0; DevBuf<short> seedSub; DevBuf<double> seedBack; DevBuf<signed char> ungSub; DevBuf<signed char> alnSub;
+        DevBuf<short> alnSub16; DevBuf<double> alnBack;
+        int ungMinAbs = 0, alnMinAbs = 0;
+        std::mutex mu;      // a sharing context may add the similar-k-mer tables to a set that was staged without them
+    };
+    struct Targets {
+        DevBuf<uint64_t> buckets; bool bucketsValid = false; size_t indexSlots = 0;      // large-footprint layout of the slot table, derived from slots / ientries on first use
+        DevBuf<uint64_t> pbits; DevBuf<uint16_t> prank; DevBuf<uint32_t> prow; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff; DevBuf<uint32_t> tkeys;
+        size_t nTargets = 0; size_t indexEntries = 0;
+        bool denseIndex = false;      // 1.5+ entries per occupied k-mer on average: k_match runs with its large footprint
+        std::mutex mu;      // the bucket table is derived by whichever sharing context needs it first
+    };
+    std::shared_ptr<Tables> tab = std::make_shared<Tables>();
+    std::shared_ptr<Targets> tgt = std::make_shared<Targets>();
     unsigned long long matchSpan[2] = {0, 0};      // wall clock at k_match's first wave start / last wave end of the last pass
     int wallKHz = 100000;            // rate of the device's constant wall clock (wall_clock64)
     bool swBiasFresh = false;        // k_prep8 of the current pass left the Smith-Waterman bias of the resident queries in swd.qcomp / swd.qbias
-    // targets
-    DevBuf<uint64_t> buckets; bool bucketsValid = false; size_t indexSlots = 0;      // large-footprint layout of the slot table, derived from slots / ientries on first use
-    DevBuf<uint64_t> pbits; DevBuf<uint16_t> prank; DevBuf<uint32_t> prow; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff; DevBuf<uint32_t> tkeys;
-    size_t nTargets = 0; size_t indexEntries = 0;
     // index construction scratch (kept for the next target set)
     DevBuf<uint32_t> ixKeys, ixKeys2, ixKeep, ixPos, ixKmer, ixHead, ixSlotOf, ixHeadPos, ixCnt, ixBefore; DevBuf<uint64_t> ixVals, ixVals2;
     DevBuf<unsigned char> ixTemp; DevBuf<float> ttProbs; DevBuf<double> ttScale, ttLr; DevBuf<unsigned long long> ixCounters;
@@ -1958,7 +1969,6 @@ struct Gpu::Impl {
     size_t qTotal = 0; uint32_t maxQLen = 0;
     std::vector<uint32_t> hQoff;
     // match / select
-    bool denseIndex = false;      // 1.5+ entries per occupied k-mer on average: k_match runs with its large footprint
     DevBuf<uint64_t> spill; DevBuf<uint32_t> heavyList; DevBuf<uint32_t> heavyCnt; DevBuf<uint8_t> heavyFlag; DevBuf<unsigned long long> wavePartial; DevBuf<uint32_t> queue; DevBuf<DiagRec> diagRec; DevBuf<uint32_t> diagQuery; DevBuf<uint16_t> diagScore; DevBuf<uint8_t> diagFlag;
     DevBuf<uint32_t> qDiagBase; DevBuf<uint32_t> qDiagCnt; DevBuf<unsigned long long> counters;
     DevBuf<GpuHit> outHits; DevBuf<GpuHit> outStage; DevBuf<uint32_t> outQuery; DevBuf<uint32_t> outCount; DevBuf<uint32_t> outBase; DevBuf<uint32_t> outOffset;
@@ -2186,16 +2196,17 @@ static bool upload(DevBuf<T> &b, const T *src, size_t n, hipStream_t s, std::str
 
 bool Gpu::uploadTables(const SubMat &seed, const SubMat &ung, const SubMat &aln, bool kmerTables, std::string &err) {
     Impl &d = *d_;
-    if (kmerTables && !d.ext3.p) {   // similar-3-mer table + count table, built on the device (sp_gpu_index.inc); not needed to align / rescore
+    std::lock_guard<std::mutex> shared(d.tab->mu);      // (contexts that share the tables write them one at a time -- the same content)
+    if (kmerTables && !d.tab->ext3.p) {   // similar-3-mer table + count table, built on the device (sp_gpu_index.inc); not needed to align / rescore
         const size_t N2 = (size_t) 8000 * 8000;
         int lo1 = 1 << 20, hi1 = -(1 << 20);
         Ext3Args ea{};
         for (int i = 0; i < 20; i++) for (int j = 0; j < 20; j++) { ea.sub[i * 20 + j] = seed.sub[i][j]; lo1 = std::min<int>(lo1, seed.sub[i][j]); hi1 = std::max<int>(hi1, seed.sub[i][j]); }
         const int lo = 3 * lo1, hi = 3 * hi1;           // the three positions are independent: extremes of the sum
         if (hi - lo + 2 > kCntW || hi - lo >= 1024) { err = "seed matrix 3-mer score range " + std::to_string(hi - lo) + " exceeds the count-table width"; return false; }
-        d.cntMin = lo;
+        d.tab->cntMin = lo;
         DevBuf<uint32_t> k1, k2, v1, v2; DevBuf<unsigned char> tmp;
-        if (!d.ext3.ensure(N2, err) || !d.ext3cnt.ensure((size_t) 8000 * kCntW, err) || !k1.ensure(N2, err) || !k2.ensure(N2, err) || !v1.ensure(N2, err) || !v2.ensure(N2, err)) return false;
+        if (!d.tab->ext3.ensure(N2, err) || !d.tab->ext3cnt.ensure((size_t) 8000 * kCntW, err) || !k1.ensure(N2, err) || !k2.ensure(N2, err) || !v1.ensure(N2, err) || !v2.ensure(N2, err)) return false;
         ea.hi = hi; ea.keys = k1.p; ea.vals = v1.p;
         hipLaunchKernelGGL(k_ext3_fill, dim3((unsigned) (N2 / 256)), dim3(256), 0, d.stream, ea);
         size_t tempBytes = 0;
@@ -2203,11 +2214,11 @@ bool Gpu::uploadTables(const SubMat &seed, const SubMat &ung, const SubMat &aln,
         if (!tmp.ensure(tempBytes + 256, err)) return false;
         tempBytes = tmp.n;
         HIP_OK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tempBytes, k1.p, k2.p, v1.p, v2.p, (int) N2, 0, 23, d.stream));
-        hipLaunchKernelGGL(k_ext3_pack, dim3((unsigned) (N2 / 256)), dim3(256), 0, d.stream, k2.p, v2.p, hi, d.ext3.p);
-        hipLaunchKernelGGL(k_ext3_count, dim3(8000), dim3(kCntW), 0, d.stream, d.ext3.p, lo, d.ext3cnt.p);
+        hipLaunchKernelGGL(k_ext3_pack, dim3((unsigned) (N2 / 256)), dim3(256), 0, d.stream, k2.p, v2.p, hi, d.tab->ext3.p);
+        hipLaunchKernelGGL(k_ext3_count, dim3(8000), dim3(kCntW), 0, d.stream, d.tab->ext3.p, lo, d.tab->ext3cnt.p);
         {   // similar k-mers of a window by the slack of its best pair (the order k_match takes the queries in; see k_heavy_calib)
-            if (!d.heavyEst.ensure(kHeavyEstW, err)) return false;
-            HeavyCalibArgs ha{d.ext3.p, d.ext3cnt.p, lo, {}, d.heavyEst.p};
+            if (!d.tab->heavyEst.ensure(kHeavyEstW, err)) return false;
+            HeavyCalibArgs ha{d.tab->ext3.p, d.tab->ext3cnt.p, lo, {}, d.tab->heavyEst.p};
             double tot = 0, run = 0;
             for (int i = 0; i < 20; i++) tot += seed.pBack[i];
             for (int i = 0; i < 20; i++) { run += seed.pBack[i]; ha.cum[i] = tot > 0 ? (float) (run / tot) : (float) (i + 1) / 20.0f; }
@@ -2228,15 +2239,28 @@ bool Gpu::uploadTables(const SubMat &seed, const SubMat &ung, const SubMat &aln,
         mn = std::min<int>(mn, ung.sub[i][j]);
         mnAln = std::min<int>(mnAln, aln.sub[i][j]);
     }
-    d.ungMinAbs = std::abs(mn);
-    d.alnMinAbs = std::abs(mnAln);
-    if (!upload(d.seedSub, s16, kAlph * kAlph, d.stream, err)) return false;
-    if (!upload(d.seedBack, seed.pBack, kAlph, d.stream, err)) return false;
-    if (!upload(d.ungSub, u8, kAlph * kAlph, d.stream, err)) return false;
-    if (!upload(d.alnSub, a8, kAlph * kAlph, d.stream, err)) return false;
-    if (!upload(d.alnSub16, a16, kAlph * kAlph, d.stream, err)) return false;
-    if (!upload(d.alnBack, aln.pBack, kAlph, d.stream, err)) return false;
+    d.tab->ungMinAbs = std::abs(mn);
+    d.tab->alnMinAbs = std::abs(mnAln);
+    if (!upload(d.tab->seedSub, s16, kAlph * kAlph, d.stream, err)) return false;
+    if (!upload(d.tab->seedBack, seed.pBack, kAlph, d.stream, err)) return false;
+    if (!upload(d.tab->ungSub, u8, kAlph * kAlph, d.stream, err)) return false;
+    if (!upload(d.tab->alnSub, a8, kAlph * kAlph, d.stream, err)) return false;
+    if (!upload(d.tab->alnSub16, a16, kAlph * kAlph, d.stream, err)) return false;
+    if (!upload(d.tab->alnBack, aln.pBack, kAlph, d.stream, err)) return false;
     HIP_OK(hipStreamSynchronize(d.stream));
+    return true;
+}
+
+// This context searches the target set `o` has staged -- same device, same matrices: the tables and the set are shared, not copied (one context writes them,
+// all read); whatever this context had staged before goes back when its last user lets go.  A later buildTargets() on either context detaches it again.
+bool Gpu::shareFrom(const Gpu &o, std::string &err) {
+    Impl &d = *d_;
+    if (&o == this) return true;
+    if (d.device != o.d_->device) { err = "shareFrom: the contexts are on different devices"; return false; }
+    if (d.stepsBegun != d.stepsEnded && !d.drained) { err = "shareFrom: a device-driven step is in flight"; return false; }
+    if (d.stream) HIP_OK(hipStreamSynchronize(d.stream));
+    if (o.d_->stream) HIP_OK(hipStreamSynchronize(o.d_->stream));      // what `o` has queued for its tables / targets is complete
+    d.tab = o.d_->tab; d.tgt = o.d_->tgt;
     return true;
 }
 
@@ -2262,16 +2286,16 @@ bool Gpu::uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std:
 bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     Impl &d = *d_;
     overflowList_.clear();
-    if (!d.ext3.p || !d.pbits.p) { err = "tables/targets not resident"; return false; }
+    if (!d.tab->ext3.p || !d.tgt->pbits.p) { err = "tables/targets not resident"; return false; }
     if (d.hitsInFlight) { (void) hipEventSynchronize(d.hitsOnHost); d.hitsInFlight = false; }     // the previous pass's hit list is still being copied
     // persistent match grid: as many blocks per CU as the LDS footprint admits.  512 hits per query live in LDS; more go to
     // the per-wave HBM scratch and come back through the pre-filter (faster than a larger LDS buffer even for dense indices:
     // 45 vs 51 ms at 2 x 10^8 residues, because three blocks per CU stay resident instead of one).
     // footprint by index density (SP_MATCH_SMALL=0/1 overrides): sparse -> small, dense -> large; the sharded search always small
     // (its ordinal arrays push the large footprint to two blocks per CU)
-    const bool small = d.knob.matchSmall >= 0 ? d.knob.matchSmall != 0 : (withOrd || !d.denseIndex);
+    const bool small = d.knob.matchSmall >= 0 ? d.knob.matchSmall != 0 : (withOrd || !d.tgt->denseIndex);
     // short queries against a sparse index, unsharded: the grouped kernel (sp_gpu_match_grp.inc) -- same records, four queries per pass of a wave
-    const bool grouped = small && !withOrd && d.knob.matchGroup != 0 && d.maxQLen <= 64 && d.nTargets < ((size_t) 1 << 30);
+    const bool grouped = small && !withOrd && d.knob.matchGroup != 0 && d.maxQLen <= 64 && d.tgt->nTargets < ((size_t) 1 << 30);
     const void *fn = grouped ? (const void *) k_match_grp :
                      small ? (withOrd ? (const void *) k_match<256, true, true> : (const void *) k_match<256, false, true>)
                            : (withOrd ? (const void *) k_match<512, true, false> : (const void *) k_match<512, false, false>);
@@ -2293,7 +2317,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     {   FillArgs fa{{d.queue.p, d.counters.p, d.heavyCnt.p, nullptr}, {8 * sizeof(uint32_t), 16 * sizeof(unsigned long long), kHeavyLists * kHeavyStride * sizeof(uint32_t), 0}, {0u, 0u, 0u, 0u}};
         hipLaunchKernelGGL(k_fill, dim3(1), dim3(256), 0, d.stream, fa); }
     SP_EV(0, 2);
-    PrepArgs pa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.seedSub.p, d.seedBack.p, d.ungSub.p, kmerThr, d.ungMinAbs, d.biasf.p, d.qthr.p, d.qcorr.p, d.qbias.p, d.qself.p};
+    PrepArgs pa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.tab->seedSub.p, d.tab->seedBack.p, d.tab->ungSub.p, kmerThr, d.tab->ungMinAbs, d.biasf.p, d.qthr.p, d.qcorr.p, d.qbias.p, d.qself.p};
     // SP_MATCH_HEAVY: similar k-mers from which a query counts as heavy and is started first (0 = none)
     // (worth its 30 us per 60 000 queries only while a wave gets few queries: with more than ~30 per wave the heavy ones no
     // longer decide when the kernel ends)
@@ -2301,14 +2325,14 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     // exact weights order the heavy queries better (k_match alone 0.43 instead of 0.47 ms on the bench workload) and cost k_prep8 two table rows per window -- 20 us alone, a
     // multiple beside other contexts' matching kernels, where the estimate wins: exact while this context is the only one searching on its device
     const bool weighExact = d.knob.weighExact > 0 || (d.knob.weighExact < 0 && g_searchers[d.device & 63].load(std::memory_order_relaxed) <= 1);
-    WeighArgs wa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, heavyThr ? heavyThr : 0xFFFFFFFFu, d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p, weighExact ? nullptr : d.heavyEst.p};
+    WeighArgs wa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.tab->ext3.p, d.tab->ext3cnt.p, d.tab->cntMin, heavyThr ? heavyThr : 0xFFFFFFFFu, d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p, weighExact ? nullptr : d.tab->heavyEst.p};
     const unsigned weighBlocks = (unsigned) std::min<size_t>((nq_ + 31) / 32, (size_t) d.numCU * 8);
     if (d.maxQLen <= 64 && !d.knob.prepSplit) {
         const uint32_t stride = std::max<uint32_t>(16u, (d.maxQLen + 7u) & ~7u);      // staging row per query (<= 64)
         // the Smith-Waterman bias of the same queries rides along when the align matrix is resident (queueAlign() then skips its own launch)
         SwDev &sd = d.swd;
-        const bool withSw = d.alnSub16.p && d.alnBack.p && sd.qcomp.ensure(d.qTotal + 1, err) && sd.qbias.ensure(nq_ + 1, err);
-        Prep8Args p8{pa, wa, stride, withSw ? SwBiasArgs{d.alnSub16.p, d.alnBack.p, d.alnMinAbs, sd.qcomp.p, sd.qbias.p} : SwBiasArgs{nullptr, nullptr, 0, nullptr, nullptr}};
+        const bool withSw = d.tab->alnSub16.p && d.tab->alnBack.p && sd.qcomp.ensure(d.qTotal + 1, err) && sd.qbias.ensure(nq_ + 1, err);
+        Prep8Args p8{pa, wa, stride, withSw ? SwBiasArgs{d.tab->alnSub16.p, d.tab->alnBack.p, d.tab->alnMinAbs, sd.qcomp.p, sd.qbias.p} : SwBiasArgs{nullptr, nullptr, 0, nullptr, nullptr}};
         d.swBiasFresh = withSw;
         if (p8.w.est || !heavyThr) hipLaunchKernelGGL(k_prep8<false>, dim3(weighBlocks), dim3(256), (size_t) 32 * stride * 12, d.stream, p8);
         else hipLaunchKernelGGL(k_prep8<true>, dim3(weighBlocks), dim3(256), (size_t) 32 * stride * 12, d.stream, p8);
@@ -2322,12 +2346,16 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
         SP_DBG_SYNC("k_weigh");
     }
     SP_EV(1, 1);
-    if (!small && !d.bucketsValid) {      // (once per target set, on the first pass with the large footprint)
-        if (!d.buckets.ensure(4 * (size_t) kSlots, err)) return false;
-        hipLaunchKernelGGL(k_idx_buckets, dim3((unsigned) ((kSlots + 255) / 256)), dim3(256), 0, d.stream, d.pbits.p, d.prank.p, d.prow.p, d.slots.p, d.ientries.p, d.buckets.p);
-        d.bucketsValid = true;
+    if (!small) {      // (the bucket table: once per target set, on the first pass with the large footprint -- of whichever context sharing the set gets here first)
+      std::lock_guard<std::mutex> shared(d.tgt->mu);
+      if (!d.tgt->bucketsValid) {
+        if (!d.tgt->buckets.ensure(4 * (size_t) kSlots, err)) return false;
+        hipLaunchKernelGGL(k_idx_buckets, dim3((unsigned) ((kSlots + 255) / 256)), dim3(256), 0, d.stream, d.tgt->pbits.p, d.tgt->prank.p, d.tgt->prow.p, d.tgt->slots.p, d.tgt->ientries.p, d.tgt->buckets.p);
+        HIP_OK(hipStreamSynchronize(d.stream));      // (complete before another context's stream reads it)
+        d.tgt->bucketsValid = true;
+      }
     }
-    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.ext3.p, d.ext3cnt.p, d.cntMin, d.pbits.p, d.prank.p, d.prow.p, d.slots.p, d.ientries.p, small ? nullptr : d.buckets.p, d.spill.p, d.queue.p,
+    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.tab->ext3.p, d.tab->ext3cnt.p, d.tab->cntMin, d.tgt->pbits.p, d.tgt->prank.p, d.tgt->prow.p, d.tgt->slots.p, d.tgt->ientries.p, small ? nullptr : d.tgt->buckets.p, d.spill.p, d.queue.p,
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
                  (uint32_t) d.knob.matchStatic, (uint32_t) d.knob.matchDChunk,
@@ -2340,7 +2368,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     else hipLaunchKernelGGL((k_match<512, false, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     SP_DBG_SYNC("k_match");
     SP_EV(2, 1);
-    ScoreArgs sa{d.diagRec.p, d.diagQuery.p, d.queue.p + 1, (uint32_t) diagCap, d.qres.p, d.qoff.p, d.qcorr.p, d.tmasked.p, d.toff.p, d.ungSub.p, d.diagScore.p, d.counters.p, d.wavePartial.p, blocks * (uint32_t) kWavesPerBlock};
+    ScoreArgs sa{d.diagRec.p, d.diagQuery.p, d.queue.p + 1, (uint32_t) diagCap, d.qres.p, d.qoff.p, d.qcorr.p, d.tgt->tmasked.p, d.tgt->toff.p, d.tab->ungSub.p, d.diagScore.p, d.counters.p, d.wavePartial.p, blocks * (uint32_t) kWavesPerBlock};
     hipLaunchKernelGGL(k_score, dim3((unsigned) d.numCU * 8), dim3(256), 0, d.stream, sa);
     SP_DBG_SYNC("k_score");
     SP_EV(3, 2);
@@ -2404,7 +2432,7 @@ bool Gpu::queueSelect(unsigned binSize, int maxHits, int minDiagScore, void *hit
     const size_t stageCap = std::max<size_t>(nq_ * (size_t) maxHits, d.diagCap);
     if (!d.outHits.ensure(nq_ * (size_t) maxHits, err) || !d.outStage.ensure(stageCap, err) || !d.outQuery.ensure(stageCap, err)) return false;
     SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.qDiagBase.p,
-                  binSize - 1, maxHits, minDiagScore, d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.counters.p, d.denseIndex ? 16u : (uint32_t) kSelChunk};
+                  binSize - 1, maxHits, minDiagScore, d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.counters.p, d.tgt->denseIndex ? 16u : (uint32_t) kSelChunk};
     hipLaunchKernelGGL(k_select, dim3(d.matchBlocks), dim3(64 * kWavesPerBlock), 0, d.stream, se);
     if (hitsLeft) HIP_OK(hipStreamWaitEvent(d.stream, static_cast<hipEvent_t>(hitsLeft), 0));      // the previous step's hit list has left outOffset / outHits
     if (!d.scanCounts(d.outCount.p, (uint32_t) nq_, d.outOffset.p, err)) return false;
@@ -2611,39 +2639,40 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
     const size_t n = ts.n;
     to = std::min(to, n); from = std::min(from, to);
     const uint64_t R = ts.offsets[n];
-    d.nTargets = n; d.indexEntries = 0; d.indexSlots = 0; d.bucketsValid = false;
+    if (d.tgt.use_count() > 1) d.tgt = std::make_shared<Impl::Targets>();      // a shared target set belongs to the others from here on: this context stages its own
+    d.tgt->nTargets = n; d.tgt->indexEntries = 0; d.tgt->indexSlots = 0; d.tgt->bucketsValid = false;
     out = TargetBuild();
-    if (!upload(d.tascii, ascii, (size_t) R, d.stream, err) || !upload(d.toff, ts.offsets.data(), n + 1, d.stream, err) ||
-        !upload(d.tkeys, ts.keys.data(), n, d.stream, err)) return false;
-    if (!d.tplain.ensure((size_t) R + 1, err) || !d.tmasked.ensure((size_t) R + 1, err) || !d.ixCounters.ensure(4, err)) return false;
+    if (!upload(d.tgt->tascii, ascii, (size_t) R, d.stream, err) || !upload(d.tgt->toff, ts.offsets.data(), n + 1, d.stream, err) ||
+        !upload(d.tgt->tkeys, ts.keys.data(), n, d.stream, err)) return false;
+    if (!d.tgt->tplain.ensure((size_t) R + 1, err) || !d.tgt->tmasked.ensure((size_t) R + 1, err) || !d.ixCounters.ensure(4, err)) return false;
     HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_aa2num), seed.aa2num, 256, 0, hipMemcpyHostToDevice, d.stream));
     HIP_OK(hipMemsetAsync(d.ixCounters.p, 0, 4 * sizeof(unsigned long long), d.stream));
     HIP_OK(hipEventRecord(d.ev[0][0], d.stream));
-    if (R) { MapArgs ma{d.tascii.p, R, d.tplain.p, d.tmasked.p}; hipLaunchKernelGGL(k_map_residues, dim3((unsigned) std::min<uint64_t>((R + 255) / 256, 65536)), dim3(256), 0, d.stream, ma); }
+    if (R) { MapArgs ma{d.tgt->tascii.p, R, d.tgt->tplain.p, d.tgt->tmasked.p}; hipLaunchKernelGGL(k_map_residues, dim3((unsigned) std::min<uint64_t>((R + 255) / 256, 65536)), dim3(256), 0, d.stream, ma); }
     if (mask && to > from) {
         TantanModel tm; tantanModel(seed, tm);
         if (!upload(d.ttLr, &tm.lr[0][0], (size_t) kAlph * kAlph, d.stream, err)) return false;
         if (!d.ttProbs.ensure((size_t) R + 1, err) || !d.ttScale.ensure((size_t) (R / 16 + n + 2), err)) return false;
         TantanArgs ta{};
-        ta.masked = d.tmasked.p; ta.toff = d.toff.p; ta.from = (uint32_t) from; ta.to = (uint32_t) to; ta.lr = d.ttLr.p;
+        ta.masked = d.tgt->tmasked.p; ta.toff = d.tgt->toff.p; ta.from = (uint32_t) from; ta.to = (uint32_t) to; ta.lr = d.ttLr.p;
         for (int i = 0; i < 50; i++) ta.b2f[i] = tm.b2f[i];
         ta.b2b = tm.b2b; ta.f2b = tm.f2b; ta.f2f0 = tm.f2f0; ta.probs = d.ttProbs.p; ta.scale = d.ttScale.p; ta.maskedCount = d.ixCounters.p;
         hipLaunchKernelGGL(k_tantan, dim3((unsigned) ((to - from + 63) / 64)), dim3(64), 0, d.stream, ta);
     }
     HIP_OK(hipEventRecord(d.ev[0][1], d.stream));
     const size_t words = kTableSize / 64;
-    d.denseIndex = false;
-    if (!d.pbits.ensure(words, err) || !d.prank.ensure(words, err) || !d.prow.ensure(kTableSize / 8000, err) || !d.slots.ensure(1, err) || !d.ientries.ensure(1, err)) return false;
-    HIP_OK(hipMemsetAsync(d.pbits.p, 0, words * sizeof(uint64_t), d.stream));
-    HIP_OK(hipMemsetAsync(d.prank.p, 0, words * sizeof(uint16_t), d.stream));
-    HIP_OK(hipMemsetAsync(d.prow.p, 0, (kTableSize / 8000) * sizeof(uint32_t), d.stream));
+    d.tgt->denseIndex = false;
+    if (!d.tgt->pbits.ensure(words, err) || !d.tgt->prank.ensure(words, err) || !d.tgt->prow.ensure(kTableSize / 8000, err) || !d.tgt->slots.ensure(1, err) || !d.tgt->ientries.ensure(1, err)) return false;
+    HIP_OK(hipMemsetAsync(d.tgt->pbits.p, 0, words * sizeof(uint64_t), d.stream));
+    HIP_OK(hipMemsetAsync(d.tgt->prank.p, 0, words * sizeof(uint16_t), d.stream));
+    HIP_OK(hipMemsetAsync(d.tgt->prow.p, 0, (kTableSize / 8000) * sizeof(uint32_t), d.stream));
     const uint64_t base = ts.offsets[from], Rs = ts.offsets[to] - base;
     if (index && Rs > 0) {
         if (Rs >= (1ull << 31)) { err = "index construction: more than 2^31 residues in one shard"; return false; }
         const uint32_t nItems = (uint32_t) Rs;
         if (!d.ixKeys.ensure(nItems, err) || !d.ixKeys2.ensure(nItems, err) || !d.ixVals.ensure(nItems, err) || !d.ixVals2.ensure(nItems, err)) return false;
         ExtractArgs ea{};
-        ea.masked = d.tmasked.p; ea.toff = d.toff.p; ea.from = (uint32_t) from; ea.to = (uint32_t) to; ea.base = base;
+        ea.masked = d.tgt->tmasked.p; ea.toff = d.tgt->toff.p; ea.from = (uint32_t) from; ea.to = (uint32_t) to; ea.base = base;
         for (int x = 0; x < kAlph; x++) ea.self[x] = (signed char) seed.sub[x][x];      // getScoreLookup, IndexBuilder.cpp:8-19
         ea.kmerThr = kmerThr; ea.keys = d.ixKeys.p; ea.vals = d.ixVals.p; ea.counters = d.ixCounters.p;
         hipLaunchKernelGGL(k_idx_extract, dim3((unsigned) (to - from)), dim3(64), 0, d.stream, ea);
@@ -2670,8 +2699,8 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
             HIP_OK(hipMemcpyAsync(&lastKeep, d.ixKeep.p + (nValid - 1), 4, hipMemcpyDeviceToHost, d.stream));
             HIP_OK(hipStreamSynchronize(d.stream));
             const uint32_t E = lastPos + lastKeep;
-            if (!d.ientries.ensure(E + 1, err) || !d.ixKmer.ensure(E + 1, err) || !d.ixHead.ensure(E + 1, err) || !d.ixSlotOf.ensure(E + 1, err)) return false;
-            hipLaunchKernelGGL(k_idx_compact, dim3(gv), dim3(256), 0, d.stream, d.ixKeys2.p, d.ixVals2.p, d.ixKeep.p, d.ixPos.p, nValid, d.ixKmer.p, d.ientries.p);
+            if (!d.tgt->ientries.ensure(E + 1, err) || !d.ixKmer.ensure(E + 1, err) || !d.ixHead.ensure(E + 1, err) || !d.ixSlotOf.ensure(E + 1, err)) return false;
+            hipLaunchKernelGGL(k_idx_compact, dim3(gv), dim3(256), 0, d.stream, d.ixKeys2.p, d.ixVals2.p, d.ixKeep.p, d.ixPos.p, nValid, d.ixKmer.p, d.tgt->ientries.p);
             const unsigned ge = (E + 255) / 256;
             hipLaunchKernelGGL(k_idx_heads, dim3(ge), dim3(256), 0, d.stream, d.ixKmer.p, E, d.ixHead.p);
             sb = d.ixTemp.n;
@@ -2681,16 +2710,16 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
             HIP_OK(hipMemcpyAsync(&lastHead, d.ixHead.p + (E - 1), 4, hipMemcpyDeviceToHost, d.stream));
             HIP_OK(hipStreamSynchronize(d.stream));
             const uint32_t nSlots = lastSlot + lastHead;
-            if (!d.ixHeadPos.ensure(nSlots + 1, err) || !d.slots.ensure(nSlots + 1, err) || !d.ixCnt.ensure(words, err) || !d.ixBefore.ensure(words + 1, err)) return false;
-            hipLaunchKernelGGL(k_idx_slots1, dim3(ge), dim3(256), 0, d.stream, d.ixKmer.p, d.ixHead.p, d.ixSlotOf.p, E, d.ixHeadPos.p, (unsigned long long *) d.pbits.p);
-            hipLaunchKernelGGL(k_idx_slots2, dim3((nSlots + 255) / 256), dim3(256), 0, d.stream, d.ixHeadPos.p, nSlots, E, d.ientries.p, d.slots.p);
-            hipLaunchKernelGGL(k_idx_popc, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, (const unsigned long long *) d.pbits.p, (uint32_t) words, d.ixCnt.p);
+            if (!d.ixHeadPos.ensure(nSlots + 1, err) || !d.tgt->slots.ensure(nSlots + 1, err) || !d.ixCnt.ensure(words, err) || !d.ixBefore.ensure(words + 1, err)) return false;
+            hipLaunchKernelGGL(k_idx_slots1, dim3(ge), dim3(256), 0, d.stream, d.ixKmer.p, d.ixHead.p, d.ixSlotOf.p, E, d.ixHeadPos.p, (unsigned long long *) d.tgt->pbits.p);
+            hipLaunchKernelGGL(k_idx_slots2, dim3((nSlots + 255) / 256), dim3(256), 0, d.stream, d.ixHeadPos.p, nSlots, E, d.tgt->ientries.p, d.tgt->slots.p);
+            hipLaunchKernelGGL(k_idx_popc, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, (const unsigned long long *) d.tgt->pbits.p, (uint32_t) words, d.ixCnt.p);
             sb = d.ixTemp.n;
             HIP_OK(hipcub::DeviceScan::ExclusiveSum(d.ixTemp.p, sb, d.ixCnt.p, d.ixBefore.p, (int) words, d.stream));
-            hipLaunchKernelGGL(k_idx_ranks, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, d.ixBefore.p, (uint32_t) words, d.prank.p, d.prow.p);
+            hipLaunchKernelGGL(k_idx_ranks, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, d.ixBefore.p, (uint32_t) words, d.tgt->prank.p, d.tgt->prow.p);
             HIP_OK(hipGetLastError());
-            d.denseIndex = (uint64_t) E * 2 >= (uint64_t) nSlots * 3;
-            d.indexEntries = E; d.indexSlots = nSlots; out.indexEntries = E; out.indexSlots = nSlots;
+            d.tgt->denseIndex = (uint64_t) E * 2 >= (uint64_t) nSlots * 3;
+            d.tgt->indexEntries = E; d.tgt->indexSlots = nSlots; out.indexEntries = E; out.indexSlots = nSlots;
         }
     }
     HIP_OK(hipEventRecord(d.ev[0][2], d.stream));
@@ -2706,12 +2735,12 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
 
 bool Gpu::downloadIndex(std::vector<uint32_t> &kmers, std::vector<uint64_t> &entries, std::string &err) {
     Impl &d = *d_;
-    kmers.resize(d.indexEntries); entries.resize(d.indexEntries);
-    if (d.indexEntries == 0) return true;
+    kmers.resize(d.tgt->indexEntries); entries.resize(d.tgt->indexEntries);
+    if (d.tgt->indexEntries == 0) return true;
     if (!d.ixKmer.p) { err = "downloadIndex: the resident index was not built on the device"; return false; }
-    std::vector<uint32_t> slot(d.indexEntries); std::vector<uint64_t> ent(d.indexEntries);
-    HIP_OK(hipMemcpy(slot.data(), d.ixKmer.p, d.indexEntries * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(ent.data(), d.ientries.p, d.indexEntries * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> slot(d.tgt->indexEntries); std::vector<uint64_t> ent(d.tgt->indexEntries);
+    HIP_OK(hipMemcpy(slot.data(), d.ixKmer.p, d.tgt->indexEntries * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(ent.data(), d.tgt->ientries.p, d.tgt->indexEntries * sizeof(uint64_t), hipMemcpyDeviceToHost));
     // back to the reference's table order: k-mer ascending, lists untouched (a stable counting sort by k-mer id)
     std::vector<uint32_t> start((size_t) kTableSize + 1, 0);
     for (uint32_t s2 : slot) start[(size_t) kmerOfSlot(s2) + 1]++;
@@ -2722,9 +2751,9 @@ bool Gpu::downloadIndex(std::vector<uint32_t> &kmers, std::vector<uint64_t> &ent
 
 bool Gpu::downloadExt3(std::vector<uint32_t> &packed, std::string &err) {
     Impl &d = *d_;
-    if (!d.ext3.p) { err = "downloadExt3: tables not resident"; return false; }
+    if (!d.tab->ext3.p) { err = "downloadExt3: tables not resident"; return false; }
     packed.resize((size_t) 8000 * 8000);
-    HIP_OK(hipMemcpy(packed.data(), d.ext3.p, packed.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(packed.data(), d.tab->ext3.p, packed.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (uint32_t &v : packed) v = (v & 0xFFFF0000u) | unperm3(v & 0xFFFFu);      // the reference's partner numbers
     return true;
 }
@@ -2732,9 +2761,9 @@ bool Gpu::downloadExt3(std::vector<uint32_t> &packed, std::string &err) {
 bool Gpu::downloadMasked(std::vector<uint8_t> &masked, std::string &err) {
     Impl &d = *d_;
     size_t R = 0;
-    { uint64_t last = 0; if (d.nTargets) HIP_OK(hipMemcpy(&last, d.toff.p + d.nTargets, sizeof(uint64_t), hipMemcpyDeviceToHost)); R = (size_t) last; }
+    { uint64_t last = 0; if (d.tgt->nTargets) HIP_OK(hipMemcpy(&last, d.tgt->toff.p + d.tgt->nTargets, sizeof(uint64_t), hipMemcpyDeviceToHost)); R = (size_t) last; }
     masked.resize(R);
-    if (R) HIP_OK(hipMemcpy(masked.data(), d.tmasked.p, R, hipMemcpyDeviceToHost));
+    if (R) HIP_OK(hipMemcpy(masked.data(), d.tgt->tmasked.p, R, hipMemcpyDeviceToHost));
     return true;
 }
 
