@@ -251,9 +251,12 @@ def launch_ranks(n, argv):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    import binascii
+    from spacepharer_amd import dist as spd
+    uid = binascii.hexlify(spd.unique_id()).decode()      # (makes the id only: nothing here touches a GPU)
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SP_DIST_ID=uid,
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
     rc = 0
@@ -290,13 +293,15 @@ def main():
     ap.add_argument("--shards", type=int, default=0, help="N > 1, target-sharded: S target shards x N / S query groups (all-gather within a group); 0 = N shards, every rank matches all queries (BASELINE configs[3])")
     ap.add_argument("--no-hybrid", action="store_true", help="N >= 4: skip the additional 2-shard x N/2-group measurement")
     ap.add_argument("--no-replica", action="store_true", help="N > 1: skip the additional query-partition (replica) measurement")
-    ap.add_argument("--exchange", default="rccl", choices=["rccl", "gloo"], help="transport of the candidate all-gather (gloo: through host memory; tests)")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "host", "gloo"], help="transport of the all-gathers: RCCL (HBM -> xGMI -> HBM), or through host memory and the library's bootstrap sockets (\"host\"; \"gloo\" is the old name) for ranks that share a GPU (tests)")
     ap.add_argument("--same-gpu", action="store_true", help="all ranks use HIP device 0 (tests of the N > 1 path on a one-GPU box; needs --exchange gloo)")
     args = ap.parse_args()
 
     env_world = os.environ.get("WORLD_SIZE")
-    if args.same_gpu and args.exchange != "gloo":
-        sys.exit("bench.py: --same-gpu needs --exchange gloo (RCCL refuses two ranks on one device)")
+    if args.exchange == "gloo":
+        args.exchange = "host"
+    if args.same_gpu and args.exchange != "host":
+        sys.exit("bench.py: --same-gpu needs --exchange host (RCCL refuses two ranks on one device)")
     if env_world is None and (args.gpus or 1) > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
@@ -309,35 +314,22 @@ def main():
     n_spacers = args.spacers or (100000 if (sharded and world > 1) else 10000)
     full = args.stage == "full"
 
-    dist = torch = None
-    gpu_dev = None
-    if world > 1 or sharded:
-        import torch
-        import torch.distributed as dist
-        if args.exchange == "rccl":
-            torch.cuda.set_device(local_rank)
-            gpu_dev = torch.device("cuda", local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl" if args.exchange == "rccl" else "gloo", rank=rank, world_size=world)
-
     import spacepharer_amd as sa
+    from spacepharer_amd import dist as spd
     from spacepharer_amd.dist import decompose_by_residues, sharded_prefilter
     L = sa.load_library()
+    # N > 1: every collective of the data path is the library's (sp_dist_* / sp_ctx_allgather_*: RCCL all-gather of device buffers, counts and timings over its bootstrap
+    # sockets).  The ranks' 128-byte id comes from SP_DIST_ID (this script's own launcher) or through torch.distributed's gloo store (torchrun) -- control plane only.
+    comm = None
+    if world > 1 or sharded:
+        L.sp_init(1 << local_rank)      # this rank's GPU, before the communicator binds to it
+        comm = spd.init_from_env(spd.TRANSPORT_RCCL if args.exchange == "rccl" else spd.TRANSPORT_HOST, rank=rank, world=world)
 
     def all_max(x):
-        if dist is None or world == 1:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=gpu_dev or "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        return x if comm is None or world == 1 else comm.allreduce([x], "max")[0]
 
     def all_sum(x):
-        if dist is None or world == 1:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=gpu_dev or "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return float(t.item())
+        return x if comm is None or world == 1 else comm.allreduce([x], "sum")[0]
 
     def measure(shard_targets, spacers, steps, regions, warmup, want_breakdown, shards=0, partition=False, pipeline=None, host_driven=None):
         """one decomposition on this rank: set-up, reference digests, `regions` timed K-step regions with digest checks.
@@ -354,8 +346,7 @@ def main():
         sub = None
         if shard_targets and G > 1:
             assert world % S == 0, "--shards must divide the number of ranks"
-            groups = [dist.new_group(ranks=list(range(g * S, (g + 1) * S))) for g in range(G)]      # (every rank creates every group, in the same order)
-            sub = groups[rank // S]
+            sub = comm.split(rank // S)      # the S shards of this rank's query group
         # batch b is searched by context b: batch 0 = the single-GPU workload's spacers; further batches / ranks draw their own
         batches = []
         for b in range(n_pipe):
@@ -367,10 +358,12 @@ def main():
                 qs = None if (rank == 0 and b == 0) else 12345 + 7919 * rank + 104729 * b
             batches.append(make_workload(spacers, args.targets, args.target_len, 12345, qs))
         tres, toff = batches[0][0], batches[0][1]
+        part_from, part_total = 0, 0
         if partition and world > 1:
             for b in range(n_pipe):
                 tr, to, qr, qo = batches[b]
                 p_from, p_cnt = decompose_by_residues(np.diff(qo).astype(np.int64) + 2, rank, world)
+                part_from, part_total = p_from, len(qo) - 1
                 lo, hi = int(qo[p_from]), int(qo[p_from + p_cnt])
                 batches[b] = (tr, to, qr[lo:hi].copy(), (qo[p_from:p_from + p_cnt + 1] - qo[p_from]).astype(qo.dtype))
             assert len({len(bb[3]) for bb in batches}) == 1, "the slices of the batches differ in size"
@@ -407,7 +400,7 @@ def main():
 
         def search(c):
             if shard_targets:
-                info = sharded_prefilter(c, q_from, q_to, group=sub, device=gpu_dev)     # own shard -> all-gather (within the query group) -> selection on the union
+                info = sharded_prefilter(c, sub or comm, q_from, q_to)     # own shard -> all-gather (within the query group) -> selection on the union
                 xch["s"] += info["exchange_s"]
                 xch["bytes"] += info["bytes"]
                 xch["n"] += 1
@@ -431,24 +424,10 @@ def main():
             if not (partition and world > 1):
                 return
             t0 = time.perf_counter()
-            dev = gpu_dev if gpu_dev is not None else torch.device("cpu")
-            n = torch.tensor([slot.n], dtype=torch.int64, device=dev)
-            ns = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-            dist.all_gather(ns, n)
-            max_n = max(1, max(int(x.item()) for x in ns))
-            mine = torch.from_numpy(np.frombuffer(C.string_at(slot.hits, 8 * slot.n), dtype=np.uint8).reshape(-1, 8).copy()) if slot.n else torch.zeros((0, 8), dtype=torch.uint8)
-            pad = torch.zeros((max_n, 8), dtype=torch.uint8, device=dev)
-            if slot.n:
-                pad[:slot.n] = mine.to(dev)
-            if dev.type != "cpu" and hasattr(dist, "all_gather_into_tensor"):
-                out = torch.empty((world * max_n, 8), dtype=torch.uint8, device=dev)
-                dist.all_gather_into_tensor(out, pad)
-                torch.cuda.synchronize(dev)
-            else:
-                parts = [torch.empty_like(pad) for _ in range(world)]
-                dist.all_gather(parts, pad)
+            before = comm.bytes_moved()
+            spd.allgather_hits(ctxs[0], comm, part_from, part_total, my_hits=slot.hits, my_offsets=slot.off, my_n=slot.n)      # (any context of this rank: the list comes from the slot)
             xch["s"] += time.perf_counter() - t0
-            xch["bytes"] += world * max_n * 8
+            xch["bytes"] += comm.bytes_moved() - before
             xch["n"] += 1
 
         def step(c, slot):
@@ -471,12 +450,10 @@ def main():
             for c in ctxs:
                 if not device_driven:
                     c.align_hits_end()                     # the last pass's alignment records are in host memory
-            if dist is not None and world > 1:
-                dist.barrier()
-            if gpu_dev is not None:
-                torch.cuda.synchronize()
             for c in ctxs:
                 c.sync()
+            if comm is not None and world > 1:
+                comm.barrier()
 
         # reference digests: every batch searched by its context ALONE, default tuning, nothing else on the GPU
         ref = []
@@ -644,9 +621,9 @@ def main():
         # the same job with TWO target shards x world / 2 query groups: the enumeration of the similar k-mers is replicated twice, not world times
         hyb = measure(True, n_spacers, max(4, args.steps // 2), max(1, min(3, args.regions)), args.warmup, False, shards=2)
     pairs_total = all_sum(float(m["pairs"][0]))      # batch 0 of every rank (sharded: the ranks' query slices add up to the batch)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
     if rank != 0:
         return
 
@@ -682,7 +659,7 @@ def main():
                                                             ("targets sharded over %d x MI355X" % world) if sharded else "1xMI355X per rank",
                                                             "prefilter + ungapped + banded-SW align" if full else "prefilter only"),
                    "stage": args.stage, "pairs_aligned_per_step": int(pairs_total), "pairs_aligned_per_step_by_batch_rank0": m["pairs"], "sensitivity": 5.7, "max_seqs": 300,
-                   "parallelism": ("target shards x%d%s, %s all-gather of candidates, selection + align by query slice" % (args.shards or world, (" x %d query groups" % (world // args.shards)) if args.shards and args.shards != world else "", "RCCL" if args.exchange == "rccl" else "gloo")) if sharded
+                   "parallelism": ("target shards x%d%s, %s all-gather of candidates, selection + align by query slice" % (args.shards or world, (" x %d query groups" % (world // args.shards)) if args.shards and args.shards != world else "", "RCCL" if args.exchange == "rccl" else "host-memory")) if sharded
                                   else ("query partition x%d, index replicated" % world),
                    "passes_in_flight_per_gpu": n_pipe, "distinct_query_batches": n_pipe,
                    "step": ("device-driven: the whole step is queued without a host round trip (sp_ctx_search_begin / _end), two steps in flight per context; %d steps met a capacity and were repeated the synchronous way" % int(m["steps_repeated"]))
@@ -721,7 +698,7 @@ def main():
         out["step_modes"] = step_modes
     if sharded:
         x = m["xch"]
-        out["exchange"] = {"transport": "RCCL all-gather (HBM -> xGMI -> HBM)" if args.exchange == "rccl" else "gloo all-gather through host memory",
+        out["exchange"] = {"transport": "RCCL all-gather (HBM -> xGMI -> HBM), sp_ctx_allgather_candidates" if args.exchange == "rccl" else "all-gather through host memory and sockets (sp_dist host transport)",
                            "rccl_ranks": world if args.exchange == "rccl" else 0, "ranks": world,
                            "allgather_bytes_per_step": x["bytes"] / max(1, x["n"]),
                            "exchange_ms_per_step": 1e3 * x["s"] / max(1, x["n"]),
@@ -746,7 +723,7 @@ def main():
         out["query_partition"] = {"value": n_spacers * k2 / qdt, "unit": "spacer-queries/s", "scaling": "strong", "ms_per_step": qdt / k2 * 1e3, "regions": qregions, "step_modes": modes,
                                   "results_checked": qpart["checked"], "allgather_bytes_per_step": x["bytes"] / max(1, x["n"]), "exchange_ms_per_step": 1e3 * x["s"] / max(1, x["n"]),
                                   "parallelism": "the same job cut by query: every rank holds the full index (it fits HBM a hundred times over) and searches 1/%d of the spacers of a step, "
-                                                 "%s, %s all-gather of the hit lists after every step" % (world, step_kind, "RCCL" if args.exchange == "rccl" else "gloo")}
+                                                 "%s, %s all-gather of the hit lists after every step" % (world, step_kind, "RCCL" if args.exchange == "rccl" else "host-memory")}
     if world > 1 and sharded:
         # the headline at N > 1: the best of the decompositions of the SAME job (100 000 spacers against the whole target set, strong scaling); all of them stay in the line
         cands = {"target_shards": out["value"]}

@@ -171,6 +171,38 @@ int sp_ctx_align_hits_end(sp_ctx *c);
    delivered, a traceback that needs the host path) is repeated the synchronous way inside _end: the results are always complete. */
 int sp_ctx_search_begin(sp_ctx *c, sp_hit_packed *hits, uint32_t *offsets, uint64_t hit_cap, sp_alignment *results, char *cigars, uint64_t cigar_cap);
 int sp_ctx_search_end(sp_ctx *c, uint64_t *n_hits, uint64_t *cigar_used);
+/* ---- multi-GPU: one process per GPU of a node (the reference's counterpart is its MPI mode: per-rank result files merged by rank 0,
+ * lib/mmseqs/src/prefiltering/Prefiltering.cpp:258-362, slices by commons/DBReader.cpp:1171-1213) ----
+ * The ranks of a job meet through a 128-byte id: one of them (or their launcher) makes it with sp_dist_unique_id and hands it to all of them by whatever control plane is
+ * at hand (environment, file, MPI, torch store); sp_dist_init is collective.  SP_TRANSPORT_RCCL: device buffers travel by RCCL all-gather over xGMI, one rank per GPU
+ * (the device this process selected with sp_init).  SP_TRANSPORT_HOST: through host memory and the bootstrap sockets -- for ranks that share a GPU (tests on a one-GPU
+ * box; RCCL refuses two ranks on a device).  Small host values (counts, timings) always use the sockets. */
+typedef struct sp_comm sp_comm;
+#define SP_DIST_ID_BYTES 128
+#define SP_TRANSPORT_RCCL 0
+#define SP_TRANSPORT_HOST 1
+int sp_dist_unique_id(unsigned char id[SP_DIST_ID_BYTES]);
+sp_comm *sp_dist_init(const unsigned char id[SP_DIST_ID_BYTES], int rank, int world, int transport);      /* NULL on failure (sp_last_error) */
+void sp_dist_destroy(sp_comm *comm);
+int sp_dist_rank(const sp_comm *comm);
+int sp_dist_world(const sp_comm *comm);
+int sp_dist_barrier(sp_comm *comm);
+/* equal-size all-gather: recv holds world x bytes, rank r's block at r x bytes; on_device: both buffers are memory of this rank's GPU */
+int sp_dist_allgather(sp_comm *comm, const void *send, uint64_t bytes, void *recv, int on_device);
+int sp_dist_allreduce_f64(sp_comm *comm, double *values, uint64_t n, int op /* 0 sum, 1 max, 2 min */);
+uint64_t sp_dist_bytes_moved(const sp_comm *comm);      /* bytes this rank has received through the communicator so far */
+/* DBReader::decomposeDomainByAminoAcid: contiguous slices balanced by data size; entry_lengths = the index `length` fields (sequence length + 2) */
+int sp_dist_decompose(const uint64_t *entry_lengths, uint64_t n, int rank, int world, uint64_t *start, uint64_t *count);
+/* Target-sharded search (every rank staged ITS target range with sp_ctx_set_targets_shard and holds ALL queries): after sp_ctx_prefilter_candidates, the shards'
+ * candidate lists are all-gathered (HBM to HBM) and the selection runs on the union for queries [q_from, q_to) -- the hits equal the unsplit search's.  exchange_s:
+ * wall time of the exchange (counts + payload), union_rows: rows of the gathered list incl. padding. */
+int sp_ctx_allgather_candidates(sp_ctx *c, sp_comm *comm, uint64_t q_from, uint64_t q_to, uint64_t *union_rows, double *exchange_s);
+/* Query-partitioned search (every rank staged the whole target set and holds ITS slice of the queries, starting at global query `query_offset`): the slices' hit lists
+ * are all-gathered; every rank receives all hits in global query order (offsets has nq_total + 1 entries).  my_hits / my_offsets: this rank's list as a search step
+ * delivered it (sp_ctx_search_end, sp_ctx_hits_view: offsets of the resident queries + 1); both NULL: the last sp_ctx_prefilter's list, taken where it lies in HBM. */
+int sp_ctx_allgather_hits(sp_ctx *c, sp_comm *comm, uint64_t query_offset, uint64_t nq_total, const sp_hit_packed *my_hits, const uint32_t *my_offsets,
+                          sp_hit_packed *hits, uint64_t *offsets, uint64_t hit_cap, uint64_t *n_hits);
+
 /* rescorediagonal core (alignment/DistanceCalculator.h:93-295): mode 0 = equal letters on the diagonal (the module's default), 1 = ungapped local score,
  * 2 = score + start/end, 3 = the whole diagonal (start/end = its first / last column, a '*' at either end skipped), 4 = the longest stretch with at most five
  * mismatches in any 20 columns.  evalue / bit_score are those of `score` (modes 1-4; the module ignores them in mode 0). */

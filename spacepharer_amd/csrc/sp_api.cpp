@@ -16,6 +16,8 @@
 #include <vector>
 
 #include "sp_gpu.h"
+#include "sp_dist.h"
+#include <hip/hip_runtime_api.h>
 #include "sp_host.h"
 #include "sp_modules.h"
 #include "sp_sets.h"
@@ -301,6 +303,75 @@ int sp_ctx_merge_candidates(sp_ctx *c, const sp_candidate *cands, uint64_t n, in
                                 sp_ctx_max_seqs(c), c->par.min_ungapped_score, err)) { g_err = err; return SP_ERR_OVERFLOW; }
     sp::KernelTimes kt = c->gpu.times();
     c->stats["hits"] = (double) c->gpu.counters().hits; c->stats["ms_select"] = kt.select;
+    return SP_OK;
+}
+
+/* ---- multi-GPU: one process per GPU, see include/spacepharer_amd.h ---- */
+struct sp_comm { sp::Comm *c; };
+int sp_dist_unique_id(unsigned char *id) {
+    std::string err;
+    if (!id || !sp::Comm::uniqueId(id, err)) { g_err = id ? err : "sp_dist_unique_id: null argument"; return SP_ERR_ARG; }
+    return SP_OK;
+}
+sp_comm *sp_dist_init(const unsigned char *id, int rank, int world, int transport) {
+    if (!id) { g_err = "sp_dist_init: null id"; return nullptr; }
+    std::string err;
+    if (transport == SP_TRANSPORT_RCCL) (void) hipSetDevice(sp::currentDevice());      // the RCCL communicator binds to this rank's GPU
+    sp::Comm *c = sp::Comm::create(id, rank, world, transport, 0, err);
+    if (!c) { g_err = err; return nullptr; }
+    return new sp_comm{c};
+}
+void sp_dist_destroy(sp_comm *comm) { if (comm) { delete comm->c; delete comm; } }
+int sp_dist_rank(const sp_comm *comm) { return comm ? comm->c->rank() : 0; }
+int sp_dist_world(const sp_comm *comm) { return comm ? comm->c->world() : 1; }
+int sp_dist_barrier(sp_comm *comm) {
+    std::string err;
+    if (!comm || !comm->c->barrier(err)) { g_err = comm ? err : "sp_dist_barrier: null communicator"; return SP_ERR_DEVICE; }
+    return SP_OK;
+}
+int sp_dist_allgather(sp_comm *comm, const void *send, uint64_t bytes, void *recv, int on_device) {
+    std::string err;
+    if (!comm || !comm->c->allgather(send, (size_t) bytes, recv, on_device != 0, err)) { g_err = comm ? err : "sp_dist_allgather: null communicator"; return SP_ERR_DEVICE; }
+    return SP_OK;
+}
+int sp_dist_allreduce_f64(sp_comm *comm, double *values, uint64_t n, int op) {
+    std::string err;
+    if (!comm || !comm->c->allreduce(values, (size_t) n, op, err)) { g_err = comm ? err : "sp_dist_allreduce_f64: null communicator"; return SP_ERR_DEVICE; }
+    return SP_OK;
+}
+uint64_t sp_dist_bytes_moved(const sp_comm *comm) { return comm ? comm->c->bytesMoved() : 0; }
+int sp_dist_decompose(const uint64_t *entry_lengths, uint64_t n, int rank, int world, uint64_t *start, uint64_t *count) {
+    size_t s = 0, k = 0;
+    if (!entry_lengths || !start || !count || world < 1 || rank < 0 || rank >= world) { g_err = "sp_dist_decompose: bad argument"; return SP_ERR_ARG; }
+    if (!sp::decomposeByResidues(entry_lengths, (size_t) n, rank, world, s, k)) { g_err = "sp_dist_decompose: more ranks than residues"; return SP_ERR_ARG; }
+    *start = s; *count = k;
+    return SP_OK;
+}
+
+int sp_ctx_allgather_candidates(sp_ctx *c, sp_comm *comm, uint64_t q_from, uint64_t q_to, uint64_t *union_rows, double *exchange_s) {
+    if (!c || !comm) { g_err = "sp_ctx_allgather_candidates: null argument"; return SP_ERR_ARG; }
+    c->gpu.makeCurrent();
+    if (c->targets.n == 0) { g_err = "sp_ctx_allgather_candidates: no target set"; return SP_ERR_STATE; }
+    std::string err; size_t rows = 0;
+    const double t0 = nowMs();
+    if (!c->gpu.allgatherCandidates(*comm->c, rows, err)) { g_err = err; return SP_ERR_DEVICE; }
+    const double t1 = nowMs();
+    if (union_rows) *union_rows = rows;
+    if (exchange_s) *exchange_s = (t1 - t0) * 1e-3;
+    if (!c->gpu.mergeCandidates(c->gpu.candidateUnionDevice(), rows, true, (size_t) q_from, (size_t) q_to, c->binSize, sp_ctx_max_seqs(c), c->par.min_ungapped_score, err)) { g_err = err; return SP_ERR_OVERFLOW; }
+    sp::KernelTimes kt = c->gpu.times();
+    c->stats["hits"] = (double) c->gpu.counters().hits; c->stats["ms_select"] = kt.select; c->stats["ms_exchange"] = t1 - t0;
+    return SP_OK;
+}
+
+int sp_ctx_allgather_hits(sp_ctx *c, sp_comm *comm, uint64_t query_offset, uint64_t nq_total, const sp_hit_packed *my_hits, const uint32_t *my_offsets,
+                          sp_hit_packed *hits, uint64_t *offsets, uint64_t hit_cap, uint64_t *n_hits) {
+    if (!c || !comm || !hits || !offsets || !n_hits || ((my_hits == nullptr) != (my_offsets == nullptr))) { g_err = "sp_ctx_allgather_hits: null argument"; return SP_ERR_ARG; }
+    c->gpu.makeCurrent();
+    std::string err; size_t n = 0;
+    if (!c->gpu.allgatherHits(*comm->c, (size_t) query_offset, (size_t) nq_total, reinterpret_cast<const sp::GpuHit *>(my_hits), my_offsets, reinterpret_cast<sp::GpuHit *>(hits), offsets,
+                              (size_t) hit_cap, n, err)) { g_err = err; return SP_ERR_DEVICE; }
+    *n_hits = n;
     return SP_OK;
 }
 

@@ -1,0 +1,229 @@
+// Multi-GPU exchange (see sp_dist.h).  The reference spreads a search over MPI ranks that each write files and lets rank 0 merge them
+// (lib/mmseqs/src/prefiltering/Prefiltering.cpp:258-362, commons/DBReader.cpp:1171-1213); here the ranks are the GPUs of one node and what they exchange -- per-shard
+// candidate lists, per-slice hit lists -- stays in HBM: RCCL all-gather over xGMI.  RCCL is loaded when the first communicator with that transport is made
+// (dlopen: a one-GPU module run never pays for it).
+#include "sp_dist.h"
+
+#include <arpa/inet.h>
+#include <dlfcn.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <thread>
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+namespace sp {
+
+namespace {
+
+struct IdLayout { char magic[8]; uint16_t port; uint16_t pad; uint32_t pad2; uint64_t token; char addr[64]; };
+static_assert(sizeof(IdLayout) <= kDistIdBytes, "id layout");
+
+bool sendAll(int fd, const void *p, size_t n) {
+    const char *c = static_cast<const char *>(p);
+    while (n) { const ssize_t w = ::send(fd, c, n, MSG_NOSIGNAL); if (w <= 0) { if (w < 0 && errno == EINTR) continue; return false; } c += w; n -= (size_t) w; }
+    return true;
+}
+bool recvAll(int fd, void *p, size_t n) {
+    char *c = static_cast<char *>(p);
+    while (n) { const ssize_t r = ::recv(fd, c, n, 0); if (r <= 0) { if (r < 0 && errno == EINTR) continue; return false; } c += r; n -= (size_t) r; }
+    return true;
+}
+void noDelay(int fd) { int one = 1; (void) setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one)); }
+
+// the RCCL entry points used, resolved from librccl.so
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*getUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*commInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*commDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*allGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*errorString)(ncclResult_t) = nullptr;
+    bool load(std::string &err) {
+        if (lib) return true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+        if (!lib) { err = std::string("RCCL is not available: ") + dlerror(); return false; }
+        getUniqueId = reinterpret_cast<decltype(getUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+        commInitRank = reinterpret_cast<decltype(commInitRank)>(dlsym(lib, "ncclCommInitRank"));
+        commDestroy = reinterpret_cast<decltype(commDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        allGather = reinterpret_cast<decltype(allGather)>(dlsym(lib, "ncclAllGather"));
+        errorString = reinterpret_cast<decltype(errorString)>(dlsym(lib, "ncclGetErrorString"));
+        if (!getUniqueId || !commInitRank || !commDestroy || !allGather || !errorString) { err = "librccl.so lacks an entry point (ncclGetUniqueId / ncclCommInitRank / ncclAllGather ...)"; return false; }
+        return true;
+    }
+};
+Rccl g_rccl;
+
+}  // namespace
+
+bool Comm::uniqueId(unsigned char *id, std::string &err) {
+    memset(id, 0, kDistIdBytes);
+    IdLayout l; memset(&l, 0, sizeof(l));
+    memcpy(l.magic, "SPDIST1", 8);
+    const char *addr = getenv("SP_DIST_ADDR");
+    snprintf(l.addr, sizeof(l.addr), "%s", addr && *addr ? addr : "127.0.0.1");
+    // a free port: bind to port 0, read it back, let go (rank 0 binds it again with SO_REUSEADDR a moment later)
+    const int fd = socket(AF_INET, SOCK_STREAM, 0);
+    if (fd < 0) { err = "sp_dist_unique_id: socket() failed"; return false; }
+    sockaddr_in sa; memset(&sa, 0, sizeof(sa)); sa.sin_family = AF_INET; sa.sin_addr.s_addr = htonl(INADDR_ANY); sa.sin_port = 0;
+    socklen_t len = sizeof(sa);
+    if (bind(fd, reinterpret_cast<sockaddr *>(&sa), sizeof(sa)) != 0 || getsockname(fd, reinterpret_cast<sockaddr *>(&sa), &len) != 0) { close(fd); err = "sp_dist_unique_id: no free port"; return false; }
+    l.port = ntohs(sa.sin_port);
+    close(fd);
+    std::random_device rd; l.token = ((uint64_t) rd() << 32) ^ rd() ^ (uint64_t) getpid();
+    memcpy(id, &l, sizeof(l));
+    return true;
+}
+
+Comm *Comm::create(const unsigned char *id, int rank, int world, int transport, int timeoutSec, std::string &err) {
+    IdLayout l; memcpy(&l, id, sizeof(l));
+    if (memcmp(l.magic, "SPDIST1", 8) != 0) { err = "sp_dist_init: not an id made by sp_dist_unique_id"; return nullptr; }
+    if (world < 1 || rank < 0 || rank >= world) { err = "sp_dist_init: rank " + std::to_string(rank) + " of " + std::to_string(world); return nullptr; }
+    if (transport != kTransportRccl && transport != kTransportHost) { err = "sp_dist_init: unknown transport"; return nullptr; }
+    Comm *c = new Comm; c->rank_ = rank; c->world_ = world; c->transport_ = transport;
+    auto failed = [&](const std::string &why) { err = why; delete c; return (Comm *) nullptr; };
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(timeoutSec > 0 ? timeoutSec : 120);
+    if (world > 1) {
+        if (rank == 0) {
+            c->listenFd_ = socket(AF_INET, SOCK_STREAM, 0);
+            int one = 1; (void) setsockopt(c->listenFd_, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+            sockaddr_in sa; memset(&sa, 0, sizeof(sa)); sa.sin_family = AF_INET; sa.sin_addr.s_addr = htonl(INADDR_ANY); sa.sin_port = htons(l.port);
+            if (c->listenFd_ < 0 || bind(c->listenFd_, reinterpret_cast<sockaddr *>(&sa), sizeof(sa)) != 0 || listen(c->listenFd_, world) != 0)
+                return failed("sp_dist_init: rank 0 cannot listen on port " + std::to_string(l.port) + ": " + strerror(errno));
+            c->fds_.assign((size_t) world, -1);
+            for (int k = 1; k < world; k++) {
+                timeval tv; const auto left = std::chrono::duration_cast<std::chrono::seconds>(deadline - std::chrono::steady_clock::now()).count();
+                tv.tv_sec = left > 1 ? left : 1; tv.tv_usec = 0;
+                (void) setsockopt(c->listenFd_, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+                const int fd = accept(c->listenFd_, nullptr, nullptr);
+                if (fd < 0) return failed("sp_dist_init: rank 0 waited in vain for " + std::to_string(world - k) + " of " + std::to_string(world - 1) + " peers");
+                noDelay(fd);
+                uint64_t hello[2] = {0, 0};
+                if (!recvAll(fd, hello, sizeof(hello)) || hello[0] != l.token || hello[1] == 0 || hello[1] >= (uint64_t) world || c->fds_[hello[1]] >= 0) { close(fd); k--; continue; }      // (not one of ours)
+                c->fds_[hello[1]] = fd;
+            }
+        } else {
+            sockaddr_in sa; memset(&sa, 0, sizeof(sa)); sa.sin_family = AF_INET; sa.sin_port = htons(l.port);
+            if (inet_pton(AF_INET, l.addr, &sa.sin_addr) != 1) return failed(std::string("sp_dist_init: bad address ") + l.addr);
+            int fd = -1;
+            for (;;) {
+                fd = socket(AF_INET, SOCK_STREAM, 0);
+                if (fd >= 0 && connect(fd, reinterpret_cast<sockaddr *>(&sa), sizeof(sa)) == 0) break;
+                if (fd >= 0) close(fd);
+                fd = -1;
+                if (std::chrono::steady_clock::now() > deadline) return failed("sp_dist_init: rank " + std::to_string(rank) + " cannot reach rank 0 at " + l.addr + ":" + std::to_string(l.port));
+                std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            }
+            noDelay(fd);
+            const uint64_t hello[2] = {l.token, (uint64_t) rank};
+            if (!sendAll(fd, hello, sizeof(hello))) { close(fd); return failed("sp_dist_init: handshake with rank 0 failed"); }
+            c->fds_.assign(1, fd);
+        }
+    }
+    if (!c->barrier(err)) { delete c; return nullptr; }
+    if (transport == kTransportRccl) {
+        if (!g_rccl.load(err)) { delete c; return nullptr; }
+        ncclUniqueId nid; memset(&nid, 0, sizeof(nid));
+        if (rank == 0) { const ncclResult_t r = g_rccl.getUniqueId(&nid); if (r != ncclSuccess) return failed(std::string("ncclGetUniqueId: ") + g_rccl.errorString(r)); }
+        std::vector<unsigned char> all((size_t) world * sizeof(nid));
+        if (!c->hostAllgather(&nid, sizeof(nid), all.data(), err)) { delete c; return nullptr; }
+        memcpy(&nid, all.data(), sizeof(nid));      // rank 0's
+        ncclComm_t comm = nullptr;
+        const ncclResult_t r = g_rccl.commInitRank(&comm, world, nid, rank);
+        if (r != ncclSuccess) return failed(std::string("ncclCommInitRank: ") + g_rccl.errorString(r) + " (one rank per GPU; ranks that share a device need the host transport)");
+        c->nccl_ = comm;
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return failed("sp_dist_init: cannot create the exchange stream");
+        c->stream_ = s;
+    }
+    return c;
+}
+
+Comm::~Comm() {
+    if (nccl_ && g_rccl.commDestroy) (void) g_rccl.commDestroy(static_cast<ncclComm_t>(nccl_));
+    if (stream_) (void) hipStreamDestroy(static_cast<hipStream_t>(stream_));
+    for (int fd : fds_) if (fd >= 0) close(fd);
+    if (listenFd_ >= 0) close(listenFd_);
+}
+
+// star over the bootstrap sockets: everybody sends to rank 0, rank 0 sends the concatenation to everybody
+bool Comm::hostAllgather(const void *send, size_t bytes, void *recv, std::string &err) {
+    if (world_ == 1) { if (recv != send) memmove(recv, send, bytes); return true; }
+    unsigned char *out = static_cast<unsigned char *>(recv);
+    if (rank_ == 0) {
+        memmove(out, send, bytes);
+        for (int k = 1; k < world_; k++) if (!recvAll(fds_[(size_t) k], out + (size_t) k * bytes, bytes)) { err = "sp_dist: rank " + std::to_string(k) + " is gone"; return false; }
+        for (int k = 1; k < world_; k++) if (!sendAll(fds_[(size_t) k], out, (size_t) world_ * bytes)) { err = "sp_dist: rank " + std::to_string(k) + " is gone"; return false; }
+    } else {
+        if (!sendAll(fds_[0], send, bytes) || !recvAll(fds_[0], out, (size_t) world_ * bytes)) { err = "sp_dist: rank 0 is gone"; return false; }
+    }
+    bytes_ += (uint64_t) world_ * bytes;
+    return true;
+}
+
+bool Comm::allgather(const void *send, size_t bytes, void *recv, bool onDevice, std::string &err) {
+    if (bytes == 0) return true;
+    if (!onDevice) return hostAllgather(send, bytes, recv, err);
+    if (transport_ == kTransportRccl) {
+        const ncclResult_t r = g_rccl.allGather(send, recv, bytes, ncclChar, static_cast<ncclComm_t>(nccl_), static_cast<hipStream_t>(stream_));
+        if (r != ncclSuccess) { err = std::string("ncclAllGather: ") + g_rccl.errorString(r); return false; }
+        if (hipStreamSynchronize(static_cast<hipStream_t>(stream_)) != hipSuccess) { err = "sp_dist: the exchange stream failed"; return false; }
+        bytes_ += (uint64_t) world_ * bytes;
+        return true;
+    }
+    // ranks that share a GPU: through host memory and the sockets
+    stage_.resize((size_t) (world_ + 1) * bytes);
+    if (hipMemcpy(stage_.data(), send, bytes, hipMemcpyDeviceToHost) != hipSuccess) { err = "sp_dist: device -> host copy failed"; return false; }
+    if (!hostAllgather(stage_.data(), bytes, stage_.data() + bytes, err)) return false;
+    if (hipMemcpy(recv, stage_.data() + bytes, (size_t) world_ * bytes, hipMemcpyHostToDevice) != hipSuccess) { err = "sp_dist: host -> device copy failed"; return false; }
+    return true;
+}
+
+bool Comm::barrier(std::string &err) {
+    unsigned char one = 1; std::vector<unsigned char> all((size_t) world_);
+    return hostAllgather(&one, 1, all.data(), err);
+}
+
+bool Comm::allreduce(double *v, size_t n, int op, std::string &err) {
+    if (world_ == 1 || n == 0) return true;
+    std::vector<double> all((size_t) world_ * n);
+    if (!hostAllgather(v, n * sizeof(double), all.data(), err)) return false;
+    for (size_t i = 0; i < n; i++) {
+        double acc = all[i];
+        for (int k = 1; k < world_; k++) { const double x = all[(size_t) k * n + i]; acc = op == 0 ? acc + x : (op == 1 ? (x > acc ? x : acc) : (x < acc ? x : acc)); }
+        v[i] = acc;
+    }
+    return true;
+}
+
+bool decomposeByResidues(const uint64_t *lengths, size_t n, int rank, int world, size_t &start, size_t &count) {
+    uint64_t dataSize = 0;
+    for (size_t i = 0; i < n; i++) dataSize += lengths[i];
+    if ((uint64_t) world > (dataSize > 1 ? dataSize : 1)) return false;
+    if (world == 1) { start = 0; count = n; return true; }
+    if (n <= (size_t) world) { start = (size_t) rank < n ? (size_t) rank : 0; count = (size_t) rank < n ? 1 : 0; return true; }
+    const uint64_t chunk = (uint64_t) std::ceil((double) dataSize / (double) world);
+    std::vector<size_t> per((size_t) world, 0);
+    size_t cur = 0; uint64_t acc = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (acc >= chunk) { acc = 0; cur++; }
+        acc += lengths[i];
+        per[cur] += 1;
+    }
+    start = 0; count = per[(size_t) rank];
+    for (int j = 0; j < rank; j++) start += per[(size_t) j];
+    return true;
+}
+
+}  // namespace sp

@@ -109,6 +109,10 @@ public:
     const std::vector<uint32_t> &overflowQueries() const { return overflowList_; }      // positions (in the batch) of the queries the last pass refused
     const Candidate *candidatesDevice() const;
     bool downloadCandidates(Candidate *out, std::string &err);
+    // multi-GPU exchange on device buffers (sp_dist.h): the shards' candidates -> candidateUnionDevice() on every rank; the slices' hit lists -> host arrays in query order
+    bool allgatherCandidates(class Comm &comm, size_t &unionRows, std::string &err);
+    const Candidate *candidateUnionDevice() const;
+    bool allgatherHits(class Comm &comm, size_t queryOffset, size_t nqTotal, const GpuHit *srcHits, const uint32_t *srcOffsets, GpuHit *hits, uint64_t *offsets, size_t hitCap, size_t &nHits, std::string &err);
     bool mergeCandidates(const Candidate *src, size_t n, bool onDevice, size_t qFrom, size_t qTo, unsigned binSize, int maxHits, int minDiagScore, std::string &err);
     // hits grouped by query (query order); offsets has nq+1 entries
     bool hostHits(const GpuHit *&hits, const uint32_t *&offsets, size_t &n, std::string &err);

@@ -18,6 +18,7 @@
 #include <string>
 
 #include "sp_gpu.h"
+#include "sp_dist.h"
 
 // the reference's AVX2 build has no FMA contraction; a few float/double expressions below must round identically
 #pragma clang fp contract(off)
@@ -1997,7 +1998,8 @@ struct Gpu::Impl {
         return true;
     }
     // target-sharded search
-    DevBuf<uint32_t> diagOrd; DevBuf<uint32_t> spillOrd; DevBuf<Candidate> cand; DevBuf<Candidate> candUnion; DevBuf<Candidate> candByQuery;
+    DevBuf<uint32_t> diagOrd; DevBuf<uint32_t> spillOrd; DevBuf<Candidate> cand; DevBuf<Candidate> candUnion; DevBuf<Candidate> candByQuery; DevBuf<Candidate> candPad;
+    DevBuf<uint32_t> xOff, xOffAll; DevBuf<GpuHit> xHit, xHitAll;      // send / receive buffers of the hit-list all-gather (query partition)
     DevBuf<uint32_t> candCnt; DevBuf<uint32_t> candFill; DevBuf<uint32_t> candOffset; DevBuf<uint64_t> mergeScratch;
     uint32_t nCand = 0;
     SwState sw;
@@ -2582,6 +2584,68 @@ bool Gpu::prefilterCandidates(int kmerThr, int minDiagScore, std::string &err) {
 
 const Candidate *Gpu::candidatesDevice() const { return d_->cand.p; }
 size_t Gpu::numCandidates() const { return d_->nCand; }
+
+// Target-sharded search: every rank has matched ALL queries against ITS target shard (prefilterCandidates); the shards' candidate lists are exchanged -- counts over the
+// bootstrap sockets, the lists themselves padded to the longest one by RCCL all-gather, HBM to HBM over xGMI -- and land in candUnion, where mergeCandidates() reads them
+// (rows of 0xFF are padding).  The reference merges the per-split result FILES of its MPI ranks (prefiltering/Prefiltering.cpp:258-362).
+bool Gpu::allgatherCandidates(Comm &comm, size_t &unionRows, std::string &err) {
+    Impl &d = *d_;
+    const int world = comm.world();
+    uint64_t mine = d.nCand; std::vector<uint64_t> all((size_t) world, 0);
+    if (!comm.allgather(&mine, sizeof(mine), all.data(), false, err)) return false;
+    uint64_t longest = 1; for (uint64_t x : all) longest = std::max(longest, x);
+    if (longest * (uint64_t) world >= (1ull << 32)) { err = "allgatherCandidates: more than 2^32 candidate rows"; return false; }
+    if (!d.candPad.ensure((size_t) longest, err) || !d.candUnion.ensure((size_t) longest * world + 1, err)) return false;
+    HIP_OK(hipMemsetAsync(d.candPad.p, 0xFF, (size_t) longest * sizeof(Candidate), d.stream));
+    if (d.nCand) HIP_OK(hipMemcpyAsync(d.candPad.p, d.cand.p, (size_t) d.nCand * sizeof(Candidate), hipMemcpyDeviceToDevice, d.stream));
+    HIP_OK(hipStreamSynchronize(d.stream));
+    if (!comm.allgather(d.candPad.p, (size_t) longest * sizeof(Candidate), d.candUnion.p, true, err)) return false;
+    unionRows = (size_t) longest * world;
+    return true;
+}
+const Candidate *Gpu::candidateUnionDevice() const { return d_->candUnion.p; }
+
+// Query-partitioned search: every rank has searched ITS slice of the queries against the whole target set; all ranks receive all hit lists in global query order.
+// counts[q] (hits of global query q) and the 8-byte hit records are gathered by two padded all-gathers of device buffers; the caller gets them in host memory.
+bool Gpu::allgatherHits(Comm &comm, size_t queryOffset, size_t nqTotal, const GpuHit *srcHits, const uint32_t *srcOffsets, GpuHit *hits, uint64_t *offsets, size_t hitCap, size_t &nHits, std::string &err) {
+    Impl &d = *d_;
+    const int world = comm.world();
+    if (queryOffset + nq_ > nqTotal) { err = "allgatherHits: this rank's slice ends behind the last query"; return false; }
+    // srcHits / srcOffsets: a delivered step's hit list in host memory (the context may already be searching the next batch); nullptr: the last pass's, still on the device
+    const uint64_t myHits = srcOffsets ? (uint64_t) srcOffsets[nq_] : (uint64_t) counters_.hits;
+    uint64_t mine[3] = {(uint64_t) queryOffset, (uint64_t) nq_, myHits}; std::vector<uint64_t> all((size_t) world * 3, 0);
+    if (!comm.allgather(mine, sizeof(mine), all.data(), false, err)) return false;
+    uint64_t maxQ = 1, maxH = 1, totalH = 0, totalQ = 0;
+    for (int r = 0; r < world; r++) { maxQ = std::max(maxQ, all[(size_t) r * 3 + 1]); maxH = std::max(maxH, all[(size_t) r * 3 + 2]); totalH += all[(size_t) r * 3 + 2]; totalQ += all[(size_t) r * 3 + 1]; }
+    if (totalQ != nqTotal) { err = "allgatherHits: the ranks' slices hold " + std::to_string(totalQ) + " queries, not " + std::to_string(nqTotal); return false; }
+    if (totalH > hitCap) { err = "allgatherHits: " + std::to_string(totalH) + " hits, room for " + std::to_string(hitCap); return false; }
+    if (!srcOffsets && d.hitsInFlight) { (void) hipEventSynchronize(d.hitsOnHost); d.hitsInFlight = false; }
+    if (!d.xOff.ensure((size_t) maxQ + 1, err) || !d.xOffAll.ensure((size_t) (maxQ + 1) * world, err) || !d.xHit.ensure((size_t) maxH, err) || !d.xHitAll.ensure((size_t) maxH * world, err)) return false;
+    hipStream_t xs = srcOffsets ? d.copyStream : d.stream;      // (a host source has nothing to wait for on the search stream)
+    HIP_OK(hipMemsetAsync(d.xOff.p, 0, (size_t) (maxQ + 1) * sizeof(uint32_t), xs));
+    if (nq_) HIP_OK(hipMemcpyAsync(d.xOff.p, srcOffsets ? (const void *) srcOffsets : (const void *) d.outOffset.p, (nq_ + 1) * sizeof(uint32_t), hipMemcpyDefault, xs));
+    if (myHits) HIP_OK(hipMemcpyAsync(d.xHit.p, srcOffsets ? (const void *) srcHits : (const void *) d.outHits.p, (size_t) myHits * sizeof(GpuHit), hipMemcpyDefault, xs));
+    HIP_OK(hipStreamSynchronize(xs));
+    if (!comm.allgather(d.xOff.p, (size_t) (maxQ + 1) * sizeof(uint32_t), d.xOffAll.p, true, err)) return false;
+    if (!comm.allgather(d.xHit.p, (size_t) maxH * sizeof(GpuHit), d.xHitAll.p, true, err)) return false;
+    std::vector<uint32_t> offAll((size_t) (maxQ + 1) * world);
+    HIP_OK(hipMemcpy(offAll.data(), d.xOffAll.p, offAll.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // the slices in the order of their first query
+    std::vector<int> order((size_t) world); for (int r = 0; r < world; r++) order[(size_t) r] = r;
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return all[(size_t) x * 3] != all[(size_t) y * 3] ? all[(size_t) x * 3] < all[(size_t) y * 3] : x < y; });
+    uint64_t at = 0, q = 0;
+    for (int r : order) {
+        const uint64_t qo = all[(size_t) r * 3], nq = all[(size_t) r * 3 + 1], nh = all[(size_t) r * 3 + 2];
+        if (nq && qo != q) { err = "allgatherHits: the ranks' slices do not tile the queries"; return false; }
+        const uint32_t *off = offAll.data() + (size_t) r * (maxQ + 1);
+        for (uint64_t i = 0; i < nq; i++) offsets[q + i] = at + off[i];
+        if (nh) HIP_OK(hipMemcpy(hits + at, d.xHitAll.p + (size_t) r * maxH, (size_t) nh * sizeof(GpuHit), hipMemcpyDeviceToHost));
+        at += nh; q += nq;
+    }
+    offsets[nqTotal] = at;
+    nHits = (size_t) at;
+    return true;
+}
 
 bool Gpu::downloadCandidates(Candidate *out, std::string &err) {
     Impl &d = *d_;

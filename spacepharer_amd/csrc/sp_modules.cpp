@@ -57,7 +57,7 @@ struct Ctx {
     sp_ctx *c = nullptr; bool cached = false; bool targetsStaged = false;
     ~Ctx() { if (c && !cached) sp_ctx_destroy(c); }
 };
-struct CachedCtx { std::string key; sp_ctx *c; uint64_t stamp; };
+struct CachedCtx { std::string key; sp_ctx *c; uint64_t stamp; std::string target; bool indexed; };
 static std::vector<CachedCtx> g_ctxCache; static uint64_t g_ctxStamp = 0; static std::mutex g_ctxMutex;
 static size_t ctxCacheSize() { const char *e = getenv("SP_CONTEXT_CACHE"); return e ? (size_t) std::max(0, atoi(e)) : 0; }
 static std::string fileIdentity(const std::string &path) {
@@ -95,12 +95,16 @@ static bool acquireCtx(const sp_search_params &p, const std::string &targetPath,
     if (!ctx.c) { err = sp_last_error(); return false; }
     if (cap) {
         std::lock_guard<std::mutex> lk(g_ctxMutex);
+        // the same target DB may already be resident for another parameter set or another module (`prefilter` staged it with its index, now `align` asks for the residues):
+        // the new context SHARES that staged set (sp_ctx_share_targets) instead of reading, mapping and uploading the DB again
+        const std::string tid = fileIdentity(targetPath); const bool wantIndex = std::string(what) == "index";
+        for (CachedCtx &e : g_ctxCache) if (e.target == tid && (e.indexed || !wantIndex) && sp_ctx_share_targets(ctx.c, e.c) == SP_OK) { ctx.targetsStaged = true; break; }
         if (g_ctxCache.size() >= cap) {      // evict the least recently used
             size_t lru = 0; for (size_t i = 1; i < g_ctxCache.size(); i++) if (g_ctxCache[i].stamp < g_ctxCache[lru].stamp) lru = i;
             forgetPrefilter(g_ctxCache[lru].c);
             sp_ctx_destroy(g_ctxCache[lru].c); g_ctxCache.erase(g_ctxCache.begin() + (long) lru);
         }
-        g_ctxCache.push_back({key, ctx.c, ++g_ctxStamp});
+        g_ctxCache.push_back({key, ctx.c, ++g_ctxStamp, tid, wantIndex});
         ctx.cached = true;
     }
     return true;

@@ -1,142 +1,175 @@
-"""Multi-GPU helpers: one process per GPU (torch.distributed; backend "nccl" == RCCL over xGMI on MI355X, "gloo" in
-the CPU tests).
+"""Multi-GPU helpers: one process per GPU.  Every collective of the data path is the library's own (include/spacepharer_amd.h, sp_dist_* / sp_ctx_allgather_*:
+RCCL all-gather of device buffers over xGMI, counts and timings over the bootstrap sockets); this module is the ctypes binding plus the one thing a launcher has to do --
+hand the 128-byte id that rank 0 makes to every rank.  Under torchrun that goes through torch.distributed's store (gloo), otherwise through SP_DIST_ID (hex) or a file.
 
-The search shards by QUERY: every rank holds the whole target index in its own 288 GB of HBM and searches a
-contiguous slice of the query DB -- the reference's default QUERY_DB_SPLIT (lib/mmseqs/src/prefiltering/
-Prefiltering.cpp:273-281,735-740), which keeps results identical to the unsplit run (a target split is not:
-Prefiltering.cpp:343-346 applies a per-split hit quota).  No data-path collective is needed; the only exchange is
-the variable-length all-gather of the per-rank hit lists so that every rank (or just rank 0) can write the result
-DB / feed the host-side aggregation steps.
-
-Target-sharded mode (for target sets that should be split across GPUs): rank g indexes the target
-range decompose_by_residues(target_lengths, g, world), all ranks search all queries, `allgather_candidates` exchanges
-the 16-byte per-(query, target) candidates (RCCL all-gather of device buffers over xGMI; gloo/host in the CPU tests) and
-every rank runs the selection on the union for its slice of the queries (SearchContext.merge_candidates*), which
-reproduces the unsplit result exactly.
+Query partition (the reference's default, lib/mmseqs/src/prefiltering/Prefiltering.cpp:273-281,735-740): every rank holds the whole target index in its own HBM and
+searches a contiguous slice of the queries (decompose_by_residues = DBReader::decomposeDomainByAminoAcid); `allgather_hits` brings all hit lists to every rank.
+Target shards: rank g indexes target range g, all ranks match all queries, `sharded_prefilter` exchanges the 16-byte per-(query, target)
+candidates and runs the selection on the union -- the unsplit result, exactly.
 """
-import math
+import binascii
+import ctypes as C
+import os
 
 import numpy as np
 
+from . import _lib
 
-def decompose_by_residues(entry_lengths, rank, world):
-    """DBReader::decomposeDomainByAminoAcid (lib/mmseqs/src/commons/DBReader.cpp:1171-1213): contiguous slices balanced
-    by data size.  entry_lengths are the index `length` fields (sequence length + 2).  Returns (start, count)."""
-    n = len(entry_lengths)
-    data_size = int(sum(int(x) for x in entry_lengths))
-    if world > max(1, data_size):
-        raise ValueError("world size %d larger than the data size %d" % (world, data_size))
-    if world == 1:
-        return 0, n
-    if n <= world:
-        return (rank if rank < n else 0), (1 if rank < n else 0)
-    chunk = int(math.ceil(float(data_size) / float(world)))
-    per = [0] * world
-    cur, acc = 0, 0
-    for length in entry_lengths:
-        if acc >= chunk:
-            acc = 0
-            cur += 1
-        acc += int(length)
-        per[cur] += 1
-    return sum(per[:rank]), per[rank]
-
-
-def allgather_hits(query_offset, offsets, hits, group=None, device=None):
-    """Variable-length all-gather of per-rank hit lists.
-
-    query_offset : index of this rank's first query in the global query order
-    offsets      : uint64[nq_local + 1] -- hits of local query i are hits[offsets[i]:offsets[i+1]]
-    hits         : int64[n_hits, 3]     -- (target index, score, diagonal)
-    Returns (global_offsets uint64[nq_total + 1], global_hits int64[n, 3]) ordered by global query index.
-    Two collectives: the counts (one int64 pair per rank), then the padded payloads -- payloads are a few MB, so on
-    xGMI this is latency-bound whatever the algorithm."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    dev = device if device is not None else torch.device("cpu")
-    counts = np.diff(np.asarray(offsets, dtype=np.int64))
-    meta = torch.tensor([int(query_offset), len(counts), int(counts.sum())], dtype=torch.int64, device=dev)
-    metas = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(metas, meta, group=group)
-    metas = [m.cpu().numpy() for m in metas]
-    max_q = max(int(m[1]) for m in metas)
-    max_h = max(int(m[2]) for m in metas)
-    cpad = torch.zeros(max(1, max_q), dtype=torch.int64, device=dev)
-    cpad[:len(counts)] = torch.from_numpy(counts).to(dev)
-    hpad = torch.zeros((max(1, max_h), 3), dtype=torch.int64, device=dev)
-    if len(hits):
-        hpad[:len(hits)] = torch.from_numpy(np.ascontiguousarray(hits, dtype=np.int64)).to(dev)
-    call = [torch.zeros_like(cpad) for _ in range(world)]
-    hall = [torch.zeros_like(hpad) for _ in range(world)]
-    dist.all_gather(call, cpad, group=group)
-    dist.all_gather(hall, hpad, group=group)
-    order = sorted(range(world), key=lambda r: int(metas[r][0]))
-    all_counts, all_hits = [], []
-    for r in order:
-        nq, nh = int(metas[r][1]), int(metas[r][2])
-        all_counts.append(call[r][:nq].cpu().numpy())
-        all_hits.append(hall[r][:nh].cpu().numpy())
-    gc = np.concatenate(all_counts) if all_counts else np.zeros(0, dtype=np.int64)
-    go = np.zeros(len(gc) + 1, dtype=np.uint64)
-    go[1:] = np.cumsum(gc).astype(np.uint64)
-    gh = np.concatenate(all_hits) if all_hits else np.zeros((0, 3), dtype=np.int64)
-    return go, gh
-
-
+TRANSPORT_RCCL, TRANSPORT_HOST = 0, 1
+ID_BYTES = 128
 CAND_BYTES = 16     # sizeof(sp_candidate)
 
 
-def allgather_candidates(local, group=None, device=None):
-    """All-gather of the per-shard candidate lists.
+def _L():
+    L = _lib.load_library()
+    if not getattr(L, "_dist_bound", False):
+        vp = C.c_void_p
+        L.sp_dist_unique_id.argtypes = [C.c_char_p]
+        L.sp_dist_init.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.sp_dist_init.restype = vp
+        L.sp_dist_destroy.argtypes = [vp]
+        L.sp_dist_destroy.restype = None
+        L.sp_dist_barrier.argtypes = [vp]
+        L.sp_dist_allgather.argtypes = [vp, vp, C.c_uint64, vp, C.c_int]
+        L.sp_dist_allreduce_f64.argtypes = [vp, C.POINTER(C.c_double), C.c_uint64, C.c_int]
+        L.sp_dist_bytes_moved.argtypes = [vp]
+        L.sp_dist_bytes_moved.restype = C.c_uint64
+        L.sp_dist_decompose.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.sp_ctx_allgather_candidates.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        L.sp_ctx_allgather_hits.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]
+        L._dist_bound = True
+    return L
 
-    local : uint8[n, 16] -- numpy array (host exchange) or torch tensor (on `device`: RCCL moves HBM to HBM)
-    Returns a torch uint8 tensor [world * max_n, 16] on `device`; unused rows are 0xFF (query == 0xFFFFFFFF = padding,
-    ignored by sp_ctx_merge_candidates).  Two collectives: the counts, then the padded payloads."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    dev = device if device is not None else torch.device("cpu")
-    if not torch.is_tensor(local):
-        local = torch.from_numpy(np.ascontiguousarray(local, dtype=np.uint8).reshape(-1, CAND_BYTES))
-    local = local.to(dev)
-    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
-    ns = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(ns, n, group=group)
-    max_n = max(1, max(int(x.item()) for x in ns))
-    pad = torch.full((max_n, CAND_BYTES), 0xFF, dtype=torch.uint8, device=dev)
-    if local.shape[0]:
-        pad[:local.shape[0]] = local
-    out = torch.empty((world * max_n, CAND_BYTES), dtype=torch.uint8, device=dev)
-    if hasattr(dist, "all_gather_into_tensor") and dev.type != "cpu":
-        dist.all_gather_into_tensor(out, pad, group=group)
+
+def unique_id():
+    """the 128 bytes every rank of a job passes to Comm(); made once, by anybody"""
+    buf = C.create_string_buffer(ID_BYTES)
+    _lib._check(_L().sp_dist_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """the ranks of one job (sp_comm).  Collective constructor."""
+
+    def __init__(self, uid, rank, world, transport=TRANSPORT_RCCL):
+        self.L = _L()
+        self.rank, self.world, self.transport = int(rank), int(world), int(transport)
+        self.h = self.L.sp_dist_init(C.c_char_p(bytes(uid)), self.rank, self.world, self.transport)
+        if not self.h:
+            raise _lib.SpError(self.L.sp_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.L.sp_dist_destroy(self.h)
+            self.h = None
+
+    def barrier(self):
+        _lib._check(self.L.sp_dist_barrier(self.h))
+
+    def allgather_host(self, arr):
+        """equal-size all-gather of a numpy array: returns [world, *arr.shape]"""
+        a = np.ascontiguousarray(arr)
+        out = np.empty((self.world,) + a.shape, dtype=a.dtype)
+        if a.nbytes:
+            _lib._check(self.L.sp_dist_allgather(self.h, a.ctypes.data, a.nbytes, out.ctypes.data, 0))
+        return out
+
+    def allgather_device(self, send_ptr, nbytes, recv_ptr):
+        _lib._check(self.L.sp_dist_allgather(self.h, send_ptr, nbytes, recv_ptr, 1))
+
+    def allgatherv_host(self, arr):
+        """ragged all-gather of numpy arrays that differ in their first dimension: list of world arrays (counts, then payloads padded to the longest)"""
+        a = np.ascontiguousarray(arr)
+        n = self.allgather_host(np.array([a.shape[0]], dtype=np.int64))[:, 0]
+        longest = max(1, int(n.max()))
+        pad = np.zeros((longest,) + a.shape[1:], dtype=a.dtype)
+        pad[:a.shape[0]] = a
+        allp = self.allgather_host(pad)
+        return [allp[r][:int(n[r])] for r in range(self.world)]
+
+    def allreduce(self, values, op="sum"):
+        v = (C.c_double * len(values))(*[float(x) for x in values])
+        _lib._check(self.L.sp_dist_allreduce_f64(self.h, v, len(values), {"sum": 0, "max": 1, "min": 2}[op]))
+        return [float(x) for x in v]
+
+    def bytes_moved(self):
+        return int(self.L.sp_dist_bytes_moved(self.h))
+
+    def split(self, color):
+        """a communicator of the ranks that pass the same color (collective over this one); ranks keep their order"""
+        colors = self.allgather_host(np.array([int(color)], dtype=np.int64))[:, 0]
+        members = [r for r in range(self.world) if colors[r] == color]
+        mine = np.frombuffer(unique_id() if members[0] == self.rank else bytes(ID_BYTES), dtype=np.uint8)
+        ids = self.allgather_host(mine)
+        return Comm(ids[members[0]].tobytes(), members.index(self.rank), len(members), self.transport)
+
+
+def init_from_env(transport=TRANSPORT_RCCL, rank=None, world=None):
+    """Comm of the job this process was launched into: RANK / WORLD_SIZE from the environment; the id from SP_DIST_ID (hex), else exchanged through torch.distributed
+    (an initialised process group, or one made here from MASTER_ADDR / MASTER_PORT with the gloo backend -- control plane only)."""
+    rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+    hexid = os.environ.get("SP_DIST_ID")
+    if hexid:
+        uid = binascii.unhexlify(hexid)
     else:
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad, group=group)
-        out = torch.cat(parts, dim=0)
-    return out
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        box = [unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    return Comm(uid, rank, world, transport)
 
 
-def sharded_prefilter(ctx, q_from=0, q_to=None, group=None, device=None):
-    """One target-sharded prefilter pass on this rank's context (targets staged with set_targets_shard*): candidates of
-    the own shard -> all-gather (RCCL when `device` is the GPU: the payload goes HBM -> xGMI -> HBM) -> selection on the
-    union for queries [q_from, q_to).  Afterwards ctx.hits_compact() / ctx.align_hits_raw() see the merged hits.
-    Returns {"union": rows of the gathered list, "bytes": bytes this rank received, "exchange_s": wall time of the exchange
-    step (counts + payload collectives, until the union is in place)}."""
-    import time
-    import torch
-    n = ctx.prefilter_candidates()
-    dev = device if device is not None else torch.device("cpu")
-    local = torch.empty((n, CAND_BYTES), dtype=torch.uint8, device=dev)
-    if n:
-        ctx.candidates_into(local.data_ptr())          # synchronises the context's stream
-    t0 = time.perf_counter()
-    union = allgather_candidates(local, group=group, device=dev)
-    if dev.type != "cpu":
-        torch.cuda.synchronize(dev)                     # the collective ran on torch's stream
-    dt = time.perf_counter() - t0
-    if dev.type != "cpu":
-        ctx.merge_candidates_device(union.data_ptr(), union.shape[0], q_from, q_to)
-    else:
-        ctx.merge_candidates(union.numpy(), q_from, q_to)
-    return {"union": int(union.shape[0]), "bytes": int(union.shape[0]) * CAND_BYTES, "exchange_s": dt}
+def decompose_by_residues(entry_lengths, rank, world):
+    """DBReader::decomposeDomainByAminoAcid (lib/mmseqs/src/commons/DBReader.cpp:1171-1213): contiguous slices balanced by data size.  entry_lengths are the index
+    `length` fields (sequence length + 2).  Returns (start, count)."""
+    a = np.ascontiguousarray(entry_lengths, dtype=np.uint64)
+    s, c = C.c_uint64(), C.c_uint64()
+    rc = _L().sp_dist_decompose(a.ctypes.data_as(C.POINTER(C.c_uint64)), len(a), int(rank), int(world), C.byref(s), C.byref(c))
+    if rc != 0:
+        raise ValueError(_L().sp_last_error().decode())
+    return int(s.value), int(c.value)
+
+
+def allgather_hits_host(comm, query_offset, offsets, hits):
+    """Ragged all-gather of per-rank hit lists that already lie in host memory (the steps behind the search: per-set scores, text entries, ...).
+    query_offset: index of this rank's first query in the global order; offsets uint64[nq_local + 1]; hits [n, k] of any dtype.
+    Returns (global_offsets uint64[nq_total + 1], global_hits [n_total, k]) ordered by global query index."""
+    counts = np.diff(np.asarray(offsets, dtype=np.int64))
+    hits = np.ascontiguousarray(hits)
+    metas = comm.allgather_host(np.array([int(query_offset), len(counts)], dtype=np.int64))
+    call = comm.allgatherv_host(counts.astype(np.int64))
+    hall = comm.allgatherv_host(hits)
+    order = sorted(range(comm.world), key=lambda r: (int(metas[r][0]), r))
+    gc = np.concatenate([call[r] for r in order]) if order else np.zeros(0, dtype=np.int64)
+    go = np.zeros(len(gc) + 1, dtype=np.uint64)
+    go[1:] = np.cumsum(gc).astype(np.uint64)
+    gh = np.concatenate([hall[r] for r in order], axis=0)
+    return go, gh
+
+
+def allgather_hits(ctx, comm, query_offset, nq_total, hit_cap=None, my_hits=None, my_offsets=None, my_n=None):
+    """query partition: the hit lists of all ranks' slices, in global query order, on every rank (sp_ctx_allgather_hits: device buffers, RCCL).
+    my_hits / my_offsets: addresses of a delivered step's list in host memory (with my_n hits); default: the context's last prefilter, where it lies in HBM.
+    Returns (offsets uint64[nq_total + 1], hits structured array of sp_hit_packed)."""
+    L = _L()
+    total = comm.allreduce([ctx.num_hits() if my_n is None else my_n], "sum")[0]
+    cap = int(hit_cap if hit_cap is not None else total) + 1
+    hits = np.zeros(cap, dtype=np.dtype([("seq_id", np.uint32), ("score", np.uint16), ("diagonal", np.int16)]))
+    offs = np.zeros(int(nq_total) + 1, dtype=np.uint64)
+    n = C.c_uint64()
+    _lib._check(L.sp_ctx_allgather_hits(ctx.ctx, comm.h, int(query_offset), int(nq_total), my_hits, my_offsets, hits.ctypes.data, offs.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n)))
+    return offs, hits[:int(n.value)]
+
+
+def sharded_prefilter(ctx, comm, q_from=0, q_to=None):
+    """One target-sharded prefilter pass on this rank's context (targets staged with set_targets_shard*): candidates of the own shard -> all-gather (RCCL: HBM -> xGMI ->
+    HBM) -> selection on the union for queries [q_from, q_to).  Afterwards ctx.hits_compact() / ctx.align_hits_raw() see the merged hits.
+    Returns {"union": rows of the gathered list, "bytes": bytes this rank received, "exchange_s": wall time of the exchange (counts + payload)}."""
+    ctx.prefilter_candidates()
+    rows, secs = C.c_uint64(), C.c_double()
+    before = comm.bytes_moved()
+    _lib._check(_L().sp_ctx_allgather_candidates(ctx.ctx, comm.h, int(q_from), int(q_to if q_to is not None else (1 << 62)), C.byref(rows), C.byref(secs)))
+    return {"union": int(rows.value), "bytes": comm.bytes_moved() - before, "exchange_s": float(secs.value)}

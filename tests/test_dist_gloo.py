@@ -1,5 +1,6 @@
-"""N > 1 path on CPU: two processes, gloo backend.  Checks the query partition (same arithmetic as the reference's
-DBReader::decomposeDomainByAminoAcid) and that the all-gathered hit lists equal the unsplit oracle result."""
+"""N > 1 path on CPU: two and three processes.  The ranks find each other through torch.distributed's gloo store (or SP_DIST_ID); the collectives are the library's
+own (sp_dist_*: host transport here, RCCL on GPUs).  Checks the query partition (the arithmetic of the reference's DBReader::decomposeDomainByAminoAcid) and that the
+all-gathered hit lists equal the unsplit oracle result."""
 import os
 import socket
 import sys
@@ -21,15 +22,17 @@ def _free_port():
 
 
 def _worker(rank, world, port, out):
-    import torch.distributed as dist
+    # the id travels through torch.distributed's gloo store (what torchrun gives a job); every collective after that is the library's own (sp_dist_*, host transport)
     from golden.make_golden import make_case
     from oracle_lib import Oracle
-    from spacepharer_amd.dist import allgather_hits, decompose_by_residues
+    from spacepharer_amd import dist as spd
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.pop("SP_DIST_ID", None)
+    comm = spd.init_from_env(spd.TRANSPORT_HOST, rank=rank, world=world)
+    assert (comm.rank, comm.world) == (rank, world)
     T, Q = make_case(seed=31, n_targets=400, n_queries=90, tmin=30, tmax=200, qmin=9, qmax=14)
-    start, count = decompose_by_residues([len(q) + 2 for q in Q], rank, world)
+    start, count = spd.decompose_by_residues([len(q) + 2 for q in Q], rank, world)
     # the checker stands in for the device here: this test is about the partition + exchange logic only
     o = Oracle()
     o.set_targets(T)
@@ -38,7 +41,9 @@ def _worker(rank, world, port, out):
         h = o.prefilter_list(q)
         hits += h
         offs.append(len(hits))
-    go, gh = allgather_hits(start, np.array(offs, dtype=np.uint64), np.array(hits, dtype=np.int64).reshape(-1, 3))
+    go, gh = spd.allgather_hits_host(comm, start, np.array(offs, dtype=np.uint64), np.array(hits, dtype=np.int64).reshape(-1, 3))
+    assert comm.allreduce([rank + 1.0, float(rank)], "sum") == [world * (world + 1) / 2.0, world * (world - 1) / 2.0]
+    assert comm.allreduce([float(rank)], "max") == [world - 1.0] and comm.allreduce([float(rank)], "min") == [0.0]
     if rank == 0:
         exp_off, exp = [0], []
         for q in Q:
@@ -46,7 +51,9 @@ def _worker(rank, world, port, out):
             exp_off.append(len(exp))
         ok = (go.tolist() == exp_off) and (gh.tolist() == exp)
         open(out, "w").write("ok" if ok else "mismatch")
-    dist.barrier()
+    comm.barrier()
+    comm.close()
+    import torch.distributed as dist
     dist.destroy_process_group()
 
 
@@ -79,23 +86,31 @@ def _cand_records(rank):
     return rec.view(np.uint8).reshape(n, 16)
 
 
-def _cand_worker(rank, world, port, out):
-    import torch.distributed as dist
-    from spacepharer_amd.dist import allgather_candidates
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    got = allgather_candidates(_cand_records(rank)).numpy()
-    keep = got[got.view(np.uint32).reshape(-1, 4)[:, 0] != 0xFFFFFFFF]       # what sp_ctx_merge_candidates keeps
+def _cand_worker(rank, world, uid_hex, out):
+    # here the id comes the other way: SP_DIST_ID in the environment (what the module fan-out gives its per-GPU workers)
+    os.environ["SP_DIST_ID"] = uid_hex
+    from spacepharer_amd import dist as spd
+    comm = spd.init_from_env(spd.TRANSPORT_HOST, rank=rank, world=world)
+    parts = comm.allgatherv_host(_cand_records(rank))
+    ok = all(parts[r].tolist() == _cand_records(r).tolist() for r in range(world)) and parts[0].shape == (0, 16)
+    # equal-size all-gather of a padded block, the shape the device path uses: padding rows are 0xFF and dropped by sp_ctx_merge_candidates
+    longest = 37 * (world - 1)
+    pad = np.full((longest, 16), 0xFF, dtype=np.uint8)
+    mine = _cand_records(rank)
+    pad[:len(mine)] = mine
+    got = comm.allgather_host(pad).reshape(-1, 16)
+    keep = got[got.view(np.uint32).reshape(-1, 4)[:, 0] != 0xFFFFFFFF]
     exp = np.concatenate([_cand_records(r) for r in range(world)], axis=0)
-    ok = got.shape[1] == 16 and got.shape[0] == world * 37 * (world - 1) and keep.tolist() == exp.tolist()
+    ok = ok and got.shape[0] == world * longest and keep.tolist() == exp.tolist() and comm.bytes_moved() > 0
     open("%s.%d" % (out, rank), "w").write("ok" if ok else "mismatch")
-    dist.barrier()
-    dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
 
 
 def test_candidate_allgather_gloo(tmp_path):
     """target-sharded mode: ragged candidate lists (one rank empty) -> padded all-gather, padding rows are 0xFF"""
+    import binascii
+    from spacepharer_amd import dist as spd
     out = str(tmp_path / "cand")
-    mp.spawn(_cand_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    mp.spawn(_cand_worker, args=(3, binascii.hexlify(spd.unique_id()).decode(), out), nprocs=3, join=True)
     assert [open("%s.%d" % (out, r)).read() for r in range(3)] == ["ok"] * 3
