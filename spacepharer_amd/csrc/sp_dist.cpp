@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <string>
+#include <vector>
 #include <thread>
 
 #include <hip/hip_runtime_api.h>
@@ -51,8 +53,13 @@ struct Rccl {
     const char *(*errorString)(ncclResult_t) = nullptr;
     bool load(std::string &err) {
         if (lib) return true;
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+        // the RCCL that belongs to the HIP runtime this library is linked against -- by PATH: a process may already hold another copy under the same soname (PyTorch
+        // bundles its own, bound to its own runtime: device pointers of this library's runtime mean nothing to it)
+        std::vector<std::string> names;
+        if (const char *e = getenv("SP_RCCL_LIB")) names.push_back(e);
+        if (const char *r = getenv("ROCM_PATH")) names.push_back(std::string(r) + "/lib/librccl.so.1");
+        names.push_back("/opt/rocm/lib/librccl.so.1"); names.push_back("librccl.so.1"); names.push_back("librccl.so");
+        for (const std::string &n : names) { lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL); if (lib) break; }
         if (!lib) { err = std::string("RCCL is not available: ") + dlerror(); return false; }
         getUniqueId = reinterpret_cast<decltype(getUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
         commInitRank = reinterpret_cast<decltype(commInitRank)>(dlsym(lib, "ncclCommInitRank"));

@@ -181,12 +181,16 @@ static int fanOut(const char *module, int argc, const char **argv, const std::st
     // leftovers of an earlier (crashed, or differently split) run must not be mixed with this run's parts: readers prefer an
     // unsplit <out> over <out>.0.., and parts with rank >= N would be appended to the data
     removeOutputs(out, n);
+    std::string distId;
+    {   unsigned char id[SP_DIST_ID_BYTES];
+        if (sp_dist_unique_id(id) == SP_OK) { static const char *hx = "0123456789abcdef"; for (unsigned char b : id) { distId.push_back(hx[b >> 4]); distId.push_back(hx[b & 15]); } } }
     std::vector<pid_t> kids;
     auto reap = [&](bool kill9) { bool ok = true; for (pid_t k : kids) { if (kill9) kill(k, SIGKILL); int st = 0; if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) ok = false; } kids.clear(); return ok; };
     for (int r = 0; r < n; r++) {
         std::vector<std::string> envs;
-        for (char **ev = environ; *ev; ev++) if (strncmp(*ev, "SP_PART=", 8) && strncmp(*ev, "LOCAL_RANK=", 11) && strncmp(*ev, "SP_SERVER=", 10)) envs.push_back(*ev);      // (a worker runs its part itself: no forwarding to a server)
+        for (char **ev = environ; *ev; ev++) if (strncmp(*ev, "SP_PART=", 8) && strncmp(*ev, "LOCAL_RANK=", 11) && strncmp(*ev, "SP_SERVER=", 10) && strncmp(*ev, "SP_DIST_ID=", 11)) envs.push_back(*ev);      // (a worker runs its part itself: no forwarding to a server)
         envs.push_back("SP_PART=" + std::to_string(r) + "/" + std::to_string(n));
+        if (!distId.empty()) envs.push_back("SP_DIST_ID=" + distId);      // target shards (SP_SHARD=targets): the workers exchange candidates through sp_dist
         envs.push_back("LOCAL_RANK=" + std::to_string(r));          // device = LOCAL_RANK mod visible devices (sp_init)
         std::vector<char *> envp; for (std::string &s : envs) envp.push_back(&s[0]); envp.push_back(nullptr);
         std::vector<std::string> args = {exe, module}; for (int i = 0; i < argc; i++) args.push_back(argv[i]);
@@ -617,11 +621,36 @@ int runSearchModule(int argc, const char **argv) {
     p.gap_open = (int) strtol(aaPart(f.str("--gap-open", "11")).c_str(), NULL, 10);
     p.gap_extend = (int) strtol(aaPart(f.str("--gap-extend", "1")).c_str(), NULL, 10);
     p.threads = (int) f.num("--threads", 0);
+    // SP_GPUS=N SP_SHARD=targets: the N workers each index 1/N of the TARGET set (for sets beyond one GPU's HBM), match ALL queries against their shard, all-gather the
+    // candidates (sp_ctx_allgather_candidates: RCCL over xGMI) and finish -- selection on the union, alignment, formatting -- their slice of the queries; the entries equal
+    // the unsplit run's.  Default (no SP_SHARD): the queries are partitioned and every worker holds the whole target set -- no exchange at all.
+    const Part myPart = currentPart();
+    const char *shardEnv = getenv("SP_SHARD");
+    const bool shardTargets = myPart.count > 1 && shardEnv && std::string(shardEnv) == "targets";
+    struct CommHolder { sp_comm *c = nullptr; ~CommHolder() { if (c) sp_dist_destroy(c); } } comm;
+    if (shardTargets) {
+        const char *hexId = getenv("SP_DIST_ID");
+        if (!hexId || strlen(hexId) != 2 * SP_DIST_ID_BYTES) return fail("search: SP_SHARD=targets needs the workers' SP_DIST_ID (set by the SP_GPUS fan-out)");
+        unsigned char id[SP_DIST_ID_BYTES];
+        for (int i = 0; i < SP_DIST_ID_BYTES; i++) { unsigned v = 0; sscanf(hexId + 2 * i, "%2x", &v); id[i] = (unsigned char) v; }
+        const char *tr = getenv("SP_DIST_TRANSPORT");
+        const int transport = tr ? (std::string(tr) == "host" ? SP_TRANSPORT_HOST : SP_TRANSPORT_RCCL) : (sp_device_count() >= myPart.count ? SP_TRANSPORT_RCCL : SP_TRANSPORT_HOST);
+        comm.c = sp_dist_init(id, myPart.rank, myPart.count, transport);
+        if (!comm.c) return fail(std::string("search: ") + sp_last_error());
+    }
     Ctx ctx;
-    if (!acquireCtx(p, f.positional[1], "index", ctx, err)) return fail("search: " + err);
+    if (shardTargets) { ctx.c = sp_ctx_create(&p); if (!ctx.c) return fail(std::string("search: ") + sp_last_error()); }      // (a shard is not a cacheable target set)
+    else if (!acquireCtx(p, f.positional[1], "index", ctx, err)) return fail("search: " + err);
     laps.lap("context (matrices, tables)");
     std::vector<char> tres, qres; std::vector<uint64_t> toff, qoff; std::vector<uint32_t> tkeys, qkeys;
-    if (!ctx.targetsStaged) {      // (a cached context -- the resident server -- holds the target set of this very DB: nothing to read)
+    if (shardTargets) {
+        if (!loadSeqDb(f.positional[1], tdb, err)) return fail("search: " + err);
+        flatten(tdb, tres, toff, tkeys);
+        std::vector<uint64_t> lens(tkeys.size()); for (size_t i = 0; i < lens.size(); i++) lens[i] = toff[i + 1] - toff[i] + 2;
+        uint64_t tFrom = 0, tCnt = 0;
+        if (sp_dist_decompose(lens.data(), lens.size(), myPart.rank, myPart.count, &tFrom, &tCnt) != SP_OK ||
+            sp_ctx_set_targets_shard(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size(), tFrom, tFrom + tCnt) != SP_OK) return fail(std::string("search: ") + sp_last_error());
+    } else if (!ctx.targetsStaged) {      // (a cached context -- the resident server -- holds the target set of this very DB: nothing to read)
         if (!loadSeqDb(f.positional[1], tdb, err)) { dropCtx(ctx); return fail("search: " + err); }
         flatten(tdb, tres, toff, tkeys);
         if (sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) { const std::string e = sp_last_error(); dropCtx(ctx); return fail("search: " + e); }
@@ -634,13 +663,13 @@ int runSearchModule(int argc, const char **argv) {
     DbWriter w; w.path = f.positional[2]; w.dbtype = 5;       // DBTYPE_ALIGNMENT_RES
     const size_t batch = 1u << 20;
     size_t qFrom = 0, nq = qkeys.size();
-    { std::vector<uint64_t> lens(qkeys.size()); for (size_t i = 0; i < lens.size(); i++) lens[i] = qoff[i + 1] - qoff[i] + 2; partRange(lens, w.part, qFrom, nq); }   // this GPU's queries
+    if (!shardTargets) { std::vector<uint64_t> lens(qkeys.size()); for (size_t i = 0; i < lens.size(); i++) lens[i] = qoff[i + 1] - qoff[i] + 2; partRange(lens, w.part, qFrom, nq); }   // this GPU's queries
     // result buffers in ordinary memory: page-locking tens of megabytes costs more (0.23 ms per MB) than a one-shot module run gains
     // from the faster copy
     sp_alignment *res = nullptr; char *cig = nullptr; uint64_t resCap = 0, cigCap = 0;
     auto freeBufs = [&]() { free(res); free(cig); res = nullptr; cig = nullptr; };
     // align the hits of the context's current batch, filter / sort / format them, one entry per key
-    auto alignAndFormat = [&](sp_ctx *c, const std::vector<uint32_t> &keys) -> bool {
+    auto alignAndFormat = [&](sp_ctx *c, const std::vector<uint32_t> &keys, size_t entryFrom = 0) -> bool {      // keys[k] names query entryFrom + k of the resident batch
         const uint64_t nHits = sp_ctx_num_hits(c);
         if (nHits + 16 > resCap || 24 * (nHits + 16) > cigCap) {
             freeBufs();
@@ -667,6 +696,7 @@ int runSearchModule(int argc, const char **argv) {
         for (size_t ci = 0; ci < nChunks; ci++) { bKeys[ci].clear(); bLens[ci].clear(); }
         parallelChunks(nEntries, threads, [&](size_t ci, size_t from, size_t to) {
             std::string block = std::move(blocks[ci]); std::vector<uint32_t> ck = std::move(bKeys[ci]); std::vector<uint64_t> cl = std::move(bLens[ci]);      // worker-local: no shared cache lines
+            from += entryFrom; to += entryFrom;
             block.reserve((size_t) ((to - from) * 40 + (ho[to] - ho[from]) * 64));
             ck.reserve(to - from); cl.reserve(to - from);
             std::vector<uint64_t> ok;
@@ -682,7 +712,7 @@ int runSearchModule(int argc, const char **argv) {
                 const size_t before = block.size();
                 for (uint64_t i : ok) appendAlnLine(block, res[i], cig + res[i].cigar_offset, true);
                 block.push_back('\0');
-                ck.push_back(keys[e]); cl.push_back(block.size() - before);
+                ck.push_back(keys[e - entryFrom]); cl.push_back(block.size() - before);
             }
             blocks[ci] = std::move(block); bKeys[ci] = std::move(ck); bLens[ci] = std::move(cl);
         });
@@ -696,6 +726,17 @@ int runSearchModule(int argc, const char **argv) {
         for (uint64_t &o : off) o -= qoff[b0];
         std::vector<uint32_t> keys(qkeys.begin() + b0, qkeys.begin() + b1);
         if (sp_ctx_set_queries(ctx.c, qres.data() + qoff[b0], off.data(), b1 - b0) != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+        if (shardTargets) {
+            // every worker matched the whole batch against its shard; this worker finishes slice `rank` of the batch
+            std::vector<uint64_t> lens(b1 - b0); for (size_t i = 0; i < lens.size(); i++) lens[i] = off[i + 1] - off[i] + 2;
+            uint64_t sFrom = 0, sCnt = 0, rows = 0; double secs = 0;
+            if (sp_dist_decompose(lens.data(), lens.size(), myPart.rank, myPart.count, &sFrom, &sCnt) != SP_OK || sp_ctx_prefilter_candidates(ctx.c) != SP_OK ||
+                sp_ctx_allgather_candidates(ctx.c, comm.c, sFrom, sFrom + sCnt, &rows, &secs) != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+            laps.lap("queries -> device, candidates, all-gather, selection");
+            std::vector<uint32_t> sliceKeys(qkeys.begin() + b0 + sFrom, qkeys.begin() + b0 + sFrom + sCnt);
+            if (!alignAndFormat(ctx.c, sliceKeys, (size_t) sFrom)) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+            continue;
+        }
         const int rc = sp_ctx_prefilter(ctx.c);
         std::vector<uint32_t> refused(rc == SP_ERR_OVERFLOW ? sp_ctx_overflow_queries(ctx.c, nullptr, 0) : 0);
         if (rc == SP_ERR_OVERFLOW && !refused.empty()) {      // the batch without the queries one pass cannot hold, then those against target shards (searchByShards)

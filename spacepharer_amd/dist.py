@@ -104,22 +104,43 @@ class Comm:
         return Comm(ids[members[0]].tobytes(), members.index(self.rank), len(members), self.transport)
 
 
-def init_from_env(transport=TRANSPORT_RCCL, rank=None, world=None):
-    """Comm of the job this process was launched into: RANK / WORLD_SIZE from the environment; the id from SP_DIST_ID (hex), else exchanged through torch.distributed
-    (an initialised process group, or one made here from MASTER_ADDR / MASTER_PORT with the gloo backend -- control plane only)."""
+def init_from_env(transport=TRANSPORT_RCCL, rank=None, world=None, via_torch=False):
+    """Comm of the job this process was launched into: RANK / WORLD_SIZE from the environment; the id from SP_DIST_ID (hex), else derived from the launcher's
+    MASTER_ADDR / MASTER_PORT (id_from_launcher_env), or -- via_torch -- made by rank 0 and broadcast through torch.distributed's gloo store."""
     rank = int(os.environ.get("RANK", "0")) if rank is None else rank
     world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
     hexid = os.environ.get("SP_DIST_ID")
     if hexid:
         uid = binascii.unhexlify(hexid)
-    else:
+    elif via_torch:
         import torch.distributed as dist
         if not dist.is_initialized():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         box = [unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
+    else:
+        uid = id_from_launcher_env()
     return Comm(uid, rank, world, transport)
+
+
+def id_from_launcher_env():
+    """the id every rank of a torchrun-style launch can write down by itself, without talking to anybody: rank 0 listens on MASTER_PORT + 1 (the launcher's own store sits
+    on MASTER_PORT), the token is a hash of what all ranks of the job share (MASTER_ADDR, MASTER_PORT, the run id).  No torch in the process: PyTorch brings its own HIP
+    runtime and its own RCCL, and a process that talks to the GPU through this library has no use for a second runtime."""
+    import hashlib
+    import struct
+    port = (int(os.environ.get("MASTER_PORT", "29533")) + 1 + int(os.environ.get("SP_DIST_PORT_OFFSET", "0"))) % 65536
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    try:
+        import socket
+        addr = socket.gethostbyname(addr)
+    except OSError:
+        addr = "127.0.0.1"
+    seed = "|".join([addr, os.environ.get("MASTER_PORT", ""), os.environ.get("TORCHELASTIC_RUN_ID", ""), os.environ.get("WORLD_SIZE", "")])
+    token = struct.unpack("<Q", hashlib.sha256(seed.encode()).digest()[:8])[0]
+    raw = b"SPDIST1\0" + struct.pack("<HHIQ", port, 0, 0, token) + addr.encode()[:63]
+    return raw + bytes(ID_BYTES - len(raw))
 
 
 def decompose_by_residues(entry_lengths, rank, world):

@@ -29,7 +29,7 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.pop("SP_DIST_ID", None)
-    comm = spd.init_from_env(spd.TRANSPORT_HOST, rank=rank, world=world)
+    comm = spd.init_from_env(spd.TRANSPORT_HOST, rank=rank, world=world, via_torch=True)
     assert (comm.rank, comm.world) == (rank, world)
     T, Q = make_case(seed=31, n_targets=400, n_queries=90, tmin=30, tmax=200, qmin=9, qmax=14)
     start, count = spd.decompose_by_residues([len(q) + 2 for q in Q], rank, world)

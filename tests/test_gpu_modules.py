@@ -305,6 +305,31 @@ def test_fused_search_module_writes_the_align_db(name, tmp_path):
     assert not os.path.exists(fused + "x.dbtype")
 
 
+@pytest.mark.parametrize("name,gpus", [("small", 2), ("family", 3), ("longq", 4)])
+def test_search_module_over_target_shards(name, gpus, tmp_path):
+    """SP_GPUS=N SP_SHARD=targets: the N workers of the `search` module each index 1/N of the TARGET set, match all queries against their shard, all-gather the
+    candidates through the library's communicator (sp_dist: RCCL with a GPU per worker; here the workers share the box's one GPU and the host transport carries the
+    device buffers) and finish their slice of the queries -- the merged alignment DB equals the reference's text and the unsplit run's entries"""
+    import subprocess
+    g = load_golden(name)
+    r = g["ref"]
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spacepharer_amd", "spacepharer-amd")
+    q, t, fused = (str(tmp_path / x) for x in ("qdb", "tdb", "fused"))
+    write_seq_db(q, g["queries"], key0=5)
+    write_seq_db(t, g["targets"])
+    flags = (PREF_FLAGS % r["maxSeqs"]).split() + ["-a", "1", "--alignment-mode", "2", "-e", "200", "--min-seq-id", "0", "--min-aln-len", "0", "--max-rejected", "2147483647",
+                                                   "--max-accept", "2147483647", "--gap-open", "nucl:10,aa:16", "--gap-extend", "2", "--num-iterations", "1", "--search-type", "0",
+                                                   "--start-sens", "4", "--sens-steps", "1", "--exhaustive-search", "0", "--remove-tmp-files", "0", "--rescore-mode", "0", "--strand", "1"]
+    env = dict(os.environ, SP_GPUS=str(gpus), SP_SHARD="targets")
+    p = subprocess.run([exe, "search", q, t, fused, str(tmp_path)] + flags, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got, dbtype = read_db(fused)
+    assert dbtype == 5 and sorted(got) == [5 + i for i in range(len(g["queries"]))]
+    for a in r["aln"]:
+        assert got[5 + a["id"]] == a["text"], (name, a["id"])
+    assert all(os.path.exists("%s.%d" % (fused, i)) for i in range(gpus))
+
+
 def test_module_calls_through_a_resident_server(tmp_path):
     """`spacepharer-amd serve <socket>` + clients with SP_SERVER set: the client forwards argv and working directory, the server runs
     the module with its runtime up and the target set cached in HBM, the exit status and the error text come back.  Same DB bytes as
