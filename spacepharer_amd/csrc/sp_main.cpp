@@ -23,6 +23,7 @@
 #include <fcntl.h>
 #include <malloc.h>
 #include <poll.h>
+#include <sys/file.h>
 #include <sys/socket.h>
 #include <sys/stat.h>
 #include <sys/time.h>
@@ -72,11 +73,21 @@ static int forward(int fd, int argc, const char **argv) {
 }
 
 // default socket of the per-user resident server (SP_SERVER=auto)
+// ($XDG_RUNTIME_DIR is the user's own; without one the socket lives in a directory this user owns, mode 0700, checked: anybody may create
+// /tmp/spacepharer-amd-<uid> first, and a socket in somebody else's directory would hand that somebody the client's argv and the say over its exit status)
 static std::string defaultSocket() {
     const char *dir = getenv("XDG_RUNTIME_DIR");
     struct stat st;
-    if (dir && *dir && stat(dir, &st) == 0 && S_ISDIR(st.st_mode)) return std::string(dir) + "/spacepharer-amd.sock";
-    return "/tmp/spacepharer-amd-" + std::to_string((long) getuid()) + ".sock";
+    if (dir && *dir && stat(dir, &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == getuid()) return std::string(dir) + "/spacepharer-amd.sock";
+    const std::string own = "/tmp/spacepharer-amd-" + std::to_string((long) getuid());
+    (void) mkdir(own.c_str(), 0700);
+    if (lstat(own.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 077) != 0) return std::string();      // not ours: no default server
+    return own + "/server.sock";
+}
+// the peer of a connected socket is this user (SO_PEERCRED): a client never talks to somebody else's server
+static bool peerIsMe(int fd) {
+    ucred cr; socklen_t len = sizeof(cr);
+    return getsockopt(fd, SOL_SOCKET, SO_PEERCRED, &cr, &len) == 0 && cr.uid == getuid();
 }
 
 // idleSeconds > 0: leave when no client has called for that long (the auto-started server)
@@ -185,7 +196,15 @@ int main(int argc, const char **argv) {
         if (known && !strncmp(srv, "auto", 4) && (srv[4] == 0 || srv[4] == ':')) {
             const std::string path = defaultSocket();
             const Module *m = findModule(argv[1]);
-            const int fd = (m && m->device) ? connectOrStart(path, argv[0], srv[4] == ':' ? std::max(1, atoi(srv + 5)) : 120) : connectTo(path.c_str());      // host-only steps and `shutdown` never start one
+            int fd = -1;
+            if (!path.empty()) {
+                // two clients starting at once must not each unlink the other's freshly bound socket: the start is serialised by a lock file next to it
+                const int lock = open((path + ".lock").c_str(), O_CREAT | O_RDWR, 0600);
+                if (lock >= 0) (void) flock(lock, LOCK_EX);
+                fd = (m && m->device) ? connectOrStart(path, argv[0], srv[4] == ':' ? std::max(1, atoi(srv + 5)) : 120) : connectTo(path.c_str());      // host-only steps and `shutdown` never start one
+                if (lock >= 0) { (void) flock(lock, LOCK_UN); close(lock); }
+                if (fd >= 0 && !peerIsMe(fd)) { close(fd); fd = -1; }      // (somebody else's process answers there: run the module in this process instead)
+            }
             if (fd >= 0) return forward(fd, argc - 1, argv + 1);
         } else if (known) { const int fd = connectTo(srv); if (fd >= 0) return forward(fd, argc - 1, argv + 1); }
         if (!strcmp(argv[1], "shutdown")) return 0;

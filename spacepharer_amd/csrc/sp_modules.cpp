@@ -70,10 +70,18 @@ static std::string fileIdentity(const std::string &path) {
 // blastp.sh:33,41 issues back to back) the hits are aligned where they are: no DB is read or parsed again, nothing is uploaded.  Any other use of the
 // context forgets the memo.
 struct PrefilterMemo { sp_ctx *c = nullptr; std::string query, target, result; std::vector<uint32_t> qkeys, tkeys; };
+// (size and mtime miss a same-size rewrite within the clock's granularity: the result DB's identity also carries a digest of its index file)
+static std::string resultIdentity(const std::string &path) {
+    std::string id = fileIdentity(path);
+    std::ifstream in(path + ".index", std::ios::binary);
+    uint64_t h = 1469598103934665603ull; char buf[65536];
+    while (in.good()) { in.read(buf, sizeof(buf)); for (std::streamsize i = 0; i < in.gcount(); i++) { h ^= (unsigned char) buf[i]; h *= 1099511628211ull; } }
+    return id + "#" + std::to_string((unsigned long long) h);
+}
 static PrefilterMemo g_memo;
 static void forgetPrefilter(const sp_ctx *c) { if (!c || g_memo.c == c) g_memo = PrefilterMemo(); }
 static void rememberPrefilter(sp_ctx *c, const std::string &q, const std::string &t, const std::string &r, const std::vector<uint32_t> &qkeys, const std::vector<uint32_t> &tkeys) {
-    g_memo.c = c; g_memo.query = fileIdentity(q); g_memo.target = fileIdentity(t); g_memo.result = fileIdentity(r); g_memo.qkeys = qkeys; g_memo.tkeys = tkeys;
+    g_memo.c = c; g_memo.query = fileIdentity(q); g_memo.target = fileIdentity(t); g_memo.result = resultIdentity(r); g_memo.qkeys = qkeys; g_memo.tkeys = tkeys;
 }
 
 // a context for (params, target DB): from the cache when serving, else a fresh one.  what = "index" (searchable) or "residues"
@@ -506,7 +514,7 @@ int runAlignModule(int argc, const char **argv) {
     const long maxAccept = f.num("--max-accept", INT_MAX), maxRejected = f.num("--max-rejected", INT_MAX);
     // serving, and this is the result DB the last `prefilter` call wrote from a context that still holds the batch: align its hits where they are
     bool resident = false;
-    if (g_memo.c && currentPart().count <= 1 && g_memo.result == fileIdentity(f.positional[2]) && g_memo.query == fileIdentity(f.positional[0]) && g_memo.target == fileIdentity(f.positional[1])) {
+    if (g_memo.c && currentPart().count <= 1 && g_memo.result == resultIdentity(f.positional[2]) && g_memo.query == fileIdentity(f.positional[0]) && g_memo.target == fileIdentity(f.positional[1])) {
         const AlignParams ap = alignParamsOf(g_memo.c);
         resident = ap.subMat == aaPart(f.str("--sub-mat", "VTML40.out")) && ap.gapOpen == (int) strtol(aaPart(f.str("--gap-open", "11")).c_str(), NULL, 10) &&
                    ap.gapExtend == (int) strtol(aaPart(f.str("--gap-extend", "1")).c_str(), NULL, 10) && ap.evalue == f.real("-e", 0.001);

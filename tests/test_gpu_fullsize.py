@@ -177,12 +177,12 @@ def _deliver(ctx, slot):
     return (C.string_at(slot.off, 4 * (slot.nq + 1)), C.string_at(slot.hits, 8 * n), bench_mod().record_fields(slot.rec, n), C.string_at(slot.cig, int(slot.used.value)))
 
 
-def test_two_contexts_in_flight_deliver_the_single_context_bytes():
-    """the configuration bench.py times: two search contexts on one GPU, each on its own host thread and HIP streams with its own query batch,
-    the bench's match_blocks_per_cu, every step queued device-driven (sp_ctx_search_begin / _end) with TWO steps in flight per context, into its
-    own page-locked buffers.  Every step of both contexts must deliver exactly the bytes (hit list, offsets, sp_alignment records, backtrace
-    pool) the same batch gives through the synchronous path when its context has the GPU to itself with default tuning.  Then the same with the
-    host-driven step (bench.py --host-driven)."""
+def test_contexts_in_flight_deliver_the_single_context_bytes():
+    """the configurations bench.py times (`step_modes`): search contexts on one GPU, each on its own host thread and HIP streams with its own query batch, ONE staged
+    target set shared by all of them (sp_ctx_share_targets), the bench's match_blocks_per_cu -- FOUR contexts with the host-driven step (what `value` comes from:
+    step_modes.value_from) and TWO with every step queued device-driven (sp_ctx_search_begin / _end, two steps in flight per context), into their own page-locked
+    buffers.  Every step of every context must deliver exactly the bytes (hit list, offsets, sp_alignment records, backtrace pool) the same batch gives through the
+    synchronous path when its context has the GPU to itself with default tuning."""
     import argparse
     import threading
     import bench
@@ -191,18 +191,23 @@ def test_two_contexts_in_flight_deliver_the_single_context_bytes():
     match_blocks = 3      # bench.py --match-blocks default
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'ap.add_argument("--match-blocks", type=int, default=%d' % match_blocks in src
-    batches = [bench.make_workload(10000, 50000, 200, 12345, qs) for qs in (None, 12345 + 104729)]
+    src_modes = src[src.index("dual = world == 1"):]
+    assert "pipeline=4, host_driven=True" in src_modes      # (the host-driven configuration of the default run: four contexts)
+    batches = [bench.make_workload(10000, 50000, 200, 12345, qs) for qs in [None] + [12345 + 104729 * b for b in range(1, 4)]]      # bench.py: batch b of context b
     ctxs, slots, ref = [], [], []
     rounds = 12
     for tres, toff, qres, qoff in batches:
         c = sa.SearchContext()
-        c.set_targets_raw(tres.tobytes(), bench.u64p(toff), len(toff) - 1)
+        if ctxs:
+            c.share_targets(ctxs[0])
+        else:
+            c.set_targets_raw(tres.tobytes(), bench.u64p(toff), len(toff) - 1)
         c.set_queries_raw(qres.tobytes(), bench.u64p(qoff), len(qoff) - 1)
         c.prefilter()
         ss = [bench.Slot(L, len(qoff) - 1, int(c.num_hits() * 1.05) + 1024, True) for _ in range(3)]
         ref.append(_deliver(c, ss[0]))                # alone on the GPU, synchronous path
         ctxs.append(c); slots.append(ss)
-    assert ref[0] != ref[1] and len(ref[0][1]) > 8 * 60000 and len(ref[1][2]) > 60 * 60000
+    assert len({r[1] for r in ref}) == 4 and len(ref[0][1]) > 8 * 60000 and len(ref[1][2]) > 60 * 60000
     for c in ctxs:
         c.set_tuning("match_blocks_per_cu", match_blocks)
 
@@ -211,7 +216,8 @@ def test_two_contexts_in_flight_deliver_the_single_context_bytes():
 
     for device_driven in (True, False):
         bad, errors = [], []
-        gate = threading.Barrier(2)
+        n_ctx = 2 if device_driven else 4
+        gate = threading.Barrier(n_ctx)
 
         def run(i):
             try:
@@ -237,7 +243,7 @@ def test_two_contexts_in_flight_deliver_the_single_context_bytes():
             except Exception as e:      # noqa: BLE001
                 errors.append(repr(e))
 
-        th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        th = [threading.Thread(target=run, args=(i,)) for i in range(n_ctx)]
         for t in th:
             t.start()
         for t in th:

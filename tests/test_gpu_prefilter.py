@@ -160,6 +160,7 @@ def test_the_order_the_queries_are_matched_in_never_changes_a_result():
     assert len(set(crcs.values())) == 1, crcs
 
 
+@pytest.mark.perf
 def test_the_matching_kernel_times_itself():
     """sp_ctx_stat("ms_match_active"): k_match from its first wave's start to its last wave's end by the device wall clock -- inside the HIP-event time of the
     same launch (the events also hold launch latency), and not much shorter when the context has the GPU to itself"""

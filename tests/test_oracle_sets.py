@@ -12,10 +12,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import sp_sets_oracle as so      # noqa: E402
 
 
-# host-only checks of the oracle itself; collected for the CPU suite and, with the `gpu` marker, for the driver's -m gpu run on the box
-@pytest.fixture(autouse=True, params=[pytest.param("cpu-suite"), pytest.param("gpu-suite", marks=pytest.mark.gpu)])
-def suite(request):
-    return request.param
+# (host-only checks of the checker itself: CPU suite only -- the -m gpu run counts tests that touch the product)
 
 
 @pytest.fixture(scope="module")
