@@ -268,7 +268,7 @@ def launch_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=100, help="steps per timed region (default 100: a region of the default workload lasts ~50 ms)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--regions", type=int, default=5, help="the K-step timed region is repeated this many times; value = median region")
     ap.add_argument("--spacers", type=int, default=None, help="default: 10 000 (N = 1, replica mode), 100 000 (target shards at N > 1)")
@@ -288,6 +288,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2], help="device-driven steps queued per context before the oldest is collected")
     ap.add_argument("--host-driven", action="store_true", help="the round-2 step: the host learns the hit count between prefilter and align and the record count after align "
                     "(sp_ctx_prefilter + sp_ctx_align_hits_begin / _end) instead of one device-driven step (sp_ctx_search_begin / _end)")
+    ap.add_argument("--no-dense", action="store_true", help="N = 1, default workload: skip the additional line on the dense index (10 000 spacers vs 2e8 residues, the density of GenBank_phage_2018_09)")
     ap.add_argument("--unshared", action="store_true", help="every search context of a GPU stages its own copy of the target set and tables (the round-3 configuration; default: one staged set, shared)")
     ap.add_argument("--no-module-e2e", action="store_true", help="N = 1: skip the files-to-files timing of the module drop-ins (tools/module_e2e.py)")
     ap.add_argument("--shards", type=int, default=0, help="N > 1, target-sharded: S target shards x N / S query groups (all-gather within a group); 0 = N shards, every rank matches all queries (BASELINE configs[3])")
@@ -331,7 +332,7 @@ def main():
     def all_sum(x):
         return x if comm is None or world == 1 else comm.allreduce([x], "sum")[0]
 
-    def measure(shard_targets, spacers, steps, regions, warmup, want_breakdown, shards=0, partition=False, pipeline=None, host_driven=None):
+    def measure(shard_targets, spacers, steps, regions, warmup, want_breakdown, shards=0, partition=False, pipeline=None, host_driven=None, targets=None):
         """one decomposition on this rank: set-up, reference digests, `regions` timed K-step regions with digest checks.
         shards (target-sharded mode): S target shards x world / S query groups -- group g = rank // S searches query slice g against the
         S shards and all-gathers within the group; 0 / world = every rank is a shard and matches all queries (BASELINE configs[3])."""
@@ -356,7 +357,7 @@ def main():
                 qs = None if b == 0 else 12345 + 104729 * b       # the same batches on every rank, each rank keeps its slice
             else:
                 qs = None if (rank == 0 and b == 0) else 12345 + 7919 * rank + 104729 * b
-            batches.append(make_workload(spacers, args.targets, args.target_len, 12345, qs))
+            batches.append(make_workload(spacers, targets or args.targets, args.target_len, 12345, qs))
         tres, toff = batches[0][0], batches[0][1]
         part_from, part_total = 0, 0
         if partition and world > 1:
@@ -620,6 +621,11 @@ def main():
     if world >= 4 and world % 2 == 0 and sharded and not args.shards and not args.no_hybrid:
         # the same job with TWO target shards x world / 2 query groups: the enumeration of the similar k-mers is replicated twice, not world times
         hyb = measure(True, n_spacers, max(4, args.steps // 2), max(1, min(3, args.regions)), args.warmup, False, shards=2)
+    dense = None
+    if dual and not args.no_dense and (n_spacers, args.targets, args.target_len) == (10000, 50000, 200):
+        # the density north_star's target DB has: the same 10 000 spacers against 10^6 x 200 residues (95 % of the k-mer slots occupied, 2 200 index hits per query):
+        # device-driven steps in two contexts (four lose there), fewer steps -- a step is ten times longer
+        dense = measure(False, 10000, max(4, args.steps // 10), max(1, min(3, args.regions)), 2, True, pipeline=2, host_driven=False, targets=1000000)
     pairs_total = all_sum(float(m["pairs"][0]))      # batch 0 of every rank (sharded: the ranks' query slices add up to the batch)
     if comm is not None:
         comm.barrier()
@@ -692,7 +698,21 @@ def main():
                      "over_wall_time": {"achieved": algo_bytes * args.steps / dt / 1e9, "frac": algo_bytes * args.steps / dt / 1e9 / 8000.0}},
         "host": host_info(),
     }
+    if dense is not None:
+        dsteps = max(4, args.steps // 10)
+        ddt, dregions = region_summary(dense, 10000 * dsteps)
+        dK, dM, dD = (dense["counters"][k] for k in ("kmers", "db_matches", "diagonals"))
+        dalgo = 22.0 * dK + 6.0 * dM + 7.0 * dD
+        dexcl = dense["stats"]["ms_match"]
+        out["dense"] = {"workload": "10000 synthetic 30-nt spacers vs 1000000 synthetic phage ORFs x 200 aa (2.0e+08 residues: the survey's estimate of GenBank_phage_2018_09), 1xMI355X, prefilter + align",
+                        "value": 10000 * dsteps / ddt, "unit": "spacer-queries/s", "ms_per_step": ddt / dsteps * 1e3, "steps": dsteps, "regions": dregions, "results_checked": dense["checked"],
+                        "pairs_aligned_per_step": dense["pairs"][0], "index_build_s": round(dense["t_index"], 3), "step": "device-driven, two contexts",
+                        "kernels_ms_per_step": {k[3:]: round(v, 4) for k, v in dense["stats"].items()},
+                        "counters_per_step": {"similar_kmers": dK, "index_entries_fetched": dM, "diagonals_scored": dD},
+                        "roofline": {"kernel": "k_match<512,false,false> (large footprint, direct bucket table)", "algorithmic_bytes_per_launch": dalgo,
+                                     "exclusive_ms_per_launch": round(dexcl, 4), "exclusive_frac": dalgo / (dexcl * 1e-3) / 1e9 / 8000.0 if dexcl > 0 else None}}
     if step_modes is not None:
+        out["config"]["step"] += " -- the better of the two step modes measured in this run (step_modes: both rates, value_from)"
         for k in ("device-driven x2", "host-driven x4"):      # the roofline fraction of a k_match launch in either mode (more passes in flight: longer launches, more work done)
             step_modes[k]["roofline_frac_per_launch"] = round(algo_bytes / (step_modes[k]["k_match_ms_per_launch"] * 1e-3) / 1e9 / 8000.0, 4) if step_modes[k]["k_match_ms_per_launch"] > 0 else None
         out["step_modes"] = step_modes
@@ -766,6 +786,15 @@ def main():
         out["cpu_baseline"]["nproc"] = hi["nproc"]
         out["cpu_baseline"]["cpu_quota_cores"] = hi["cpu_quota_cores"]
         out["cpu_baseline"]["cpu_model"] = hi["cpu_model"]
+    if dense is not None and args.cpu_sample > 0 and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_harness")):
+        try:      # the reference on the same dense workload: a bounded sample of the peptides (its index build alone takes seconds there)
+            tres_d, toff_d, qres_d, qoff_d = dense["batches"][0]
+            cb = cpu_baseline_reference(tres_d, toff_d, qres_d, qoff_d, min(len(qoff_d) - 1, 200 * cores), cores, target_s=3.0)
+            cb.pop("pairs", None)
+            out["dense"]["cpu_baseline"] = cb
+            out["dense"]["x_reference_search_loops"] = out["dense"]["value"] / cb["value"]
+        except Exception as e:      # noqa: BLE001
+            out["dense"]["cpu_baseline"] = {"error": repr(e)[:300]}
     if world == 1 and not args.no_module_e2e and not sharded and (n_spacers, args.targets, args.target_len) == (10000, 50000, 200):
         # the boundary the workflow scripts use: module calls on DB triples, "DBs on disk" -> "result DB written", as fresh processes
         # of the front-end binary and warm inside one process; two modules (prefilter, align) and the fused search
@@ -789,6 +818,17 @@ def main():
                     run["reference_module_wall_s_estimate"] = ref_s
                     run["x_reference"] = {"process": ref_s / min(run["process_s"]), "auto_server_first": ref_s / run["auto_server_s"][0], "auto_server_next": ref_s / min(run["auto_server_s"][1:]),
                                           "served": ref_s / min(run["served_s"][1:])}
+            # SURVEY section 8d's own boundary -- "DBs resident -> result DBs written" -- as named values: 100 000 spacers, module calls on DB triples
+            f2f = {"what": "files to files at 100 000 spacers (query / target DBs on disk -> alignment DB on disk; module argv as the workflow scripts pass it); the bench's `value` is the "
+                           "search step with inputs resident in HBM and results delivered into page-locked host memory", "spacers": 100000}
+            for run in out["module_e2e"]["runs"]:
+                if run["spacers"] != 100000:
+                    continue
+                tag = "fused_search" if "search" in run["mode"] or "fused" in run["mode"] else "prefilter_then_align"
+                f2f[tag] = {"fresh_processes_spacer_queries_per_s": run["process_spacer_queries_per_s"], "served_spacer_queries_per_s": run["served_spacer_queries_per_s"],
+                            "auto_server_next_spacer_queries_per_s": run["auto_server_next_spacer_queries_per_s"], "x_reference": run.get("x_reference"),
+                            "reference_module_wall_s_estimate": run.get("reference_module_wall_s_estimate")}
+            out["files_to_files"] = f2f
         except Exception as e:      # noqa: BLE001
             out["module_e2e"] = {"error": repr(e)[:300]}
     C.CDLL(None).fflush(None)      # library chatter buffered in C stdio (RCCL prints its path) goes out BEFORE the result line
