@@ -607,6 +607,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
         for (uint32_t t = dChunkUsed + lane; t < dChunkCap; t += 64) if ((uint64_t) dChunkBase + t < a.diagCap) a.diagQuery[dChunkBase + t] = 0xFFFFFFFFu;
     };
     SP_T_DECL
+    const unsigned long long tWaveStart = wall_clock64();
     if (threadIdx.x == 0) atomicMax(&a.counters[6], ~(unsigned long long) wall_clock64());      // (max of the complement = the earliest start; counters are zeroed per pass)
 
     // one atomic pops kQueryChunk queries: a single counter word serialises at ~12 ns per atomic (60 000 pops = 0.7 ms)
@@ -1265,7 +1266,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
     SP_T_FLUSH(a.counters);
     if (lane == 0) atomicMax(&a.counters[7], (unsigned long long) wall_clock64());
     markUnused();
-    if (lane == 0) { unsigned long long *wp = a.wavePartial + (size_t) waveGlobal * 4; wp[0] = kmersTotal; wp[1] = matchesTotal; wp[2] = diagTotal; }
+    if (lane == 0) { unsigned long long *wp = a.wavePartial + (size_t) waveGlobal * 4; wp[0] = kmersTotal; wp[1] = matchesTotal; wp[2] = diagTotal; wp[3] = wall_clock64() - tWaveStart; }
 }
 
 #include "sp_gpu_match_grp.inc"
@@ -2393,6 +2394,22 @@ bool Gpu::finishPrefilter(bool matched, std::string &err) {
     counters_.overflowQueries = c[2]; counters_.hits = totalHits;
     d.hitsInFlight = false;
     d.nCand = qv[4];
+    if (matched && d.knob.debug && d.matchBlocks) {      // how evenly the matching kernel's waves were busy
+        std::vector<unsigned long long> wp((size_t) d.matchBlocks * kWavesPerBlock * 4);
+        if (hipMemcpy(wp.data(), d.wavePartial.p, wp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            double sum = 0, mx = 0; std::vector<double> v;
+            for (size_t w = 0; w < wp.size() / 4; w++) { const double t = (double) wp[w * 4 + 3] / (double) d.wallKHz * 1e3; sum += t; mx = std::max(mx, t); v.push_back(t); }
+            std::sort(v.begin(), v.end());
+            fprintf(stderr, "[sp] k_match waves %zu: busy mean %.1f us, median %.1f, p90 %.1f, p99 %.1f, max %.1f us; kernel span %.1f us\n", v.size(), sum / (double) v.size(), v[v.size() / 2],
+                    v[v.size() * 9 / 10], v[v.size() * 99 / 100], mx, (double) (c[7] - ~c[6]) / (double) d.wallKHz * 1e3);
+            std::vector<size_t> idx(wp.size() / 4); for (size_t w = 0; w < idx.size(); w++) idx[w] = w;
+            std::sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return wp[x * 4 + 3] > wp[y * 4 + 3]; });
+            double km = 0; for (size_t w = 0; w < idx.size(); w++) km += (double) wp[w * 4];
+            fprintf(stderr, "[sp]   busiest waves (us, similar k-mers, index hits; the mean wave has %.0f k-mers):", km / (double) idx.size());
+            for (size_t k = 0; k < 6 && k < idx.size(); k++) fprintf(stderr, "  %.0f us %llu k %llu h", (double) wp[idx[k] * 4 + 3] / (double) d.wallKHz * 1e3, wp[idx[k] * 4], wp[idx[k] * 4 + 1]);
+            fprintf(stderr, "\n");
+        }
+    }
 #ifdef SP_GRP_STATS
     if (matched) fprintf(stderr, "[sp] grp stats: groups %llu hits %llu rounds %llu survivors %llu passes %llu passHits %llu | waves %llu mean busy %.1f us of span %.1f us\n", c[8], c[9], c[10], c[11], c[12], c[13], c[15],
                          c[15] ? (double) c[14] / (double) c[15] / (double) d.wallKHz * 1e3 : 0.0, (double) (c[7] - ~c[6]) / (double) d.wallKHz * 1e3);
