@@ -679,7 +679,7 @@ def main():
         "kernels_ms_source": "HIP events around every stage in 3 extra steps of ONE context AFTER the timed regions (the timed steps bracket k_match only: "
                              "%.4f ms per launch with %d passes in flight)" % (ms_match, n_pipe),
         "counters_per_step": {"similar_kmers": K, "index_entries_fetched": M, "diagonals_scored": D, "diag_residues": R, "hits": H},
-        "roofline": {"bound": "hbm", "kernel": "k_match", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "k_match_grp (the matching kernel for short queries on a sparse index; k_match otherwise)" if (args.target_len * args.targets <= 50000000 and not sharded) else "k_match", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": traffic,
                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
                      "measured_streaming_read_GBps": pmc_traffic.measured_stream,

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 for m in "device_driven_x2:--pipeline 2" "host_driven_x4:--pipeline 4 --host-driven"; do
   name=${m%%:*}; flags=${m#*:}
   rm -rf /tmp/st_$name
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$name -o s -- python3 $R/bench.py --steps 100 --warmup 3 --regions 2 --cpu-sample 0 --no-module-e2e $flags 2>/dev/null | grep "^{" | tail -1 > $R/gpurun_out/stats_$name.json
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$name -o s -- python3 $R/bench.py --steps 100 --warmup 3 --regions 2 --cpu-sample 0 --no-module-e2e --no-dense $flags 2>/dev/null | grep "^{" | tail -1 > $R/gpurun_out/stats_$name.json
   cp /tmp/st_$name/s_kernel_stats.csv $R/gpurun_out/stats_$name.csv
   python3 - $R/gpurun_out/stats_$name.json $R/gpurun_out/stats_$name.csv $name <<'PY'
 import sys, json, csv

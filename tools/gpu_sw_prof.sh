@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_sw $R/gpurun_out/pmc_sw1 $R/gpurun_out/pmc_sw2
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_sw -o sw -- python3 $R/bench.py --steps 60 --warmup 3 --regions 2 --cpu-sample 0 --no-module-e2e > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_sw -o sw -- python3 $R/bench.py --steps 60 --warmup 3 --regions 2 --cpu-sample 0 --no-module-e2e --no-dense > /dev/null 2>&1
 cut -c1-160 $R/gpurun_out/prof_sw/sw_kernel_stats.csv | head -14
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/pmc_sw1 -o p -- python3 $R/tools/pmc_workload.py full > /dev/null 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU --output-format csv -d $R/gpurun_out/pmc_sw2 -o p -- python3 $R/tools/pmc_workload.py full > /dev/null 2>&1

@@ -116,6 +116,64 @@ def search_and_score(ctx, dbs, tname, times, keep=False):
     return score, n
 
 
+def reference_timing(d, dbs, threads=16, sample=24000):
+    """The reference on the same inputs, on this box's host cores (oracle/_ref: the reference's own translation units compiled by oracle/Makefile): its six target- /
+    query-side modules on the same DB triples (ref_sets), and its search loops (ref_harness --bench: Prefiltering::runSplit + Alignment::run as the reference's classes
+    run them, index build and k-mer tables reported separately) on a bounded SAMPLE of the query peptides against the whole target set -- scaled to all peptides and
+    doubled for the control search, whose set is as large.  The set-level chain behind the searches is not timed for the reference (it needs the alignment DBs as files)."""
+    import subprocess
+    sets_bin, harness = os.path.join(ROOT, "oracle", "_ref", "ref_sets"), os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if not (os.path.exists(sets_bin) and os.path.exists(harness)):
+        return {"error": "oracle/_ref is not built"}
+    P = lambda x: os.path.join(d, x)      # noqa: E731
+    out = {"threads": threads, "modules_s": {}}
+    th = ["--threads", str(threads)]
+    for name in ("q_nucl", "t_nucl"):      # the reference's extractorfs reads the header DB beside the sequence DB (createdb writes both)
+        if not os.path.exists(P(name + "_h")):
+            keys = read_table(P(name + ".index"), [0])[0]
+            pm.write_db(P(name + "_h"), [(int(k), "c%d\n" % int(k)) for k in keys], 12)
+    for name, args in (("extractorfs q", ["extractorfs", P("q_nucl"), P("ref_q_orf"), "--min-length", "9", "--orf-start-mode", "1", "--create-lookup", "1"]),
+                       ("translatenucs q", ["translatenucs", P("ref_q_orf"), P("ref_q")]),
+                       ("extractorfs t", ["extractorfs", P("t_nucl"), P("ref_t_orf"), "--min-length", "30", "--orf-start-mode", "0", "--create-lookup", "1"]),
+                       ("translatenucs t", ["translatenucs", P("ref_t_orf"), P("ref_t")]),
+                       ("reverseseqbycodon", ["reverseseqbycodon", P("ref_t_orf"), P("ref_c_orf")]),
+                       ("translatenucs c", ["translatenucs", P("ref_c_orf"), P("ref_c")])):
+        t0 = time.perf_counter()
+        r = subprocess.run([sets_bin] + args + th, capture_output=True, text=True)
+        out["modules_s"][name] = round(time.perf_counter() - t0, 4)
+        if r.returncode != 0:
+            out["modules_s"][name] = "failed: " + (r.stderr or r.stdout)[-200:]
+    out["six_modules_s"] = round(sum(v for v in out["modules_s"].values() if isinstance(v, float)), 4)
+    # the search loops on a sample of the peptides
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import matrix_text
+    q, t = dbs["q"]["aa"], dbs["t"]["aa"]
+    n_s = min(sample, q.n)
+    pick = np.linspace(0, q.n - 1, n_s).astype(np.int64)
+    tf, qf, of = P("ref_t.txt"), P("ref_q.txt"), P("ref_o.json")
+    open(P("VTML80.out"), "w").write(matrix_text("VTML80")); open(P("VTML40.out"), "w").write(matrix_text("VTML40"))
+    with open(tf, "wb") as f:
+        res = t.res.tobytes()
+        f.write(b"\n".join(res[int(t.off[i]):int(t.off[i + 1])] for i in range(t.n)) + b"\n")
+    with open(qf, "wb") as f:
+        res = q.res.tobytes()
+        f.write(b"\n".join(res[int(q.off[i]):int(q.off[i + 1])] for i in pick) + b"\n")
+    t0 = time.perf_counter()
+    r = subprocess.run([harness, P("VTML80.out"), P("VTML40.out"), tf, qf, of, "--bench-reps", "1", "--bench-threads", str(threads)], capture_output=True, text=True)
+    out["harness_wall_s"] = round(time.perf_counter() - t0, 3)
+    if r.returncode != 0:
+        out["search"] = {"error": (r.stderr or r.stdout)[-300:]}
+        return out
+    b = json.load(open(of))["bench"]
+    scale = q.n / float(n_s)
+    out["search"] = {"sample_peptides": n_s, "of": q.n, "index_build_s": b["index_build_s"], "kmer_tables_s": b["table_s"], "prefilter_s_sample": b["prefilter_s"], "align_s_sample": b["align_s"],
+                     "pairs_sample": b["pairs"], "search_loops_s_all_peptides_one_set": round((b["prefilter_s"] + b["align_s"]) * scale, 3),
+                     "one_search_module_pair_s_estimate": round(b["index_build_s"] + b["table_s"] + (b["prefilter_s"] + b["align_s"]) * scale, 3)}
+    out["two_searches_s_estimate"] = round(2 * out["search"]["one_search_module_pair_s_estimate"], 3)
+    out["prep_plus_two_searches_s_estimate"] = round(out["six_modules_s"] + out["two_searches_s_estimate"], 3)
+    return out
+
+
 def run(unique_genomes=900, genome_nt=20000, replicas=10, n_arrays=5000, per_array=20, threads=16, keep_dir=None, seed=2024):
     import spacepharer_amd as sa
     t_all = time.perf_counter()
@@ -163,7 +221,14 @@ def run(unique_genomes=900, genome_nt=20000, replicas=10, n_arrays=5000, per_arr
 
 
 if __name__ == "__main__":
-    a = [int(x) for x in sys.argv[1:]]
+    want_ref = "--reference" in sys.argv
+    a = [int(x) for x in sys.argv[1:] if x != "--reference"]
     info, st = run(*a)
     st["ctx"].close()
+    if want_ref:
+        info["reference_on_this_box"] = reference_timing(st["dir"], st["dbs"])
+        ref = info["reference_on_this_box"]
+        if "prep_plus_two_searches_s_estimate" in ref:
+            mine = info["seconds"]["six_host_modules_s"] + sum(info["seconds"][x][k] for x in ("t", "c") for k in ("stage_targets_s", "prefilter_s", "align_s"))
+            info["x_reference_prep_plus_two_searches"] = round(ref["prep_plus_two_searches_s_estimate"] / mine, 1)
     print(json.dumps(info))

@@ -92,6 +92,7 @@ def main():
     mine = {"aa": FlatSlice(q["aa"], i0, i1), "nucl": FlatSlice(q["nucl"], i0, i1), "set": np.ascontiguousarray(q["set"][i0:i1])}
     local_dbs = {"q": mine, "t": dbs["t"], "c": dbs["c"]}
     ctx = sa.SearchContext()
+    if comm: comm.barrier()      # (every rank has its DBs in memory: the clock starts together)
     t0 = time.perf_counter()
     score, n_t = pf.search_and_score(ctx, local_dbs, "t", times)
     score_rev, n_c = pf.search_and_score(ctx, local_dbs, "c", times)
