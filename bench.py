@@ -277,7 +277,7 @@ def main():
     ap.add_argument("--stage", default="full", choices=["full", "prefilter"])
     ap.add_argument("--cpu-sample", type=int, default=3000, help="0 = skip the CPU baseline; < 3000: that many peptides per core instead of the whole workload")
     ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the reference CPU baseline (one process each); 0 = all usable cores")
-    ap.add_argument("--match-blocks", type=int, default=3, help="k_match blocks per CU while several search contexts share the GPU (0 = all that fit); "
+    ap.add_argument("--match-blocks", type=int, default=0, help="matching-kernel blocks per CU while several search contexts share the GPU (0 = the library's own choice: two for the grouped kernel; -1 = all that fit); "
                     "the small footprint fits four, three leave room for the other context's aligner")
     ap.add_argument("--tune", action="append", default=[], metavar="NAME=VALUE", help="sp_ctx_set_tuning(name, value) on every search context of the timed region (experiments)")
     ap.add_argument("--pipeline", type=int, default=None,
@@ -557,7 +557,7 @@ def main():
         if want_breakdown:      # per-stage breakdown: one context alone, HIP events around every stage, outside the timed regions
             stats = {"ms_match": 0.0, "ms_prep": 0.0, "ms_score": 0.0, "ms_select": 0.0, "ms_sw_forward": 0.0, "ms_sw_reverse": 0.0, "ms_traceback": 0.0}
             ctx.set_timing(2)
-            ctx.set_tuning("match_blocks_per_cu", 0)       # alone on the GPU the matcher wants all the LDS
+            ctx.set_tuning("match_blocks_per_cu", -1)      # alone on the GPU the matcher wants all the LDS (the other contexts of the region are idle now)
             for _ in range(3):
                 step(ctx, ref_slot[0])
                 for k in stats:

@@ -2081,7 +2081,7 @@ static hipError_t spinSync(hipStream_t s) {
 static float evMs(int timing, int level, hipEvent_t a, hipEvent_t b) {
     float t = 0; if (timing < level || hipEventElapsedTime(&t, a, b) != hipSuccess) return __builtin_nanf(""); return t;
 }
-void Gpu::setMatchBlocksPerCU(int n) { d_->matchPerCU = n < 0 ? 0 : n; }
+void Gpu::setMatchBlocksPerCU(int n) { d_->matchPerCU = n < 0 ? -1 : n; }      // n > 0: at most n; 0: the library's choice (matchAndScore); -1: all that fit
 // scheduling knobs of k_match (they change the order of the work, never a result): footprint -1 by index density / 0 large / 1 small;
 // similar k-mers from which a query is started first, -1 = by batch size, 0 = no list.  Initial values: SP_MATCH_SMALL / SP_MATCH_HEAVY.
 bool Gpu::setKnob(const std::string &name, int value) {
@@ -2305,6 +2305,10 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     int perCU = 2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, fn, 64 * kWavesPerBlock, 0) != hipSuccess || perCU < 1) perCU = 2;
     if (d.matchPerCU > 0) perCU = std::min(perCU, d.matchPerCU);
+    // Several search contexts on one GPU: the grouped kernel at TWO blocks per CU leaves half of every CU -- LDS, wave slots, registers -- to the other contexts' Smith-Waterman,
+    // traceback and selection kernels and loses 13 % alone (0.533 against 0.468 ms; k_match loses 22 %): four host-driven contexts reach 23.4 M spacer-queries/s with two blocks,
+    // 21.2 M with three, 20.6 M with four (profiles/r04_blocks_sweep.txt).  A context that searches alone takes all that fit.
+    else if (d.matchPerCU == 0 && grouped && g_searchers[d.device & 63].load(std::memory_order_relaxed) >= 2) perCU = std::min(perCU, 2);
     if (d.knob.matchPerCU > 0) perCU = d.knob.matchPerCU;
     const bool dbg = d.knob.debug;
     if (dbg) fprintf(stderr, "[sp] k_match footprint=%s ord=%d blocks/CU=%d\n", grouped ? "grouped" : (small ? "small" : "large"), (int) withOrd, perCU);
