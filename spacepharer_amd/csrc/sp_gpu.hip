@@ -15,7 +15,10 @@
 #include <memory>
 #include <mutex>
 #include <sched.h>
+#include <set>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "sp_gpu.h"
 #include "sp_dist.h"
@@ -126,26 +129,56 @@ __device__ void waveBitonicSort(uint64_t *keys, uint32_t n, int lane) {
 }
 
 
-// Slot numbering of the device index.  The reference numbers a k-mer  first3mer + 8000 * second3mer  (Indexer); the similar
-// k-mers of a window are enumerated first-3-mer-major, so neighbouring lanes of a probe share the FIRST 3-mer and walk
-// through similar SECOND 3-mers.  Numbering slots  second3mer + 8000 * first3mer  puts those probes into one 1000-byte row
-// of occupancy bits (a handful of 128-byte lines per load instruction instead of 64 different ones).
-// Inside a row the second 3-mers are numbered with the residues in an order that keeps exchangeable ones next to each other
-// (C | G A S T P | N D E Q | K R H | Y W F | M L I V instead of the alphabet): the similar second 3-mers of a window differ from
-// it in a few positions by such residues, so their slots bunch into fewer 128-byte lines of the probe table -- line traffic is
-// what bounds the search once two passes are in flight.  The renumbering lives in the tables only (the partner indices stored
-// in the similar-3-mer table and the keys of the index construction are already permuted; perm3 / unperm3 are build- and
-// test-time functions), never in the matching kernel.
-__host__ __device__ __forceinline__ uint32_t perm3(uint32_t idx) {       // reference 3-mer number -> permuted number
-    constexpr uint8_t pi[20] = {2, 0, 7, 8, 15, 1, 12, 18, 10, 17, 16, 6, 5, 9, 11, 3, 4, 19, 14, 13};     // A C D E F G H I K L M N P Q R S T V W Y
-    return pi[idx % 20u] + 20u * pi[(idx / 20u) % 20u] + 400u * pi[idx / 400u];
+// Slot numbering of the device index.  The reference numbers a k-mer  first3mer + 8000 * second3mer  (Indexer).  What bounds the search is the number
+// of different 128-byte lines of the occupancy bitmap that the similar k-mers of a window touch, so slots are numbered for that:
+//  - 3-mers are renumbered along a Z-curve: residues in an order that keeps exchangeable ones next to each other (C | G A S T P | N D E Q | K R H | Y W F |
+//    M L I V instead of the alphabet), the three positions' 5-bit digits bit-interleaved, the 8000 used codes ranked 0..7999.  The similar 3-mers of a
+//    3-mer differ from it in a few positions by such residues: on the curve they fall into a few short runs.
+//  - a k-mer (first 3-mer a', second 3-mer b', both renumbered) lies in the 32 x 32 tile (a' / 32, b' / 32), and a tile is the 1024 bits of one 128-byte
+//    line: the similar k-mers of a window -- (run of a') x (run of b') -- cover a few tiles instead of one row of 8000 slots per a'.
+// slot = tile x 1024 + (a' % 32) x 32 + b' % 32 = slotA(a') + slotB(b').  The renumbering lives in the tables (the partner indices stored in the
+// similar-3-mer table and the keys of the index construction are renumbered; unperm3 / kmerOfSlot are test-time functions).
+struct Perm3Tables { uint16_t fwd[8000], inv[8000]; };
+static const Perm3Tables &perm3Host() {
+    static const Perm3Tables t = [] {
+        constexpr uint8_t pi[20] = {2, 0, 7, 8, 15, 1, 12, 18, 10, 17, 16, 6, 5, 9, 11, 3, 4, 19, 14, 13};     // A C D E F G H I K L M N P Q R S T V W Y -> position
+        std::vector<std::pair<uint32_t, uint32_t>> code(8000);
+        for (uint32_t idx = 0; idx < 8000; idx++) {
+            const uint32_t d[3] = {pi[idx % 20u], pi[(idx / 20u) % 20u], pi[idx / 400u]};
+            uint32_t z = 0;
+            for (int bit = 0; bit < 5; bit++) for (int j = 0; j < 3; j++) z |= ((d[j] >> bit) & 1u) << (3 * bit + j);
+            code[idx] = {z, idx};
+        }
+        std::sort(code.begin(), code.end());
+        Perm3Tables r;
+        for (uint32_t rank = 0; rank < 8000; rank++) { r.fwd[code[rank].second] = (uint16_t) rank; r.inv[rank] = (uint16_t) code[rank].second; }
+        return r;
+    }();
+    return t;
+}
+__device__ uint16_t g_perm3[8000], g_unperm3[8000];        // filled per device by Gpu::init
+__host__ __device__ __forceinline__ uint32_t perm3(uint32_t idx) {       // reference 3-mer number -> renumbered
+#if defined(__HIP_DEVICE_COMPILE__)
+    return g_perm3[idx];
+#else
+    return perm3Host().fwd[idx];
+#endif
 }
 __host__ __device__ __forceinline__ uint32_t unperm3(uint32_t idx) {
-    constexpr uint8_t inv[20] = {1, 5, 0, 15, 16, 12, 11, 2, 3, 13, 8, 14, 6, 19, 18, 4, 10, 9, 7, 17};
-    return inv[idx % 20u] + 20u * inv[(idx / 20u) % 20u] + 400u * inv[idx / 400u];
+#if defined(__HIP_DEVICE_COMPILE__)
+    return g_unperm3[idx];
+#else
+    return perm3Host().inv[idx];
+#endif
 }
-__host__ __device__ __forceinline__ uint32_t slotOfKmer(uint32_t first3p, uint32_t second3p) { return second3p + 8000u * first3p; }      // permuted 3-mer numbers in
-__host__ __device__ __forceinline__ uint32_t kmerOfSlot(uint32_t slot) { return unperm3(slot / 8000u) + 8000u * unperm3(slot % 8000u); }  // reference k-mer id out
+constexpr uint32_t kTilesPerSide = 250u;                    // 8000 / 32
+__host__ __device__ __forceinline__ uint32_t slotA(uint32_t first3p) { return (first3p >> 5) * (kTilesPerSide * 1024u) + ((first3p & 31u) << 5); }
+__host__ __device__ __forceinline__ uint32_t slotB(uint32_t second3p) { return ((second3p >> 5) << 10) | (second3p & 31u); }
+__host__ __device__ __forceinline__ uint32_t slotOfKmer(uint32_t first3p, uint32_t second3p) { return slotA(first3p) + slotB(second3p); }      // renumbered 3-mers in
+__host__ __device__ __forceinline__ uint32_t kmerOfSlot(uint32_t slot) {                                                                        // reference k-mer id out
+    const uint32_t tile = slot >> 10, a3 = ((tile / kTilesPerSide) << 5) | ((slot >> 5) & 31u), b3 = ((tile % kTilesPerSide) << 5) | (slot & 31u);
+    return unperm3(a3) + 8000u * unperm3(b3);
+}
 
 __device__ __forceinline__ int extScore(uint32_t packed) { return (int) (packed >> 16) - 32768; }
 __device__ __forceinline__ uint32_t extIndex(uint32_t packed) { return packed & 0xFFFFu; }
@@ -2141,6 +2174,15 @@ bool Gpu::init(int device, std::string &err) {
             it = propCache.emplace(device % n, std::make_pair(std::string(prop.name), (int) prop.multiProcessorCount)).first;
         }
         name_ = it->second.first; d_->numCU = it->second.second;
+    }
+    {   // the 3-mer renumbering tables of this device (once per process and device)
+        static std::mutex permMutex; static std::set<int> permDone;
+        std::lock_guard<std::mutex> lock(permMutex);
+        if (!permDone.count(d_->device)) {
+            HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_perm3), perm3Host().fwd, sizeof(g_perm3)));
+            HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_unperm3), perm3Host().inv, sizeof(g_unperm3)));
+            permDone.insert(d_->device);
+        }
     }
     if (!takeStreams(d_->device, d_->stream, d_->copyStream)) { err = "hipStreamCreate failed"; return false; }
     { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, d_->device) == hipSuccess && khz > 0) d_->wallKHz = khz; }
