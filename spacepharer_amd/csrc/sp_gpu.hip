@@ -558,7 +558,8 @@ struct MatchArgs {
 #define SP_T_FLUSH(ctr) do { } while (0)
 #endif
 
-constexpr size_t kSpillWordsPerWave = 65536 + 65536 / 64;   // keys + kept-bitmap (as u64 words)
+constexpr size_t kSpillKeysPerWave = 65536 + 512;             // (+ 512: the dense index writes its hits behind a gap the size of the LDS buffer, see kRing)
+constexpr size_t kSpillWordsPerWave = kSpillKeysPerWave + 65536 / 64;   // keys + kept-bitmap (as u64 words)
 
 __device__ void markKept(const uint64_t *keys, uint32_t M, uint32_t *bits, int lane) {
     for (uint32_t base = 0; base < M; base += 64) {
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
     uint64_t *defSlot = s_defSlot[w]; uint32_t *defMeta = s_defMeta[w]; uint32_t *defOrd = s_defOrd[w];
     const uint32_t waveGlobal = blockIdx.x * kWavesPerBlock + w;
     uint64_t *spillKeys = a.spill + (size_t) waveGlobal * kSpillWordsPerWave;
-    uint32_t *spillBits = (uint32_t *) (spillKeys + 65536);
+    uint32_t *spillBits = (uint32_t *) (spillKeys + kSpillKeysPerWave);
     uint32_t *spillOrd = kOrd ? a.spillOrd + (size_t) waveGlobal * 65536 : nullptr;
     unsigned long long kmersTotal = 0, matchesTotal = 0, diagTotal = 0;
     uint32_t dChunkBase = 0, dChunkUsed = 0, dChunkCap = 0;
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
         const int L = (int) ((kSmall ? (uint32_t) __builtin_amdgcn_readlane((int) offL, cur + 1) : uni(a.qoff[qi + 1])) - qo);
         const uint8_t *q = a.qres + qo;
         const int nScan = L - kSpan;        // windows 0 .. L-9 ; the last window (L-8) is never scanned
-        uint32_t M = 0;
+        uint32_t M = 0, ringBase = 0;
         uint32_t qK0 = 0;                   // similar k-mers of the windows before the current one
         bool overflow = false;
         // residues and thresholds of the first 64 positions live in lanes (readlane per window)
@@ -744,12 +745,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
         constexpr int kBktShift = kSuper == 1024 ? 18 : 19;
         constexpr uint32_t kMul0 = 2654435761u;                       // the first round's multiplier
         if constexpr (!kSmall) { for (uint32_t t = lane * 4; t < (uint32_t) kSuper; t += 256) *reinterpret_cast<uint4 *>(occList + t) = make_uint4(0u, 0u, 0u, 0u); waveSync(); }
+        // Dense index: a query has thousands of hits and the LDS buffer holds kHitCap of them.  The buffer is a window [ringBase, ringBase + kHitCap) of the
+        // hit stream: when the next batch of lists does not fit, the window's content goes to the per-wave HBM scratch in whole lines (8 bytes per lane,
+        // consecutive) and the window moves on -- the hits themselves are emitted into LDS.  (Stored from the emission directly, a list entry per lane at a
+        // stride of the list length, the same bytes cost three partial writes per line: 0.9 of 3.1 ms at 2 x 10^8 residues.)  In the scratch the stream lies
+        // kHitCap entries behind its position, so that the pre-filter below can compact in place: LDS content first, then the scratch.
+        constexpr bool kRing = !kSmall && !kOrd;
         auto emit = [&](uint64_t ent, uint32_t h, uint32_t ord, int win) {
             const uint32_t seqId = (uint32_t) ent;
             const uint32_t diag = (uint32_t) (win - (int) (uint32_t) ((ent >> 32) & 0xFFFF)) & 0xFFFFu;
             const uint64_t key = ((uint64_t) seqId << 32) | ((uint64_t) (h & 0xFFFFu) << 16) | diag;
-            if (h < (uint32_t) kHitCap) { keys[h] = key; if (kOrd) ordL[h] = ord; }
-            else if (h < (uint32_t) kSpillCap) { spillKeys[h] = key; if (kOrd) spillOrd[h] = ord; }
+            if (h - ringBase < (uint32_t) kHitCap) { keys[h - ringBase] = key; if (kOrd) ordL[h] = ord; }
+#if !(defined(SP_ABLATE_DENSE) && SP_ABLATE_DENSE == 4)
+            else if (h < (uint32_t) kSpillCap) { spillKeys[kRing ? h + (uint32_t) kHitCap : h] = key; if (kOrd) spillOrd[h] = ord; }
+#endif
+#if defined(SP_ABLATE_DENSE) && SP_ABLATE_DENSE == 6
+            return;
+#endif
             if constexpr (!kSmall) {
                 if (h < (uint32_t) kSpillCap) { const uint32_t bkt = (seqId * kMul0) >> kBktShift, bit = 1u << (bkt & 31u); if (atomicOr(&seen[bkt >> 5], bit) & bit) atomicOr(&again[bkt >> 5], bit); }
             }
@@ -782,6 +794,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
             }
             defN = 0;
             waveSync();
+        };
+        auto moveRing = [&](uint32_t upTo) {      // the window's content [ringBase, upTo) -> scratch, in whole lines; the window continues at upTo
+            waveSync();
+            const uint32_t cnt = upTo - ringBase < (uint32_t) kHitCap ? upTo - ringBase : (uint32_t) kHitCap;      // (what lies beyond went to the scratch directly)
+#if !(defined(SP_ABLATE_DENSE) && SP_ABLATE_DENSE == 7)
+            for (uint32_t t = lane; t < cnt; t += 64) if (ringBase + t < (uint32_t) kSpillCap) spillKeys[(uint32_t) kHitCap + ringBase + t] = keys[t];
+#endif
+            waveSync();
+            ringBase = upTo;
         };
         for (;;) {
             int i, thr; uint32_t ia, ib;
@@ -972,22 +993,49 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
                         // list} -- read with the slot number itself.  At 2 x 10^8 residues 95 % of the slots are occupied and lists average three entries: the
                         // occupancy probe (a quarter of the L2 misses there: the 8 MB bit table does not fit one XCD's L2), the rank lookup, the compaction of
                         // the occupied slots and the second random line per list (slot word -> entry array) all go; only the tail of a longer list is walked.
+                        // (the buckets of the NEXT batch are in flight while this one is emitted: a super-round has up to eight batches)
+                        uint64_t hdN[kOccRegs], e0N[kOccRegs], e1N[kOccRegs], e2N[kOccRegs];
+#pragma unroll
+                        for (int r = 0; r < kOccRegs; r++) {
+                            hdN[r] = 0ull; e0N[r] = 0ull; e1N[r] = 0ull; e2N[r] = 0ull;
+                            const uint32_t km = kmerR[r];
+                            if (km != 0xFFFFFFFFu) {
+                                const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(a.buckets + 4ull * km);
+                                const ulonglong2 v0 = bp[0], v1 = bp[1];
+                                hdN[r] = v0.x; e0N[r] = v0.y; e1N[r] = v1.x; e2N[r] = v1.y;
+                            }
+                        }
 #pragma unroll
                         for (int g = 0; g < kSuper / 64; g += kOccRegs) {
                             if (s0 + 64u * (uint32_t) g >= tileK) break;                   // (uniform: the rounds beyond the list hold nothing)
                             uint64_t hdR[kOccRegs], e0R[kOccRegs], e1R[kOccRegs], e2R[kOccRegs]; uint32_t lenR[kOccRegs], hR[kOccRegs], ordR[kOccRegs];
 #pragma unroll
                             for (int r = 0; r < kOccRegs; r++) {
-                                hdR[r] = 0ull; e0R[r] = 0ull; e1R[r] = 0ull; e2R[r] = 0ull; lenR[r] = 0u; ordR[r] = 0u;
-                                const uint32_t km = kmerR[g + r];
-                                if (km != 0xFFFFFFFFu) {
-                                    const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(a.buckets + 4ull * km);
-                                    const ulonglong2 v0 = bp[0], v1 = bp[1];
-                                    hdR[r] = v0.x; e0R[r] = v0.y; e1R[r] = v1.x; e2R[r] = v1.y;
-                                    lenR[r] = (uint32_t) (hdR[r] >> 32);
-                                    if (kOrd) ordR[r] = qK0 + kBase + s0 + 64u * (uint32_t) (g + r) + (uint32_t) lane;
+                                hdR[r] = hdN[r]; e0R[r] = e0N[r]; e1R[r] = e1N[r]; e2R[r] = e2N[r];
+                                lenR[r] = (uint32_t) (hdR[r] >> 32); ordR[r] = 0u;
+                                if (kOrd) ordR[r] = qK0 + kBase + s0 + 64u * (uint32_t) (g + r) + (uint32_t) lane;
+                            }
+                            if (g + kOccRegs < kSuper / 64) {
+                                if (s0 + 64u * (uint32_t) (g + kOccRegs) < tileK) {        // (uniform)
+#pragma unroll
+                                    for (int r = 0; r < kOccRegs; r++) {
+                                        hdN[r] = 0ull; e0N[r] = 0ull; e1N[r] = 0ull; e2N[r] = 0ull;
+                                        const uint32_t km = kmerR[(g + kOccRegs + r) % (kSuper / 64)];
+                                        if (km != 0xFFFFFFFFu) {
+                                            const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(a.buckets + 4ull * km);
+                                            const ulonglong2 v0 = bp[0], v1 = bp[1];
+                                            hdN[r] = v0.x; e0N[r] = v0.y; e1N[r] = v1.x; e2N[r] = v1.y;
+                                        }
+                                    }
                                 }
                             }
+#if defined(SP_ABLATE_DENSE) && SP_ABLATE_DENSE == 2
+                            { uint64_t acc = 0;
+#pragma unroll
+                              for (int r = 0; r < kOccRegs; r++) acc ^= hdR[r] ^ e0R[r] ^ e1R[r] ^ e2R[r];
+                              if (acc == 0x123456789ull) a.counters[7] = 1; }
+                            continue;
+#endif
                             uint32_t lenLong = 0, run = M;
 #pragma unroll
                             for (int r = 0; r < kOccRegs; r++) {
@@ -998,6 +1046,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
                                 run += lane63(incl);
                                 if (lenR[r] > 3u && lenR[r] > lenLong) lenLong = lenR[r];
                             }
+                            if constexpr (kRing) {
+                                if (run - ringBase > (uint32_t) kHitCap && M > ringBase) {      // this batch does not fit behind what the window holds
+                                    if (defN) flushDeferred();                                   // (parked list tails have their positions in the window that leaves)
+                                    moveRing(M);
+                                }
+                            }
                             uint32_t nLong = 0;
 #pragma unroll
                             for (int r = 0; r < kOccRegs; r++) {
@@ -1006,6 +1060,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
                                 if (lenR[r] >= 3u) emit(e2R[r], hR[r] + 2u, ordR[r], i);
                                 nLong += (uint32_t) __popcll(__ballot(lenR[r] > 3u));
                             }
+#if defined(SP_ABLATE_DENSE) && SP_ABLATE_DENSE == 3
+                            nLong = 0;
+#endif
                             // tails of lists longer than three entries: parked (their stream positions are assigned) and fetched together, kDeferCap lists
                             // at a time -- walking the ~20 long lists of a batch on the spot costs as many dependent round trips as the longest of them has steps
                             if (nLong > 0 && nLong <= (uint32_t) kDeferCap && defN + nLong > (uint32_t) kDeferCap) flushDeferred();
@@ -1137,11 +1194,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
             qK0 += kBase;
         }
         if (defN) flushDeferred();
+        if constexpr (kRing) { if (M - ringBase > (uint32_t) kHitCap) moveRing(M); }      // (an oversized last batch: the scratch holds [0, ringBase) without a gap)
         // The rows of the NEXT query's first window were requested during this query's last window; everything requested since has been waited for (memory
         // operations retire in order), so this wait costs nothing -- and it must stand HERE: the same wait at the next window's start would also wait for the
         // record stores of this query's tail, issued a few hundred cycles before it (gfx9 counts stores in vmcnt), a full write latency per query.
         if constexpr (kSmall) { if (!stagedLanded) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stagedLanded = true; } }
-#if defined(SP_ABLATE) && SP_ABLATE >= 1
+#if (defined(SP_ABLATE) && SP_ABLATE >= 1) || (defined(SP_ABLATE_DENSE) && SP_ABLATE_DENSE >= 3 && SP_ABLATE_DENSE <= 7)
         M = 0;
 #endif
         matchesTotal += M;
@@ -1168,15 +1226,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
                     const uint32_t bkt = ((uint32_t) (k >> 32) * mul) >> kBktShift, bit = 1u << (bkt & 31u);
                     if (atomicOr(&seen[bkt >> 5], bit) & bit) atomicOr(&again[bkt >> 5], bit);
                 };
-                const uint32_t mLds = M < (uint32_t) kHitCap ? M : (uint32_t) kHitCap;
+                // (kRing, first round: LDS holds the END of the stream, [ringBase, M), the scratch [0, ringBase) at kHitCap + position; the survivors are
+                // compacted into the usual layout -- keys[0 .. kHitCap), then spillKeys[kHitCap ..) -- and a survivor's place is never ahead of the reader)
+                const bool ring0 = kRing && round == 0;
+                const uint32_t mLds = ring0 ? M - ringBase : (M < (uint32_t) kHitCap ? M : (uint32_t) kHitCap);
+#if defined(SP_ABLATE_DENSE) && SP_ABLATE_DENSE == 8
+                const uint32_t spEnd = (uint32_t) kHitCap;
+#else
+                const uint32_t spEnd = ring0 ? (uint32_t) kHitCap + ringBase : M;
+#endif
                 if (!marked) {
                     for (uint32_t t = lane; t < mLds; t += 64) mark(keys[t]);
-                    for (uint32_t base = (uint32_t) kHitCap; base < M; base += 64u * kTailKeys) {
+                    for (uint32_t base = (uint32_t) kHitCap; base < spEnd; base += 64u * kTailKeys) {
                         uint64_t k4[kTailKeys];
 #pragma unroll
-                        for (int u = 0; u < kTailKeys; u++) { const uint32_t t = base + 64u * u + lane; k4[u] = t < M ? spillKeys[t] : 0ull; }
+                        for (int u = 0; u < kTailKeys; u++) { const uint32_t t = base + 64u * u + lane; k4[u] = t < spEnd ? spillKeys[t] : 0ull; }
 #pragma unroll
-                        for (int u = 0; u < kTailKeys; u++) if (base + 64u * u + lane < M) mark(k4[u]);
+                        for (int u = 0; u < kTailKeys; u++) if (base + 64u * u + lane < spEnd) mark(k4[u]);
                     }
                     waveSync();
                 }
@@ -1188,13 +1254,28 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
                     if (keep) { const uint32_t at = wr + lanePrefixCount(m); if (at < (uint32_t) kHitCap) keys[at] = k; else spillKeys[at] = k; }
                     wr += (uint32_t) __popcll(m);
                 };
+                // the scratch is read two steps ahead of the sifting (a step = kSiftKeys keys per lane): a query of the dense index has a dozen such steps, and
+                // waiting out every one of them was a third of the kernel
+                constexpr int kSiftKeys = kTailKeys;
+                uint64_t kA[kSiftKeys], kB[kSiftKeys];
+                auto fetch = [&](uint64_t (&k)[kSiftKeys], uint32_t base) {
+#pragma unroll
+                    for (int u = 0; u < kSiftKeys; u++) { const uint32_t t = base + 64u * u + lane; k[u] = t < spEnd ? spillKeys[t] : 0ull; }
+                };
+                auto siftStep = [&](const uint64_t (&k)[kSiftKeys], uint32_t base) {
+#pragma unroll
+                    for (int u = 0; u < kSiftKeys; u++) { if (base + 64u * u >= spEnd) break; sift(k[u], base + 64u * u + lane < spEnd); }
+                };
+                constexpr uint32_t kStep = 64u * kSiftKeys;
+                if ((uint32_t) kHitCap < spEnd) fetch(kA, (uint32_t) kHitCap);
+                if ((uint32_t) kHitCap + kStep < spEnd) fetch(kB, (uint32_t) kHitCap + kStep);
                 for (uint32_t base = 0; base < mLds; base += 64) { const uint32_t t = base + lane; sift(t < mLds ? keys[t] : 0ull, t < mLds); }
-                for (uint32_t base = (uint32_t) kHitCap; base < M; base += 64u * kTailKeys) {
-                    uint64_t k4[kTailKeys];
-#pragma unroll
-                    for (int u = 0; u < kTailKeys; u++) { const uint32_t t = base + 64u * u + lane; k4[u] = t < M ? spillKeys[t] : 0ull; }
-#pragma unroll
-                    for (int u = 0; u < kTailKeys; u++) { if (base + 64u * u >= M) break; sift(k4[u], base + 64u * u + lane < M); }
+                for (uint32_t base = (uint32_t) kHitCap; base < spEnd; base += 2u * kStep) {
+                    siftStep(kA, base);
+                    if (base + 2u * kStep < spEnd) fetch(kA, base + 2u * kStep);
+                    if (base + kStep >= spEnd) break;
+                    siftStep(kB, base + kStep);
+                    if (base + 3u * kStep < spEnd) fetch(kB, base + 3u * kStep);
                 }
                 waveSync();
                 const uint32_t before = M;
@@ -1202,6 +1283,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
                 if (M <= 64u || (uint64_t) M * 8u > (uint64_t) before * 7u) break;      // fits the register path, or what is left are real multi-hit targets
             }
         }
+        if constexpr (!kSmall) SP_T(4);      // (dense index: the pre-filter rounds; the sparse footprints count their occupancy probes here)
         const bool spilled = M > (uint32_t) kHitCap;
         // reserve room for D diagonal records: kDiagChunk at a time per wave (one atomic per query on a single word would
         // serialise); unused slots of a chunk stay marked invalid (diagQuery == ~0)
