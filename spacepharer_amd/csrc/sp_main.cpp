@@ -32,16 +32,44 @@
 #include <unistd.h>
 #include <vector>
 
-#include "../../include/spacepharer_amd.h"
+#include <dlfcn.h>
 
-struct Module { const char *name; int (*run)(int, const char **); bool device; };
+// The front end does NOT link the library: a client that forwards its call to the resident server is a few system calls, and a process that links
+// libspacepharer_amd.so maps the HIP runtime and its dependencies before main() -- 10-25 ms, a third of a served module call at 10^5 spacers.
+// The library (next to this binary) is loaded when a module runs in THIS process.
+static void *g_lib = nullptr;
+static void *libSym(const char *name) {
+    if (!g_lib) {
+        char exe[4096]; const ssize_t n = readlink("/proc/self/exe", exe, sizeof(exe) - 1);
+        if (n > 0) {
+            exe[n] = 0;
+            std::string dir(exe); const size_t cut = dir.rfind('/'); dir = cut == std::string::npos ? "." : dir.substr(0, cut);
+            const char *lib = getenv("SP_LIB_NAME");
+            g_lib = dlopen((dir + "/" + (lib ? lib : "libspacepharer_amd.so")).c_str(), RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!g_lib) g_lib = dlopen("libspacepharer_amd.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!g_lib) { fprintf(stderr, "spacepharer-amd: cannot load libspacepharer_amd.so: %s\n", dlerror()); exit(1); }
+    }
+    void *f = dlsym(g_lib, name);
+    if (!f) { fprintf(stderr, "spacepharer-amd: libspacepharer_amd.so has no %s\n", name); exit(1); }
+    return f;
+}
+static int sp_init(int mask) { return ((int (*)(int)) libSym("sp_init"))(mask); }
+static void sp_shutdown() { ((void (*)()) libSym("sp_shutdown"))(); }
+static const char *sp_last_error() { return ((const char *(*)()) libSym("sp_last_error"))(); }
+constexpr int SP_OK = 0;
+
+struct Module {
+    const char *name; const char *symbol; bool device;
+    int run(int argc, const char **argv) const { return ((int (*)(int, const char **)) libSym(symbol))(argc, argv); }
+};
 static const Module kModules[] = {
-    {"prefilter", sp_prefilter_run, true}, {"align", sp_align_run, true}, {"rescorediagonal", sp_rescorediagonal_run, true}, {"search", sp_search_run, true},
+    {"prefilter", "sp_prefilter_run", true}, {"align", "sp_align_run", true}, {"rescorediagonal", "sp_rescorediagonal_run", true}, {"search", "sp_search_run", true},
     // the set-level steps are host-only: no device is touched for them
-    {"extractorfs", sp_extractorfs_run, false}, {"translatenucs", sp_translatenucs_run, false}, {"reverseseqbycodon", sp_reverseseqbycodon_run, false},
-    {"proteinaln2nucl", sp_proteinaln2nucl_run, false}, {"combineprotnuclaln", sp_combineprotnuclaln_run, false}, {"besthitperset", sp_besthitperset_run, false},
-    {"mergeresultsbyset", sp_mergeresultsbyset_run, false}, {"combinescore", sp_combinescore_run, false}, {"filtermatchbyfdr", sp_filtermatchbyfdr_run, false},
-    {"summarizeresults", sp_summarizeresults_run, false}};
+    {"extractorfs", "sp_extractorfs_run", false}, {"translatenucs", "sp_translatenucs_run", false}, {"reverseseqbycodon", "sp_reverseseqbycodon_run", false},
+    {"proteinaln2nucl", "sp_proteinaln2nucl_run", false}, {"combineprotnuclaln", "sp_combineprotnuclaln_run", false}, {"besthitperset", "sp_besthitperset_run", false},
+    {"mergeresultsbyset", "sp_mergeresultsbyset_run", false}, {"combinescore", "sp_combinescore_run", false}, {"filtermatchbyfdr", "sp_filtermatchbyfdr_run", false},
+    {"summarizeresults", "sp_summarizeresults_run", false}};
 
 static const Module *findModule(const char *name) { for (const Module &m : kModules) if (!strcmp(name, m.name)) return &m; return nullptr; }
 

@@ -73,10 +73,24 @@ struct PrefilterMemo { sp_ctx *c = nullptr; std::string query, target, result; s
 // (size and mtime miss a same-size rewrite within the clock's granularity: the result DB's identity also carries a digest of its index file)
 static std::string resultIdentity(const std::string &path) {
     std::string id = fileIdentity(path);
-    std::ifstream in(path + ".index", std::ios::binary);
-    uint64_t h = 1469598103934665603ull; char buf[65536];
-    while (in.good()) { in.read(buf, sizeof(buf)); for (std::streamsize i = 0; i < in.gcount(); i++) { h ^= (unsigned char) buf[i]; h *= 1099511628211ull; } }
-    return id + "#" + std::to_string((unsigned long long) h);
+    // (eight bytes per step, four independent lanes: the index of 6 x 10^5 entries is 12 MB and a byte-wise hash of it cost 9 ms of every served call -- twice)
+    uint64_t h[4] = {1469598103934665603ull, 0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull};
+    if (FILE *in = fopen((path + ".index").c_str(), "rb")) {
+        std::vector<char> buf(1u << 20);
+        size_t n;
+        while ((n = fread(buf.data(), 1, buf.size(), in)) > 0) {
+            size_t i = 0;
+            for (; i + 32 <= n; i += 32) {
+                uint64_t w[4]; memcpy(w, buf.data() + i, 32);
+                for (int k = 0; k < 4; k++) { h[k] = (h[k] ^ w[k]) * 0x100000001B3ull; h[k] ^= h[k] >> 29; }
+            }
+            for (; i < n; i++) { h[0] = (h[0] ^ (unsigned char) buf[i]) * 0x100000001B3ull; }
+            h[1] += n;
+        }
+        fclose(in);
+    }
+    const uint64_t all = (h[0] * 31 + h[1]) ^ (h[2] * 0x9E3779B97F4A7C15ull + h[3]);
+    return id + "#" + std::to_string((unsigned long long) all);
 }
 static PrefilterMemo g_memo;
 static void forgetPrefilter(const sp_ctx *c) { if (!c || g_memo.c == c) g_memo = PrefilterMemo(); }
@@ -140,16 +154,22 @@ static bool loadSeqDb(const std::string &path, Db &db, std::string &err) {
 }
 
 static void flatten(const Db &db, std::vector<char> &res, std::vector<uint64_t> &off, std::vector<uint32_t> &keys) {
-    off.assign(1, 0); keys.clear(); res.clear();
-    off.reserve(db.entries.size() + 1); keys.reserve(db.entries.size()); res.reserve(db.dataSize());
-    for (size_t i = 0; i < db.entries.size(); i++) {
-        const char *p = db.ptr(i); uint64_t L = db.seqLen(i);
-        uint64_t l = L;                                                            // Sequence::mapSequence stops at \n / \0
-        if (const void *nl = memchr(p, '\n', (size_t) l)) l = (uint64_t) ((const char *) nl - p);
-        if (const void *z = memchr(p, '\0', (size_t) l)) l = (uint64_t) ((const char *) z - p);
-        res.insert(res.end(), p, p + l);
-        off.push_back(res.size()); keys.push_back(db.entries[i].key);
-    }
+    // two passes over contiguous ranges of entries on a few threads -- lengths, then the copy: one entry at a time on one thread was 10 of the 38 ms a served
+    // `prefilter` of 6 x 10^5 peptides spends in its process
+    const size_t n = db.entries.size();
+    const int threads = n >= (1u << 16) ? std::min(16, defaultThreads()) : 1;
+    off.assign(n + 1, 0); keys.resize(n);
+    parallelChunks(n, threads, [&](size_t, size_t from, size_t to) {
+        for (size_t i = from; i < to; i++) {
+            const char *p = db.ptr(i); uint64_t l = db.seqLen(i);                    // Sequence::mapSequence stops at \n / \0
+            if (const void *nl = memchr(p, '\n', (size_t) l)) l = (uint64_t) ((const char *) nl - p);
+            if (const void *z = memchr(p, '\0', (size_t) l)) l = (uint64_t) ((const char *) z - p);
+            off[i + 1] = l; keys[i] = db.entries[i].key;
+        }
+    });
+    for (size_t i = 0; i < n; i++) off[i + 1] += off[i];
+    res.resize(off[n]);
+    parallelChunks(n, threads, [&](size_t, size_t from, size_t to) { for (size_t i = from; i < to; i++) memcpy(res.data() + off[i], db.ptr(i), (size_t) (off[i + 1] - off[i])); });
     if (res.empty()) res.push_back('X');
 }
 
@@ -231,6 +251,30 @@ static int fanOut(const char *module, int argc, const char **argv, const std::st
     { std::ofstream o(out + ".dbtype", std::ios::binary); o.write((const char *) &dbtype, 4); if (!o.good()) return fail(std::string(module) + ": cannot write " + out + ".dbtype"); }
     return 0;
 }
+
+// Alignment records + CIGAR text of a module call.  A one-shot process takes ordinary memory (page-locking tens of megabytes costs more, 0.23 ms per MB, than
+// one run gains from the faster copy); a resident server keeps ONE page-locked pair for all its calls: the device writes into it at the link's rate (a copy into
+// pageable memory is staged by the runtime at a fraction of it -- 12 of the 19 ms of a served `align` at 10^5 spacers) and no call touches fresh pages.
+struct ResultBufs {
+    sp_alignment *res = nullptr; char *cig = nullptr; uint64_t resCap = 0, cigCap = 0; bool pinned = false;
+    void release() { if (pinned) { sp_host_free(res); sp_host_free(cig); } else { free(res); free(cig); } res = nullptr; cig = nullptr; resCap = cigCap = 0; }
+    bool ensure(uint64_t nRes, uint64_t nCig) {
+        if (nRes <= resCap && nCig <= cigCap) return true;
+        const uint64_t r = std::max(resCap, nRes + nRes / 4 + 1024), g = std::max(cigCap, nCig + nCig / 4 + 1024);
+        release();
+        res = static_cast<sp_alignment *>(pinned ? sp_host_alloc(r * sizeof(sp_alignment)) : malloc(r * sizeof(sp_alignment)));
+        cig = static_cast<char *>(pinned ? sp_host_alloc(g) : malloc(g));
+        if (!res || !cig) { release(); sp::setLastError("out of memory for the alignment records"); return false; }
+        resCap = r; cigCap = g;
+        return true;
+    }
+};
+static ResultBufs g_servedBufs;      // (a server runs one module call at a time)
+struct ResultBufsRef {               // the served pair, or a pair of this call's own that goes with it
+    ResultBufs own, *b;
+    explicit ResultBufsRef(bool serving) : b(serving ? &g_servedBufs : &own) { if (serving) g_servedBufs.pinned = true; }
+    ~ResultBufsRef() { own.release(); }
+};
 
 // SP_MODULE_TIMES=1: wall-clock laps of a module run on stderr
 struct Laps {
@@ -388,6 +432,7 @@ int runPrefilterModule(int argc, const char **argv) {
         for (uint64_t &o : off) o -= qoff[b0];
         std::vector<uint32_t> keys(qkeys.begin() + b0, qkeys.begin() + b1);
         if (sp_ctx_set_queries(ctx.c, qres.data() + qoff[b0], off.data(), b1 - b0) != SP_OK) return fail(std::string("prefilter: ") + sp_last_error());
+        laps.lap("  queries -> device");
         int rc = sp_ctx_prefilter(ctx.c);
         std::vector<uint32_t> refused(rc == SP_ERR_OVERFLOW ? sp_ctx_overflow_queries(ctx.c, nullptr, 0) : 0);
         if (rc == SP_ERR_OVERFLOW && !refused.empty()) {      // search the batch without them, then them against target shards
@@ -509,7 +554,7 @@ int runAlignModule(int argc, const char **argv) {
     Laps laps("align");
     Ctx ctx; Db qdb, tdb, rdb; std::vector<uint32_t> qkeys, tkeys; std::vector<char> qres; std::vector<uint64_t> qoff;
     Triples tr;
-    std::vector<sp_alignment> res; std::vector<char> cig; uint64_t used = 0;
+    uint64_t used = 0;
     const double minSeqId = f.real("--min-seq-id", 0.0); const long minAlnLen = f.num("--min-aln-len", 0);
     const long maxAccept = f.num("--max-accept", INT_MAX), maxRejected = f.num("--max-rejected", INT_MAX);
     // serving, and this is the result DB the last `prefilter` call wrote from a context that still holds the batch: align its hits where they are
@@ -519,13 +564,14 @@ int runAlignModule(int argc, const char **argv) {
         resident = ap.subMat == aaPart(f.str("--sub-mat", "VTML40.out")) && ap.gapOpen == (int) strtol(aaPart(f.str("--gap-open", "11")).c_str(), NULL, 10) &&
                    ap.gapExtend == (int) strtol(aaPart(f.str("--gap-extend", "1")).c_str(), NULL, 10) && ap.evalue == f.real("-e", 0.001);
     }
+    ResultBufsRef bufs(g_memo.c != nullptr || getenv("SP_CONTEXT_CACHE") != nullptr);      // (serving)
     if (resident) {
         sp_ctx *c = g_memo.c;
         const sp_hit_packed *hits = nullptr; const uint32_t *ho = nullptr; uint64_t nHits = 0;
         if (sp_ctx_hits_view(c, &hits, &ho, &nHits) != SP_OK) return fail(std::string("align: ") + sp_last_error());
-        res.resize(std::max<uint64_t>(1, nHits)); cig.resize(64 * ((size_t) nHits + 16));
-        int rc = sp_ctx_align_hits(c, res.data(), cig.data(), cig.size(), &used);
-        if (rc == SP_ERR_OVERFLOW && used > cig.size()) { cig.resize(used + 16); rc = sp_ctx_align_hits(c, res.data(), cig.data(), cig.size(), &used); }
+        if (!bufs.b->ensure(nHits + 16, 24 * (nHits + 16))) return fail(std::string("align: ") + sp_last_error());
+        int rc = sp_ctx_align_hits(c, bufs.b->res, bufs.b->cig, bufs.b->cigCap, &used);
+        if (rc == SP_ERR_OVERFLOW && used > bufs.b->cigCap) { if (!bufs.b->ensure(nHits + 16, used + 16)) return fail(std::string("align: ") + sp_last_error()); rc = sp_ctx_align_hits(c, bufs.b->res, bufs.b->cig, bufs.b->cigCap, &used); }
         if (rc != SP_OK) return fail(std::string("align: ") + sp_last_error());
         // entries in the order the ordinary path takes them -- the result DB's data order (Db::load), which is the batch order the prefilter call
         // wrote -- with the records of query q at the offsets of its hits
@@ -539,12 +585,13 @@ int runAlignModule(int argc, const char **argv) {
         KeyMap qIndex, tIndex; qIndex.build(qkeys); tIndex.build(tkeys);
         if (!collectTriples(rdb, qIndex, tIndex, tr, err)) return fail("align: " + err);
         laps.lap("read + parse result DB");
-        res.resize(std::max<size_t>(1, tr.q.size())); cig.resize(64 * (tr.q.size() + 16));
-        int rc = sp_ctx_align(ctx.c, tr.q.data(), tr.t.data(), tr.q.size(), res.data(), cig.data(), cig.size(), &used);
-        if (rc == SP_ERR_OVERFLOW && used > cig.size()) { cig.resize(used + 16); rc = sp_ctx_align(ctx.c, tr.q.data(), tr.t.data(), tr.q.size(), res.data(), cig.data(), cig.size(), &used); }
+        if (!bufs.b->ensure(tr.q.size() + 16, 24 * (tr.q.size() + 16))) return fail(std::string("align: ") + sp_last_error());
+        int rc = sp_ctx_align(ctx.c, tr.q.data(), tr.t.data(), tr.q.size(), bufs.b->res, bufs.b->cig, bufs.b->cigCap, &used);
+        if (rc == SP_ERR_OVERFLOW && used > bufs.b->cigCap) { if (!bufs.b->ensure(tr.q.size() + 16, used + 16)) return fail(std::string("align: ") + sp_last_error()); rc = sp_ctx_align(ctx.c, tr.q.data(), tr.t.data(), tr.q.size(), bufs.b->res, bufs.b->cig, bufs.b->cigCap, &used); }
         if (rc != SP_OK) return fail(std::string("align: ") + sp_last_error());
         laps.lap("align on the device");
     }
+    const sp_alignment *res = bufs.b->res; const char *cig = bufs.b->cig;
     DbWriter w; w.path = f.positional[3]; w.dbtype = 5;       // DBTYPE_ALIGNMENT_RES
     // entries are formatted by --threads workers over contiguous ranges and appended in order
     const size_t nEntries = tr.entryKey.size();
@@ -569,7 +616,7 @@ int runAlignModule(int argc, const char **argv) {
             }
             if (ok.size() > 1) std::sort(ok.begin(), ok.end(), [&](uint64_t a, uint64_t b) { return alnLess(res[a], res[b]); });
             const size_t before = block.size();
-            for (uint64_t i : ok) appendAlnLine(block, res[i], cig.data() + res[i].cigar_offset, true);
+            for (uint64_t i : ok) appendAlnLine(block, res[i], cig + res[i].cigar_offset, true);
             block.push_back('\0');
             ck.push_back(tr.entryKey[e]); cl.push_back(block.size() - before);
         }
@@ -672,26 +719,20 @@ int runSearchModule(int argc, const char **argv) {
     const size_t batch = 1u << 20;
     size_t qFrom = 0, nq = qkeys.size();
     if (!shardTargets) { std::vector<uint64_t> lens(qkeys.size()); for (size_t i = 0; i < lens.size(); i++) lens[i] = qoff[i + 1] - qoff[i] + 2; partRange(lens, w.part, qFrom, nq); }   // this GPU's queries
-    // result buffers in ordinary memory: page-locking tens of megabytes costs more (0.23 ms per MB) than a one-shot module run gains
-    // from the faster copy
-    sp_alignment *res = nullptr; char *cig = nullptr; uint64_t resCap = 0, cigCap = 0;
-    auto freeBufs = [&]() { free(res); free(cig); res = nullptr; cig = nullptr; };
+    ResultBufsRef bufs(ctx.cached);
+    auto freeBufs = [&]() { };      // (the buffers go with `bufs`)
     // align the hits of the context's current batch, filter / sort / format them, one entry per key
     auto alignAndFormat = [&](sp_ctx *c, const std::vector<uint32_t> &keys, size_t entryFrom = 0) -> bool {      // keys[k] names query entryFrom + k of the resident batch
         const uint64_t nHits = sp_ctx_num_hits(c);
-        if (nHits + 16 > resCap || 24 * (nHits + 16) > cigCap) {
-            freeBufs();
-            resCap = nHits + nHits / 4 + 1024; cigCap = 24 * resCap;
-            res = static_cast<sp_alignment *>(malloc(resCap * sizeof(sp_alignment))); cig = static_cast<char *>(malloc(cigCap));
-            if (!res || !cig) { sp::setLastError("search: out of memory"); return false; }
-        }
+        if (!bufs.b->ensure(nHits + 16, 24 * (nHits + 16))) return false;
         uint64_t used = 0;
-        int rc = sp_ctx_align_hits(c, res, cig, cigCap, &used);
-        if (rc == SP_ERR_OVERFLOW && used > cigCap) {
-            free(cig); cigCap = used + 1024; cig = static_cast<char *>(malloc(cigCap));
-            rc = sp_ctx_align_hits(c, res, cig, cigCap, &used);
+        int rc = sp_ctx_align_hits(c, bufs.b->res, bufs.b->cig, bufs.b->cigCap, &used);
+        if (rc == SP_ERR_OVERFLOW && used > bufs.b->cigCap) {
+            if (!bufs.b->ensure(nHits + 16, used + 1024)) return false;
+            rc = sp_ctx_align_hits(c, bufs.b->res, bufs.b->cig, bufs.b->cigCap, &used);
         }
         if (rc != SP_OK) return false;
+        const sp_alignment *res = bufs.b->res; const char *cig = bufs.b->cig;
         const sp_hit_packed *hits = nullptr; const uint32_t *ho = nullptr; uint64_t nh = 0;
         if (sp_ctx_hits_view(c, &hits, &ho, &nh) != SP_OK) return false;
         laps.lap("align on the device");
