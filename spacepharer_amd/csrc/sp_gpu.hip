@@ -532,7 +532,7 @@ struct MatchArgs {
     const uint64_t *slots;          // per OCCUPIED slot (rank order): the entry itself (seqId | pos << 32) when the list has one
                                     // entry, else bit 63 | len << 32 | offset into ientries
     const uint64_t *ientries;       // seqId | pos << 32, lists concatenated in k-mer order
-    const uint64_t *buckets;        // large footprint only: 4 words per k-mer SLOT (20^6 of them, 2 GB): offset | length << 32 (0 = no list), entries 0..2 of the list
+    const uint64_t *buckets;        // large footprint only: 32 bytes per k-mer SLOT (20^6 of them, 2 GB): up to five entries of a list, or three and where the rest is (k_idx_buckets)
     uint64_t *spill;                // per-wave scratch: kSpillCap+1 keys (+ bitmap) each
     uint32_t *queue;                // work counter
     DiagRec *diagRec; uint32_t *diagQuery; uint32_t diagCap; uint32_t *diagCursor;
@@ -989,10 +989,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
                     continue;
 #endif
                     if constexpr (!kSmall) {
-                        // Dense index (the large footprint): a DIRECT table of 32-byte buckets, one per k-mer slot -- {offset | length << 32, entries 0..2 of the
-                        // list} -- read with the slot number itself.  At 2 x 10^8 residues 95 % of the slots are occupied and lists average three entries: the
-                        // occupancy probe (a quarter of the L2 misses there: the 8 MB bit table does not fit one XCD's L2), the rank lookup, the compaction of
-                        // the occupied slots and the second random line per list (slot word -> entry array) all go; only the tail of a longer list is walked.
+                        // Dense index (the large footprint): a DIRECT table of 32-byte buckets, one per k-mer slot, read with the slot number itself.  At
+                        // 2 x 10^8 residues 95 % of the slots are occupied and lists average three entries: the occupancy probe (a quarter of the L2 misses
+                        // there: the 8 MB bit table does not fit one XCD's L2), the rank lookup, the compaction of the occupied slots and the second random
+                        // access per list (slot word -> entry array) all go.  A bucket is 16 halfwords: h0 = length (0..5) and up to FIVE entries of 6 bytes
+                        // {position, target id} -- or h0 = 0xFFFF, three entries, the length in words 5 and the list's offset in word 7 for the 9 % of the
+                        // lists that are longer: only those cost a second, dependent access (with 8-byte entries three fit and 37 % of the lists paid it --
+                        // a quarter of the kernel).
                         // (the buckets of the NEXT batch are in flight while this one is emitted: a super-round has up to eight batches)
                         uint64_t hdN[kOccRegs], e0N[kOccRegs], e1N[kOccRegs], e2N[kOccRegs];
 #pragma unroll
@@ -1012,7 +1015,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
 #pragma unroll
                             for (int r = 0; r < kOccRegs; r++) {
                                 hdR[r] = hdN[r]; e0R[r] = e0N[r]; e1R[r] = e1N[r]; e2R[r] = e2N[r];
-                                lenR[r] = (uint32_t) (hdR[r] >> 32); ordR[r] = 0u;
+                                ordR[r] = 0u;
                                 if (kOrd) ordR[r] = qK0 + kBase + s0 + 64u * (uint32_t) (g + r) + (uint32_t) lane;
                             }
                             if (g + kOccRegs < kSuper / 64) {
@@ -1036,6 +1039,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
                               if (acc == 0x123456789ull) a.counters[7] = 1; }
                             continue;
 #endif
+#ifdef SP_PHASE_SPLIT
+                            SP_T(5); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SP_T(0);      // p5: issue, p0: wait for the buckets
+#endif
+                            // unpack: D0..D7 = the bucket's words
+                            uint64_t ent[kOccRegs][5]; uint32_t nIn[kOccRegs], offR[kOccRegs]; bool isLong[kOccRegs];
+#pragma unroll
+                            for (int r = 0; r < kOccRegs; r++) {
+                                const uint32_t D0 = (uint32_t) hdR[r], D1 = (uint32_t) (hdR[r] >> 32), D2 = (uint32_t) e0R[r], D3 = (uint32_t) (e0R[r] >> 32);
+                                const uint32_t D4 = (uint32_t) e1R[r], D5 = (uint32_t) (e1R[r] >> 32), D6 = (uint32_t) e2R[r], D7 = (uint32_t) (e2R[r] >> 32);
+                                const uint32_t h0 = D0 & 0xFFFFu;
+                                isLong[r] = h0 == 0xFFFFu;
+                                lenR[r] = isLong[r] ? D5 : h0; nIn[r] = isLong[r] ? 3u : h0; offR[r] = D7;
+                                ent[r][0] = ((uint64_t) (D0 >> 16) << 32) | D1;
+                                ent[r][1] = ((uint64_t) (D2 & 0xFFFFu) << 32) | __builtin_amdgcn_alignbit(D3, D2, 16);
+                                ent[r][2] = ((uint64_t) (D3 >> 16) << 32) | D4;
+                                ent[r][3] = ((uint64_t) (D5 & 0xFFFFu) << 32) | __builtin_amdgcn_alignbit(D6, D5, 16);
+                                ent[r][4] = ((uint64_t) (D6 >> 16) << 32) | D7;
+                            }
                             uint32_t lenLong = 0, run = M;
 #pragma unroll
                             for (int r = 0; r < kOccRegs; r++) {
@@ -1044,53 +1065,60 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kSmall ? (kOrd ? 3 : 4) : (kOr
                                 const uint32_t incl = waveInclusiveScan(lenR[r], lane);
                                 hR[r] = run + incl - lenR[r];
                                 run += lane63(incl);
-                                if (lenR[r] > 3u && lenR[r] > lenLong) lenLong = lenR[r];
+                                if (isLong[r] && lenR[r] > lenLong) lenLong = lenR[r];
                             }
                             if constexpr (kRing) {
-                                if (run - ringBase > (uint32_t) kHitCap && M > ringBase) {      // this batch does not fit behind what the window holds
-                                    if (defN) flushDeferred();                                   // (parked list tails have their positions in the window that leaves)
-                                    moveRing(M);
-                                }
+                                // this batch does not fit behind what the window holds.  (Parked list tails whose positions lie in the window that leaves go to
+                                // the scratch directly when they are fetched -- emit() -- : one list in eleven; flushing them first cost a memory round trip per move)
+                                if (run - ringBase > (uint32_t) kHitCap && M > ringBase) moveRing(M);
                             }
+#ifdef SP_PHASE_SPLIT
+                            SP_T(1);      // p1: scans, window moves (with the flush of parked lists in front of them)
+#endif
                             uint32_t nLong = 0;
 #pragma unroll
                             for (int r = 0; r < kOccRegs; r++) {
-                                if (lenR[r] >= 1u) emit(e0R[r], hR[r], ordR[r], i);
-                                if (lenR[r] >= 2u) emit(e1R[r], hR[r] + 1u, ordR[r], i);
-                                if (lenR[r] >= 3u) emit(e2R[r], hR[r] + 2u, ordR[r], i);
-                                nLong += (uint32_t) __popcll(__ballot(lenR[r] > 3u));
+#pragma unroll
+                                for (int j = 0; j < 5; j++) if ((uint32_t) j < nIn[r]) emit(ent[r][j], hR[r] + (uint32_t) j, ordR[r], i);
+                                nLong += (uint32_t) __popcll(__ballot(isLong[r]));
                             }
 #if defined(SP_ABLATE_DENSE) && SP_ABLATE_DENSE == 3
                             nLong = 0;
 #endif
-                            // tails of lists longer than three entries: parked (their stream positions are assigned) and fetched together, kDeferCap lists
+#ifdef SP_PHASE_SPLIT
+                            SP_T(2);      // p2: emission
+#endif
+                            // tails of lists longer than five entries: parked (their stream positions are assigned) and fetched together, kDeferCap lists
                             // at a time -- walking the ~20 long lists of a batch on the spot costs as many dependent round trips as the longest of them has steps
                             if (nLong > 0 && nLong <= (uint32_t) kDeferCap && defN + nLong > (uint32_t) kDeferCap) flushDeferred();
                             if (nLong > (uint32_t) kDeferCap) {
                                 for (uint32_t e0 = 3; e0 < lenLong; e0 += kWalkStep) {      // (never with two buckets per lane: a batch has 128 lists)
-                                    uint64_t ent[kWalkStep][kOccRegs];
+                                    uint64_t entW[kWalkStep][kOccRegs];
 #pragma unroll
                                     for (int u = 0; u < kWalkStep; u++)
 #pragma unroll
-                                        for (int r = 0; r < kOccRegs; r++) ent[u][r] = (e0 + u < lenR[r]) ? a.ientries[(uint32_t) hdR[r] + e0 + u] : 0ull;
+                                        for (int r = 0; r < kOccRegs; r++) entW[u][r] = (isLong[r] && e0 + u < lenR[r]) ? a.ientries[offR[r] + e0 + u] : 0ull;
 #pragma unroll
                                     for (int u = 0; u < kWalkStep; u++)
 #pragma unroll
-                                        for (int r = 0; r < kOccRegs; r++) if (e0 + u < lenR[r]) emit(ent[u][r], hR[r] + e0 + u, ordR[r], i);
+                                        for (int r = 0; r < kOccRegs; r++) if (isLong[r] && e0 + u < lenR[r]) emit(entW[u][r], hR[r] + e0 + u, ordR[r], i);
                                 }
                             } else if (nLong > 0) {
 #pragma unroll
                                 for (int r = 0; r < kOccRegs; r++) {
-                                    const bool longList = lenR[r] > 3u && hR[r] < (uint32_t) kSpillCap;
+                                    const bool longList = isLong[r] && hR[r] < (uint32_t) kSpillCap;
                                     const uint64_t m = __ballot(longList);
                                     if (longList) {
                                         const uint32_t at = defN + lanePrefixCount(m);
-                                        defSlot[at] = (1ull << 63) | hdR[r]; defMeta[at] = hR[r] | ((uint32_t) i << 16); if (kOrd) defOrd[at] = ordR[r];
+                                        defSlot[at] = (1ull << 63) | ((uint64_t) lenR[r] << 32) | offR[r]; defMeta[at] = hR[r] | ((uint32_t) i << 16); if (kOrd) defOrd[at] = ordR[r];
                                     }
                                     defN += (uint32_t) __popcll(m);
                                 }
                             }
                             M = run;
+#ifdef SP_PHASE_SPLIT
+                            SP_T(3);      // p3: parking / flushing list tails
+#endif
                         }
                         waveSync();
                         SP_T(5);
