@@ -264,6 +264,7 @@ struct WeighArgs {
     const uint32_t *ext3; const uint16_t *ext3cnt; int cntMin; uint32_t heavyThr;
     uint32_t *heavyList; uint8_t *heavyFlag; uint32_t *heavyCount;
     const uint32_t *est;            // k_prep8 only: similar k-mers of a window by the slack of its best pair (k_heavy_calib); nullptr = count exactly
+    uint32_t *weight;               // k_prep8 only, optional: the count / estimate per query (k_order_* sort the batch by it; then nobody is listed as heavy)
 };
 __global__ __launch_bounds__(256) void k_weigh(WeighArgs a) {
     // 8 lanes per query share the score values of a window (the loads of one lane would be a long dependent chain); a block
@@ -444,6 +445,7 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
 #pragma unroll
             for (int d = 1; d < 8; d <<= 1) Ke += (uint32_t) __shfl_xor((int) Ke, d, 8);
             const bool heavyE = have && sub == 0 && Ke >= wa.heavyThr;
+            if (have && sub == 0 && wa.weight) wa.weight[qi] = Ke;
             if (have && sub == 0) wa.heavyFlag[qi] = heavyE ? 1 : 0;
             if (heavyE) { const uint32_t at = atomicAdd(&s_n, 1u); if (at < 1024u) s_list[at] = qi; else wa.heavyFlag[qi] = 0; }
             __syncthreads();
@@ -482,6 +484,7 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
 #pragma unroll
         for (int d = 1; d < 8; d <<= 1) K += (uint32_t) __shfl_xor((int) K, d, 8);
         const bool heavy = have && sub == 0 && K >= wa.heavyThr;
+        if (have && sub == 0 && wa.weight) wa.weight[qi] = K;
         if (have && sub == 0) wa.heavyFlag[qi] = heavy ? 1 : 0;
         if (heavy) { const uint32_t at = atomicAdd(&s_n, 1u); if (at < 1024u) s_list[at] = qi; else wa.heavyFlag[qi] = 0; }
         __syncthreads();
@@ -491,6 +494,58 @@ __global__ __launch_bounds__(256) void k_prep8(Prep8Args a8) {
     if (threadIdx.x == 0 && n) s_base = atomicAdd(wa.heavyCount + hl * kHeavyStride, n);
     __syncthreads();
     for (uint32_t x = threadIdx.x; x < n; x += blockDim.x) wa.heavyList[(size_t) hl * a.nq + s_base + x] = s_list[x];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The batch in the order of decreasing weight (k_match_grp, short queries): a counting sort by 64 quarter-octave classes of the similar-k-mer count,
+// tiles of kOrderTile queries.  The matching kernel hands the queries out in this order -- longest first, the classic list schedule: a wave that
+// holds one of the heaviest queries (20 000 similar k-mers against 850 on average) takes nothing else meanwhile, and the light queries fill in at the
+// end -- through tickets on kOrderQueues counters (one counter for 60 000 queries is a line that 4 096 waves queue on).  A ticket is one query
+// while the queries are heavy, then two, four, eight: OrderHeader holds the positions where the size changes.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kOrderTile = 2048, kOrderClasses = 64, kOrderQueues = 16, kOrderQueueStride = 32;
+struct OrderHeader { uint32_t p[4]; uint32_t t[4]; };      // p[k]: first position of step k + 1 (p[3] = nq); t[k]: tickets before step k + 1 (t[3] = all)
+__device__ __forceinline__ uint32_t weightClass(uint32_t w) {
+    if (w < 4u) return w;
+    const uint32_t l = 31u - (uint32_t) __clz((int) w), c = 4u * l + ((w >> (l - 2u)) & 3u);
+    return c < (uint32_t) kOrderClasses ? c : (uint32_t) kOrderClasses - 1u;
+}
+__global__ __launch_bounds__(256) void k_order_count(const uint32_t *weight, uint32_t nq, uint32_t *tileHist) {
+    __shared__ uint32_t s_h[kOrderClasses];
+    if (threadIdx.x < kOrderClasses) s_h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (uint32_t) kOrderTile; i += 256) { const uint32_t q = blockIdx.x * kOrderTile + i; if (q < nq) atomicAdd(&s_h[weightClass(weight[q])], 1u); }
+    __syncthreads();
+    if (threadIdx.x < kOrderClasses) tileHist[blockIdx.x * kOrderClasses + threadIdx.x] = s_h[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void k_order_scatter(const uint32_t *weight, uint32_t nq, const uint32_t *tileHist, uint32_t nTiles, uint32_t *order, OrderHeader *header,
+                                                       uint32_t *queues, uint32_t firstTickets) {
+    __shared__ uint32_t s_tot[kOrderClasses], s_before[kOrderClasses], s_base[kOrderClasses], s_cur[kOrderClasses];
+    if (threadIdx.x < kOrderClasses) {
+        uint32_t tot = 0, before = 0;
+        for (uint32_t t = 0; t < nTiles; t++) { const uint32_t v = tileHist[t * kOrderClasses + threadIdx.x]; tot += v; if (t < blockIdx.x) before += v; }
+        s_tot[threadIdx.x] = tot; s_before[threadIdx.x] = before; s_cur[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int c = kOrderClasses - 1; c >= 0; c--) { s_base[c] = run + s_before[c]; run += s_tot[c]; }      // descending classes
+        if (blockIdx.x == 0) {
+            // a ticket holds 1 query from 2 048 similar k-mers up (class 44), 2 from 1 024 (40), 4 from 512 (36), 8 below
+            uint32_t p1 = 0, p2 = 0, p3 = 0;
+            for (int c = kOrderClasses - 1; c >= 36; c--) { if (c >= 44) p1 += s_tot[c]; if (c >= 40) p2 += s_tot[c]; p3 += s_tot[c]; }
+            OrderHeader h;
+            h.p[0] = p1; h.p[1] = p2; h.p[2] = p3; h.p[3] = nq;
+            h.t[0] = p1; h.t[1] = h.t[0] + (p2 - p1 + 1u) / 2u; h.t[2] = h.t[1] + (p3 - p2 + 3u) / 4u; h.t[3] = h.t[2] + (nq - p3 + 7u) / 8u;
+            *header = h;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (uint32_t) kOrderQueues) queues[threadIdx.x * kOrderQueueStride] = firstTickets;      // (every wave starts with the ticket of its own number)
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (uint32_t) kOrderTile; i += 256) {
+        const uint32_t q = blockIdx.x * kOrderTile + i;
+        if (q < nq) { const uint32_t c = weightClass(weight[q]); order[s_base[c] + atomicAdd(&s_cur[c], 1u)] = q; }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -545,6 +600,7 @@ struct MatchArgs {
     const uint32_t *heavyList; const uint8_t *heavyFlag; const uint32_t *heavyCount;   // k_weigh: queries to start with
     unsigned long long *wavePartial;   // [wave][4]: similar k-mers, index entries, diagonals of this wave (summed by k_score: 9 000 atomics on
                                        // one cache line at the end of the kernel, when all waves finish together, cost tens of microseconds)
+    const uint32_t *order; const OrderHeader *orderHeader; uint32_t *orderQueues;   // k_match_grp, optional: the batch by decreasing weight and its tickets (k_order_*)
 };
 
 // phase timers (build with -DSP_PHASE_TIMERS): shader-clock ticks per phase, summed over waves into counters[8 + phase]
@@ -2075,11 +2131,11 @@ struct Gpu::Impl {
     int numCU = 256;
     // environment knobs (diagnostics / experiments), read once per context instead of once per pass
     struct Knobs {
-        int matchSmall = -1, matchPerCU = 0, matchHeavy = -1, matchStatic = 4, matchDChunk = 4, weighExact = -1, matchGroup = 1;
+        int matchSmall = -1, matchPerCU = 0, matchHeavy = -1, matchStatic = 4, matchDChunk = 4, weighExact = -1, matchGroup = 1, matchOrder = 1;
         bool debug = false, prepSplit = false, swRows32 = false, swRows16 = false, swOldForward = false;
         void read() {
             auto num = [](const char *k, int d) { const char *e = getenv(k); return e ? atoi(e) : d; };
-            matchSmall = num("SP_MATCH_SMALL", -1); matchGroup = num("SP_MATCH_GROUP", 1); { const int we = num("SP_MATCH_WEIGH_EXACT", -1); weighExact = we < 0 ? -1 : (we ? 1 : 0); } matchPerCU = num("SP_MATCH_PERCU", 0); matchHeavy = num("SP_MATCH_HEAVY", -1);
+            matchSmall = num("SP_MATCH_SMALL", -1); matchGroup = num("SP_MATCH_GROUP", 1); matchOrder = num("SP_MATCH_ORDER", 1); { const int we = num("SP_MATCH_WEIGH_EXACT", -1); weighExact = we < 0 ? -1 : (we ? 1 : 0); } matchPerCU = num("SP_MATCH_PERCU", 0); matchHeavy = num("SP_MATCH_HEAVY", -1);
             matchStatic = std::min(8, std::max(0, num("SP_MATCH_STATIC", 4))); matchDChunk = std::min(32, std::max(1, num("SP_MATCH_DCHUNK", 4)));      // (a chunk's offsets live in the lanes of a wave)
             debug = getenv("SP_DEBUG") != nullptr; prepSplit = getenv("SP_PREP_SPLIT") != nullptr; swRows32 = getenv("SP_SW_ROWS32") != nullptr;
             swRows16 = getenv("SP_SW_ROWS16") != nullptr; swOldForward = getenv("SP_SW_OLD_FORWARD") != nullptr;
@@ -2114,7 +2170,7 @@ struct Gpu::Impl {
     size_t qTotal = 0; uint32_t maxQLen = 0;
     std::vector<uint32_t> hQoff;
     // match / select
-    DevBuf<uint64_t> spill; DevBuf<uint32_t> heavyList; DevBuf<uint32_t> heavyCnt; DevBuf<uint8_t> heavyFlag; DevBuf<unsigned long long> wavePartial; DevBuf<uint32_t> queue; DevBuf<DiagRec> diagRec; DevBuf<uint32_t> diagQuery; DevBuf<uint16_t> diagScore; DevBuf<uint8_t> diagFlag;
+    DevBuf<uint32_t> qweight, qorder, orderHist, orderHeader, orderQueues; DevBuf<uint64_t> spill; DevBuf<uint32_t> heavyList; DevBuf<uint32_t> heavyCnt; DevBuf<uint8_t> heavyFlag; DevBuf<unsigned long long> wavePartial; DevBuf<uint32_t> queue; DevBuf<DiagRec> diagRec; DevBuf<uint32_t> diagQuery; DevBuf<uint16_t> diagScore; DevBuf<uint8_t> diagFlag;
     DevBuf<uint32_t> qDiagBase; DevBuf<uint32_t> qDiagCnt; DevBuf<unsigned long long> counters;
     DevBuf<GpuHit> outHits; DevBuf<GpuHit> outStage; DevBuf<uint32_t> outQuery; DevBuf<uint32_t> outCount; DevBuf<uint32_t> outBase; DevBuf<uint32_t> outOffset;
     uint32_t matchBlocks = 0;
@@ -2232,6 +2288,7 @@ bool Gpu::setKnob(const std::string &name, int value) {
     if (name == "match_chunk") { d_->knob.matchDChunk = std::min(32, std::max(1, value)); return true; }      // queries per pop of the dynamically dealt part
     if (name == "match_static") { d_->knob.matchStatic = std::min(8, std::max(0, value)); return true; }      // eighths of the queries dealt round-robin without atomics
     if (name == "match_small") { d_->knob.matchSmall = value < 0 ? -1 : (value ? 1 : 0); return true; }
+    if (name == "match_order") { d_->knob.matchOrder = value ? 1 : 0; return true; }      // k_match_grp takes the batch in the order of decreasing weight (list schedule); 0: heavy queries first, then shares
     if (name == "match_group") { d_->knob.matchGroup = value ? 1 : 0; return true; }      // k_match_grp (queries matched four at a time) where its preconditions hold; 0: always k_match
     if (name == "match_heavy_threshold") { d_->knob.matchHeavy = value < 0 ? -1 : value; return true; }
     if (name == "step_capacity") { d_->stepCap = value < 0 ? 0 : (size_t) value; return true; }      // pairs the next device-driven step is sized for (0 = estimate again); tests
@@ -2484,7 +2541,13 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     // exact weights order the heavy queries better (k_match alone 0.43 instead of 0.47 ms on the bench workload) and cost k_prep8 two table rows per window -- 20 us alone, a
     // multiple beside other contexts' matching kernels, where the estimate wins: exact while this context is the only one searching on its device
     const bool weighExact = d.knob.weighExact > 0 || (d.knob.weighExact < 0 && g_searchers[d.device & 63].load(std::memory_order_relaxed) <= 1);
-    WeighArgs wa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.tab->ext3.p, d.tab->ext3cnt.p, d.tab->cntMin, heavyThr ? heavyThr : 0xFFFFFFFFu, d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p, weighExact ? nullptr : d.tab->heavyEst.p};
+    // the grouped kernel takes its queries in the order of decreasing weight (k_order_*) instead of "heavy ones first, then shares": needs the weights (k_prep8)
+    const bool ordered = grouped && heavyThr != 0 && d.knob.matchOrder != 0 && d.maxQLen <= 64 && !d.knob.prepSplit;
+    const uint32_t orderTiles = (uint32_t) ((nq_ + kOrderTile - 1) / kOrderTile);
+    if (ordered && (!d.qweight.ensure(nq_ + 1, err) || !d.qorder.ensure(nq_ + 1, err) || !d.orderHist.ensure((size_t) orderTiles * kOrderClasses, err) || !d.orderHeader.ensure(8, err) ||
+                    !d.orderQueues.ensure(kOrderQueues * kOrderQueueStride, err))) return false;
+    WeighArgs wa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.tab->ext3.p, d.tab->ext3cnt.p, d.tab->cntMin, ordered ? 0xFFFFFFFEu : (heavyThr ? heavyThr : 0xFFFFFFFFu), d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p,
+                 weighExact ? nullptr : d.tab->heavyEst.p, ordered ? d.qweight.p : nullptr};
     const unsigned weighBlocks = (unsigned) std::min<size_t>((nq_ + 31) / 32, (size_t) d.numCU * 8);
     if (d.maxQLen <= 64 && !d.knob.prepSplit) {
         const uint32_t stride = std::max<uint32_t>(16u, (d.maxQLen + 7u) & ~7u);      // staging row per query (<= 64)
@@ -2496,6 +2559,12 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
         if (p8.w.est || !heavyThr) hipLaunchKernelGGL(k_prep8<false>, dim3(weighBlocks), dim3(256), (size_t) 32 * stride * 12, d.stream, p8);
         else hipLaunchKernelGGL(k_prep8<true>, dim3(weighBlocks), dim3(256), (size_t) 32 * stride * 12, d.stream, p8);
         SP_DBG_SYNC("k_prep8");
+        if (ordered) {
+            hipLaunchKernelGGL(k_order_count, dim3(orderTiles), dim3(256), 0, d.stream, d.qweight.p, (uint32_t) nq_, d.orderHist.p);
+            hipLaunchKernelGGL(k_order_scatter, dim3(orderTiles), dim3(256), 0, d.stream, d.qweight.p, (uint32_t) nq_, d.orderHist.p, orderTiles, d.qorder.p, reinterpret_cast<OrderHeader *>(d.orderHeader.p),
+                               d.orderQueues.p, blocks * (uint32_t) kWavesPerBlock / (uint32_t) kOrderQueues);
+            SP_DBG_SYNC("k_order");
+        }
     } else {
         d.swBiasFresh = false;
         hipLaunchKernelGGL(k_prep, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, pa);
@@ -2518,7 +2587,8 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
                  (uint32_t) d.knob.matchStatic, (uint32_t) d.knob.matchDChunk,
-                 d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p, d.wavePartial.p};
+                 d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p, d.wavePartial.p,
+                 ordered ? d.qorder.p : nullptr, ordered ? reinterpret_cast<const OrderHeader *>(d.orderHeader.p) : nullptr, ordered ? d.orderQueues.p : nullptr};
     if (grouped) hipLaunchKernelGGL(k_match_grp, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     else if (small) {
         if (withOrd) hipLaunchKernelGGL((k_match<256, true, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
