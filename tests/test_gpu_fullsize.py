@@ -109,6 +109,13 @@ def test_work_order_and_timing_level_do_not_change_results(full):
             assert same(), thr
     finally:
         ctx.set_tuning("match_heavy_threshold", -1)
+    # the list schedule of the grouped kernel (batch sorted by weight, tickets) against heavy-first + dealt shares, estimated against exact weights, the ungrouped kernel
+    try:
+        for knob, value in (("match_order", 0), ("match_weigh_exact", 1), ("match_order", 1), ("match_group", 0), ("match_weigh_exact", 0)):
+            ctx.set_tuning(knob, value)
+            assert same(), (knob, value)
+    finally:
+        ctx.set_tuning("match_order", 1); ctx.set_tuning("match_weigh_exact", -1); ctx.set_tuning("match_group", 1)
     try:
         ctx.set_timing(0); assert same(); assert ctx.stat("ms_match") != ctx.stat("ms_match")          # NaN
         ctx.set_timing(2); assert same(); assert ctx.stat("ms_match") > 0 and ctx.stat("ms_select") > 0
