@@ -239,7 +239,7 @@ int sp_ctx_set_queries(sp_ctx *c, const char *residues, const uint64_t *offsets,
         const size_t T = (size_t) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::min(16, std::max(1, c->threads)), R / (1u << 19) + 1));
         auto map = [&](size_t t) { for (uint64_t i = R * t / T, e = R * (t + 1) / T; i < e; i++) c->qres[i] = c->seed.aa2num[(uint8_t) residues[i]]; };
         if (T == 1) map(0);
-        else { std::vector<std::thread> pool; for (size_t t = 0; t < T; t++) pool.emplace_back(map, t); for (auto &th : pool) th.join(); }
+        else sp::runTasks(T, map);
     }
     std::string err;
     if (!c->gpu.uploadQueries(c->qres.data(), c->qoff.data(), (size_t) n, err)) { g_err = err; return SP_ERR_DEVICE; }

@@ -13,6 +13,9 @@
 #include <fstream>
 #include <sstream>
 #include <sched.h>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <unistd.h>
 
@@ -22,17 +25,55 @@ namespace sp {
 
 const int kPatternPos[kKmer] = {0, 1, 3, 4, 5, 7};
 
+// ---- the worker pool behind runTasks() ------------------------------------------------------------------------
+namespace {
+struct WorkPool {
+    std::mutex m; std::condition_variable wake, finished;
+    std::vector<std::thread> workers;
+    const std::function<void(size_t)> *job = nullptr; size_t tasks = 0; std::atomic<size_t> next{0}; size_t pending = 0; uint64_t generation = 0; bool busy = false, stop = false;
+    void workerLoop() {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(size_t)> *f; size_t n;
+            {   std::unique_lock<std::mutex> lk(m);
+                wake.wait(lk, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation; f = job; n = tasks; }
+            for (size_t t = next.fetch_add(1); t < n; t = next.fetch_add(1)) (*f)(t);
+            {   std::lock_guard<std::mutex> lk(m); if (--pending == 0) finished.notify_all(); }
+        }
+    }
+    void run(size_t n, const std::function<void(size_t)> &f) {
+        if (n <= 1) { if (n) f(0); return; }
+        std::unique_lock<std::mutex> lk(m);
+        if (busy || stop) { lk.unlock(); for (size_t t = 0; t < n; t++) f(t); return; }      // (a section inside a section, or two callers at once)
+        busy = true;
+        const size_t want = std::min<size_t>(n - 1, 63);
+        while (workers.size() < want) workers.emplace_back([this] { workerLoop(); });
+        job = &f; tasks = n; next = 0; pending = workers.size(); generation++;
+        lk.unlock();
+        wake.notify_all();
+        for (size_t t = next.fetch_add(1); t < n; t = next.fetch_add(1)) f(t);
+        lk.lock();
+        finished.wait(lk, [&] { return pending == 0; });      // (every worker has looked at this job: none is left inside f)
+        job = nullptr; busy = false;
+    }
+    ~WorkPool() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        wake.notify_all();
+        for (std::thread &t : workers) t.join();
+    }
+};
+WorkPool &workPool() { static WorkPool *p = new WorkPool; return *p; }      // (never destroyed: a process that leaves through _exit must not wait for it, and exit() need not)
+}  // namespace
+void runTasks(size_t tasks, const std::function<void(size_t)> &f) { workPool().run(tasks, f); }
+
 template <typename F>
 static void parallelFor(size_t n, int threads, F f) {
     threads = std::max(1, std::min<int>(threads, (int) std::max<size_t>(1, n)));
     if (threads == 1) { f(0, 0, n); return; }
-    std::vector<std::thread> pool;
-    size_t chunk = (n + threads - 1) / threads;
-    for (int t = 0; t < threads; t++) {
-        size_t a = std::min(n, t * chunk), b = std::min(n, a + chunk);
-        pool.emplace_back([=]() { f(t, a, b); });
-    }
-    for (auto &th : pool) th.join();
+    const size_t chunk = (n + threads - 1) / threads;
+    runTasks((size_t) threads, [&](size_t t) { const size_t a = std::min(n, t * chunk), b = std::min(n, a + chunk); f((int) t, a, b); });
 }
 
 // ---------------------------------------------------------------------------------------------------------------

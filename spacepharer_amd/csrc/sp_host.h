@@ -6,6 +6,7 @@
 #pragma once
 #include <cstdint>
 #include <cstddef>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -69,6 +70,12 @@ struct KmerIndex {
 void prepareTargets(const SubMat &seed, const char *residues, const uint64_t *offsets, const uint32_t *keys, size_t n,
                     bool mask, int threads, TargetSet &ts, size_t from = 0, size_t to = (size_t) -1);
 void buildIndex(const SubMat &seed, const TargetSet &ts, int kmerThr, int threads, KmerIndex &idx, size_t from = 0, size_t to = (size_t) -1);
+
+// Parallel sections of the host code: run f(0) .. f(tasks - 1) on the calling thread and the workers of ONE process-wide pool.  The workers are kept: a module
+// call has eight or nine short parallel sections (index parse, flatten, residue mapping, two formatters, two index texts ...) and spawning 16 threads for each
+// costs 0.3-0.5 ms a time (tools/micro/thread_spawn.cpp).  One section at a time: a section started while another one runs (or from inside one) runs on the
+// calling thread alone.
+void runTasks(size_t tasks, const std::function<void(size_t)> &f);
 
 // host threads to use when the caller does not say: the CPUs this process may run on, capped by the cgroup CPU quota of its container
 int defaultThreads();
