@@ -15,6 +15,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <set>
 #include <sstream>
 #include <string>
@@ -171,6 +172,32 @@ static void flatten(const Db &db, std::vector<char> &res, std::vector<uint64_t> 
     res.resize(off[n]);
     parallelChunks(n, threads, [&](size_t, size_t from, size_t to) { for (size_t i = from; i < to; i++) memcpy(res.data() + off[i], db.ptr(i), (size_t) (off[i + 1] - off[i])); });
     if (res.empty()) res.push_back('X');
+}
+
+// A sequence DB as the search takes it (residues back to back, offsets, keys).  A resident server keeps the last few by file identity (real path, sizes and
+// modification times of the data, index and dbtype files -- what the staged target sets are keyed by): predictmatch searches the SAME query set against the targets
+// and then against the control set, and reading + parsing + flattening 6 x 10^5 entries is 9 of the 27 ms of a served `prefilter` call.
+struct FlatDb { std::string id; std::vector<char> res; std::vector<uint64_t> off; std::vector<uint32_t> keys; uint64_t stamp = 0; };
+static std::vector<std::shared_ptr<FlatDb>> g_flatCache; static uint64_t g_flatStamp = 0;
+static std::shared_ptr<const FlatDb> flatSeqDb(const std::string &path, std::string &err) {
+    const bool serving = ctxCacheSize() > 0;
+    const std::string id = serving ? fileIdentity(path) : std::string();
+    if (serving) {
+        std::lock_guard<std::mutex> lk(g_ctxMutex);
+        for (auto &e : g_flatCache) if (e->id == id) { e->stamp = ++g_flatStamp; return e; }
+    }
+    Db db;
+    if (!loadSeqDb(path, db, err)) return nullptr;
+    auto f = std::make_shared<FlatDb>();
+    flatten(db, f->res, f->off, f->keys);
+    if (serving) {
+        f->id = id;
+        std::lock_guard<std::mutex> lk(g_ctxMutex);
+        f->stamp = ++g_flatStamp;
+        if (g_flatCache.size() >= 4) { size_t old = 0; for (size_t i = 1; i < g_flatCache.size(); i++) if (g_flatCache[i]->stamp < g_flatCache[old]->stamp) old = i; g_flatCache.erase(g_flatCache.begin() + (long) old); }
+        g_flatCache.push_back(f);
+    }
+    return f;
 }
 
 // Path of the front-end binary that workers are started from: $SP_WORKER_EXE, else `spacepharer-amd` next to this library.
@@ -354,8 +381,8 @@ int runPrefilterModule(int argc, const char **argv) {
         return fail("prefilter: " + err);
     { const int rc = fanOut("prefilter", argc, argv, f.positional[2]); if (rc >= 0) return rc; }
     Laps laps("prefilter");
-    Db qdb, tdb;
-    if (!loadSeqDb(f.positional[0], qdb, err) || !loadSeqDb(f.positional[1], tdb, err)) return fail("prefilter: " + err);
+    std::shared_ptr<const FlatDb> qf = flatSeqDb(f.positional[0], err), tf = qf ? flatSeqDb(f.positional[1], err) : nullptr;
+    if (!qf || !tf) return fail("prefilter: " + err);
     laps.lap("read DBs");
     sp_search_params p; sp_default_params(&p);
     std::string seed = aaPart(f.str("--seed-sub-mat", "VTML80.out")), sub = aaPart(f.str("--sub-mat", "VTML40.out"));
@@ -369,8 +396,7 @@ int runPrefilterModule(int argc, const char **argv) {
     Ctx ctx;
     if (!acquireCtx(p, f.positional[1], "index", ctx, err)) return fail("prefilter: " + err);
     laps.lap("context (matrices, tables)");
-    std::vector<char> tres, qres; std::vector<uint64_t> toff, qoff; std::vector<uint32_t> tkeys, qkeys;
-    flatten(tdb, tres, toff, tkeys);
+    const std::vector<char> &tres = tf->res, &qres = qf->res; const std::vector<uint64_t> &toff = tf->off, &qoff = qf->off; const std::vector<uint32_t> &tkeys = tf->keys, &qkeys = qf->keys;
     if (!ctx.targetsStaged && sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) {
         // serving: cached target sets of earlier calls may be what fills the device; a fresh process would have succeeded, so drop them all and stage again
         std::string e = sp_last_error();
@@ -384,7 +410,6 @@ int runPrefilterModule(int argc, const char **argv) {
         if (!e.empty()) return fail("prefilter: " + e);
     }
     laps.lap("targets -> device, index");
-    flatten(qdb, qres, qoff, qkeys);
     DbWriter w; w.path = f.positional[2]; w.dbtype = 7;      // DBTYPE_PREFILTER_RES
     const size_t batch = 1u << 20;
     size_t qFrom = 0, nq = qkeys.size();
@@ -661,8 +686,9 @@ int runSearchModule(int argc, const char **argv) {
     if (f.num("-a", 0) != 1) return fail("search: only -a 1 (backtrace => score, coverage and sequence identity) is implemented, which is what predictmatch passes");
     { const int rc = fanOut("search", argc, argv, f.positional[2]); if (rc >= 0) return rc; }
     Laps laps("search");
-    Db qdb, tdb;
-    if (!loadSeqDb(f.positional[0], qdb, err)) return fail("search: " + err);
+    Db tdb;
+    std::shared_ptr<const FlatDb> qf = flatSeqDb(f.positional[0], err);
+    if (!qf) return fail("search: " + err);
     laps.lap("read query DB");
     sp_search_params p; sp_default_params(&p);
     std::string seed = aaPart(f.str("--seed-sub-mat", "VTML80.out")), sub = aaPart(f.str("--sub-mat", "VTML40.out"));
@@ -697,7 +723,8 @@ int runSearchModule(int argc, const char **argv) {
     if (shardTargets) { ctx.c = sp_ctx_create(&p); if (!ctx.c) return fail(std::string("search: ") + sp_last_error()); }      // (a shard is not a cacheable target set)
     else if (!acquireCtx(p, f.positional[1], "index", ctx, err)) return fail("search: " + err);
     laps.lap("context (matrices, tables)");
-    std::vector<char> tres, qres; std::vector<uint64_t> toff, qoff; std::vector<uint32_t> tkeys, qkeys;
+    std::vector<char> tres; std::vector<uint64_t> toff; std::vector<uint32_t> tkeys;
+    const std::vector<char> &qres = qf->res; const std::vector<uint64_t> &qoff = qf->off; const std::vector<uint32_t> &qkeys = qf->keys;
     if (shardTargets) {
         if (!loadSeqDb(f.positional[1], tdb, err)) return fail("search: " + err);
         flatten(tdb, tres, toff, tkeys);
@@ -711,7 +738,6 @@ int runSearchModule(int argc, const char **argv) {
         if (sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) { const std::string e = sp_last_error(); dropCtx(ctx); return fail("search: " + e); }
     }
     laps.lap("targets -> device, index");
-    flatten(qdb, qres, qoff, qkeys);
     const double minSeqId = f.real("--min-seq-id", 0.0); const long minAlnLen = f.num("--min-aln-len", 0);
     const long maxAccept = f.num("--max-accept", INT_MAX), maxRejected = f.num("--max-rejected", INT_MAX);
     const int threads = (int) f.num("--threads", 0) > 0 ? (int) f.num("--threads", 0) : defaultThreads();

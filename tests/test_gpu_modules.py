@@ -436,6 +436,17 @@ def test_auto_started_server_and_align_on_resident_hits(tmp_path):
     assert open(str(tmp_path / "server.log")).read().count("resident hits") == n_res
     # ... and another query DB under the memo's result name
     assert pair(env, "_e", qdb="qdb2") == pair(direct, "_e_ref", qdb="qdb2")
+    # ... a query DB rewritten IN PLACE (same path, same sizes, other sequences) behind the server's cache of flattened sequence DBs, and back
+    import shutil
+    for ext in ("", ".index", ".dbtype"):
+        shutil.copy(str(tmp_path / ("qdb" + ext)), str(tmp_path / ("qdb_keep" + ext)))
+    time.sleep(0.02)
+    write_seq_db(str(tmp_path / "qdb"), g["queries"][::-1], keys=qkeys)
+    assert pair(env, "_g") == pair(direct, "_g_ref") and pair(env, "_g2") != ref
+    time.sleep(0.02)
+    for ext in ("", ".index", ".dbtype"):
+        shutil.copy(str(tmp_path / ("qdb_keep" + ext)), str(tmp_path / ("qdb" + ext)))
+    assert pair(env, "_h") == ref
     # idle: the server leaves and takes its socket with it; the next call starts a new one
     for _ in range(200):
         if not os.path.exists(sock):
