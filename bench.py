@@ -624,8 +624,9 @@ def main():
     dense = None
     if dual and not args.no_dense and (n_spacers, args.targets, args.target_len) == (10000, 50000, 200):
         # the density north_star's target DB has: the same 10 000 spacers against 10^6 x 200 residues (95 % of the k-mer slots occupied, 2 200 index hits per query):
-        # device-driven steps in two contexts (four lose there), fewer steps -- a step is ten times longer
-        dense = measure(False, 10000, max(4, args.steps // 10), max(1, min(3, args.regions)), 2, True, pipeline=2, host_driven=False, targets=1000000)
+        # host-driven steps in two contexts, fewer steps -- a step is ten times longer.  (The dense matching kernel fills every CU's LDS: more contexts LOSE there
+        # -- three 1.4 M, four 1.7 M spacer-queries/s -- and the device-driven step in two contexts 2.1 M against 2.5 M: profiles/r04_dense_step_modes.txt)
+        dense = measure(False, 10000, max(4, args.steps // 10), max(1, min(3, args.regions)), 2, True, pipeline=2, host_driven=True, targets=1000000)
     pairs_total = all_sum(float(m["pairs"][0]))      # batch 0 of every rank (sharded: the ranks' query slices add up to the batch)
     if comm is not None:
         comm.barrier()
@@ -706,7 +707,7 @@ def main():
         dexcl = dense["stats"]["ms_match"]
         out["dense"] = {"workload": "10000 synthetic 30-nt spacers vs 1000000 synthetic phage ORFs x 200 aa (2.0e+08 residues: the survey's estimate of GenBank_phage_2018_09), 1xMI355X, prefilter + align",
                         "value": 10000 * dsteps / ddt, "unit": "spacer-queries/s", "ms_per_step": ddt / dsteps * 1e3, "steps": dsteps, "regions": dregions, "results_checked": dense["checked"],
-                        "pairs_aligned_per_step": dense["pairs"][0], "index_build_s": round(dense["t_index"], 3), "step": "device-driven, two contexts",
+                        "pairs_aligned_per_step": dense["pairs"][0], "index_build_s": round(dense["t_index"], 3), "step": "host-driven, two contexts",
                         "kernels_ms_per_step": {k[3:]: round(v, 4) for k, v in dense["stats"].items()},
                         "counters_per_step": {"similar_kmers": dK, "index_entries_fetched": dM, "diagonals_scored": dD},
                         "roofline": {"kernel": "k_match<512,false,false> (large footprint, direct bucket table)", "algorithmic_bytes_per_launch": dalgo,
