@@ -639,7 +639,10 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     // SP_MATCH_HEAVY: similar k-mers from which a query counts as heavy and is started first (0 = none)
     // (worth its 30 us per 60 000 queries only while a wave gets few queries: with more than ~30 per wave the heavy ones no
     // longer decide when the kernel ends)
-    const uint32_t heavyThr = d.knob.matchHeavy >= 0 ? (uint32_t) d.knob.matchHeavy : (nq_ <= (size_t) blocks * kWavesPerBlock * 32 ? 4000u : 0u);
+    // (the grouped kernel's list schedule wants the weights of ANY batch: 6 x 10^5 peptides -- 146 per wave -- still end 5 % apart, 2.98 -> 2.82 ms for 0.07 ms of weighing
+    // and sorting)
+    const uint32_t heavyThr = d.knob.matchHeavy >= 0 ? (uint32_t) d.knob.matchHeavy
+                            : ((nq_ <= (size_t) blocks * kWavesPerBlock * 32 || (grouped && d.knob.matchOrder != 0 && d.maxQLen <= 64 && !d.knob.prepSplit)) ? 4000u : 0u);
     // exact weights order the heavy queries better (k_match alone 0.43 instead of 0.47 ms on the bench workload) and cost k_prep8 two table rows per window -- 20 us alone, a
     // multiple beside other contexts' matching kernels, where the estimate wins: exact while this context is the only one searching on its device
     // (... while the heavy queries were LISTED by a threshold.  With the batch sorted by weight -- `ordered` below, the grouped kernel -- the estimate orders it well enough: 0.353 ms
