@@ -642,12 +642,12 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     // (the grouped kernel's list schedule wants the weights of ANY batch: 6 x 10^5 peptides -- 146 per wave -- still end 5 % apart, 2.98 -> 2.82 ms for 0.07 ms of weighing
     // and sorting)
     const uint32_t heavyThr = d.knob.matchHeavy >= 0 ? (uint32_t) d.knob.matchHeavy
-                            : ((nq_ <= (size_t) blocks * kWavesPerBlock * 32 || (grouped && d.knob.matchOrder != 0 && d.maxQLen <= 64 && !d.knob.prepSplit)) ? 4000u : 0u);
+                            : ((nq_ <= (size_t) blocks * kWavesPerBlock * 32 || ((grouped || !small) && d.knob.matchOrder != 0 && d.maxQLen <= 64 && !d.knob.prepSplit)) ? 4000u : 0u);
     // exact weights order the heavy queries better (k_match alone 0.43 instead of 0.47 ms on the bench workload) and cost k_prep8 two table rows per window -- 20 us alone, a
     // multiple beside other contexts' matching kernels, where the estimate wins: exact while this context is the only one searching on its device
     // (... while the heavy queries were LISTED by a threshold.  With the batch sorted by weight -- `ordered` below, the grouped kernel -- the estimate orders it well enough: 0.353 ms
     // + 0.044 prep against 0.365 + 0.064 with exact counts; exact there only on request)
-    const bool orderedPossible = grouped && heavyThr != 0 && d.knob.matchOrder != 0 && d.maxQLen <= 64 && !d.knob.prepSplit;
+    const bool orderedPossible = (grouped || !small) && heavyThr != 0 && d.knob.matchOrder != 0 && d.maxQLen <= 64 && !d.knob.prepSplit;      // (k_match_grp, and k_match on the dense index)
     const bool weighExact = d.knob.weighExact > 0 || (d.knob.weighExact < 0 && !orderedPossible && g_searchers[d.device & 63].load(std::memory_order_relaxed) <= 1);
     // the grouped kernel takes its queries in the order of decreasing weight (k_order_*) instead of "heavy ones first, then shares": needs the weights (k_prep8)
     const bool ordered = orderedPossible;
