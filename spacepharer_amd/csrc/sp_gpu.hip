@@ -785,7 +785,7 @@ bool Gpu::queueSelect(unsigned binSize, int maxHits, int minDiagScore, void *hit
     const size_t stageCap = std::max<size_t>(nq_ * (size_t) maxHits, d.diagCap);
     if (!d.outHits.ensure(nq_ * (size_t) maxHits, err) || !d.outStage.ensure(stageCap, err) || !d.outQuery.ensure(stageCap, err)) return false;
     SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.qDiagBase.p,
-                  binSize - 1, maxHits, minDiagScore, d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.counters.p, d.tgt->denseIndex ? 16u : (uint32_t) kSelChunk};
+                  binSize - 1, maxHits, minDiagScore, d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.counters.p, d.tgt->denseIndex ? 4u : (uint32_t) kSelChunk};      // (dense index: every query takes the whole-wave path -- small chunks deal them evenly)
     hipLaunchKernelGGL(k_select, dim3(d.matchBlocks), dim3(64 * kWavesPerBlock), 0, d.stream, se);
     if (hitsLeft) HIP_OK(hipStreamWaitEvent(d.stream, static_cast<hipEvent_t>(hitsLeft), 0));      // the previous step's hit list has left outOffset / outHits
     if (!d.scanCounts(d.outCount.p, (uint32_t) nq_, d.outOffset.p, err)) return false;
