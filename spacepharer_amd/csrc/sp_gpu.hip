@@ -652,7 +652,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     // the grouped kernel takes its queries in the order of decreasing weight (k_order_*) instead of "heavy ones first, then shares": needs the weights (k_prep8)
     const bool ordered = orderedPossible;
     const uint32_t orderTiles = (uint32_t) ((nq_ + kOrderTile - 1) / kOrderTile);
-    if (ordered && (!d.qweight.ensure(nq_ + 1, err) || !d.qorder.ensure(nq_ + 1, err) || !d.orderHist.ensure((size_t) orderTiles * kOrderClasses, err) || !d.orderHeader.ensure(8, err) ||
+    if (ordered && (!d.qweight.ensure(nq_ + 1, err) || !d.qorder.ensure(nq_ + 1, err) || !d.orderHist.ensure((size_t) orderTiles * kOrderClasses, err) || !d.orderHeader.ensure(16, err) ||
                     !d.orderQueues.ensure(kOrderQueues * kOrderQueueStride, err))) return false;
     WeighArgs wa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.tab->ext3.p, d.tab->ext3cnt.p, d.tab->cntMin, ordered ? 0xFFFFFFFEu : (heavyThr ? heavyThr : 0xFFFFFFFFu), d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p,
                  weighExact ? nullptr : d.tab->heavyEst.p, ordered ? d.qweight.p : nullptr};
@@ -670,7 +670,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
         if (ordered) {
             hipLaunchKernelGGL(k_order_count, dim3(orderTiles), dim3(256), 0, d.stream, d.qweight.p, (uint32_t) nq_, d.orderHist.p);
             hipLaunchKernelGGL(k_order_scatter, dim3(orderTiles), dim3(256), 0, d.stream, d.qweight.p, (uint32_t) nq_, d.orderHist.p, orderTiles, d.qorder.p, reinterpret_cast<OrderHeader *>(d.orderHeader.p),
-                               d.orderQueues.p, blocks * (uint32_t) kWavesPerBlock / (uint32_t) kOrderQueues);
+                               d.orderQueues.p, blocks * (uint32_t) kWavesPerBlock / (uint32_t) kOrderQueues, small ? 0u : 1u);
             SP_DBG_SYNC("k_order");
         }
     } else {
