@@ -177,7 +177,9 @@ struct DbWriter {
     void addBlock(const std::vector<uint32_t> &keys, const std::vector<uint64_t> &lengths, std::string &&block) {
         if (!data.empty()) { blocks.emplace_back(data.begin(), data.end()); blockBytes += data.size(); data.clear(); }
         uint64_t at = blockBytes;
-        for (size_t i = 0; i < keys.size(); i++) { DbEntry e; e.key = keys[i]; e.offset = at; e.length = lengths[i]; entries.push_back(e); at += lengths[i]; }
+        const size_t first = entries.size(); entries.resize(first + keys.size());
+        DbEntry *e = entries.data() + first;
+        for (size_t i = 0; i < keys.size(); i++) { e[i].key = keys[i]; e[i].offset = at; e[i].length = lengths[i]; at += lengths[i]; }
         blockBytes += block.size();
         blocks.push_back(std::move(block));
     }
@@ -381,25 +383,46 @@ inline char *fmtE3(double x, char *p) {
     return r.ptr;
 }
 
+// "%.3E" through a small cache keyed by the double's bits: E-values are a function of (score, query length) and repeat by the thousand in a result DB
+inline char *fmtE3Cached(double x, char *p) {
+    struct Slot { uint64_t bits; uint8_t len; char text[15]; };
+    static thread_local Slot cache[1024] = {};
+    uint64_t bits; memcpy(&bits, &x, 8);
+    Slot &s = cache[(bits * 0x9E3779B97F4A7C15ull) >> 54];
+    if (s.len == 0 || s.bits != bits) {
+        char tmp[40]; char *e = fmtE3(x, tmp);
+        if ((size_t) (e - tmp) > sizeof(s.text)) { memcpy(p, tmp, (size_t) (e - tmp)); return p + (e - tmp); }      // (inf / nan / exponents of three digits: not cached)
+        s.bits = bits; s.len = (uint8_t) (e - tmp); memcpy(s.text, tmp, s.len);
+    }
+    memcpy(p, s.text, s.len);
+    return p + s.len;
+}
+
 inline void appendAlnLine(std::string &out, const sp_alignment &r, const char *cigar, bool addBacktrace) {
-    char buf[256]; char *p = buf;
+    // the whole line in a local buffer, one append (flushed in between only for a backtrace of hundreds of runs)
+    char buf[512]; char *p = buf;
     p = u32toa(r.db_key, p); *p++ = '\t';
     p = i32toa(r.bit_score, p); *p++ = '\t';
     // Util::fastSeqIdToBuffer (Util.cpp:278-306): for 1.0 the caller overwrites the third '0' with the tab
     if (r.seq_id == 1.0) { memcpy(p, "1.00", 4); p += 4; }
     else { *p++ = '0'; *p++ = '.'; if (r.seq_id < 0.10) *p++ = '0'; if (r.seq_id < 0.01) *p++ = '0'; p = i32toa((int) (r.seq_id * 1000), p); }
     *p++ = '\t';
-    p = fmtE3(r.evalue, p); *p++ = '\t';
+    p = fmtE3Cached(r.evalue, p); *p++ = '\t';
     p = i32toa(r.q_start, p); *p++ = '\t'; p = i32toa(r.q_end, p); *p++ = '\t'; p = i32toa((int) r.q_len, p); *p++ = '\t';
     p = i32toa(r.db_start, p); *p++ = '\t'; p = i32toa(r.db_end, p); *p++ = '\t'; p = i32toa((int) r.db_len, p);
-    out.append(buf, p - buf);
     if (addBacktrace) {          // Matcher::compressAlignment (Matcher.cpp:211-230)
-        out.push_back('\t');
-        char state = 'M'; size_t counter = 0; char nb[16];
-        for (const char *c = cigar; *c; c++) { if (*c != state) { char *e = u32toa((uint32_t) counter, nb); out.append(nb, e - nb); out.push_back(state); state = *c; counter = 1; } else counter++; }
-        char *e = u32toa((uint32_t) counter, nb); out.append(nb, e - nb); out.push_back(state);
+        *p++ = '\t';
+        char state = 'M'; uint32_t counter = 0;
+        for (const char *c = cigar; *c; c++) {
+            if (*c != state) {
+                p = u32toa(counter, p); *p++ = state; state = *c; counter = 1;
+                if (p > buf + sizeof(buf) - 32) { out.append(buf, (size_t) (p - buf)); p = buf; }
+            } else counter++;
+        }
+        p = u32toa(counter, p); *p++ = state;
     }
-    out.push_back('\n');
+    *p++ = '\n';
+    out.append(buf, (size_t) (p - buf));
 }
 
 inline bool alnLess(const sp_alignment &a, const sp_alignment &b) {      // Matcher::compareHits, Matcher.h:156-167
