@@ -325,6 +325,8 @@ def main():
     if world > 1 or sharded:
         L.sp_init(1 << local_rank)      # this rank's GPU, before the communicator binds to it
         comm = spd.init_from_env(spd.TRANSPORT_RCCL if args.exchange == "rccl" else spd.TRANSPORT_HOST, rank=rank, world=world)
+        if args.exchange == "rccl" and comm.transport != spd.TRANSPORT_RCCL:
+            args.exchange = "host"      # (all ranks agreed on the host transport: RCCL could not be set up on one of them -- the reason is on stderr; the line below says which transport ran)
 
     def all_max(x):
         return x if comm is None or world == 1 else comm.allreduce([x], "max")[0]

@@ -186,6 +186,9 @@ sp_comm *sp_dist_init(const unsigned char id[SP_DIST_ID_BYTES], int rank, int wo
 void sp_dist_destroy(sp_comm *comm);
 int sp_dist_rank(const sp_comm *comm);
 int sp_dist_world(const sp_comm *comm);
+/* the transport the job ended up with: SP_TRANSPORT_RCCL, or SP_TRANSPORT_HOST -- asked for, or agreed on by all ranks because RCCL could not be set up on one of them
+   (SP_DIST_STRICT=1 in the environment: sp_dist_init fails instead) */
+int sp_dist_transport(const sp_comm *comm);
 int sp_dist_barrier(sp_comm *comm);
 /* equal-size all-gather: recv holds world x bytes, rank r's block at r x bytes; on_device: both buffers are memory of this rank's GPU */
 int sp_dist_allgather(sp_comm *comm, const void *send, uint64_t bytes, void *recv, int on_device);

@@ -324,6 +324,7 @@ sp_comm *sp_dist_init(const unsigned char *id, int rank, int world, int transpor
 void sp_dist_destroy(sp_comm *comm) { if (comm) { delete comm->c; delete comm; } }
 int sp_dist_rank(const sp_comm *comm) { return comm ? comm->c->rank() : 0; }
 int sp_dist_world(const sp_comm *comm) { return comm ? comm->c->world() : 1; }
+int sp_dist_transport(const sp_comm *comm) { return comm ? comm->c->transport() : SP_TRANSPORT_HOST; }
 int sp_dist_barrier(sp_comm *comm) {
     std::string err;
     if (!comm || !comm->c->barrier(err)) { g_err = comm ? err : "sp_dist_barrier: null communicator"; return SP_ERR_DEVICE; }

@@ -14,6 +14,7 @@
 #include <cerrno>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <random>
@@ -140,19 +141,37 @@ Comm *Comm::create(const unsigned char *id, int rank, int world, int transport, 
     }
     if (!c->barrier(err)) { delete c; return nullptr; }
     if (transport == kTransportRccl) {
-        if (!g_rccl.load(err)) { delete c; return nullptr; }
+        // Every step of the RCCL set-up may fail on ONE rank only (a library that does not load, a device another rank already holds, a fabric that is not there).  The
+        // ranks therefore agree on the outcome over the bootstrap sockets: all of them hold an RCCL communicator, or all of them fall back to the host transport -- a rank
+        // that returned an error here while the others went on would leave them waiting in their first collective.  SP_DIST_STRICT=1: no fallback, the error comes back.
+        std::string why;
+        bool ok = g_rccl.load(why);
         ncclUniqueId nid; memset(&nid, 0, sizeof(nid));
-        if (rank == 0) { const ncclResult_t r = g_rccl.getUniqueId(&nid); if (r != ncclSuccess) return failed(std::string("ncclGetUniqueId: ") + g_rccl.errorString(r)); }
-        std::vector<unsigned char> all((size_t) world * sizeof(nid));
-        if (!c->hostAllgather(&nid, sizeof(nid), all.data(), err)) { delete c; return nullptr; }
-        memcpy(&nid, all.data(), sizeof(nid));      // rank 0's
-        ncclComm_t comm = nullptr;
-        const ncclResult_t r = g_rccl.commInitRank(&comm, world, nid, rank);
-        if (r != ncclSuccess) return failed(std::string("ncclCommInitRank: ") + g_rccl.errorString(r) + " (one rank per GPU; ranks that share a device need the host transport)");
-        c->nccl_ = comm;
-        hipStream_t s = nullptr;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return failed("sp_dist_init: cannot create the exchange stream");
-        c->stream_ = s;
+        if (ok && rank == 0) { const ncclResult_t r = g_rccl.getUniqueId(&nid); if (r != ncclSuccess) { ok = false; why = std::string("ncclGetUniqueId: ") + g_rccl.errorString(r); } }
+        std::vector<unsigned char> all((size_t) world * (sizeof(nid) + 1)), mine(sizeof(nid) + 1);
+        memcpy(mine.data(), &nid, sizeof(nid)); mine[sizeof(nid)] = ok ? 1 : 0;
+        if (!c->hostAllgather(mine.data(), mine.size(), all.data(), err)) { delete c; return nullptr; }
+        bool allOk = true; for (int k = 0; k < world; k++) allOk = allOk && all[(size_t) k * mine.size() + sizeof(nid)] != 0;
+        ncclComm_t comm = nullptr; hipStream_t s = nullptr;
+        if (allOk) {
+            memcpy(&nid, all.data(), sizeof(nid));      // rank 0's
+            const ncclResult_t r = g_rccl.commInitRank(&comm, world, nid, rank);
+            if (r != ncclSuccess) { ok = false; comm = nullptr; why = std::string("ncclCommInitRank: ") + g_rccl.errorString(r) + " (one rank per GPU; ranks that share a device need the host transport)"; }
+            else if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { ok = false; why = "sp_dist_init: cannot create the exchange stream"; }
+            std::vector<unsigned char> flags((size_t) world); const unsigned char f = ok ? 1 : 0;
+            if (!c->hostAllgather(&f, 1, flags.data(), err)) { if (comm) (void) g_rccl.commDestroy(comm); if (s) (void) hipStreamDestroy(s); delete c; return nullptr; }
+            for (int k = 0; k < world; k++) allOk = allOk && flags[(size_t) k] != 0;
+        }
+        if (allOk) { c->nccl_ = comm; c->stream_ = s; }
+        else {
+            if (comm) (void) g_rccl.commDestroy(comm);
+            if (s) (void) hipStreamDestroy(s);
+            if (why.empty()) why = "another rank could not set up RCCL";
+            const char *strict = getenv("SP_DIST_STRICT");
+            if (strict && *strict && *strict != '0') return failed(why);
+            fprintf(stderr, "[sp] rank %d: RCCL is not available to this job (%s) -- the exchange goes through host memory and the bootstrap sockets instead\n", rank, why.c_str());
+            c->transport_ = kTransportHost;
+        }
     }
     return c;
 }

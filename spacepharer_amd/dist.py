@@ -57,6 +57,8 @@ class Comm:
         self.h = self.L.sp_dist_init(C.c_char_p(bytes(uid)), self.rank, self.world, self.transport)
         if not self.h:
             raise _lib.SpError(self.L.sp_last_error().decode())
+        self.L.sp_dist_transport.argtypes = [C.c_void_p]
+        self.transport = int(self.L.sp_dist_transport(self.h))      # (RCCL asked for, host transport agreed on: see sp_dist_init)
 
     def close(self):
         if self.h:

@@ -85,3 +85,38 @@ def test_rccl_transport_single_rank(tmp_path):
     p = ctx.Process(target=_rank_main, args=(0, 1, uid, spd.TRANSPORT_RCCL, "small", out))
     p.start(); p.join(600)
     assert p.exitcode == 0 and open(out + ".0").read() == "ok"
+
+
+def _fallback_main(rank, world, uid_hex, out):
+    sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
+    from spacepharer_amd import dist as spd
+    comm = spd.Comm(binascii.unhexlify(uid_hex), rank, world, spd.TRANSPORT_RCCL)
+    open("%s.t%d" % (out, rank), "w").write(str(comm.transport))
+    comm.close()
+
+
+def test_ranks_that_cannot_have_rccl_agree_on_the_host_transport(tmp_path, monkeypatch):
+    """RCCL asked for by two ranks that share a GPU (ncclCommInitRank refuses that): every rank ends on the host transport -- none of them returns an error while the
+    others wait in a collective -- and the search over it gives the unsplit bytes; with SP_DIST_STRICT=1 the error comes back instead, on every rank"""
+    from spacepharer_amd import dist as spd
+    ctx = mp.get_context("spawn")
+    uid = binascii.hexlify(spd.unique_id()).decode()
+    out = str(tmp_path / "fb")
+    procs = [ctx.Process(target=_fallback_main, args=(r, 2, uid, out)) for r in range(2)]
+    for p in procs: p.start()
+    for p in procs: p.join(600)
+    assert [p.exitcode for p in procs] == [0, 0]
+    assert [open("%s.t%d" % (out, r)).read() for r in range(2)] == [str(spd.TRANSPORT_HOST)] * 2
+    uid = binascii.hexlify(spd.unique_id()).decode()
+    out = str(tmp_path / "rank")
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, uid, spd.TRANSPORT_RCCL, "small", out)) for r in range(2)]
+    for p in procs: p.start()
+    for p in procs: p.join(600)
+    assert [p.exitcode for p in procs] == [0, 0] and [open("%s.%d" % (out, r)).read() for r in range(2)] == ["ok", "ok"]
+    monkeypatch.setenv("SP_DIST_STRICT", "1")
+    uid = binascii.hexlify(spd.unique_id()).decode()
+    out = str(tmp_path / "strict")
+    procs = [ctx.Process(target=_fallback_main, args=(r, 2, uid, out)) for r in range(2)]
+    for p in procs: p.start()
+    for p in procs: p.join(600)
+    assert all(p.exitcode not in (0, None) for p in procs)      # (SpError in both ranks: nobody hangs)
