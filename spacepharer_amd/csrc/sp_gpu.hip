@@ -670,7 +670,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
         if (ordered) {
             hipLaunchKernelGGL(k_order_count, dim3(orderTiles), dim3(256), 0, d.stream, d.qweight.p, (uint32_t) nq_, d.orderHist.p);
             hipLaunchKernelGGL(k_order_scatter, dim3(orderTiles), dim3(256), 0, d.stream, d.qweight.p, (uint32_t) nq_, d.orderHist.p, orderTiles, d.qorder.p, reinterpret_cast<OrderHeader *>(d.orderHeader.p),
-                               d.orderQueues.p, blocks * (uint32_t) kWavesPerBlock / (uint32_t) kOrderQueues, small ? 0u : 1u);      // (finer tickets on the sparse index: 0.353 -> 0.360 ms -- its groups of four queries want whole tickets)
+                               d.orderQueues.p, blocks * (uint32_t) kWavesPerBlock / (uint32_t) kOrderQueues, small ? 0u : 1u, (small && nq_ <= (size_t) blocks * kWavesPerBlock * 32) ? 36u : 44u);      // (finer tickets on the sparse index: 0.353 -> 0.360 ms -- its groups of four queries want whole tickets)
             SP_DBG_SYNC("k_order");
         }
     } else {
