@@ -124,3 +124,16 @@ def test_bench_reads_the_committed_counter_summary():
     k = doc["kernels"]["k_match"]
     assert abs(traffic - (k["fetch_bytes_corrected"] + k["write_bytes_raw"])) < 1.0
     assert 0.5e9 < traffic < 20e9
+
+
+def test_front_end_does_not_link_the_library_or_the_hip_runtime():
+    """the front end loads libspacepharer_amd.so when it runs a module ITSELF: a client that forwards its call to the resident server must not map the HIP runtime first
+    (30 ms per process start against 2; csrc/sp_main.cpp)"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spacepharer_amd", "spacepharer-amd")
+    if not os.path.exists(exe):
+        pytest.skip("front end not built")
+    libs = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libamdhip64" not in libs and "libspacepharer_amd" not in libs and "libhsa-runtime" not in libs, libs
+    p = subprocess.run([exe, "no_such_module"], capture_output=True, text=True)       # (answers without loading anything)
+    assert p.returncode == 1 and "unknown module" in p.stderr
