@@ -363,13 +363,15 @@ def main():
         tres, toff = batches[0][0], batches[0][1]
         part_from, part_total = 0, 0
         if partition and world > 1:
+            parts = []
             for b in range(n_pipe):
                 tr, to, qr, qo = batches[b]
                 p_from, p_cnt = decompose_by_residues(np.diff(qo).astype(np.int64) + 2, rank, world)
                 part_from, part_total = p_from, len(qo) - 1
+                parts.append((p_from, p_cnt, part_total))
                 lo, hi = int(qo[p_from]), int(qo[p_from + p_cnt])
                 batches[b] = (tr, to, qr[lo:hi].copy(), (qo[p_from:p_from + p_cnt + 1] - qo[p_from]).astype(qo.dtype))
-            assert len({len(bb[3]) for bb in batches}) == 1, "the slices of the batches differ in size"
+            assert len({len(bb[3]) for bb in batches}) == 1 and len(set(parts)) == 1, "the batches decompose differently: exchange_hits() passes ONE (part_from, part_total) for every slot"
         if shard_targets and G > 1:      # this rank's group holds query slice g of every batch only
             for b in range(n_pipe):
                 tr, to, qr, qo = batches[b]

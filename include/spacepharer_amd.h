@@ -265,7 +265,7 @@ uint64_t sp_ctx_overflow_queries(const sp_ctx *c, uint32_t *out, uint64_t cap);
    "ms_score", "ms_select", "ms_sw_forward", "ms_sw_reverse", "ms_traceback", "ms_assemble",
    "ms_index_build", "ms_upload" */
 double sp_ctx_stat(const sp_ctx *c, const char *name);
-/* wait for everything queued on the context's stream */
+/* wait for everything queued on the context's streams (search + copy); SP_ERR_DEVICE with the HIP error text in sp_last_error() when a kernel or copy failed */
 int sp_ctx_sync(sp_ctx *c);
 /* HIP-event timing inside the pipeline (sp_ctx_stat "ms_*"): 0 = none, 1 = the k-mer matching kernel only (default; every
    event record between two kernels costs ~6 us of idle GPU), 2 = every stage.  Stages that are not timed report NaN. */

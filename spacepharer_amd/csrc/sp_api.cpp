@@ -713,7 +713,7 @@ int sp_ctx_get_masked(sp_ctx *c, char *out) {
 
 void *sp_host_alloc(uint64_t bytes) { return sp::pinnedAlloc((size_t) bytes); }
 void sp_host_free(void *p) { sp::pinnedFree(p); }
-int sp_ctx_sync(sp_ctx *c) { c->gpu.makeCurrent(); c->gpu.sync(); return SP_OK; }
+int sp_ctx_sync(sp_ctx *c) { c->gpu.makeCurrent(); std::string err; if (!c->gpu.sync(err)) { g_err = "sp_ctx_sync: " + err; return SP_ERR_DEVICE; } return SP_OK; }
 int sp_ctx_set_timing(sp_ctx *c, int level) { c->gpu.setTiming(level); return SP_OK; }
 int sp_ctx_set_tuning(sp_ctx *c, const char *name, int value) {
     if (c && name && !strcmp(name, "match_blocks_per_cu")) { c->gpu.setMatchBlocksPerCU(value); return SP_OK; }

@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
@@ -17,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <random>
 #include <string>
 #include <vector>
@@ -73,6 +76,35 @@ struct Rccl {
 };
 Rccl g_rccl;
 
+// sockets bound by uniqueId() and not yet taken by a rank 0 of this process (a handful at most: an id nobody uses keeps its port until the process ends or eight newer ones exist)
+std::mutex g_probeMu;
+std::map<uint64_t, int> g_probes;
+std::vector<uint64_t> g_probeOrder;
+void keepProbe(uint64_t token, int fd) {
+    std::lock_guard<std::mutex> lk(g_probeMu);
+    g_probes[token] = fd; g_probeOrder.push_back(token);
+    while (g_probeOrder.size() > 8) { auto it = g_probes.find(g_probeOrder.front()); if (it != g_probes.end()) { close(it->second); g_probes.erase(it); } g_probeOrder.erase(g_probeOrder.begin()); }
+}
+int takeProbe(uint64_t token) {
+    std::lock_guard<std::mutex> lk(g_probeMu);
+    auto it = g_probes.find(token);
+    if (it == g_probes.end()) return -1;
+    const int fd = it->second; g_probes.erase(it);
+    for (size_t k = 0; k < g_probeOrder.size(); k++) if (g_probeOrder[k] == token) { g_probeOrder.erase(g_probeOrder.begin() + (long) k); break; }
+    return fd;
+}
+// wait until fd is readable or the deadline has passed
+bool readableBefore(int fd, std::chrono::steady_clock::time_point deadline) {
+    for (;;) {
+        const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
+        if (left <= 0) return false;
+        pollfd p; p.fd = fd; p.events = POLLIN; p.revents = 0;
+        const int r = poll(&p, 1, (int) (left > 1000 ? 1000 : left));
+        if (r > 0) return true;
+        if (r < 0 && errno != EINTR) return false;
+    }
+}
+
 }  // namespace
 
 bool Comm::uniqueId(unsigned char *id, std::string &err) {
@@ -81,15 +113,19 @@ bool Comm::uniqueId(unsigned char *id, std::string &err) {
     memcpy(l.magic, "SPDIST1", 8);
     const char *addr = getenv("SP_DIST_ADDR");
     snprintf(l.addr, sizeof(l.addr), "%s", addr && *addr ? addr : "127.0.0.1");
-    // a free port: bind to port 0, read it back, let go (rank 0 binds it again with SO_REUSEADDR a moment later)
+    // a free port ON THE ID'S ADDRESS (loopback unless SP_DIST_ADDR says otherwise -- a one-node job has no business listening on every interface): bind to port 0,
+    // read it back, and KEEP the socket: the process that made the id is the one that becomes rank 0 in every caller this library has, and Comm::create() listens on
+    // this very socket (no window in which somebody else can take the port).  An id that travels to another process' rank 0 is bound again there (SO_REUSEADDR).
     const int fd = socket(AF_INET, SOCK_STREAM, 0);
     if (fd < 0) { err = "sp_dist_unique_id: socket() failed"; return false; }
-    sockaddr_in sa; memset(&sa, 0, sizeof(sa)); sa.sin_family = AF_INET; sa.sin_addr.s_addr = htonl(INADDR_ANY); sa.sin_port = 0;
+    int one = 1; (void) setsockopt(fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    sockaddr_in sa; memset(&sa, 0, sizeof(sa)); sa.sin_family = AF_INET; sa.sin_port = 0;
+    if (inet_pton(AF_INET, l.addr, &sa.sin_addr) != 1) { close(fd); err = std::string("sp_dist_unique_id: bad address ") + l.addr; return false; }
     socklen_t len = sizeof(sa);
-    if (bind(fd, reinterpret_cast<sockaddr *>(&sa), sizeof(sa)) != 0 || getsockname(fd, reinterpret_cast<sockaddr *>(&sa), &len) != 0) { close(fd); err = "sp_dist_unique_id: no free port"; return false; }
+    if (bind(fd, reinterpret_cast<sockaddr *>(&sa), sizeof(sa)) != 0 || getsockname(fd, reinterpret_cast<sockaddr *>(&sa), &len) != 0) { close(fd); err = std::string("sp_dist_unique_id: no free port on ") + l.addr; return false; }
     l.port = ntohs(sa.sin_port);
-    close(fd);
     std::random_device rd; l.token = ((uint64_t) rd() << 32) ^ rd() ^ (uint64_t) getpid();
+    keepProbe(l.token, fd);
     memcpy(id, &l, sizeof(l));
     return true;
 }
@@ -104,21 +140,30 @@ Comm *Comm::create(const unsigned char *id, int rank, int world, int transport, 
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(timeoutSec > 0 ? timeoutSec : 120);
     if (world > 1) {
         if (rank == 0) {
-            c->listenFd_ = socket(AF_INET, SOCK_STREAM, 0);
-            int one = 1; (void) setsockopt(c->listenFd_, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-            sockaddr_in sa; memset(&sa, 0, sizeof(sa)); sa.sin_family = AF_INET; sa.sin_addr.s_addr = htonl(INADDR_ANY); sa.sin_port = htons(l.port);
-            if (c->listenFd_ < 0 || bind(c->listenFd_, reinterpret_cast<sockaddr *>(&sa), sizeof(sa)) != 0 || listen(c->listenFd_, world) != 0)
-                return failed("sp_dist_init: rank 0 cannot listen on port " + std::to_string(l.port) + ": " + strerror(errno));
+            // the socket uniqueId() bound (same process), or a fresh one on the id's address and port
+            c->listenFd_ = takeProbe(l.token);
+            if (c->listenFd_ < 0) {
+                c->listenFd_ = socket(AF_INET, SOCK_STREAM, 0);
+                int one = 1; (void) setsockopt(c->listenFd_, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+                sockaddr_in sa; memset(&sa, 0, sizeof(sa)); sa.sin_family = AF_INET; sa.sin_port = htons(l.port);
+                if (inet_pton(AF_INET, l.addr, &sa.sin_addr) != 1) return failed(std::string("sp_dist_init: bad address ") + l.addr);
+                if (c->listenFd_ < 0 || bind(c->listenFd_, reinterpret_cast<sockaddr *>(&sa), sizeof(sa)) != 0)
+                    return failed("sp_dist_init: rank 0 cannot bind " + std::string(l.addr) + ":" + std::to_string(l.port) + ": " + strerror(errno));
+            }
+            if (listen(c->listenFd_, world) != 0) return failed("sp_dist_init: rank 0 cannot listen on " + std::string(l.addr) + ":" + std::to_string(l.port) + ": " + strerror(errno));
             c->fds_.assign((size_t) world, -1);
             for (int k = 1; k < world; k++) {
-                timeval tv; const auto left = std::chrono::duration_cast<std::chrono::seconds>(deadline - std::chrono::steady_clock::now()).count();
-                tv.tv_sec = left > 1 ? left : 1; tv.tv_usec = 0;
-                (void) setsockopt(c->listenFd_, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+                // the deadline bounds accept() and the hello only (poll): the accepted sockets carry NO receive timeout, so a peer that reaches a collective minutes
+                // after rank 0 -- a target shard still being read from a cold disk -- is waited for, as on every other rank
+                if (!readableBefore(c->listenFd_, deadline)) return failed("sp_dist_init: rank 0 waited in vain for " + std::to_string(world - k) + " of " + std::to_string(world - 1) + " peers");
                 const int fd = accept(c->listenFd_, nullptr, nullptr);
-                if (fd < 0) return failed("sp_dist_init: rank 0 waited in vain for " + std::to_string(world - k) + " of " + std::to_string(world - 1) + " peers");
+                if (fd < 0) { k--; continue; }
                 noDelay(fd);
                 uint64_t hello[2] = {0, 0};
-                if (!recvAll(fd, hello, sizeof(hello)) || hello[0] != l.token || hello[1] == 0 || hello[1] >= (uint64_t) world || c->fds_[hello[1]] >= 0) { close(fd); k--; continue; }      // (not one of ours)
+                { timeval tv; tv.tv_sec = 5; tv.tv_usec = 0; (void) setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv)); }      // (the 16 bytes of the hello only ...
+                const bool greeted = readableBefore(fd, deadline) && recvAll(fd, hello, sizeof(hello));
+                { timeval tv; tv.tv_sec = 0; tv.tv_usec = 0; (void) setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv)); }      // ... the data path waits without a limit)
+                if (!greeted || hello[0] != l.token || hello[1] == 0 || hello[1] >= (uint64_t) world || c->fds_[hello[1]] >= 0) { close(fd); k--; continue; }      // (not one of ours)
                 c->fds_[hello[1]] = fd;
             }
         } else {

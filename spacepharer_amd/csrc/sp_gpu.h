@@ -152,7 +152,7 @@ public:
     // profiling aid: streaming read of `bytes` with laneBytes (4/8/16) per lane, to calibrate the FETCH_SIZE counter
     bool diagStreamRead(uint64_t bytes, int laneBytes, double &ms, std::string &err);
 
-    void sync();
+    bool sync(std::string &err);
     void setTiming(int level);
     void setMatchBlocksPerCU(int n);   // 0 = as many as fit
     bool setKnob(const std::string &name, int value);      // "match_small", "match_heavy_threshold"; false: unknown

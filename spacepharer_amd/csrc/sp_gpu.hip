@@ -464,7 +464,14 @@ bool Gpu::init(int device, std::string &err) {
     return true;
 }
 
-void Gpu::sync() { (void) hipStreamSynchronize(d_->stream); }
+// waits for the search stream AND the copy stream; a faulted kernel or copy comes back as an error text (sp_ctx_sync -> SP_ERR_DEVICE) instead of being swallowed
+bool Gpu::sync(std::string &err) {
+    hipError_t e = hipStreamSynchronize(d_->stream);
+    if (e == hipSuccess && d_->copyStream) e = hipStreamSynchronize(d_->copyStream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { err = std::string("the context's stream failed: ") + hipGetErrorString(e); return false; }
+    return true;
+}
 
 // ---- counter calibration (profiles/ only): streaming read of a known byte count, W bytes per lane per load.  The
 // rocprofv3 FETCH_SIZE counter is calibrated against these launches before it is quoted for k_match.
@@ -939,17 +946,31 @@ size_t Gpu::numCandidates() const { return d_->nCand; }
 // Target-sharded search: every rank has matched ALL queries against ITS target shard (prefilterCandidates); the shards' candidate lists are exchanged -- counts over the
 // bootstrap sockets, the lists themselves padded to the longest one by RCCL all-gather, HBM to HBM over xGMI -- and land in candUnion, where mergeCandidates() reads them
 // (rows of 0xFF are padding).  The reference merges the per-split result FILES of its MPI ranks (prefiltering/Prefiltering.cpp:258-362).
+// The ranks of a job fail TOGETHER: a condition only one rank can see (a slice out of range, a buffer that cannot grow) is exchanged before the next collective, so that nobody
+// is left waiting in an all-gather for a rank that has already returned an error.
+static bool agreeOk(Comm &comm, bool localOk, std::string &err) {
+    unsigned char mine = localOk ? 1 : 0; std::vector<unsigned char> all((size_t) comm.world(), 0);
+    std::string xerr;
+    if (!comm.allgather(&mine, 1, all.data(), false, xerr)) { if (localOk) err = xerr; return false; }
+    for (int r = 0; r < comm.world(); r++) if (!all[(size_t) r]) { if (localOk) err = "rank " + std::to_string(r) + " of the exchange failed before the collective (see its own error)"; return false; }
+    return true;
+}
+
 bool Gpu::allgatherCandidates(Comm &comm, size_t &unionRows, std::string &err) {
     Impl &d = *d_;
     const int world = comm.world();
     uint64_t mine = d.nCand; std::vector<uint64_t> all((size_t) world, 0);
     if (!comm.allgather(&mine, sizeof(mine), all.data(), false, err)) return false;
     uint64_t longest = 1; for (uint64_t x : all) longest = std::max(longest, x);
-    if (longest * (uint64_t) world >= (1ull << 32)) { err = "allgatherCandidates: more than 2^32 candidate rows"; return false; }
-    if (!d.candPad.ensure((size_t) longest, err) || !d.candUnion.ensure((size_t) longest * world + 1, err)) return false;
-    HIP_OK(hipMemsetAsync(d.candPad.p, 0xFF, (size_t) longest * sizeof(Candidate), d.stream));
-    if (d.nCand) HIP_OK(hipMemcpyAsync(d.candPad.p, d.cand.p, (size_t) d.nCand * sizeof(Candidate), hipMemcpyDeviceToDevice, d.stream));
-    HIP_OK(hipStreamSynchronize(d.stream));
+    if (longest * (uint64_t) world >= (1ull << 32)) { err = "allgatherCandidates: more than 2^32 candidate rows"; return false; }      // (every rank sees the same numbers)
+    bool ok = d.candPad.ensure((size_t) longest, err) && d.candUnion.ensure((size_t) longest * world + 1, err);
+    if (ok) {
+        ok = hipMemsetAsync(d.candPad.p, 0xFF, (size_t) longest * sizeof(Candidate), d.stream) == hipSuccess &&
+             (!d.nCand || hipMemcpyAsync(d.candPad.p, d.cand.p, (size_t) d.nCand * sizeof(Candidate), hipMemcpyDeviceToDevice, d.stream) == hipSuccess) &&
+             hipStreamSynchronize(d.stream) == hipSuccess;
+        if (!ok) err = "allgatherCandidates: staging the candidate rows failed";
+    }
+    if (!agreeOk(comm, ok, err)) return false;
     if (!comm.allgather(d.candPad.p, (size_t) longest * sizeof(Candidate), d.candUnion.p, true, err)) return false;
     unionRows = (size_t) longest * world;
     return true;
@@ -961,22 +982,28 @@ const Candidate *Gpu::candidateUnionDevice() const { return d_->candUnion.p; }
 bool Gpu::allgatherHits(Comm &comm, size_t queryOffset, size_t nqTotal, const GpuHit *srcHits, const uint32_t *srcOffsets, GpuHit *hits, uint64_t *offsets, size_t hitCap, size_t &nHits, std::string &err) {
     Impl &d = *d_;
     const int world = comm.world();
-    if (queryOffset + nq_ > nqTotal) { err = "allgatherHits: this rank's slice ends behind the last query"; return false; }
+    const bool sliceOk = queryOffset + nq_ <= nqTotal;      // (travels in the meta record: the others must not wait for a rank that stops here)
     // srcHits / srcOffsets: a delivered step's hit list in host memory (the context may already be searching the next batch); nullptr: the last pass's, still on the device
     const uint64_t myHits = srcOffsets ? (uint64_t) srcOffsets[nq_] : (uint64_t) counters_.hits;
-    uint64_t mine[3] = {(uint64_t) queryOffset, (uint64_t) nq_, myHits}; std::vector<uint64_t> all((size_t) world * 3, 0);
+    uint64_t mine[3] = {sliceOk ? (uint64_t) queryOffset : ~0ull, (uint64_t) nq_, myHits}; std::vector<uint64_t> all((size_t) world * 3, 0);
     if (!comm.allgather(mine, sizeof(mine), all.data(), false, err)) return false;
+    for (int r = 0; r < world; r++) if (all[(size_t) r * 3] == ~0ull) { err = "allgatherHits: the slice of rank " + std::to_string(r) + " ends behind the last query"; return false; }
     uint64_t maxQ = 1, maxH = 1, totalH = 0, totalQ = 0;
     for (int r = 0; r < world; r++) { maxQ = std::max(maxQ, all[(size_t) r * 3 + 1]); maxH = std::max(maxH, all[(size_t) r * 3 + 2]); totalH += all[(size_t) r * 3 + 2]; totalQ += all[(size_t) r * 3 + 1]; }
     if (totalQ != nqTotal) { err = "allgatherHits: the ranks' slices hold " + std::to_string(totalQ) + " queries, not " + std::to_string(nqTotal); return false; }
-    if (totalH > hitCap) { err = "allgatherHits: " + std::to_string(totalH) + " hits, room for " + std::to_string(hitCap); return false; }
+    const bool roomOk = totalH <= hitCap;      // (the caller's buffer: a rank-local condition, agreed on below)
+    if (!roomOk) err = "allgatherHits: " + std::to_string(totalH) + " hits, room for " + std::to_string(hitCap);
     if (!srcOffsets && d.hitsInFlight) { (void) hipEventSynchronize(d.hitsOnHost); d.hitsInFlight = false; }
-    if (!d.xOff.ensure((size_t) maxQ + 1, err) || !d.xOffAll.ensure((size_t) (maxQ + 1) * world, err) || !d.xHit.ensure((size_t) maxH, err) || !d.xHitAll.ensure((size_t) maxH * world, err)) return false;
+    bool ok = roomOk && d.xOff.ensure((size_t) maxQ + 1, err) && d.xOffAll.ensure((size_t) (maxQ + 1) * world, err) && d.xHit.ensure((size_t) maxH, err) && d.xHitAll.ensure((size_t) maxH * world, err);
     hipStream_t xs = srcOffsets ? d.copyStream : d.stream;      // (a host source has nothing to wait for on the search stream)
-    HIP_OK(hipMemsetAsync(d.xOff.p, 0, (size_t) (maxQ + 1) * sizeof(uint32_t), xs));
-    if (nq_) HIP_OK(hipMemcpyAsync(d.xOff.p, srcOffsets ? (const void *) srcOffsets : (const void *) d.outOffset.p, (nq_ + 1) * sizeof(uint32_t), hipMemcpyDefault, xs));
-    if (myHits) HIP_OK(hipMemcpyAsync(d.xHit.p, srcOffsets ? (const void *) srcHits : (const void *) d.outHits.p, (size_t) myHits * sizeof(GpuHit), hipMemcpyDefault, xs));
-    HIP_OK(hipStreamSynchronize(xs));
+    if (ok) {
+        ok = hipMemsetAsync(d.xOff.p, 0, (size_t) (maxQ + 1) * sizeof(uint32_t), xs) == hipSuccess &&
+             (!nq_ || hipMemcpyAsync(d.xOff.p, srcOffsets ? (const void *) srcOffsets : (const void *) d.outOffset.p, (nq_ + 1) * sizeof(uint32_t), hipMemcpyDefault, xs) == hipSuccess) &&
+             (!myHits || hipMemcpyAsync(d.xHit.p, srcOffsets ? (const void *) srcHits : (const void *) d.outHits.p, (size_t) myHits * sizeof(GpuHit), hipMemcpyDefault, xs) == hipSuccess) &&
+             hipStreamSynchronize(xs) == hipSuccess;
+        if (!ok) err = "allgatherHits: staging the hit list failed";
+    }
+    if (!agreeOk(comm, ok, err)) return false;
     if (!comm.allgather(d.xOff.p, (size_t) (maxQ + 1) * sizeof(uint32_t), d.xOffAll.p, true, err)) return false;
     if (!comm.allgather(d.xHit.p, (size_t) maxH * sizeof(GpuHit), d.xHitAll.p, true, err)) return false;
     std::vector<uint32_t> offAll((size_t) (maxQ + 1) * world);
@@ -1035,9 +1062,9 @@ bool Gpu::mergeCandidates(const Candidate *src, size_t n, bool onDevice, size_t 
     HIP_OK(hipMemsetAsync(d.candCnt.p, 0, (nq_ + 1) * sizeof(uint32_t), d.stream));
     HIP_OK(hipMemsetAsync(d.candFill.p, 0, (nq_ + 1) * sizeof(uint32_t), d.stream));
     SP_EV(3, 2);
-    if (n) hipLaunchKernelGGL(k_cand_count, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, u, (uint32_t) n, (uint32_t) qFrom, (uint32_t) qTo, d.candCnt.p);
+    if (n) hipLaunchKernelGGL(k_cand_count, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, u, (uint32_t) n, (uint32_t) qFrom, (uint32_t) qTo, (uint32_t) std::min<size_t>(d.tgt->nTargets, 0xFFFFFFFFull), d.candCnt.p);
     if (!d.scanCounts(d.candCnt.p, (uint32_t) nq_, d.candOffset.p, err)) return false;
-    if (n) hipLaunchKernelGGL(k_cand_scatter, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, u, (uint32_t) n, (uint32_t) qFrom, (uint32_t) qTo, d.candOffset.p, d.candFill.p, d.candByQuery.p);
+    if (n) hipLaunchKernelGGL(k_cand_scatter, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, u, (uint32_t) n, (uint32_t) qFrom, (uint32_t) qTo, (uint32_t) std::min<size_t>(d.tgt->nTargets, 0xFFFFFFFFull), d.candOffset.p, d.candFill.p, d.candByQuery.p);
     MergeArgs me{(uint32_t) nq_, d.candByQuery.p, d.candOffset.p, d.qbias.p, d.qself.p, d.qoff.p, d.mergeScratch.p, d.queue.p + 2, binSize - 1, maxHits, minDiagScore,
                  d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.queue.p + 3, d.counters.p};
     hipLaunchKernelGGL(k_select_merged, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, me);
