@@ -116,7 +116,7 @@ def host_info():
     return {"nproc": os.cpu_count() or 1, "usable_cores": usable, "cpu_quota_cores": quota, "cores_for_cpu_baseline": cores, "cpu_model": model, "mem_available_bytes": avail}
 
 
-def cpu_baseline_reference(tres, toff, qres, qoff, n_sample, threads, target_s=4.0):
+def cpu_baseline_reference(tres, toff, qres, qoff, n_sample, threads, target_s=4.0, want_results=False):
     """The REAL reference classes (oracle/_ref/ref_harness --bench: QueryMatcher::matchQuery + Matcher::getSWResult, AVX2,
     compiled from /root/reference by oracle/Makefile) on `threads` host cores: ONE process whose worker threads share the index
     table, the sequence store and the similar-k-mer tables and own a QueryMatcher / Matcher each, like the reference's OpenMP
@@ -140,20 +140,62 @@ def cpu_baseline_reference(tres, toff, qres, qoff, n_sample, threads, target_s=4
             f.write(b"\n".join(tres[i * tl:(i + 1) * tl].tobytes() for i in range(n_t)) + b"\n")
         with open(qf, "wb") as f:
             f.write(b"\n".join(qres[i * ql:(i + 1) * ql].tobytes() for i in range(n_sample)) + b"\n")
-        subprocess.run([harness, m80, m40, tf, qf, of, "--bench-reps", str(reps), "--bench-threads", str(threads)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        df = os.path.join(d, "dump.txt")
+        subprocess.run([harness, m80, m40, tf, qf, of, "--bench-reps", str(reps), "--bench-threads", str(threads)] + (["--bench-dump", df] if want_results else []),
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
         r = json.load(open(of))["bench"]
+        results = open(df).read().split("\n")[:n_sample] if want_results else None
     t_pass = r["prefilter_s"] + r["align_s"]
     # what a `prefilter` + `align` module pair of the reference pays for this sample on the same threads: the index is rebuilt in every prefilter
     # process (tantan masking + IndexTable, Prefiltering.cpp:499-537) and the similar-k-mer tables are computed at start-up; DB I/O and text formatting
     # are not in the harness and not counted
     t_module = r["index_build_s"] + r["table_s"] + t_pass
-    return {"value": (n_sample / 6.0) / t_pass, "unit": "spacer-queries/s", "cores": r["threads"], "kind": "reference", "pairs": r["pairs"],
+    return {"value": (n_sample / 6.0) / t_pass, "unit": "spacer-queries/s", "cores": r["threads"], "kind": "reference", "pairs": r["pairs"], "results": results,
             "index_build_s": r["index_build_s"], "kmer_tables_s": r["table_s"], "search_loops_s": t_pass, "module_wall_s": t_module,
             "module_value": (n_sample / 6.0) / t_module,
             "sample": "%d of the workload's peptides (%d SW alignments) in one process of oracle/_ref/ref_harness (reference QueryMatcher + Matcher classes, AVX2, "
                       "g++ -O3) with %d worker threads sharing one index; value = search loops only, %d passes, %.4f s per pass (prefilter %.4f s + align %.4f s); "
                       "module_value additionally counts what every prefilter process of the reference pays: index build %.3f s (masking + both index passes + list sort, "
                       "same threads) + similar-k-mer tables %.3f s" % (n_sample, r["pairs"], r["threads"], reps, t_pass, r["prefilter_s"], r["align_s"], r["index_build_s"], r["table_s"])}
+
+
+def reference_results_equal_gpu(tres, toff, qres, qoff, n_sample, results):
+    """The hit lists and alignments the reference classes produced in the timed loops of cpu_baseline_reference() (ref_harness --bench-dump: per query, per hit
+    seqId, prefilter score, diagonal | bit score, starts, ends, length, E-value as a hex double, accepted, backtrace) against one search of the same sampled
+    peptides on the GPU: every field, bit for bit.  Returns a small report; "equal" is what the bench line carries."""
+    import spacepharer_amd as sa
+    ql = int(qoff[1])
+    ctx = sa.SearchContext()
+    try:
+        ctx.set_targets_raw(tres.tobytes(), u64p(toff), len(toff) - 1)
+        sub_off = (np.arange(n_sample + 1, dtype=np.uint64) * np.uint64(ql))
+        ctx.set_queries_raw(qres[:n_sample * ql].tobytes(), u64p(sub_off), n_sample)
+        ctx.prefilter()
+        hits = ctx.hits()
+        pairs = [(q, h[0]) for q in range(n_sample) for h in hits[q]]
+        aln = ctx.align(pairs) if pairs else []
+        k = n_hits = n_aln = 0
+        for q in range(n_sample):
+            exp = [e for e in results[q].split(";") if e]
+            if len(exp) != len(hits[q]):
+                return {"equal": False, "first_difference": "query %d: %d hits on the GPU, %d in the reference" % (q, len(hits[q]), len(exp))}
+            for h, e in zip(hits[q], exp):
+                f = e.split(",")
+                res, cig = aln[k]
+                k += 1
+                n_hits += 1
+                if [int(h[0]), int(h[1]), int(h[2])] != [int(f[0]), int(f[1]), int(f[2])]:
+                    return {"equal": False, "first_difference": "query %d: hit %s on the GPU, %s in the reference" % (q, list(h), f[:3])}
+                ok = int(f[10])
+                same = (res.bit_score, res.q_end, res.db_end, int(res.passed)) == (int(f[3]), int(f[5]), int(f[7]), ok)
+                if same and ok:
+                    same = (res.q_start, res.db_start, res.aln_len) == (int(f[4]), int(f[6]), int(f[8])) and res.evalue == float.fromhex(f[9]) and cig == f[11]
+                    n_aln += 1
+                if not same:
+                    return {"equal": False, "first_difference": "query %d target %d: alignment differs (%s)" % (q, int(h[0]), e[:120])}
+        return {"equal": True, "peptides": n_sample, "hits_compared": n_hits, "accepted_alignments_compared": n_aln}
+    finally:
+        ctx.close()
 
 
 def cpu_baseline(tres, toff, qres, qoff, n_sample):
@@ -780,9 +822,13 @@ def main():
         if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_harness")):
             try:
                 n_s = nq if args.cpu_sample >= 3000 else min(args.cpu_sample * cores, nq)
-                out["cpu_baseline"] = cpu_baseline_reference(tres, toff, qres, qoff, n_s, cores)
+                out["cpu_baseline"] = cpu_baseline_reference(tres, toff, qres, qoff, n_s, cores, want_results=not sharded)
+                res_ref = out["cpu_baseline"].pop("results", None)
                 if n_s == nq and not sharded:     # whole workload: the reference must align exactly the pairs the GPU aligned
                     out["cpu_baseline"]["pairs_equal_gpu"] = bool(out["cpu_baseline"].pop("pairs") == m["pairs"][0])
+                if res_ref is not None:           # ... and a sample of its hit lists and alignments, field by field, must be the GPU's (after the clock stopped)
+                    n_cmp = min(n_s, 3000)
+                    out["cpu_baseline"]["results_equal_gpu"] = reference_results_equal_gpu(tres, toff, qres, qoff, n_cmp, res_ref)
             except Exception as e:      # noqa: BLE001 -- fall back to the port, say why
                 out["cpu_baseline"] = cpu_baseline(tres, toff, qres, qoff, min(args.cpu_sample, nq))
                 out["cpu_baseline"]["sample"] += " (reference harness unavailable: %s)" % e
@@ -794,8 +840,11 @@ def main():
     if dense is not None and args.cpu_sample > 0 and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_harness")):
         try:      # the reference on the same dense workload: a bounded sample of the peptides (its index build alone takes seconds there)
             tres_d, toff_d, qres_d, qoff_d = dense["batches"][0]
-            cb = cpu_baseline_reference(tres_d, toff_d, qres_d, qoff_d, min(len(qoff_d) - 1, 200 * cores), cores, target_s=3.0)
+            n_d = min(len(qoff_d) - 1, 200 * cores)
+            cb = cpu_baseline_reference(tres_d, toff_d, qres_d, qoff_d, n_d, cores, target_s=3.0, want_results=True)
             cb.pop("pairs", None)
+            # the REAL reference classes at the density of the real DB: their hit lists and alignments for the sample, compared with the GPU's field by field
+            cb["results_equal_gpu"] = reference_results_equal_gpu(tres_d, toff_d, qres_d, qoff_d, n_d, cb.pop("results"))
             out["dense"]["cpu_baseline"] = cb
             out["dense"]["x_reference_search_loops"] = out["dense"]["value"] / cb["value"]
         except Exception as e:      # noqa: BLE001
@@ -836,6 +885,34 @@ def main():
             out["files_to_files"] = f2f
         except Exception as e:      # noqa: BLE001
             out["module_e2e"] = {"error": repr(e)[:300]}
+        if dense is not None and "files_to_files" in out:
+            # the target statement's own configuration: 100 000 spacers against the density of GenBank_phage_2018_09 (2e8 residues), files to files, next to what the
+            # reference's module pair pays there (index build + similar-k-mer tables once per prefilter process + the search loops, from the dense reference sample)
+            try:
+                pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "module_e2e.py"), "100000", "--targets", "1000000", "--light"], capture_output=True, text=True, timeout=1500)
+                doc = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])["module_e2e"]
+                dcb = out["dense"].get("cpu_baseline", {})
+                ref_s = None
+                if dcb.get("kind") == "reference" and dcb.get("search_loops_s"):
+                    n_d = min(len(dense["batches"][0][3]) - 1, 200 * cores) if args.cpu_sample > 0 else None
+                    ref_s = dcb["index_build_s"] + dcb["kmer_tables_s"] + dcb["search_loops_s"] * (600000.0 / n_d) if n_d else None
+                fd = {"what": "files to files, 100 000 spacers (6e5 peptides) vs 1 000 000 ORFs x 200 aa = 2e8 residues (query / target DBs on disk -> alignment DB on disk); "
+                              "fresh = one fresh process of the front end per module call, auto_server = the same calls with SP_SERVER=auto (first pays for the server's start), served = a resident server",
+                      "spacers": 100000, "target_residues": 200000000, "reference_module_wall_s_estimate": ref_s,
+                      "reference_estimate_from": "dense.cpu_baseline: index build + similar-k-mer tables + search loops scaled from the sample to 6e5 peptides (DB I/O and text not counted)"}
+                for run in doc:
+                    tag = "fused_search" if run["mode"] == "fused" else "prefilter_then_align"
+                    ent = {"fresh_process_s": run["process_total_s"], "fresh_processes_spacer_queries_per_s": run["process_spacer_queries_per_s"],
+                           "auto_server_s": run["auto_server_total_s"], "auto_server_next_spacer_queries_per_s": run["auto_server_next_spacer_queries_per_s"],
+                           "served_s": run["served_total_s"], "served_spacer_queries_per_s": run["served_spacer_queries_per_s"], "in_process_s": [x["total_s"] for x in run["runs"]],
+                           "aln_db_bytes": run["aln_db_bytes"], "aln_db_crc": run["aln_db_crc"]}
+                    if ref_s:
+                        ent["x_reference"] = {"fresh_process": ref_s / min(run["process_total_s"]), "auto_server_first": ref_s / run["auto_server_total_s"][0],
+                                              "auto_server_next": ref_s / min(run["auto_server_total_s"][1:]), "served": ref_s / min(run["served_total_s"][1:])}
+                    fd[tag] = ent
+                out["files_to_files"]["dense"] = fd
+            except Exception as e:      # noqa: BLE001
+                out["files_to_files"]["dense"] = {"error": repr(e)[:300]}
     C.CDLL(None).fflush(None)      # library chatter buffered in C stdio (RCCL prints its path) goes out BEFORE the result line
     print(json.dumps(out), flush=True)
 

@@ -110,3 +110,45 @@ def test_spill_regime_sample_against_oracle():
     assert checked > 100
     o.close()
     ctx.close()
+
+
+def test_real_density_sample_against_oracle():
+    """2 x 10^8 residues -- the density three of BASELINE.json's five configs name -- against the CPU oracle itself (not against the GPU's own shards):
+    600 sampled peptides of the bench's dense workload, hit lists and alignments field by field.  (The oracle indexes 10^6 targets in about a minute on
+    one core; bench.py's dense leg makes the same comparison against the REAL reference classes, `dense.cpu_baseline.results_equal_gpu`.)"""
+    import bench
+    import spacepharer_amd as sa
+    from oracle_lib import Alp, Oracle
+    n_t, tl = 1000000, 200
+    tres, toff, qres, qoff = bench.make_workload(10000, n_t, tl, 12345)
+    nq = len(qoff) - 1
+    ctx = sa.SearchContext()
+    ctx.set_targets_raw(tres.tobytes(), bench.u64p(toff), n_t)
+    ctx.set_queries_raw(qres.tobytes(), bench.u64p(qoff), nq)
+    ctx.prefilter()
+    h, off, n = _hits_np(ctx)
+    assert ctx.stat("db_matches") / nq > 2000
+    aln, cig, na = ctx.align_hits_raw()
+    o = Oracle()
+    o.set_targets([tres[i * tl:(i + 1) * tl].tobytes() for i in range(n_t)])
+    g = json.load(gzip.open(os.path.join(ROOT, "tests/golden/spacer.json.gz")))["ref"]
+    o.set_alp(Alp.from_ref(g["alpGapped"]), Alp.from_ref(g["alpGapless"]))
+    rnd = random.Random(5)
+    checked = accepted = 0
+    for q in rnd.sample(range(nq), 600):
+        qs = qres[q * 10:(q + 1) * 10].tobytes().decode()
+        exp = o.prefilter_list(qs)
+        got = [[int(x[0]), int(x[1]), ((int(x[2]) & 0xFFFF) ^ 0x8000) - 0x8000] for x in h[off[q]:off[q + 1]]]
+        assert got == exp, q
+        for k, e in enumerate(exp):
+            r = aln[off[q] + k]
+            a = o.align(qs, e[0])
+            assert (r.raw_score, r.bit_score, r.q_end, r.db_end, r.passed) == (a.rawScore, a.score, a.qEndPos, a.dbEndPos, a.passed)
+            if a.passed:
+                assert (r.q_start, r.db_start, r.evalue) == (a.qStartPos, a.dbStartPos, a.eval)
+                assert C.string_at(C.addressof(cig) + r.cigar_offset).decode() == a.backtrace.decode()
+                accepted += 1
+            checked += 1
+    assert checked > 5000 and accepted > 500, (checked, accepted)
+    o.close()
+    ctx.close()

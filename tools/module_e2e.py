@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def worker(n_spacers, d, mode):
+def worker(n_spacers, d, mode, n_targets=50000, light=False):
     import bench
     import spacepharer_amd as sa
     from test_gpu_modules import ALN_FLAGS, PREF_FLAGS, write_seq_db
@@ -24,14 +24,14 @@ def worker(n_spacers, d, mode):
     pf = [x if x != "8" or PREF_FLAGS.split()[i - 1] != "--threads" else threads for i, x in enumerate((PREF_FLAGS % 300).split())]
     af = [x if x != "8" or ALN_FLAGS.split()[i - 1] != "--threads" else threads for i, x in enumerate(ALN_FLAGS.split())]
     sf = pf + [x for i, x in enumerate(af) if not (x in pf and x.startswith("-")) and not (i > 0 and af[i - 1] in pf and af[i - 1].startswith("-"))]
-    tres, toff, qres, qoff = bench.make_workload(n_spacers, 50000, 200, 12345)
+    tres, toff, qres, qoff = bench.make_workload(n_spacers, n_targets, 200, 12345)
     T = [tres[int(toff[i]):int(toff[i + 1])].tobytes().decode() for i in range(len(toff) - 1)]
     Q = [qres[int(qoff[i]):int(qoff[i + 1])].tobytes().decode() for i in range(len(qoff) - 1)]
     q, t, pref, aln = (os.path.join(d, x) for x in ("qdb", "tdb", "pref", "aln"))
     write_seq_db(q, Q)
     write_seq_db(t, T)
-    out = {"spacers": n_spacers, "threads": int(threads), "mode": mode, "runs": []}
-    for rep in range(3):
+    out = {"spacers": n_spacers, "targets": n_targets, "target_residues": int(toff[-1]), "threads": int(threads), "mode": mode, "runs": []}
+    for rep in range(2 if light else 3):
         for f in os.listdir(d):
             if f.startswith("pref") or f.startswith("aln"):
                 os.remove(os.path.join(d, f))
@@ -48,7 +48,7 @@ def worker(n_spacers, d, mode):
     # runtime start-up, similar-3-mer table, first touch of every device buffer
     exe = os.path.join(ROOT, "spacepharer_amd", "spacepharer-amd")
     procs = []
-    for rep in range(2):
+    for rep in range(1 if light else 2):
         for f in os.listdir(d):
             if f.startswith("pref") or f.startswith("aln"):
                 os.remove(os.path.join(d, f))
@@ -70,7 +70,7 @@ def worker(n_spacers, d, mode):
         time.sleep(0.01)
     served = []
     env = dict(os.environ, SP_SERVER=sock)
-    for rep in range(4):
+    for rep in range(3 if light else 4):
         for f in os.listdir(d):
             if f.startswith("pref") or f.startswith("aln"):
                 os.remove(os.path.join(d, f))
@@ -92,7 +92,7 @@ def worker(n_spacers, d, mode):
     os.makedirs(rt, exist_ok=True)
     env = dict(os.environ, SP_SERVER="auto:30", XDG_RUNTIME_DIR=rt)
     auto = []
-    for rep in range(4):
+    for rep in range(3 if light else 4):
         for f in os.listdir(d):
             if f.startswith("pref") or f.startswith("aln"):
                 os.remove(os.path.join(d, f))
@@ -117,14 +117,17 @@ def worker(n_spacers, d, mode):
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--worker":
-        worker(int(sys.argv[2]), sys.argv[3], sys.argv[4])
+        worker(int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else 50000, len(sys.argv) > 6 and sys.argv[6] == "light")
         sys.exit(0)
-    sizes = [int(a) for a in sys.argv[1:]] or [10000, 100000]
+    # --targets N: the target set (default 50 000 x 200 aa = the bench proxy; 1 000 000 = the survey's estimate of GenBank_phage_2018_09); --light: fewer repetitions
+    n_targets = int(sys.argv[sys.argv.index("--targets") + 1]) if "--targets" in sys.argv else 50000
+    light = "--light" in sys.argv
+    sizes = [int(a) for i, a in enumerate(sys.argv[1:], 1) if a.isdigit() and sys.argv[i - 1] != "--targets"] or [10000, 100000]
     res = []
     for n in sizes:      # a fresh process per size and mode: its first call is the cold one
         for mode in ("two_step", "fused"):
             with tempfile.TemporaryDirectory() as d:
-                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", str(n), d, mode], capture_output=True, text=True, timeout=1800)
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", str(n), d, mode, str(n_targets)] + (["light"] if light else []), capture_output=True, text=True, timeout=1800)
                 if p.returncode != 0:
                     sys.exit(p.stderr[-3000:])
                 res.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]))
