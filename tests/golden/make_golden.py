@@ -179,7 +179,7 @@ def cross_check(d, T, Q, ref, flags):
 def main():
     if not os.path.exists(HARNESS):
         sys.exit("build the harness first: make -C oracle ref")
-    only = sys.argv[1:]
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
     for name, (seed, nt, nq, tmin, tmax, qmin, qmax, fam, flags) in CASES.items():
         if only and name not in only:
             continue
@@ -194,6 +194,12 @@ def main():
             print(name, "real prefilter + align modules equal the harness:", ref["cross_checked_with_reference_binary"])
         doc = {"case": name, "seed": seed, "targets": T, "queries": Q, "flags": flags, "ref": ref}
         out = os.path.join(HERE, name + ".json.gz")
+        # a fixture that WAS checked against the real modules is not silently replaced by one that was not (a container without the survey's build of the
+        # reference binary): tests/test_oracle_golden.py::test_committed_fixtures_were_cross_checked would fail on the result anyway
+        if os.path.exists(out) and not ref["cross_checked_with_reference_binary"] and "--bin-size" not in flags and "--allow-unchecked" not in sys.argv:
+            was = json.load(gzip.open(out))["ref"].get("cross_checked_with_reference_binary")
+            if was:
+                sys.exit("%s: the committed fixture was cross-checked against the reference binary, this run cannot (no %s); not overwriting (--allow-unchecked to force)" % (name, REF_BINARY))
         with gzip.GzipFile(out, "wb", mtime=0) as f:
             f.write(json.dumps(doc, separators=(",", ":")).encode())
         print(name, "->", out, os.path.getsize(out), "bytes")

@@ -201,3 +201,12 @@ def test_rescorediagonal(name):
             for mode, exp in zip((0, 3, 4), three):
                 r = o.rescore(q, hit[0], hit[2], mode)
                 assert [r.score, r.startPos, r.endPos, r.diagonalLen, r.distToDiagonal, r.diagonal] == exp, (a["id"], hit, mode)
+
+
+def test_committed_fixtures_were_cross_checked():
+    """The harness mirrors the control loops of Prefiltering / Alignment (oracle/ref_harness.cpp:8-15); what ties those loops to the real modules is
+    make_golden.py's cross-check against the reference binary.  The committed fixtures must carry that check: a regeneration in a container without the
+    binary records `false` -- and fails here instead of passing silently.  (`family16` forces --bin-size, which no module flag can: exempt.)"""
+    for name in ("small", "spacer", "family", "longq", "longt"):
+        assert load_golden(name)["ref"]["cross_checked_with_reference_binary"] is True, name
+    assert load_golden("family16")["ref"]["cross_checked_with_reference_binary"] is False
