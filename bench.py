@@ -337,6 +337,7 @@ def main():
     ap.add_argument("--no-hybrid", action="store_true", help="N >= 4: skip the additional 2-shard x N/2-group measurement")
     ap.add_argument("--no-replica", action="store_true", help="N > 1: skip the additional query-partition (replica) measurement")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "host", "gloo"], help="transport of the all-gathers: RCCL (HBM -> xGMI -> HBM), or through host memory and the library's bootstrap sockets (\"host\"; \"gloo\" is the old name) for ranks that share a GPU (tests)")
+    ap.add_argument("--stagger-us", type=int, default=0, help="host-driven steps: context i enters a timed region i x this many microseconds after context 0 (experiment)")
     ap.add_argument("--strict-rccl", action="store_true", help="N > 1: fail instead of falling back to the host transport when RCCL cannot be set up on every rank (exchange.rccl_ranks == world or no line)")
     ap.add_argument("--same-gpu", action="store_true", help="all ranks use HIP device 0 (tests of the N > 1 path on a one-GPU box; needs --exchange gloo)")
     args = ap.parse_args()
@@ -555,6 +556,10 @@ def main():
                 if prev is not None:
                     collect(prev)
                 return
+            if args.stagger_us > 0 and i > 0:      # the contexts enter a region one after the other instead of all at once (their matching kernels would meet in phase)
+                t_go = time.perf_counter() + i * args.stagger_us * 1e-6
+                while time.perf_counter() < t_go:
+                    pass
             for j in range(share[i]):
                 acc[i][1] = step(c, slots[i][j])
                 done[id(slots[i][j])].set()           # (host-driven: the hit list is in host memory when step() returns)

@@ -266,7 +266,7 @@ struct Gpu::Impl {
     bool swBiasFresh = false;        // k_prep8 of the current pass left the Smith-Waterman bias of the resident queries in swd.qcomp / swd.qbias
     // index construction scratch (kept for the next target set)
     DevBuf<uint32_t> ixKeys, ixKeys2, ixKeep, ixPos, ixKmer, ixHead, ixSlotOf, ixHeadPos, ixCnt, ixBefore; DevBuf<uint64_t> ixVals, ixVals2;
-    DevBuf<unsigned char> ixTemp; DevBuf<float> ttProbs; DevBuf<double> ttScale, ttLr; DevBuf<unsigned long long> ixCounters;
+    DevBuf<unsigned char> ixTemp; DevBuf<float> ttProbs; DevBuf<double> ttScale, ttLr; DevBuf<uint64_t> ttPlane; DevBuf<unsigned long long> ixCounters;
     // queries
     DevBuf<uint8_t> qres; DevBuf<uint32_t> qoff; DevBuf<float> biasf; DevBuf<short> qthr; DevBuf<signed char> qcorr; DevBuf<int> qbias; DevBuf<int> qself;
     size_t qTotal = 0; uint32_t maxQLen = 0;
@@ -1094,11 +1094,21 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
     if (mask && to > from) {
         TantanModel tm; tantanModel(seed, tm);
         if (!upload(d.ttLr, &tm.lr[0][0], (size_t) kAlph * kAlph, d.stream, err)) return false;
-        if (!d.ttProbs.ensure((size_t) R + 1, err) || !d.ttScale.ensure((size_t) (R / 16 + n + 2), err)) return false;
+        // per block of 64 sequences a plane [position][lane] of probabilities (and one of rescaling factors at a sixteenth of its offset + 64 per block): as many
+        // positions as the block's longest sequence has
+        const size_t nTtBlocks = (to - from + 63) / 64;
+        std::vector<uint64_t> planeBase(nTtBlocks + 1, 0);
+        for (size_t b = 0; b < nTtBlocks; b++) {
+            uint64_t longest = 0;
+            for (size_t k = from + 64 * b; k < std::min<size_t>(to, from + 64 * (b + 1)); k++) longest = std::max<uint64_t>(longest, ts.offsets[k + 1] - ts.offsets[k]);
+            planeBase[b + 1] = planeBase[b] + 64 * ((longest + 15) / 16 * 16);
+        }
+        if (!d.ttProbs.ensure((size_t) planeBase[nTtBlocks] + 64, err) || !d.ttScale.ensure((size_t) (planeBase[nTtBlocks] / 16 + 64 * nTtBlocks + 64), err) ||
+            !upload(d.ttPlane, planeBase.data(), planeBase.size(), d.stream, err)) return false;
         TantanArgs ta{};
         ta.masked = d.tgt->tmasked.p; ta.toff = d.tgt->toff.p; ta.from = (uint32_t) from; ta.to = (uint32_t) to; ta.lr = d.ttLr.p;
         for (int i = 0; i < 50; i++) ta.b2f[i] = tm.b2f[i];
-        ta.b2b = tm.b2b; ta.f2b = tm.f2b; ta.f2f0 = tm.f2f0; ta.probs = d.ttProbs.p; ta.scale = d.ttScale.p; ta.maskedCount = d.ixCounters.p;
+        ta.b2b = tm.b2b; ta.f2b = tm.f2b; ta.f2f0 = tm.f2f0; ta.probs = d.ttProbs.p; ta.scale = d.ttScale.p; ta.planeBase = d.ttPlane.p; ta.maskedCount = d.ixCounters.p;
         hipLaunchKernelGGL(k_tantan, dim3((unsigned) ((to - from + 63) / 64)), dim3(64), 0, d.stream, ta);
     }
     HIP_OK(hipEventRecord(d.ev[0][1], d.stream));
