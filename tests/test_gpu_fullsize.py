@@ -277,9 +277,10 @@ def test_bench_checks_every_delivered_result(tmp_path):
     assert out["results_checked"]["steps"] == 12 and out["results_checked"]["equal_to_single_context_result"] is True
     assert out["regions"]["n"] == 2
     assert out["regions"]["min"] <= out["value"] <= out["regions"]["max"]
-    # no mode asked for: both step modes are measured, the better one is the value
+    # no mode asked for: both step modes are measured, ONE fixed configuration carries the value (host-driven steps in four contexts), the other stays beside it
     modes = out["step_modes"]
     assert set(modes) == {"device-driven x2", "host-driven x4", "value_from"}
-    assert out["config"]["distinct_query_batches"] == (2 if modes["value_from"] == "device-driven x2" else 4)
-    assert abs(out["value"] - max(modes[k]["spacer_queries_per_s"] for k in ("device-driven x2", "host-driven x4"))) < 1e-6 * out["value"]
-    assert abs(out["value"] - modes[modes["value_from"]]["spacer_queries_per_s"]) < 1e-6 * out["value"]
+    assert modes["value_from"].startswith("host-driven x4")
+    assert out["config"]["distinct_query_batches"] == 4
+    assert abs(out["value"] - modes["host-driven x4"]["spacer_queries_per_s"]) < 1e-6 * out["value"]
+    assert modes["device-driven x2"]["spacer_queries_per_s"] > 0

@@ -137,8 +137,11 @@ def test_bench_self_launches_the_target_sharded_run_with_several_ranks(ranks):
     assert out["n_gpus"] == ranks and out["scaling"] == "strong"
     # the headline is the best decomposition of the same job; all of them are in the line
     dec = out["decompositions"]
-    assert set(dec["spacer_queries_per_s"]) >= {"target_shards", "query_partition"} and dec["value_from"] in dec["spacer_queries_per_s"]
-    assert out["value"] == max(dec["spacer_queries_per_s"].values())
+    # the headline at N > 1 is BASELINE configs[3]'s decomposition (target shards + candidate all-gather), fixed; the other cuts of the same job are side figures
+    assert set(dec["spacer_queries_per_s"]) >= {"target_shards", "query_partition"} and dec["value_from"].startswith("target_shards") and dec["best_measured"] in dec["spacer_queries_per_s"]
+    assert out["value"] == dec["spacer_queries_per_s"]["target_shards"]
+    assert out["weak_replica"]["scaling"] == "weak" and "scaling_note" in out
+    assert out["exchange"]["requested"] in ("host", "gloo") and out["exchange"]["as_requested"] is True and out["exchange"]["rccl_ranks"] == 0
     assert ("target shards x%d" % ranks) in out["config"]["parallelism"] or "target shards" in out["config"]["parallelism"]
     qp = out["query_partition"]
     assert qp["scaling"] == "strong" and qp["results_checked"] > 0 and qp["allgather_bytes_per_step"] > 0 and qp["exchange_ms_per_step"] > 0
@@ -215,6 +218,6 @@ def test_bench_two_shards_times_two_query_groups_on_four_ranks():
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["hybrid"]["value"] > 0 and out["hybrid"]["results_checked"] > 0
-    dec = out["decompositions"]["spacer_queries_per_s"]      # four shards and 2 x 2, the better one is the headline
-    assert set(dec) == {"target_shards", "hybrid"} and out["value"] == max(dec.values()) and "target shards" in out["config"]["parallelism"]
+    dec = out["decompositions"]["spacer_queries_per_s"]      # four shards and 2 x 2: the four shards (configs[3]) carry the headline, the hybrid stays beside it
+    assert set(dec) == {"target_shards", "hybrid"} and out["value"] == dec["target_shards"] and "target shards" in out["config"]["parallelism"]
     assert out["config"]["pairs_aligned_per_step"] == one["config"]["pairs_aligned_per_step"]
