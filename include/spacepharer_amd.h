@@ -265,6 +265,15 @@ uint64_t sp_ctx_overflow_queries(const sp_ctx *c, uint32_t *out, uint64_t cap);
    "ms_score", "ms_select", "ms_sw_forward", "ms_sw_reverse", "ms_traceback", "ms_assemble",
    "ms_index_build", "ms_upload" */
 double sp_ctx_stat(const sp_ctx *c, const char *name);
+/* Result-DB entries as TEXT, formatted on the device (csrc/sp_gpu_text.inc) -- what the `prefilter` and `align` / `search` modules write into their data files:
+   one entry per query of the resident batch, in query order, each its lines followed by a NUL; entry_len[q] (n_queries values) = bytes of entry q, *text_used = their sum.
+   text / entry_len: caller's buffers (page-locked for speed: sp_host_alloc).  SP_ERR_OVERFLOW: text_cap is too small, *text_used says what is needed (nothing copied).
+     sp_ctx_hits_text        after sp_ctx_prefilter(): "<target key>\t<score>\t<diagonal>\n" per hit (QueryMatcher::prefilterHitToBuffer, prefiltering/QueryMatcher.h:114-126)
+     sp_ctx_align_hits_text  aligns the resident hits like sp_ctx_align_hits() and writes, per query, the accepted alignments (Alignment::checkCriteria with
+                             min_seq_id / min_aln_len, alignment/Alignment.cpp:555-574) sorted by Matcher::compareHits as Matcher::resultToBuffer lines with
+                             backtrace (alignment/Matcher.cpp:211-230,323-370).  SP_ERR_UNSUPPORTED: this batch needs the host path (sp_ctx_align_hits + own formatting). */
+int sp_ctx_hits_text(sp_ctx *c, char *text, uint64_t text_cap, uint64_t *text_used, uint32_t *entry_len);
+int sp_ctx_align_hits_text(sp_ctx *c, double min_seq_id, uint32_t min_aln_len, char *text, uint64_t text_cap, uint64_t *text_used, uint32_t *entry_len);
 /* wait for everything queued on the context's streams (search + copy); SP_ERR_DEVICE with the HIP error text in sp_last_error() when a kernel or copy failed */
 int sp_ctx_sync(sp_ctx *c);
 /* HIP-event timing inside the pipeline (sp_ctx_stat "ms_*"): 0 = none, 1 = the k-mer matching kernel only (default; every

@@ -122,6 +122,8 @@ def load_library():
     L.sp_ctx_stat.restype = C.c_double
     L.sp_ctx_stat.argtypes = [vp, C.c_char_p]
     L.sp_ctx_sync.argtypes = [vp]
+    L.sp_ctx_hits_text.argtypes = [vp, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.sp_ctx_align_hits_text.argtypes = [vp, C.c_double, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     L.sp_ctx_set_timing.argtypes = [vp, C.c_int]
     L.sp_ctx_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
     L.sp_ctx_stream.restype = vp
@@ -389,6 +391,33 @@ class SearchContext:
             cig = C.string_at(C.addressof(buf) + r.cigar_offset).decode() if r.aln_len else ""
             out.append((r, cig))
         return out
+
+    def _text(self, call):
+        """result-DB text formatted on the device: list of entries (bytes, without the closing NUL), one per query"""
+        lens = (C.c_uint32 * max(1, self.n_queries))()
+        used = C.c_uint64()
+        cap = 1 << 16
+        while True:
+            buf = C.create_string_buffer(cap)
+            rc = call(buf, cap, C.byref(used), lens)
+            if rc == -5 and used.value > cap:
+                cap = int(used.value) + 16
+                continue
+            _check(rc)
+            break
+        raw, out, at = buf.raw, [], 0
+        for q in range(self.n_queries):
+            out.append(raw[at:at + lens[q] - 1])
+            assert raw[at + lens[q] - 1] == 0
+            at += lens[q]
+        assert at == used.value
+        return out
+
+    def hits_text(self):
+        return self._text(lambda buf, cap, used, lens: self.L.sp_ctx_hits_text(self.ctx, buf, cap, used, lens))
+
+    def align_hits_text(self, min_seq_id=0.0, min_aln_len=0):
+        return self._text(lambda buf, cap, used, lens: self.L.sp_ctx_align_hits_text(self.ctx, min_seq_id, min_aln_len, buf, cap, used, lens))
 
     def sync(self):
         _check(self.L.sp_ctx_sync(self.ctx))

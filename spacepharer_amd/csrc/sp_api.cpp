@@ -455,6 +455,17 @@ static void buildGate(sp_ctx *c) {
     }
     if (c->bitRow.size() != g.stride) { c->bitRow.resize(g.stride); for (uint32_t sc = 0; sc < g.stride; sc++) c->bitRow[sc] = (int) (c->evGapped.bitScore((double) sc) + 0.5); }
     g.bits.assign(c->bitRow.begin(), c->bitRow.end());
+    // "%.3E" of every table entry for the device-side result text (sp_gpu_text.inc): 16 bytes each; left empty -- the host formats then -- when the table is large
+    // (long queries: stride = 32 x the longest query) or an entry does not fit (inf / nan / three-digit exponents)
+    g.evalText.clear();
+    if (g.evalue.size() <= ((size_t) 1 << 20)) {
+        g.evalText.assign(g.evalue.size() * 16, 0);
+        for (size_t i = 0; i < g.evalue.size(); i++) {
+            char tmp[48]; const size_t n = (size_t) (sp::fmtE3(g.evalue[i], tmp) - tmp);
+            if (n == 0 || n > 15) { g.evalText[i * 16] = 255; continue; }      // (the kernel reports such a record and the caller falls back)
+            g.evalText[i * 16] = (unsigned char) n; memcpy(&g.evalText[i * 16 + 1], tmp, n);
+        }
+    }
     g.evalueThr = c->par.evalue;
     g.version = ++c->gateSerial;
     c->gateValid = true;
@@ -552,6 +563,28 @@ int sp_ctx_align_hits(sp_ctx *c, sp_alignment *res, char *cigars, uint64_t cigar
     int rc = finishDirectOrHost(c, direct, res, cigars, cigarCap, cigarUsed);
     if (dbg) fprintf(stderr, "[sp] align_hits: gate %.3f  gpu.align %.3f  finish %.3f ms\n", t1 - t0, t2 - t1, nowMs() - t2);
     return rc;
+}
+
+/* result-DB text formatted on the device: see include/spacepharer_amd.h */
+int sp_ctx_hits_text(sp_ctx *c, char *text, uint64_t textCap, uint64_t *textUsed, uint32_t *entryLen) {
+    if (c) c->gpu.makeCurrent();
+    if (!c || c->targets.n == 0 || !textUsed || !entryLen) { g_err = "sp_ctx_hits_text: no target set / missing output"; return SP_ERR_STATE; }
+    std::string err; uint64_t used = 0;
+    if (!c->gpu.hitsText(text, text ? textCap : 0, used, entryLen, err)) { g_err = "sp_ctx_hits_text: " + err; return SP_ERR_DEVICE; }
+    *textUsed = used;
+    return used > (text ? textCap : 0) ? SP_ERR_OVERFLOW : SP_OK;
+}
+int sp_ctx_align_hits_text(sp_ctx *c, double minSeqId, uint32_t minAlnLen, char *text, uint64_t textCap, uint64_t *textUsed, uint32_t *entryLen) {
+    if (c) c->gpu.makeCurrent();
+    if (!c || c->targets.n == 0 || !textUsed || !entryLen) { g_err = "sp_ctx_align_hits_text: no target set / missing output"; return SP_ERR_STATE; }
+    std::string err;
+    if (!ensureEvaluers(c, true, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
+    buildGate(c);
+    uint64_t used = 0; bool fellBack = false;
+    if (!c->gpu.alignHitsText(c->par.gap_open, c->par.gap_extend, c->gate, c->alnHost, minSeqId, minAlnLen, text, text ? textCap : 0, used, entryLen, fellBack, err)) { g_err = "sp_ctx_align_hits_text: " + err; return SP_ERR_DEVICE; }
+    if (fellBack) { g_err = "sp_ctx_align_hits_text: this batch needs the host's formatting (a pair took the host-driven traceback, or an E-value has no table text): use sp_ctx_align_hits"; return SP_ERR_UNSUPPORTED; }
+    *textUsed = used;
+    return used > (text ? textCap : 0) ? SP_ERR_OVERFLOW : SP_OK;
 }
 
 /* split form of sp_ctx_align_hits(): _begin returns when the device work is done and the results are on their way to

@@ -174,14 +174,26 @@ struct DbWriter {
     // a block of consecutive entries formatted elsewhere (payloads concatenated, each followed by its NUL); the block is kept as it
     // is and written behind what came before it (no copy into one buffer)
     std::vector<std::string> blocks; uint64_t blockBytes = 0;
+    std::vector<std::pair<const char *, size_t>> blockView;      // per block: (nullptr, 0) = blocks[i] itself, else memory of the caller's that outlives close() (addExternal)
+    // a block formatted ELSEWHERE and left where it is -- the device-side result text in the caller's page-locked buffer (sp_ctx_hits_text / sp_ctx_align_hits_text):
+    // entry k has key keys[k] and lengths[k] bytes (its NUL included); `text` must stay valid until close() has returned
+    void addExternal(const uint32_t *keys, const uint32_t *lengths, size_t n, const char *text, size_t bytes) {
+        if (!data.empty()) { blocks.emplace_back(data.begin(), data.end()); blockView.emplace_back(nullptr, 0); blockBytes += data.size(); data.clear(); }
+        uint64_t at = blockBytes;
+        const size_t first = entries.size(); entries.resize(first + n);
+        DbEntry *e = entries.data() + first;
+        for (size_t i = 0; i < n; i++) { e[i].key = keys[i]; e[i].offset = at; e[i].length = lengths[i]; at += lengths[i]; }
+        blockBytes += bytes;
+        blocks.emplace_back(); blockView.emplace_back(text, bytes);
+    }
     void addBlock(const std::vector<uint32_t> &keys, const std::vector<uint64_t> &lengths, std::string &&block) {
-        if (!data.empty()) { blocks.emplace_back(data.begin(), data.end()); blockBytes += data.size(); data.clear(); }
+        if (!data.empty()) { blocks.emplace_back(data.begin(), data.end()); blockView.emplace_back(nullptr, 0); blockBytes += data.size(); data.clear(); }
         uint64_t at = blockBytes;
         const size_t first = entries.size(); entries.resize(first + keys.size());
         DbEntry *e = entries.data() + first;
         for (size_t i = 0; i < keys.size(); i++) { e[i].key = keys[i]; e[i].offset = at; e[i].length = lengths[i]; at += lengths[i]; }
         blockBytes += block.size();
-        blocks.push_back(std::move(block));
+        blocks.push_back(std::move(block)); blockView.emplace_back(nullptr, 0);
     }
     static bool writeAll(int fd, const char *p, size_t n) { while (n) { const ssize_t k = ::write(fd, p, n); if (k <= 0) return false; p += k; n -= (size_t) k; } return true; }
     static bool writeFile(const std::string &path, const char *p, size_t n) {
@@ -205,12 +217,19 @@ struct DbWriter {
         std::atomic<bool> dataOk{dataFd >= 0};
         std::vector<std::thread> dataWriters;
         if (dataFd >= 0) {
-            std::vector<uint64_t> at(blocks.size() + 1, 0);
-            for (size_t i = 0; i < blocks.size(); i++) at[i + 1] = at[i] + blocks[i].size();
-            const size_t W = blockBytes + data.size() >= (4u << 20) ? std::min<size_t>(4, blocks.size() + 1) : 1;
-            auto job = [this, dataFd, at, W, &dataOk](size_t w) {
-                for (size_t i = w; i <= blocks.size(); i += W) {
-                    const char *p = i < blocks.size() ? blocks[i].data() : data.data(); size_t n = i < blocks.size() ? blocks[i].size() : data.size(); uint64_t o = at[i];
+            // segments of at most 4 MB (a block formatted on the device is ONE piece of tens of megabytes), dealt to the writers
+            struct Seg { const char *p; size_t n; uint64_t o; };
+            std::vector<Seg> segs;
+            uint64_t o = 0;
+            for (size_t i = 0; i <= blocks.size(); i++) {
+                const char *p = i < blocks.size() ? (blockView[i].first ? blockView[i].first : blocks[i].data()) : data.data();
+                size_t n = i < blocks.size() ? (blockView[i].first ? blockView[i].second : blocks[i].size()) : data.size();
+                while (n) { const size_t k = std::min<size_t>(n, (size_t) 4 << 20); segs.push_back({p, k, o}); p += k; n -= k; o += k; }
+            }
+            const size_t W = blockBytes + data.size() >= (4u << 20) ? std::min<size_t>(4, std::max<size_t>(1, segs.size())) : 1;
+            auto job = [dataFd, segs, W, &dataOk](size_t w) {
+                for (size_t i = w; i < segs.size(); i += W) {
+                    const char *p = segs[i].p; size_t n = segs[i].n; uint64_t o = segs[i].o;
                     while (n) { const ssize_t k = ::pwrite(dataFd, p, n, (off_t) o); if (k <= 0) { dataOk = false; return; } p += k; n -= (size_t) k; o += (uint64_t) k; }
                 }
             };
@@ -268,7 +287,7 @@ struct DbWriter {
         { const int32_t v = dbtype; if (!writeFile(typePath, (const char *) &v, 4)) { err = "cannot write " + typePath; return false; } }
         {   BufferPool &pool = BufferPool::mine();      // everything is on disk: the buffers go back to the pool with their capacity
             for (std::string &b : blocks) pool.give(std::move(b));
-            blocks.clear();
+            blocks.clear(); blockView.clear();
             pool.give(std::move(entries)); }
         return true;
     }

@@ -26,12 +26,14 @@ struct SwFull {
 // evalue[slot * stride + score] and bits[score] are the statistics the result records carry (doubles computed by the host's libm);
 // version changes whenever the content does, so that the device copy is refreshed only then
 struct GateTable { uint32_t stride = 0; std::vector<uint16_t> slotOf; std::vector<uint8_t> pass; std::vector<double> evalue; std::vector<int32_t> bits;
+                   std::vector<unsigned char> evalText;      // "%.3E" of every table entry, 16 bytes each (length, characters): the device formats result lines from it; empty when the table would be large
                    double evalueThr = 0; uint64_t version = 0; };
 // device-assembled result record: layout of sp_alignment (include/spacepharer_amd.h), checked by a static_assert in sp_api.cpp
 struct AlnRec { uint32_t dbKey; int32_t bitScore, rawScore; float seqId; double evalue; int32_t qStart, qEnd; uint32_t qLen; int32_t dbStart, dbEnd; uint32_t dbLen, alnLen, cigarOffset; int32_t passed; };
 // where align() may put finished records directly (host memory of the caller, ideally page-locked: sp_host_alloc)
 // async: return as soon as the copies are queued; the caller collects them with Gpu::waitAlignCopy()
-struct AlignDirect { void *records = nullptr; char *cigars = nullptr; uint64_t cigarCap = 0; uint64_t cigarUsed = 0; bool done = false; bool overflow = false; bool async = false; };
+struct AlignDirect { void *records = nullptr; char *cigars = nullptr; uint64_t cigarCap = 0; uint64_t cigarUsed = 0; bool done = false; bool overflow = false; bool async = false;
+                     bool deviceOnly = false; };      // deviceOnly: assemble records + packed backtraces on the device and leave them there (the text kernels read them)
 // one device-driven search step (Gpu::stepBegin / stepEnd): where its results go (caller-owned, page-locked: sp_host_alloc) ...
 struct StepOut { GpuHit *hits = nullptr; uint32_t *offsets = nullptr; uint64_t hitCap = 0; AlnRec *records = nullptr; char *cigars = nullptr; uint64_t recordCap = 0, cigarCap = 0; };
 // ... and what the host learns when it collects the step
@@ -153,6 +155,12 @@ public:
     bool diagStreamRead(uint64_t bytes, int laneBytes, double &ms, std::string &err);
 
     bool sync(std::string &err);
+    // result-DB text formatted on the device (sp_gpu_text.inc): entries of the resident batch in query order, each followed by a NUL; entryLen[q] = bytes of entry q.
+    // hitsText: the prefilter entries of the last pass's hit list.  alignHitsText: aligns the resident hits and writes the alignment entries (accepted records, sorted);
+    // fellBack = true (and nothing written): a pair needed the host-driven traceback or an E-value has no table text -- the caller formats on the host.
+    // used > cap: nothing copied, `used` says how much room the text needs.
+    bool hitsText(char *text, uint64_t cap, uint64_t &used, uint32_t *entryLen, std::string &err);
+    bool alignHitsText(int gapOpen, int gapExtend, const GateTable &gate, AlignHost &host, double minSeqId, uint32_t minAlnLen, char *text, uint64_t cap, uint64_t &used, uint32_t *entryLen, bool &fellBack, std::string &err);
     void setTiming(int level);
     void setMatchBlocksPerCU(int n);   // 0 = as many as fit
     bool setKnob(const std::string &name, int value);      // "match_small", "match_heavy_threshold"; false: unknown

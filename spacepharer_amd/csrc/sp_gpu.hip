@@ -189,6 +189,7 @@ __device__ __forceinline__ uint32_t extIndex(uint32_t packed) { return packed & 
 #include "sp_gpu_select.inc"
 
 #include "sp_gpu_sw.inc"
+#include "sp_gpu_text.inc"
 #include "sp_gpu_index.inc"
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -267,6 +268,7 @@ struct Gpu::Impl {
     // index construction scratch (kept for the next target set)
     DevBuf<uint32_t> ixKeys, ixKeys2, ixKeep, ixPos, ixKmer, ixHead, ixSlotOf, ixHeadPos, ixCnt, ixBefore; DevBuf<uint64_t> ixVals, ixVals2;
     DevBuf<unsigned char> ixTemp; DevBuf<float> ttProbs; DevBuf<double> ttScale, ttLr; DevBuf<uint64_t> ttPlane; DevBuf<unsigned long long> ixCounters;
+    DevBuf<uint32_t> txLen, txOff, txLineOff, txLineLen, txFlags; DevBuf<char> txText; DevBuf<unsigned char> txEval; uint64_t txEvalVersion = 0;      // device-side result text (sp_gpu_text.inc)
     // queries
     DevBuf<uint8_t> qres; DevBuf<uint32_t> qoff; DevBuf<float> biasf; DevBuf<short> qthr; DevBuf<signed char> qcorr; DevBuf<int> qbias; DevBuf<int> qself;
     size_t qTotal = 0; uint32_t maxQLen = 0;
@@ -1023,6 +1025,71 @@ bool Gpu::allgatherHits(Comm &comm, size_t queryOffset, size_t nqTotal, const Gp
     }
     offsets[nqTotal] = at;
     nHits = (size_t) at;
+    return true;
+}
+
+// ---- result-DB text on the device (sp_gpu_text.inc) ---------------------------------------------------------------------------------------------------------
+bool Gpu::hitsText(char *text, uint64_t cap, uint64_t &used, uint32_t *entryLen, std::string &err) {
+    Impl &d = *d_;
+    used = 0;
+    if (nq_ == 0) return true;
+    if (d.stepsBegun != d.stepsEnded && !d.drained) { err = "hitsText: a device-driven step is in flight"; return false; }
+    const size_t nHits = (size_t) counters_.hits;
+    if (!d.txLen.ensure(nq_ + 1, err) || !d.txOff.ensure(nq_ + 2, err) || !d.txLineOff.ensure(nHits + 1, err)) return false;
+    HitTextArgs a{d.outHits.p, d.outOffset.p, d.outQuery.p, (uint32_t) nq_, d.outOffset.p + nq_, d.tgt->tkeys.p, d.txLen.p, d.txOff.p, d.txLineOff.p, nullptr};
+    hipLaunchKernelGGL(k_hits_text_len, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, a);
+    if (!d.scanCounts(d.txLen.p, (uint32_t) nq_, d.txOff.p, err)) return false;
+    uint32_t total = 0;
+    HIP_OK(hipMemcpyAsync(&total, d.txOff.p + nq_, sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipStreamSynchronize(d.stream));
+    used = total;
+    if (used > cap) return true;
+    if (!d.txText.ensure((size_t) total + 16, err)) return false;
+    a.text = d.txText.p;
+    if (nHits) hipLaunchKernelGGL(k_hits_text_write, dim3((unsigned) ((nHits + 255) / 256)), dim3(256), 0, d.stream, a);
+    hipLaunchKernelGGL(k_text_entry_ends, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.txLen.p, d.txOff.p, (uint32_t) nq_, d.txText.p);
+    HIP_OK(hipMemcpyAsync(text, d.txText.p, total, hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipMemcpyAsync(entryLen, d.txLen.p, nq_ * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipStreamSynchronize(d.stream));
+    return true;
+}
+
+bool Gpu::alignHitsText(int gapOpen, int gapExtend, const GateTable &gate, AlignHost &host, double minSeqId, uint32_t minAlnLen, char *text, uint64_t cap, uint64_t &used, uint32_t *entryLen,
+                        bool &fellBack, std::string &err) {
+    Impl &d = *d_;
+    SwDev &s = d.swd;
+    used = 0; fellBack = false;
+    if (nq_ == 0) return true;
+    if (gate.evalText.empty()) { fellBack = true; return true; }
+    AlignDirect direct; direct.deviceOnly = true;
+    if (!align(nullptr, 0, gapOpen, gapExtend, gate, host, &direct, err)) return false;
+    if (!direct.done) { fellBack = true; return true; }      // (a pair took the host-driven traceback: the records are not all on the device)
+    const size_t n = (size_t) counters_.hits;
+    if (!d.txLen.ensure(nq_ + 1, err) || !d.txOff.ensure(nq_ + 2, err) || !d.txLineOff.ensure(n + 1, err) || !d.txLineLen.ensure(n + 1, err) || !d.txFlags.ensure(4, err)) return false;
+    if (d.txEvalVersion != gate.version || !d.txEval.p) {
+        if (!upload(d.txEval, gate.evalText.data(), gate.evalText.size(), d.stream, err)) return false;
+        HIP_OK(hipStreamSynchronize(d.stream));
+        d.txEvalVersion = gate.version;
+    }
+    HIP_OK(hipMemsetAsync(d.txFlags.p, 0, 4 * sizeof(uint32_t), d.stream));
+    AlnTextArgs a{s.rec.p, s.cig.p, d.outOffset.p, d.outQuery.p, (uint32_t) nq_, d.outOffset.p + nq_, minSeqId, minAlnLen, d.txEval.p, s.gateSlot.p, gate.stride,
+                  d.txLineLen.p, d.txLineOff.p, d.txLen.p, d.txOff.p, nullptr, d.txFlags.p};
+    hipLaunchKernelGGL(k_aln_text_measure, dim3((unsigned) ((nq_ + 63) / 64)), dim3(64), 0, d.stream, a);
+    if (!d.scanCounts(d.txLen.p, (uint32_t) nq_, d.txOff.p, err)) return false;
+    uint32_t back[2] = {0, 0};
+    HIP_OK(hipMemcpyAsync(&back[0], d.txOff.p + nq_, sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipMemcpyAsync(&back[1], d.txFlags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipStreamSynchronize(d.stream));
+    if (back[1] != 0) { fellBack = true; return true; }
+    used = back[0];
+    if (used > cap) return true;
+    if (!d.txText.ensure((size_t) back[0] + 16, err)) return false;
+    a.text = d.txText.p;
+    if (n) hipLaunchKernelGGL(k_aln_text_write, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, a);
+    hipLaunchKernelGGL(k_text_entry_ends, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.txLen.p, d.txOff.p, (uint32_t) nq_, d.txText.p);
+    HIP_OK(hipMemcpyAsync(text, d.txText.p, back[0], hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipMemcpyAsync(entryLen, d.txLen.p, nq_ * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipStreamSynchronize(d.stream));
     return true;
 }
 

@@ -303,6 +303,41 @@ struct ResultBufsRef {               // the served pair, or a pair of this call'
     ~ResultBufsRef() { own.release(); }
 };
 
+// Result text formatted on the device (sp_ctx_hits_text / sp_ctx_align_hits_text): the page-locked buffer it lands in is handed to the DbWriter as it is (addExternal)
+// and must outlive the writer's close() -- it belongs to the module call, or to the server between calls.  SP_DEVICE_TEXT=0: the host formats (the round-4 path, also
+// taken for whatever the device path declines: --max-accept / --max-rejected, runs of several batches, target shards, queries retried through shards, batches with a pair
+// that needs the host-driven traceback).
+struct TextBufs {
+    char *text = nullptr; uint32_t *lens = nullptr; uint64_t textCap = 0, lenCap = 0;
+    void release() { sp_host_free(text); sp_host_free(lens); text = nullptr; lens = nullptr; textCap = lenCap = 0; }
+    bool ensure(uint64_t nText, uint64_t nLens) {
+        if (nText > textCap) { sp_host_free(text); textCap = nText + nText / 4 + 4096; text = static_cast<char *>(sp_host_alloc(textCap)); if (!text) { textCap = 0; sp::setLastError("out of page-locked memory for the result text"); return false; } }
+        if (nLens > lenCap) { sp_host_free(lens); lenCap = nLens + nLens / 4 + 1024; lens = static_cast<uint32_t *>(sp_host_alloc(lenCap * sizeof(uint32_t))); if (!lens) { lenCap = 0; sp::setLastError("out of page-locked memory for the result text"); return false; } }
+        return true;
+    }
+};
+static TextBufs g_servedText;
+struct TextBufsRef {
+    TextBufs own, *b;
+    explicit TextBufsRef(bool serving) : b(serving ? &g_servedText : &own) {}
+    ~TextBufsRef() { own.release(); }
+};
+static bool deviceTextEnabled() { const char *e = getenv("SP_DEVICE_TEXT"); return !(e && *e == '0'); }
+// the entries of the context's resident batch as one external block of `w`: 1 = added, 0 = the device path declined (the caller formats on the host), -1 = error
+static int deviceTextBlock(sp_ctx *c, bool alignments, double minSeqId, long minAlnLen, const std::vector<uint32_t> &keys, TextBufs &tb, DbWriter &w) {
+    const uint64_t nHits = sp_ctx_num_hits(c);
+    if (!tb.ensure(nHits * (alignments ? 72 : 24) + keys.size() + (1u << 16), keys.size() + 1)) return -1;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        uint64_t used = 0;
+        const int rc = alignments ? sp_ctx_align_hits_text(c, minSeqId, (uint32_t) std::max<long>(0, minAlnLen), tb.text, tb.textCap, &used, tb.lens)
+                                  : sp_ctx_hits_text(c, tb.text, tb.textCap, &used, tb.lens);
+        if (rc == SP_OK) { w.addExternal(keys.data(), tb.lens, keys.size(), tb.text, (size_t) used); return 1; }
+        if (rc == SP_ERR_UNSUPPORTED) return 0;
+        if (rc != SP_ERR_OVERFLOW || attempt == 1 || !tb.ensure(used + 16, keys.size() + 1)) return -1;
+    }
+    return -1;
+}
+
 // SP_MODULE_TIMES=1: wall-clock laps of a module run on stderr
 struct Laps {
     bool on = getenv("SP_MODULE_TIMES") != nullptr; const char *module;
@@ -451,6 +486,7 @@ int runPrefilterModule(int argc, const char **argv) {
         return true;
     };
     bool oneBatch = false;
+    TextBufsRef text(ctx.cached);
     for (size_t b0 = qFrom; b0 < nq; b0 += batch) {
         const size_t b1 = std::min(nq, b0 + batch);
         std::vector<uint64_t> off(qoff.begin() + b0, qoff.begin() + b1 + 1);
@@ -477,7 +513,13 @@ int runPrefilterModule(int argc, const char **argv) {
         }
         if (rc != SP_OK) return fail(std::string("prefilter: ") + sp_last_error());
         laps.lap("queries -> device, search");
-        if (!writeBatch(ctx.c, keys)) return fail(std::string("prefilter: ") + sp_last_error());
+        int viaDevice = 0;
+        if (b0 == qFrom && b1 == nq && deviceTextEnabled()) {      // the whole run is this batch: its entries come as text from the device, in the buffer the writer reads
+            viaDevice = deviceTextBlock(ctx.c, false, 0.0, 0, keys, *text.b, w);
+            if (viaDevice < 0) return fail(std::string("prefilter: ") + sp_last_error());
+            if (viaDevice) laps.lap("  entries formatted on the device");
+        }
+        if (!viaDevice && !writeBatch(ctx.c, keys)) return fail(std::string("prefilter: ") + sp_last_error());
         oneBatch = b0 == 0 && b1 == qkeys.size();
     }
     laps.lap("format hits");
@@ -590,6 +632,19 @@ int runAlignModule(int argc, const char **argv) {
                    ap.gapExtend == (int) strtol(aaPart(f.str("--gap-extend", "1")).c_str(), NULL, 10) && ap.evalue == f.real("-e", 0.001);
     }
     ResultBufsRef bufs(g_memo.c != nullptr || getenv("SP_CONTEXT_CACHE") != nullptr);      // (serving)
+    TextBufsRef text(g_memo.c != nullptr || getenv("SP_CONTEXT_CACHE") != nullptr);
+    if (resident && deviceTextEnabled() && maxAccept == INT_MAX && maxRejected == INT_MAX) {
+        // ... and write the entries where the records are: aligned, accepted, sorted and formatted on the device, one block of text for the writer
+        DbWriter w; w.path = f.positional[3]; w.dbtype = 5;
+        const int via = deviceTextBlock(g_memo.c, true, minSeqId, minAlnLen, g_memo.qkeys, *text.b, w);
+        if (via < 0) return fail(std::string("align: ") + sp_last_error());
+        if (via) {
+            laps.lap("align + entries on the device (resident hits)");
+            if (!w.close(err)) return fail("align: " + err);
+            laps.lap("write DB");
+            return 0;
+        }
+    }
     if (resident) {
         sp_ctx *c = g_memo.c;
         const sp_hit_packed *hits = nullptr; const uint32_t *ho = nullptr; uint64_t nHits = 0;
@@ -746,6 +801,7 @@ int runSearchModule(int argc, const char **argv) {
     size_t qFrom = 0, nq = qkeys.size();
     if (!shardTargets) { std::vector<uint64_t> lens(qkeys.size()); for (size_t i = 0; i < lens.size(); i++) lens[i] = qoff[i + 1] - qoff[i] + 2; partRange(lens, w.part, qFrom, nq); }   // this GPU's queries
     ResultBufsRef bufs(ctx.cached);
+    TextBufsRef text(ctx.cached);
     auto freeBufs = [&]() { };      // (the buffers go with `bufs`)
     // align the hits of the context's current batch, filter / sort / format them, one entry per key
     auto alignAndFormat = [&](sp_ctx *c, const std::vector<uint32_t> &keys, size_t entryFrom = 0) -> bool {      // keys[k] names query entryFrom + k of the resident batch
@@ -836,7 +892,13 @@ int runSearchModule(int argc, const char **argv) {
         }
         if (rc != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
         laps.lap("queries -> device, prefilter");
-        if (!alignAndFormat(ctx.c, keys)) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+        int viaDevice = 0;
+        if (b0 == qFrom && b1 == nq && deviceTextEnabled() && maxAccept == INT_MAX && maxRejected == INT_MAX) {      // the whole run is this batch: aligned, accepted, sorted, formatted on the device
+            viaDevice = deviceTextBlock(ctx.c, true, minSeqId, minAlnLen, keys, *text.b, w);
+            if (viaDevice < 0) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+            if (viaDevice) laps.lap("align + entries on the device");
+        }
+        if (!viaDevice && !alignAndFormat(ctx.c, keys)) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
     }
     freeBufs();
     if (!w.close(err)) return fail("search: " + err);

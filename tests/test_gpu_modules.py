@@ -300,6 +300,16 @@ def test_fused_search_module_writes_the_align_db(name, tmp_path):
     sa.module_prefilter([q, t, pref] + (PREF_FLAGS % r["maxSeqs"]).split())
     sa.module_align([q, t, pref, aln] + ALN_FLAGS.split())
     assert open(aln, "rb").read() == open(fused, "rb").read() and open(aln + ".index").read() == open(fused + ".index").read()
+    # the entries above were formatted on the device (csrc/sp_gpu_text.inc) where the batch allows it; the host's formatters (SP_DEVICE_TEXT=0) must write the same files
+    os.environ["SP_DEVICE_TEXT"] = "0"
+    try:
+        hpref, hfused = str(tmp_path / "hpref"), str(tmp_path / "hfused")
+        sa.module_search([q, t, hfused, str(tmp_path)] + flags)
+        sa.module_prefilter([q, t, hpref] + (PREF_FLAGS % r["maxSeqs"]).split())
+    finally:
+        del os.environ["SP_DEVICE_TEXT"]
+    assert open(hfused, "rb").read() == open(fused, "rb").read() and open(hfused + ".index").read() == open(fused + ".index").read()
+    assert open(hpref, "rb").read() == open(pref, "rb").read() and open(hpref + ".index").read() == open(pref + ".index").read()
     with pytest.raises(sa.SpError):
         sa.module_search([q, t, fused + "x", str(tmp_path)] + flags + ["--num-iterations", "3"])      # iterative profile search: not this path
     assert not os.path.exists(fused + "x.dbtype")
