@@ -574,6 +574,14 @@ int sp_ctx_hits_text(sp_ctx *c, char *text, uint64_t textCap, uint64_t *textUsed
     *textUsed = used;
     return used > (text ? textCap : 0) ? SP_ERR_OVERFLOW : SP_OK;
 }
+int sp_ctx_text_index(sp_ctx *c, const uint32_t *keys, uint64_t n, uint64_t base, char *text, uint64_t textCap, uint64_t *textUsed) {
+    if (c) c->gpu.makeCurrent();
+    if (!c || !keys || !textUsed) { g_err = "sp_ctx_text_index: null argument"; return SP_ERR_ARG; }
+    std::string err; uint64_t used = 0;
+    if (!c->gpu.textIndex(keys, (size_t) n, base, text, text ? textCap : 0, used, err)) { g_err = "sp_ctx_text_index: " + err; return SP_ERR_STATE; }
+    *textUsed = used;
+    return used > (text ? textCap : 0) ? SP_ERR_OVERFLOW : SP_OK;
+}
 int sp_ctx_align_hits_text(sp_ctx *c, double minSeqId, uint32_t minAlnLen, char *text, uint64_t textCap, uint64_t *textUsed, uint32_t *entryLen) {
     if (c) c->gpu.makeCurrent();
     if (!c || c->targets.n == 0 || !textUsed || !entryLen) { g_err = "sp_ctx_align_hits_text: no target set / missing output"; return SP_ERR_STATE; }

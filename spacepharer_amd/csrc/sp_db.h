@@ -174,6 +174,8 @@ struct DbWriter {
     // a block of consecutive entries formatted elsewhere (payloads concatenated, each followed by its NUL); the block is kept as it
     // is and written behind what came before it (no copy into one buffer)
     std::vector<std::string> blocks; uint64_t blockBytes = 0;
+    const char *extIndex = nullptr; size_t extIndexBytes = 0, extIndexEntries = 0;      // (see close())
+    void setExternalIndex(const char *text, size_t bytes, size_t nEntries) { extIndex = text; extIndexBytes = bytes; extIndexEntries = nEntries; }
     std::vector<std::pair<const char *, size_t>> blockView;      // per block: (nullptr, 0) = blocks[i] itself, else memory of the caller's that outlives close() (addExternal)
     // a block formatted ELSEWHERE and left where it is -- the device-side result text in the caller's page-locked buffer (sp_ctx_hits_text / sp_ctx_align_hits_text):
     // entry k has key keys[k] and lengths[k] bytes (its NUL included); `text` must stay valid until close() has returned
@@ -247,7 +249,13 @@ struct DbWriter {
         bool sorted = true;
         for (size_t i = 1; i < entries.size() && sorted; i++) sorted = entries[i - 1].key <= entries[i].key;
         if (!sorted) std::sort(entries.begin(), entries.end(), [](const DbEntry &a, const DbEntry &b) { return a.key < b.key; });   // DBWriter.cpp:645-660
-        {   // index text: formatted by a few threads over contiguous ranges, written with one call
+        // an index text that came with the external block (formatted on the device, sp_ctx_text_index) stands for the whole DB when that block is all there is and its
+        // keys ascend -- the order the index is written in (a part of a fan-out run writes its own .idxpart the same way)
+        const bool useExtIndex = extIndex && sorted && entries.size() == extIndexEntries && blocks.size() == 1 && blockView[0].first && data.empty();
+        if (useExtIndex) {
+            if (timed) tw2 = now();
+            if (!writeFile(indexPath, extIndex, extIndexBytes)) { finishData(); err = "cannot write " + indexPath; return false; }
+        } else {   // index text: formatted by a few threads over contiguous ranges, written with one call
             const size_t n = entries.size();
             const size_t T = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(32, (size_t) defaultThreads()), n / 16384 + 1));
             std::vector<std::string> texts = pooledBlocks(T);

@@ -160,6 +160,8 @@ public:
     // fellBack = true (and nothing written): a pair needed the host-driven traceback or an E-value has no table text -- the caller formats on the host.
     // used > cap: nothing copied, `used` says how much room the text needs.
     bool hitsText(char *text, uint64_t cap, uint64_t &used, uint32_t *entryLen, std::string &err);
+    // the index text of the entries the last hitsText / alignHitsText call produced ("<key>\t<offset>\t<length>\n", offsets from `base`): keys[e] names entry e
+    bool textIndex(const uint32_t *keys, size_t n, uint64_t base, char *text, uint64_t cap, uint64_t &used, std::string &err);
     bool alignHitsText(int gapOpen, int gapExtend, const GateTable &gate, AlignHost &host, double minSeqId, uint32_t minAlnLen, char *text, uint64_t cap, uint64_t &used, uint32_t *entryLen, bool &fellBack, std::string &err);
     void setTiming(int level);
     void setMatchBlocksPerCU(int n);   // 0 = as many as fit

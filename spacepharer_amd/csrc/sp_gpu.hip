@@ -268,7 +268,7 @@ struct Gpu::Impl {
     // index construction scratch (kept for the next target set)
     DevBuf<uint32_t> ixKeys, ixKeys2, ixKeep, ixPos, ixKmer, ixHead, ixSlotOf, ixHeadPos, ixCnt, ixBefore; DevBuf<uint64_t> ixVals, ixVals2;
     DevBuf<unsigned char> ixTemp; DevBuf<float> ttProbs; DevBuf<double> ttScale, ttLr; DevBuf<uint64_t> ttPlane; DevBuf<unsigned long long> ixCounters;
-    DevBuf<uint32_t> txLen, txOff, txLineOff, txLineLen, txFlags; DevBuf<char> txText; DevBuf<unsigned char> txEval; uint64_t txEvalVersion = 0;      // device-side result text (sp_gpu_text.inc)
+    DevBuf<uint32_t> txLen, txOff, txLineOff, txLineLen, txFlags; DevBuf<char> txText, txIdxText; DevBuf<uint32_t> txKeys, txIdxLen, txIdxOff; DevBuf<unsigned char> txEval; uint64_t txEvalVersion = 0;      // device-side result text (sp_gpu_text.inc)
     // queries
     DevBuf<uint8_t> qres; DevBuf<uint32_t> qoff; DevBuf<float> biasf; DevBuf<short> qthr; DevBuf<signed char> qcorr; DevBuf<int> qbias; DevBuf<int> qself;
     size_t qTotal = 0; uint32_t maxQLen = 0;
@@ -1050,6 +1050,28 @@ bool Gpu::hitsText(char *text, uint64_t cap, uint64_t &used, uint32_t *entryLen,
     hipLaunchKernelGGL(k_text_entry_ends, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.txLen.p, d.txOff.p, (uint32_t) nq_, d.txText.p);
     HIP_OK(hipMemcpyAsync(text, d.txText.p, total, hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipMemcpyAsync(entryLen, d.txLen.p, nq_ * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipStreamSynchronize(d.stream));
+    return true;
+}
+
+bool Gpu::textIndex(const uint32_t *keys, size_t n, uint64_t base, char *text, uint64_t cap, uint64_t &used, std::string &err) {
+    Impl &d = *d_;
+    used = 0;
+    if (n == 0) return true;
+    if (n != nq_ || !d.txLen.p || !d.txOff.p) { err = "textIndex: no entries of this batch on the device (call hitsText / alignHitsText first)"; return false; }
+    if (!upload(d.txKeys, keys, n, d.stream, err) || !d.txIdxLen.ensure(n + 1, err) || !d.txIdxOff.ensure(n + 2, err)) return false;
+    IndexTextArgs a{d.txKeys.p, d.txLen.p, d.txOff.p, (uint32_t) n, base, d.txIdxLen.p, d.txIdxOff.p, nullptr};
+    hipLaunchKernelGGL(k_index_text_len, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, a);
+    if (!d.scanCounts(d.txIdxLen.p, (uint32_t) n, d.txIdxOff.p, err)) return false;
+    uint32_t total = 0;
+    HIP_OK(hipMemcpyAsync(&total, d.txIdxOff.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipStreamSynchronize(d.stream));
+    used = total;
+    if (used > cap) return true;
+    if (!d.txIdxText.ensure((size_t) total + 16, err)) return false;
+    a.text = d.txIdxText.p;
+    hipLaunchKernelGGL(k_index_text_write, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, a);
+    HIP_OK(hipMemcpyAsync(text, d.txIdxText.p, total, hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipStreamSynchronize(d.stream));
     return true;
 }

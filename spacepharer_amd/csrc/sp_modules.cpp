@@ -309,7 +309,14 @@ struct ResultBufsRef {               // the served pair, or a pair of this call'
 // that needs the host-driven traceback).
 struct TextBufs {
     char *text = nullptr; uint32_t *lens = nullptr; uint64_t textCap = 0, lenCap = 0;
-    void release() { sp_host_free(text); sp_host_free(lens); text = nullptr; lens = nullptr; textCap = lenCap = 0; }
+    char *index = nullptr; uint64_t indexCap = 0;
+    void release() { sp_host_free(text); sp_host_free(lens); sp_host_free(index); text = nullptr; lens = nullptr; index = nullptr; textCap = lenCap = indexCap = 0; }
+    bool ensureIndex(uint64_t n) {
+        if (n <= indexCap) return true;
+        sp_host_free(index); indexCap = n + n / 4 + 4096; index = static_cast<char *>(sp_host_alloc(indexCap));
+        if (!index) { indexCap = 0; sp::setLastError("out of page-locked memory for the index text"); return false; }
+        return true;
+    }
     bool ensure(uint64_t nText, uint64_t nLens) {
         if (nText > textCap) { sp_host_free(text); textCap = nText + nText / 4 + 4096; text = static_cast<char *>(sp_host_alloc(textCap)); if (!text) { textCap = 0; sp::setLastError("out of page-locked memory for the result text"); return false; } }
         if (nLens > lenCap) { sp_host_free(lens); lenCap = nLens + nLens / 4 + 1024; lens = static_cast<uint32_t *>(sp_host_alloc(lenCap * sizeof(uint32_t))); if (!lens) { lenCap = 0; sp::setLastError("out of page-locked memory for the result text"); return false; } }
@@ -331,7 +338,17 @@ static int deviceTextBlock(sp_ctx *c, bool alignments, double minSeqId, long min
         uint64_t used = 0;
         const int rc = alignments ? sp_ctx_align_hits_text(c, minSeqId, (uint32_t) std::max<long>(0, minAlnLen), tb.text, tb.textCap, &used, tb.lens)
                                   : sp_ctx_hits_text(c, tb.text, tb.textCap, &used, tb.lens);
-        if (rc == SP_OK) { w.addExternal(keys.data(), tb.lens, keys.size(), tb.text, (size_t) used); return 1; }
+        if (rc == SP_OK) {
+            w.addExternal(keys.data(), tb.lens, keys.size(), tb.text, (size_t) used);
+            // the index text too while the lengths are on the device (the writer takes it when this block turns out to be the whole DB with ascending keys)
+            if (w.part.count <= 1 && tb.ensureIndex(keys.size() * 24 + 64)) {
+                uint64_t iu = 0;
+                int ri = sp_ctx_text_index(c, keys.data(), keys.size(), 0, tb.index, tb.indexCap, &iu);
+                if (ri == SP_ERR_OVERFLOW && tb.ensureIndex(iu + 16)) ri = sp_ctx_text_index(c, keys.data(), keys.size(), 0, tb.index, tb.indexCap, &iu);
+                if (ri == SP_OK) w.setExternalIndex(tb.index, (size_t) iu, keys.size());
+            }
+            return 1;
+        }
         if (rc == SP_ERR_UNSUPPORTED) return 0;
         if (rc != SP_ERR_OVERFLOW || attempt == 1 || !tb.ensure(used + 16, keys.size() + 1)) return -1;
     }
