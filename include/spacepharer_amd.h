@@ -235,6 +235,18 @@ typedef struct { uint64_t n; uint32_t *keys; uint64_t *offsets; char *text; } sp
 int sp_ctx_set_scores(sp_ctx *c, const sp_set_layout *l, const sp_alignment *aln, const char *cigars, int stage, sp_text_db *out);
 void sp_text_db_free(sp_text_db *db);
 
+/* A sequence DB (MMseqs2 triple <path>, <path>.index, <path>.dbtype; split data files tolerated) read by the library's own reader and flattened into what
+   sp_ctx_set_targets / sp_ctx_set_queries / sp_set_layout take: residues back to back (entry terminators removed), offsets[n + 1], keys[n] in key order -- and
+   sets[n], the third column of <path>.lookup ("key\tname\tset", commons/DBReader.h) per entry, when that file exists (else NULL).  The arrays belong to the handle. */
+typedef struct sp_flat_db sp_flat_db;
+sp_flat_db *sp_flat_db_open(const char *path);      /* NULL + sp_last_error() on failure */
+void sp_flat_db_close(sp_flat_db *f);
+uint64_t sp_flat_db_entries(const sp_flat_db *f);
+const char *sp_flat_db_residues(const sp_flat_db *f);
+const uint64_t *sp_flat_db_offsets(const sp_flat_db *f);
+const uint32_t *sp_flat_db_keys(const sp_flat_db *f);
+const uint32_t *sp_flat_db_sets(const sp_flat_db *f);
+
 /* ---- target-sharded search (one context per GPU) ----
  * Every GPU holds all target residues (align needs them) but masks and indexes only targets [shard_from, shard_to);
  * sequence ids stay global.  Per query batch: sp_ctx_prefilter_candidates() on every shard, gather the candidate lists of

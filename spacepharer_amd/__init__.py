@@ -3,4 +3,4 @@ rescorediagonal).  The product is the C-ABI shared library built from spacephare
 C++ host code); this package is only the thin ctypes binding that bench.py and the tests use.  There is no CPU path:
 importing works anywhere, but every compute call needs a HIP device and the in-tree library."""
 from ._lib import (SearchContext, SearchParams, Hit, Alignment, Rescore, load_library, library_path, build_library,  # noqa: F401
-                   module_prefilter, module_align, module_rescorediagonal, module_search, module_host, HOST_MODULES, SpError)
+                   module_prefilter, module_align, module_rescorediagonal, module_search, module_host, HOST_MODULES, SpError, FlatDb)

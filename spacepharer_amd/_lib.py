@@ -122,6 +122,15 @@ def load_library():
     L.sp_ctx_stat.restype = C.c_double
     L.sp_ctx_stat.argtypes = [vp, C.c_char_p]
     L.sp_ctx_sync.argtypes = [vp]
+    L.sp_flat_db_open.restype = vp
+    L.sp_flat_db_open.argtypes = [C.c_char_p]
+    L.sp_flat_db_close.argtypes = [vp]
+    L.sp_flat_db_entries.restype = C.c_uint64
+    L.sp_flat_db_entries.argtypes = [vp]
+    for name, rt in (("residues", C.c_void_p), ("offsets", C.POINTER(C.c_uint64)), ("keys", C.POINTER(C.c_uint32)), ("sets", C.POINTER(C.c_uint32))):
+        fn = getattr(L, "sp_flat_db_" + name)
+        fn.restype = rt
+        fn.argtypes = [vp]
     L.sp_ctx_hits_text.argtypes = [vp, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     L.sp_ctx_align_hits_text.argtypes = [vp, C.c_double, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     L.sp_ctx_set_timing.argtypes = [vp, C.c_int]
@@ -535,3 +544,29 @@ class SearchContext:
 
     def stat(self, name):
         return self.L.sp_ctx_stat(self.ctx, name.encode())
+
+
+class FlatDb:
+    """A sequence DB read and flattened by the library's DB reader (sp_flat_db_open): residues / offsets / keys / sets as ctypes views that live as long as this object."""
+
+    def __init__(self, path):
+        self.L = load_library()
+        self.h = self.L.sp_flat_db_open(path.encode())
+        if not self.h:
+            raise SpError(self.L.sp_last_error().decode())
+        self.n = int(self.L.sp_flat_db_entries(self.h))
+        self.residues = C.cast(self.L.sp_flat_db_residues(self.h), C.c_char_p)
+        self.offsets = self.L.sp_flat_db_offsets(self.h)
+        self.keys = self.L.sp_flat_db_keys(self.h)
+        self.sets = self.L.sp_flat_db_sets(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.sp_flat_db_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001
+            pass

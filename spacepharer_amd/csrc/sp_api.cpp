@@ -720,6 +720,20 @@ int sp_ctx_set_scores(sp_ctx *c, const sp_set_layout *l, const sp_alignment *aln
     out->offsets[keys.size()] = at;
     return SP_OK;
 }
+/* a sequence DB read and flattened by the library's own (threaded, memory-mapped) DB reader: see include/spacepharer_amd.h */
+struct sp_flat_db { std::vector<char> res; std::vector<uint64_t> off; std::vector<uint32_t> keys, sets; };
+sp_flat_db *sp_flat_db_open(const char *path) {
+    if (!path) { g_err = "sp_flat_db_open: null path"; return nullptr; }
+    sp_flat_db *f = new sp_flat_db; std::string err;
+    if (!sp::loadFlatForAbi(path, f->res, f->off, f->keys, f->sets, err)) { g_err = "sp_flat_db_open: " + err; delete f; return nullptr; }
+    return f;
+}
+void sp_flat_db_close(sp_flat_db *f) { delete f; }
+uint64_t sp_flat_db_entries(const sp_flat_db *f) { return f ? f->keys.size() : 0; }
+const char *sp_flat_db_residues(const sp_flat_db *f) { return f ? f->res.data() : nullptr; }
+const uint64_t *sp_flat_db_offsets(const sp_flat_db *f) { return f ? f->off.data() : nullptr; }
+const uint32_t *sp_flat_db_keys(const sp_flat_db *f) { return f ? f->keys.data() : nullptr; }
+const uint32_t *sp_flat_db_sets(const sp_flat_db *f) { return f && !f->sets.empty() ? f->sets.data() : nullptr; }
 void sp_text_db_free(sp_text_db *db) { if (!db) return; free(db->keys); free(db->offsets); free(db->text); memset(db, 0, sizeof(*db)); }
 
 double sp_ctx_stat(const sp_ctx *c, const char *name) {

@@ -355,6 +355,39 @@ static int deviceTextBlock(sp_ctx *c, bool alignments, double minSeqId, long min
     return -1;
 }
 
+// a sequence DB as the in-memory interface takes it (sp_flat_db_open): residues back to back, offsets, keys -- and, when <path>.lookup exists, the set number of
+// every entry (third column, commons/DBReader.h lookup format "key\tname\tset") in entry order
+bool loadFlatForAbi(const std::string &path, std::vector<char> &res, std::vector<uint64_t> &off, std::vector<uint32_t> &keys, std::vector<uint32_t> &sets, std::string &err) {
+    Db db;
+    if (!db.load(path, err)) return false;
+    if (db.type() != 0 && db.type() != 1) { err = path + ": a sequence DB (dbtype 0 amino acids or 1 nucleotides) is expected, got " + std::to_string(db.type()); return false; }
+    if (db.compressed()) { err = path + ": compressed DBs are not supported (the workflows pass --compressed 0)"; return false; }
+    flatten(db, res, off, keys);
+    sets.clear();
+    MappedFile lk;
+    if (lk.open(path + ".lookup")) {
+        // lines "key\tname\tset"; entries of the DB in key order hold the sets in the same order when the lookup is keyed alike (createsetdb / extractorfs --create-lookup 1)
+        std::vector<std::pair<uint32_t, uint32_t>> kv; kv.reserve(keys.size());
+        const char *b = lk.p, *e = lk.p + lk.n;
+        while (b < e) {
+            const char *nl = static_cast<const char *>(memchr(b, '\n', (size_t) (e - b))); if (!nl) nl = e;
+            const char *t1 = static_cast<const char *>(memchr(b, '\t', (size_t) (nl - b)));
+            const char *t2 = t1 ? static_cast<const char *>(memchr(t1 + 1, '\t', (size_t) (nl - t1 - 1))) : nullptr;
+            if (t1 && t2) kv.emplace_back((uint32_t) strtoul(b, nullptr, 10), (uint32_t) strtoul(t2 + 1, nullptr, 10));
+            b = nl + 1;
+        }
+        const bool sortedKv = std::is_sorted(kv.begin(), kv.end());
+        if (!sortedKv) std::sort(kv.begin(), kv.end());
+        sets.resize(keys.size());
+        for (size_t i = 0; i < keys.size(); i++) {
+            auto it = std::lower_bound(kv.begin(), kv.end(), std::make_pair(keys[i], 0u));
+            if (it == kv.end() || it->first != keys[i]) { err = path + ".lookup has no line for key " + std::to_string(keys[i]); return false; }
+            sets[i] = it->second;
+        }
+    }
+    return true;
+}
+
 // SP_MODULE_TIMES=1: wall-clock laps of a module run on stderr
 struct Laps {
     bool on = getenv("SP_MODULE_TIMES") != nullptr; const char *module;
