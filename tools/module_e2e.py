@@ -48,7 +48,7 @@ def worker(n_spacers, d, mode, n_targets=50000, light=False):
     # runtime start-up, similar-3-mer table, first touch of every device buffer
     exe = os.path.join(ROOT, "spacepharer_amd", "spacepharer-amd")
     procs = []
-    for rep in range(1 if light else 2):
+    for rep in range(2):      # (the first fresh process on a box also pays for the driver's own warm-up: the better of two counts)
         for f in os.listdir(d):
             if f.startswith("pref") or f.startswith("aln"):
                 os.remove(os.path.join(d, f))
