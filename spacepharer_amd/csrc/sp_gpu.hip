@@ -294,7 +294,7 @@ struct Gpu::Impl {
     // Small inputs: one block (k_scan_counts); larger ones: rocPRIM's decoupled look-back scan.
     bool scanCounts(const uint32_t *count, uint32_t n, uint32_t *offset, std::string &err) {
         if (n <= 4096) { hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, stream, count, n, offset); return true; }
-        if (n <= 64u * kScanTile) { hipLaunchKernelGGL(k_scan_counts_tiles, dim3((n + kScanTile - 1) / kScanTile), dim3(1024), 0, stream, count, n, offset); return true; }
+        if (n <= 64u * kScanTile) { hipLaunchKernelGGL(k_scan_counts_tiles, dim3((n + kScanTile - 1) / kScanTile), dim3(256), 0, stream, count, n, offset); return true; }
         size_t bytes = 0;
         if (hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, count, offset, (int) (n + 1), stream) != hipSuccess) { err = "scan: temp size query failed"; return false; }
         if (!scanTemp.ensure(bytes + 256, err)) return false;
