@@ -38,7 +38,7 @@ def test_prefilter_matches_reference_golden(name):
         assert [list(h) for h in got[q["id"]]] == q["hits"], (name, q["id"])
     # double-hit diagonals found over all queries (QueryMatcher::match output sizes)
     assert ctx.stat("diagonals") == sum(len(q["diag"]) for q in r["queries"])
-    # k_match has two footprints and picks by the index' density (DESIGN.md section 7): the other one must find the same
+    # k_match has two footprints and picks by the index' density (DESIGN.md section 4): the other one must find the same
     # ... and for short queries against a sparse index there are two kernels: k_match_grp (four queries per pass of a wave, the default where its
     # preconditions hold) and k_match itself (match_group 0)
     try:

@@ -128,7 +128,7 @@ def test_bench_reads_the_committed_counter_summary():
 
 def test_front_end_does_not_link_the_library_or_the_hip_runtime():
     """the front end loads libspacepharer_amd.so when it runs a module ITSELF: a client that forwards its call to the resident server must not map the HIP runtime first
-    (30 ms per process start against 2; csrc/sp_main.cpp)"""
+    (30 ms per process start against 2; csrc/sp_main.cpp, DESIGN.md section 6 / DESIGN_HISTORY.md section 6c)"""
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spacepharer_amd", "spacepharer-amd")
     if not os.path.exists(exe):

@@ -1,7 +1,7 @@
 """Register / LDS budget of the kernels whose speed hangs on occupancy (cross-compiled for gfx950, no GPU needed).
 
 k_match is latency-bound: its large footprint (dense index) runs three waves per SIMD only while it stays at or below 168 VGPRs and
-53 KB of LDS per block of four waves (DESIGN.md section 7), its small footprint (sparse index) four waves at 128 VGPRs and 40 KB.  A
+53 KB of LDS per block of four waves (DESIGN.md section 4), its small footprint (sparse index) four waves at 128 VGPRs and 40 KB.  A
 change that pushes either over the edge costs a third / a quarter of the occupancy and 15-50 % of the kernel time without failing any
 parity test -- this test fails instead."""
 import os
