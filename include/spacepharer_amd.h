@@ -236,7 +236,7 @@ int sp_ctx_set_scores(sp_ctx *c, const sp_set_layout *l, const sp_alignment *aln
 void sp_text_db_free(sp_text_db *db);
 
 /* A sequence DB (MMseqs2 triple <path>, <path>.index, <path>.dbtype; split data files tolerated) read by the library's own reader and flattened into what
-   sp_ctx_set_targets / sp_ctx_set_queries / sp_set_layout take: residues back to back (entry terminators removed), offsets[n + 1], keys[n] in key order -- and
+   sp_ctx_set_targets / sp_ctx_set_queries / sp_set_layout take: residues back to back (entry terminators removed), offsets[n + 1], keys[n], entries in the order of the data file (DBReader's LINEAR_ACCCESS order) -- and
    sets[n], the third column of <path>.lookup ("key\tname\tset", commons/DBReader.h) per entry, when that file exists (else NULL).  The arrays belong to the handle. */
 typedef struct sp_flat_db sp_flat_db;
 sp_flat_db *sp_flat_db_open(const char *path);      /* NULL + sp_last_error() on failure */

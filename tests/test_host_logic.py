@@ -137,3 +137,37 @@ def test_front_end_does_not_link_the_library_or_the_hip_runtime():
     assert "libamdhip64" not in libs and "libspacepharer_amd" not in libs and "libhsa-runtime" not in libs, libs
     p = subprocess.run([exe, "no_such_module"], capture_output=True, text=True)       # (answers without loading anything)
     assert p.returncode == 1 and "unknown module" in p.stderr
+
+
+def test_flat_db_reader(lib, tmp_path):
+    """sp_flat_db_open: a sequence DB triple (split data files, keys that are not 0..n-1, a lookup with the set column) comes back as residues / offsets / keys / sets
+    in the order of the data file (the reference's DBReader in its LINEAR_ACCCESS sort mode) -- what sp_ctx_set_targets / sp_ctx_set_queries and sp_set_layout take"""
+    import struct
+    import spacepharer_amd as sa
+    seqs = {7: "MKTAYIAKQR", 3: "ACDEFGHIK", 12: "WWWW", 5: "LLLLLLLLLLLLLLLLLLLL"}
+    order = [7, 3, 12, 5]                                  # data order differs from key order
+    path = str(tmp_path / "db")
+    parts, idx, off = [b"", b""], {}, 0
+    for i, k in enumerate(order):
+        e = seqs[k].encode() + b"\n\0"
+        parts[0 if i < 2 else 1] += e
+        idx[k] = (off, len(e))
+        off += len(e)
+    open(path + ".0", "wb").write(parts[0])
+    open(path + ".1", "wb").write(parts[1])
+    open(path + ".index", "w").write("".join("%d\t%d\t%d\n" % (k, idx[k][0], idx[k][1]) for k in sorted(seqs)))
+    open(path + ".dbtype", "wb").write(struct.pack("<i", 0))
+    open(path + ".lookup", "w").write("".join("%d\tname%d\t%d\n" % (k, k, 100 + k % 3) for k in sorted(seqs)))
+    f = sa.FlatDb(path)
+    keys = order
+    assert f.n == 4 and [f.keys[i] for i in range(4)] == keys
+    raw = C.string_at(C.cast(f.residues, C.c_void_p).value, int(f.offsets[4]))
+    assert [raw[int(f.offsets[i]):int(f.offsets[i + 1])].decode() for i in range(4)] == [seqs[k] for k in keys]
+    assert [f.sets[i] for i in range(4)] == [100 + k % 3 for k in keys]
+    f.close()
+    with pytest.raises(sa.SpError):
+        sa.FlatDb(str(tmp_path / "missing"))
+    os.remove(path + ".lookup")
+    g = sa.FlatDb(path)
+    assert g.n == 4 and not g.sets
+    g.close()
