@@ -228,7 +228,7 @@ struct DbWriter {
                 size_t n = i < blocks.size() ? (blockView[i].first ? blockView[i].second : blocks[i].size()) : data.size();
                 while (n) { const size_t k = std::min<size_t>(n, (size_t) 4 << 20); segs.push_back({p, k, o}); p += k; n -= k; o += k; }
             }
-            const size_t W = blockBytes + data.size() >= (4u << 20) ? std::min<size_t>(4, std::max<size_t>(1, segs.size())) : 1;
+            const size_t W = blockBytes + data.size() >= (4u << 20) ? std::min<size_t>(blockBytes + data.size() >= (64u << 20) ? 8 : 4, std::max<size_t>(1, segs.size())) : 1;      // (eight writers for a data file of 64 MB and more: the copy into the page cache is what takes the time)
             auto job = [dataFd, segs, W, &dataOk](size_t w) {
                 for (size_t i = w; i < segs.size(); i += W) {
                     const char *p = segs[i].p; size_t n = segs[i].n; uint64_t o = segs[i].o;

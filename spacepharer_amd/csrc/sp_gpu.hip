@@ -1095,8 +1095,11 @@ bool Gpu::alignHitsText(int gapOpen, int gapExtend, const GateTable &gate, Align
     }
     HIP_OK(hipMemsetAsync(d.txFlags.p, 0, 4 * sizeof(uint32_t), d.stream));
     AlnTextArgs a{s.rec.p, s.cig.p, d.outOffset.p, d.outQuery.p, (uint32_t) nq_, d.outOffset.p + nq_, minSeqId, minAlnLen, d.txEval.p, s.gateSlot.p, gate.stride,
-                  d.txLineLen.p, d.txLineOff.p, d.txLen.p, d.txOff.p, nullptr, d.txFlags.p};
+                  d.txLineLen.p, d.txLineOff.p, d.txLen.p, d.txOff.p, nullptr, d.txFlags.p, 0u};
+    a.waveServes = n >= 2 * nq_ ? 1u : 0u;
+    if (const char *e = getenv("SP_TEXT_WAVE")) a.waveServes = *e != '0' ? 1u : 0u;      // (tests: either kernel on any batch)      // (two or more alignments per query on average -- the dense index: a wave per query for those with 2 .. 64 records)
     hipLaunchKernelGGL(k_aln_text_measure, dim3((unsigned) ((nq_ + 63) / 64)), dim3(64), 0, d.stream, a);
+    if (a.waveServes) hipLaunchKernelGGL(k_aln_text_measure_wave, dim3((unsigned) std::min<size_t>((nq_ + 3) / 4, (size_t) d.numCU * 8)), dim3(256), 0, d.stream, a);
     if (!d.scanCounts(d.txLen.p, (uint32_t) nq_, d.txOff.p, err)) return false;
     uint32_t back[2] = {0, 0};
     HIP_OK(hipMemcpyAsync(&back[0], d.txOff.p + nq_, sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));

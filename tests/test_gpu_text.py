@@ -33,6 +33,13 @@ def test_prefilter_and_alignment_entries_equal_the_reference_text(name):
             ctx.align_hits_text()
     else:
         aln = ctx.align_hits_text()
+        import os
+        for force in ("0", "1"):      # the lane-per-query and the wave-per-query measuring kernels on the same batch
+            os.environ["SP_TEXT_WAVE"] = force
+            try:
+                assert ctx.align_hits_text() == aln, force
+            finally:
+                del os.environ["SP_TEXT_WAVE"]
         gapped = 0
         for q, got in enumerate(aln):
             assert got.decode() == exp_aln.get(q, ""), (q, got[:160], exp_aln.get(q, "")[:160])

@@ -6,7 +6,7 @@ sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import bench
 from test_gpu_modules import write_seq_db, PREF_FLAGS, ALN_FLAGS
 n = int(os.environ.get("SPACERS", "100000"))
-tres, toff, qres, qoff = bench.make_workload(n, 50000, 200, 12345)
+tres, toff, qres, qoff = bench.make_workload(n, int(os.environ.get("TARGETS", "50000")), 200, 12345)
 T = [tres[int(toff[i]):int(toff[i + 1])].tobytes().decode() for i in range(len(toff) - 1)]
 Q = [qres[int(qoff[i]):int(qoff[i + 1])].tobytes().decode() for i in range(len(qoff) - 1)]
 d = tempfile.mkdtemp()
