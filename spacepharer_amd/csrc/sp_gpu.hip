@@ -619,8 +619,8 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     // (its ordinal arrays push the large footprint to two blocks per CU)
     const bool small = d.knob.matchSmall >= 0 ? d.knob.matchSmall != 0 : (withOrd || !d.tgt->denseIndex);
     // short queries against a sparse index, unsharded: the grouped kernel (sp_gpu_match_grp.inc) -- same records, four queries per pass of a wave
-    const bool grouped = small && !withOrd && d.knob.matchGroup != 0 && d.maxQLen <= 64 && d.tgt->nTargets < ((size_t) 1 << 30);
-    const void *fn = grouped ? (const void *) k_match_grp :
+    const bool grouped = small && d.knob.matchGroup != 0 && d.maxQLen <= 64 && d.tgt->nTargets < ((size_t) 1 << 30);      // (with ordinals too since round 5: the target-sharded search)
+    const void *fn = grouped ? (withOrd ? (const void *) k_match_grp<true> : (const void *) k_match_grp<false>) :
                      small ? (withOrd ? (const void *) k_match<256, true, true> : (const void *) k_match<256, false, true>)
                            : (withOrd ? (const void *) k_match<512, true, false> : (const void *) k_match<512, false, false>);
     int perCU = 2;
@@ -707,7 +707,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
                  (uint32_t) d.knob.matchStatic, (uint32_t) d.knob.matchDChunk,
                  d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p, d.wavePartial.p,
                  ordered ? d.qorder.p : nullptr, ordered ? reinterpret_cast<const OrderHeader *>(d.orderHeader.p) : nullptr, ordered ? d.orderQueues.p : nullptr};
-    if (grouped) hipLaunchKernelGGL(k_match_grp, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+    if (grouped) { if (withOrd) hipLaunchKernelGGL(k_match_grp<true>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma); else hipLaunchKernelGGL(k_match_grp<false>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma); }
     else if (small) {
         if (withOrd) hipLaunchKernelGGL((k_match<256, true, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
         else hipLaunchKernelGGL((k_match<256, false, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
