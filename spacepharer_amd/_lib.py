@@ -111,6 +111,14 @@ def load_library():
     L.sp_ctx_set_targets_shard.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint64, C.c_uint64, C.c_uint64]
     L.sp_ctx_share_targets.argtypes = [vp, vp]
     L.sp_ctx_prefilter_candidates.argtypes = [vp]
+    L.sp_ctx_shard_occupancy.argtypes = [vp, vp, C.c_int]
+    L.sp_ctx_probe_set_shards.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.sp_ctx_probe_enumerate.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.sp_ctx_probe_get.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    L.sp_ctx_probe_keys_device.argtypes = [vp, C.c_int]; L.sp_ctx_probe_keys_device.restype = vp
+    L.sp_ctx_probe_vals_device.argtypes = [vp, C.c_int]; L.sp_ctx_probe_vals_device.restype = vp
+    L.sp_ctx_probe_fetch.argtypes = [vp, vp, vp, C.c_uint64, C.c_int]
+    L.sp_ctx_probe_search.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]
     L.sp_ctx_num_candidates.restype = C.c_uint64
     L.sp_ctx_overflow_queries.restype = C.c_uint64
     L.sp_ctx_overflow_queries.argtypes = [vp, C.POINTER(C.c_uint32), C.c_uint64]
@@ -288,6 +296,47 @@ class SearchContext:
         """match + ungapped scoring against this shard; returns the number of candidates left in HBM"""
         _check(self.L.sp_ctx_prefilter_candidates(self.ctx))
         return int(self.L.sp_ctx_num_candidates(self.ctx))
+
+    # ---- the probe-list cut of the target-sharded search (include/spacepharer_amd.h: sp_ctx_probe_*)
+    def shard_occupancy(self):
+        """this shard's occupancy map: numpy uint8[SP_SHARD_MAP_BYTES]"""
+        import numpy as np
+        out = np.zeros(8000000, dtype=np.uint8)
+        _check(self.L.sp_ctx_shard_occupancy(self.ctx, out.ctypes.data, 0))
+        return out
+
+    def probe_set_shards(self, maps):
+        """maps: the shards' occupancy maps in shard order (list of uint8 arrays)"""
+        import numpy as np
+        cat = np.ascontiguousarray(np.concatenate(maps), dtype=np.uint8)
+        _check(self.L.sp_ctx_probe_set_shards(self.ctx, cat.ctypes.data, len(maps), 0))
+        self.n_shards = len(maps)
+
+    def probe_enumerate(self, q_from, q_to):
+        """queries [q_from, q_to) -> per destination shard (keys uint32[n], vals uint64[n]) host copies"""
+        import numpy as np
+        counts = (C.c_uint64 * 8)()
+        _check(self.L.sp_ctx_probe_enumerate(self.ctx, q_from, q_to, counts))
+        out = []
+        for s in range(self.n_shards):
+            k = np.zeros(max(1, counts[s]), dtype=np.uint32); v = np.zeros(max(1, counts[s]), dtype=np.uint64)
+            _check(self.L.sp_ctx_probe_get(self.ctx, s, k.ctypes.data, v.ctypes.data, 0))
+            out.append((k[:counts[s]], v[:counts[s]]))
+        return out
+
+    def probe_fetch(self, keys, vals):
+        """the probes addressed to this shard -> its candidates (returns their number)"""
+        import numpy as np
+        keys = np.ascontiguousarray(keys, dtype=np.uint32); vals = np.ascontiguousarray(vals, dtype=np.uint64)
+        assert len(keys) == len(vals)
+        _check(self.L.sp_ctx_probe_fetch(self.ctx, keys.ctypes.data, vals.ctypes.data, len(keys), 0))
+        return int(self.L.sp_ctx_num_candidates(self.ctx))
+
+    def probe_search(self, comm, q_from, q_to):
+        """collective over `comm` (rank r = shard r); returns (candidates of this shard, seconds of exchange)"""
+        x = C.c_double()
+        _check(self.L.sp_ctx_probe_search(self.ctx, comm, q_from, q_to, C.byref(x)))
+        return int(self.L.sp_ctx_num_candidates(self.ctx)), x.value
 
     def candidates(self):
         """numpy uint8[n, 16] view of this shard's sp_candidate records (host copy)"""

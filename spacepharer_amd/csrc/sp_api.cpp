@@ -278,6 +278,62 @@ int sp_ctx_prefilter_candidates(sp_ctx *c) {
     return SP_OK;
 }
 
+struct sp_comm { sp::Comm *c; };
+// ---- the probe-list cut (Gpu::probe*)
+int sp_ctx_shard_occupancy(sp_ctx *c, void *out, int on_device) {
+    if (!c || !out) { g_err = "sp_ctx_shard_occupancy: null argument"; return SP_ERR_ARG; }
+    c->gpu.makeCurrent();
+    if (c->targets.n == 0) { g_err = "sp_ctx_shard_occupancy: no target set"; return SP_ERR_STATE; }
+    std::string err;
+    if (!c->gpu.shardOccupancy(out, on_device != 0, err)) { g_err = err; return SP_ERR_DEVICE; }
+    return SP_OK;
+}
+int sp_ctx_probe_set_shards(sp_ctx *c, const void *maps, int n_shards, int on_device) {
+    if (!c || !maps) { g_err = "sp_ctx_probe_set_shards: null argument"; return SP_ERR_ARG; }
+    c->gpu.makeCurrent();
+    std::string err;
+    if (!c->gpu.probeSetShardMaps(maps, n_shards, on_device != 0, err)) { g_err = err; return n_shards < 1 || n_shards > SP_MAX_PROBE_SHARDS ? SP_ERR_ARG : SP_ERR_DEVICE; }
+    return SP_OK;
+}
+int sp_ctx_probe_enumerate(sp_ctx *c, uint64_t q_from, uint64_t q_to, uint64_t *counts) {
+    if (!c) { g_err = "sp_ctx_probe_enumerate: null argument"; return SP_ERR_ARG; }
+    c->gpu.makeCurrent();
+    std::string err;
+    if (!c->gpu.probeEnumerate(c->kmerThr, (size_t) q_from, (size_t) q_to, counts, err)) { g_err = err; return SP_ERR_OVERFLOW; }
+    return SP_OK;
+}
+int sp_ctx_probe_get(sp_ctx *c, int dest, uint32_t *keys, uint64_t *vals, int on_device) {
+    if (!c || !keys || !vals || dest < 0 || dest >= SP_MAX_PROBE_SHARDS) { g_err = "sp_ctx_probe_get: bad argument"; return SP_ERR_ARG; }
+    c->gpu.makeCurrent();
+    const size_t n = c->gpu.probeCount(dest);
+    if (n && (hipMemcpy(keys, c->gpu.probeKeysDevice(dest), n * sizeof(uint32_t), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost) != hipSuccess ||
+              hipMemcpy(vals, c->gpu.probeValsDevice(dest), n * sizeof(uint64_t), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost) != hipSuccess)) { g_err = "sp_ctx_probe_get: copy failed"; return SP_ERR_DEVICE; }
+    return SP_OK;
+}
+const void *sp_ctx_probe_keys_device(const sp_ctx *c, int dest) { return c && dest >= 0 && dest < SP_MAX_PROBE_SHARDS ? c->gpu.probeKeysDevice(dest) : nullptr; }
+const void *sp_ctx_probe_vals_device(const sp_ctx *c, int dest) { return c && dest >= 0 && dest < SP_MAX_PROBE_SHARDS ? c->gpu.probeValsDevice(dest) : nullptr; }
+int sp_ctx_probe_fetch(sp_ctx *c, const uint32_t *keys, const uint64_t *vals, uint64_t n, int on_device) {
+    if (!c || (n && (!keys || !vals))) { g_err = "sp_ctx_probe_fetch: null argument"; return SP_ERR_ARG; }
+    c->gpu.makeCurrent();
+    if (c->targets.n == 0) { g_err = "sp_ctx_probe_fetch: no target set"; return SP_ERR_STATE; }
+    std::string err;
+    if (!c->gpu.probeFetch(keys, reinterpret_cast<const unsigned long long *>(vals), (size_t) n, on_device != 0, c->kmerThr, c->par.min_ungapped_score, err)) { g_err = err; return SP_ERR_OVERFLOW; }
+    prefilterStats(c);
+    c->stats["candidates"] = (double) c->gpu.numCandidates();
+    return SP_OK;
+}
+int sp_ctx_probe_search(sp_ctx *c, sp_comm *comm, uint64_t q_from, uint64_t q_to, double *exchange_s) {
+    if (!c || !comm) { g_err = "sp_ctx_probe_search: null argument"; return SP_ERR_ARG; }
+    c->gpu.makeCurrent();
+    if (c->targets.n == 0) { g_err = "sp_ctx_probe_search: no target set"; return SP_ERR_STATE; }
+    std::string err; double ms = 0;
+    if (!c->gpu.probeSearch(*comm->c, c->kmerThr, c->par.min_ungapped_score, (size_t) q_from, (size_t) q_to, &ms, err)) { g_err = err; return SP_ERR_OVERFLOW; }
+    if (exchange_s) *exchange_s = ms * 1e-3;
+    prefilterStats(c);
+    c->stats["candidates"] = (double) c->gpu.numCandidates(); c->stats["ms_probe_exchange"] = ms;
+    return SP_OK;
+}
+
 uint64_t sp_ctx_num_candidates(const sp_ctx *c) { return (uint64_t) c->gpu.numCandidates(); }
 uint64_t sp_ctx_overflow_queries(const sp_ctx *c, uint32_t *out, uint64_t cap) {
     const std::vector<uint32_t> &l = c->gpu.overflowQueries();
@@ -307,7 +363,6 @@ int sp_ctx_merge_candidates(sp_ctx *c, const sp_candidate *cands, uint64_t n, in
 }
 
 /* ---- multi-GPU: one process per GPU, see include/spacepharer_amd.h ---- */
-struct sp_comm { sp::Comm *c; };
 int sp_dist_unique_id(unsigned char *id) {
     std::string err;
     if (!id || !sp::Comm::uniqueId(id, err)) { g_err = id ? err : "sp_dist_unique_id: null argument"; return SP_ERR_ARG; }

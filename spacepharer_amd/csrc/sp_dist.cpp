@@ -55,6 +55,10 @@ struct Rccl {
     ncclResult_t (*commDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*allGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*errorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;      // (point to point: the all-to-all of the probe-list cut; optional)
+    ncclResult_t (*recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*groupStart)() = nullptr;
+    ncclResult_t (*groupEnd)() = nullptr;
     bool load(std::string &err) {
         if (lib) return true;
         // the RCCL that belongs to the HIP runtime this library is linked against -- by PATH: a process may already hold another copy under the same soname (PyTorch
@@ -70,6 +74,8 @@ struct Rccl {
         commDestroy = reinterpret_cast<decltype(commDestroy)>(dlsym(lib, "ncclCommDestroy"));
         allGather = reinterpret_cast<decltype(allGather)>(dlsym(lib, "ncclAllGather"));
         errorString = reinterpret_cast<decltype(errorString)>(dlsym(lib, "ncclGetErrorString"));
+        send = reinterpret_cast<decltype(send)>(dlsym(lib, "ncclSend")); recv = reinterpret_cast<decltype(recv)>(dlsym(lib, "ncclRecv"));
+        groupStart = reinterpret_cast<decltype(groupStart)>(dlsym(lib, "ncclGroupStart")); groupEnd = reinterpret_cast<decltype(groupEnd)>(dlsym(lib, "ncclGroupEnd"));
         if (!getUniqueId || !commInitRank || !commDestroy || !allGather || !errorString) { err = "librccl.so lacks an entry point (ncclGetUniqueId / ncclCommInitRank / ncclAllGather ...)"; return false; }
         return true;
     }
@@ -258,6 +264,76 @@ bool Comm::allgather(const void *send, size_t bytes, void *recv, bool onDevice, 
     if (hipMemcpy(stage_.data(), send, bytes, hipMemcpyDeviceToHost) != hipSuccess) { err = "sp_dist: device -> host copy failed"; return false; }
     if (!hostAllgather(stage_.data(), bytes, stage_.data() + bytes, err)) return false;
     if (hipMemcpy(recv, stage_.data() + bytes, (size_t) world_ * bytes, hipMemcpyHostToDevice) != hipSuccess) { err = "sp_dist: host -> device copy failed"; return false; }
+    return true;
+}
+
+// Every rank sends a block of its own size to every rank (sendBytes[r] to rank r, recvBytes[r] from rank r; the sizes were agreed on by the caller).  Device buffers over
+// RCCL: one group of point-to-point sends and receives, HBM to HBM over the xGMI links of the pairs themselves.  Otherwise through rank 0 over the bootstrap sockets.
+bool Comm::alltoallv(const void *const *send, const size_t *sendBytes, void *const *recv, const size_t *recvBytes, bool onDevice, std::string &err) {
+    const size_t me = (size_t) rank_, W = (size_t) world_;
+    if (sendBytes[me] != recvBytes[me]) { err = "sp_dist alltoallv: a rank's block to itself has two sizes"; return false; }
+    auto selfCopy = [&]() -> bool {
+        if (!sendBytes[me] || send[me] == recv[me]) return true;
+        if (onDevice) return hipMemcpy(recv[me], send[me], sendBytes[me], hipMemcpyDeviceToDevice) == hipSuccess;
+        memmove(recv[me], send[me], sendBytes[me]); return true;
+    };
+    if (world_ == 1) { if (!selfCopy()) { err = "sp_dist alltoallv: copy failed"; return false; } return true; }
+    if (onDevice && transport_ == kTransportRccl && g_rccl.send && g_rccl.recv && g_rccl.groupStart && g_rccl.groupEnd) {
+        ncclComm_t nc = static_cast<ncclComm_t>(nccl_); hipStream_t st = static_cast<hipStream_t>(stream_);
+        ncclResult_t r = g_rccl.groupStart();
+        for (size_t k = 0; k < W && r == ncclSuccess; k++) {
+            if (k == me) continue;
+            if (sendBytes[k]) r = g_rccl.send(send[k], sendBytes[k], ncclChar, (int) k, nc, st);
+            if (r == ncclSuccess && recvBytes[k]) r = g_rccl.recv(recv[k], recvBytes[k], ncclChar, (int) k, nc, st);
+        }
+        const ncclResult_t e = g_rccl.groupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) { err = std::string("ncclSend/ncclRecv: ") + g_rccl.errorString(r); return false; }
+        if (!selfCopy() || hipStreamSynchronize(st) != hipSuccess) { err = "sp_dist: the exchange stream failed"; return false; }
+        for (size_t k = 0; k < W; k++) if (k != me) bytes_ += recvBytes[k];
+        return true;
+    }
+    // through rank 0: everybody hands it all its blocks (sizes first), it hands everybody the blocks addressed to them, in the order of the senders
+    std::vector<uint64_t> mineSz(W), mat(W * W);
+    for (size_t k = 0; k < W; k++) mineSz[k] = sendBytes[k];
+    if (!hostAllgather(mineSz.data(), W * sizeof(uint64_t), mat.data(), err)) return false;
+    for (size_t k = 0; k < W; k++) if (mat[k * W + me] != recvBytes[k]) { err = "sp_dist alltoallv: rank " + std::to_string(k) + " sends another size than this rank expects"; return false; }
+    size_t sendTotal = 0, recvTotal = 0;
+    for (size_t k = 0; k < W; k++) { sendTotal += sendBytes[k]; recvTotal += recvBytes[k]; }
+    std::vector<unsigned char> out(sendTotal + 1), in(recvTotal + 1);
+    {   size_t at = 0;
+        for (size_t k = 0; k < W; k++) {
+            if (sendBytes[k]) { if (onDevice) { if (hipMemcpy(out.data() + at, send[k], sendBytes[k], hipMemcpyDeviceToHost) != hipSuccess) { err = "sp_dist: device -> host copy failed"; return false; } } else memcpy(out.data() + at, send[k], sendBytes[k]); }
+            at += sendBytes[k];
+        } }
+    if (rank_ == 0) {
+        std::vector<std::vector<unsigned char>> from(W);      // rank k's blocks back to back
+        for (size_t k = 1; k < W; k++) {
+            size_t tot = 0; for (size_t j = 0; j < W; j++) tot += (size_t) mat[k * W + j];
+            from[k].resize(tot + 1);
+            if (tot && !recvAll(fds_[k], from[k].data(), tot)) { err = "sp_dist: rank " + std::to_string(k) + " is gone"; return false; }
+        }
+        auto blockOf = [&](size_t src, size_t dst) -> const unsigned char * {
+            size_t at = 0; for (size_t j = 0; j < dst; j++) at += (size_t) mat[src * W + j];
+            return (src == 0 ? out.data() : from[src].data()) + at;
+        };
+        for (size_t dst = 0; dst < W; dst++) {
+            std::vector<unsigned char> cat; size_t tot = 0;
+            for (size_t src = 0; src < W; src++) tot += (size_t) mat[src * W + dst];
+            cat.reserve(tot + 1);
+            for (size_t src = 0; src < W; src++) cat.insert(cat.end(), blockOf(src, dst), blockOf(src, dst) + (size_t) mat[src * W + dst]);
+            if (dst == 0) memcpy(in.data(), cat.data(), tot);
+            else if (tot && !sendAll(fds_[dst], cat.data(), tot)) { err = "sp_dist: rank " + std::to_string(dst) + " is gone"; return false; }
+        }
+    } else {
+        if ((sendTotal && !sendAll(fds_[0], out.data(), sendTotal)) || (recvTotal && !recvAll(fds_[0], in.data(), recvTotal))) { err = "sp_dist: rank 0 is gone"; return false; }
+    }
+    {   size_t at = 0;
+        for (size_t k = 0; k < W; k++) {
+            if (recvBytes[k]) { if (onDevice) { if (hipMemcpy(recv[k], in.data() + at, recvBytes[k], hipMemcpyHostToDevice) != hipSuccess) { err = "sp_dist: host -> device copy failed"; return false; } } else memcpy(recv[k], in.data() + at, recvBytes[k]); }
+            at += recvBytes[k];
+        } }
+    bytes_ += recvTotal;
     return true;
 }
 

@@ -25,6 +25,8 @@ public:
     int transport() const { return transport_; }
     // equal-size all-gather: recv holds world x bytes, rank r's block at r x bytes.  onDevice: both buffers are device memory of this rank's GPU
     bool allgather(const void *send, size_t bytes, void *recv, bool onDevice, std::string &err);
+    // block k of `send` (sendBytes[k] bytes) goes to rank k, recv[k] takes rank k's block for this rank (recvBytes[k] bytes, agreed on beforehand)
+    bool alltoallv(const void *const *send, const size_t *sendBytes, void *const *recv, const size_t *recvBytes, bool onDevice, std::string &err);
     bool barrier(std::string &err);
     bool allreduce(double *v, size_t n, int op /* 0 sum, 1 max, 2 min */, std::string &err);
     uint64_t bytesMoved() const { return bytes_; }

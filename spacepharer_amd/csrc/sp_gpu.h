@@ -107,6 +107,16 @@ public:
     // target-sharded search (every GPU indexes a target range, all queries resident): candidates of this shard, then the
     // selection over the union of all shards' candidates (gathered by the caller, e.g. RCCL all-gather)
     bool prefilterCandidates(int kmerThr, int minDiagScore, std::string &err);
+    // ... its probe-list cut (sp_gpu.hip: "the probe-list cut"): this shard's occupancy map; all shards' maps; enumerate a query slice -> probes by destination shard;
+    // fetch the probes addressed to this shard -> candidates; the four steps over a communicator
+    bool shardOccupancy(void *out, bool onDevice, std::string &err);
+    bool probeSetShardMaps(const void *maps, int nShards, bool onDevice, std::string &err);
+    bool probeEnumerate(int kmerThr, size_t qFrom, size_t qTo, uint64_t *counts, std::string &err);
+    size_t probeCount(int dest) const;
+    const uint32_t *probeKeysDevice(int dest) const;
+    const unsigned long long *probeValsDevice(int dest) const;
+    bool probeFetch(const uint32_t *keys, const unsigned long long *vals, size_t n, bool onDevice, int kmerThr, int minDiagScore, std::string &err);
+    bool probeSearch(class Comm &comm, int kmerThr, int minDiagScore, size_t qFrom, size_t qTo, double *exchangeMs, std::string &err);
     size_t numCandidates() const;
     const std::vector<uint32_t> &overflowQueries() const { return overflowList_; }      // positions (in the batch) of the queries the last pass refused
     const Candidate *candidatesDevice() const;
@@ -174,7 +184,8 @@ private:
     // recordsLeft / hitsLeft: HIP events (or nullptr) the kernels that rewrite the record / hit buffers wait for on the device
     bool queueAlign(size_t cap, const uint32_t *nDev, const SwPair *hostPairs, int gapOpen, int gapExtend, const GateTable &gate, bool assemble, bool prefetch, void *recordsLeft, std::string &err);
     bool queueSelect(unsigned binSize, int maxHits, int minDiagScore, void *hitsLeft, std::string &err);
-    bool matchAndScore(int kmerThr, bool withOrd, std::string &err);
+    bool candidatesTail(int minDiagScore, std::string &err);
+    bool matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMode = 0, size_t qFrom = 0, size_t qTo = 0);
     bool finishPrefilter(bool matched, std::string &err);
     struct Impl;
     Impl *d_;

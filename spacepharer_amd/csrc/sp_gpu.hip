@@ -187,6 +187,7 @@ __device__ __forceinline__ uint32_t extIndex(uint32_t packed) { return packed & 
 #include "sp_gpu_match.inc"
 #include "sp_gpu_match_grp.inc"
 #include "sp_gpu_select.inc"
+#include "sp_gpu_probe.inc"
 
 #include "sp_gpu_sw.inc"
 #include "sp_gpu_text.inc"
@@ -234,11 +235,11 @@ struct Gpu::Impl {
     int numCU = 256;
     // environment knobs (diagnostics / experiments), read once per context instead of once per pass
     struct Knobs {
-        int matchSmall = -1, matchPerCU = 0, matchHeavy = -1, matchStatic = 4, matchDChunk = 4, weighExact = -1, matchGroup = 1, matchOrder = 1, selChunkDense = 8, selDynamic = 0;
+        int matchSmall = -1, matchPerCU = 0, matchHeavy = -1, matchStatic = 4, matchDChunk = 4, weighExact = -1, matchGroup = 1, matchOrder = 1, selChunkDense = 8, selDynamic = 0, probePerQuery = 1024;
         bool debug = false, prepSplit = false, swRows32 = false, swRows16 = false, swOldForward = false;
         void read() {
             auto num = [](const char *k, int d) { const char *e = getenv(k); return e ? atoi(e) : d; };
-            matchSmall = num("SP_MATCH_SMALL", -1); matchGroup = num("SP_MATCH_GROUP", 1); matchOrder = num("SP_MATCH_ORDER", 1); { const int we = num("SP_MATCH_WEIGH_EXACT", -1); weighExact = we < 0 ? -1 : (we ? 1 : 0); } matchPerCU = num("SP_MATCH_PERCU", 0); selChunkDense = num("SP_SEL_CHUNK", 8); selDynamic = num("SP_SEL_DYNAMIC", 0); matchHeavy = num("SP_MATCH_HEAVY", -1);
+            matchSmall = num("SP_MATCH_SMALL", -1); matchGroup = num("SP_MATCH_GROUP", 1); matchOrder = num("SP_MATCH_ORDER", 1); { const int we = num("SP_MATCH_WEIGH_EXACT", -1); weighExact = we < 0 ? -1 : (we ? 1 : 0); } matchPerCU = num("SP_MATCH_PERCU", 0); selChunkDense = num("SP_SEL_CHUNK", 8); selDynamic = num("SP_SEL_DYNAMIC", 0); matchHeavy = num("SP_MATCH_HEAVY", -1); probePerQuery = num("SP_PROBE_PER_QUERY", 1024);
             matchStatic = std::min(8, std::max(0, num("SP_MATCH_STATIC", 4))); matchDChunk = std::min(32, std::max(1, num("SP_MATCH_DCHUNK", 4)));      // (a chunk's offsets live in the lanes of a wave)
             debug = getenv("SP_DEBUG") != nullptr; prepSplit = getenv("SP_PREP_SPLIT") != nullptr; swRows32 = getenv("SP_SW_ROWS32") != nullptr;
             swRows16 = getenv("SP_SW_ROWS16") != nullptr; swOldForward = getenv("SP_SW_OLD_FORWARD") != nullptr;
@@ -254,7 +255,7 @@ struct Gpu::Impl {
         std::mutex mu;      // a sharing context may add the similar-k-mer tables to a set that was staged without them
     };
     struct Targets {
-        DevBuf<uint64_t> buckets; bool bucketsValid = false; size_t indexSlots = 0;      // large-footprint layout of the slot table, derived from slots / ientries on first use
+        DevBuf<uint64_t> buckets; bool bucketsValid = false; size_t indexSlots = 0; uint64_t buildSerial = 0;      // large-footprint layout of the slot table, derived from slots / ientries on first use
         DevBuf<uint64_t> pbits; DevBuf<uint16_t> prank; DevBuf<uint32_t> prow; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff; DevBuf<uint32_t> tkeys;
         size_t nTargets = 0; size_t indexEntries = 0;
         bool denseIndex = false;      // 1.5+ entries per occupied k-mer on average: k_match runs with its large footprint
@@ -306,6 +307,11 @@ struct Gpu::Impl {
     DevBuf<uint32_t> diagOrd; DevBuf<uint32_t> spillOrd; DevBuf<Candidate> cand; DevBuf<Candidate> candUnion; DevBuf<Candidate> candByQuery; DevBuf<Candidate> candPad;
     DevBuf<uint32_t> xOff, xOffAll; DevBuf<GpuHit> xHit, xHitAll;      // send / receive buffers of the hit-list all-gather (query partition)
     DevBuf<uint32_t> candCnt; DevBuf<uint32_t> candFill; DevBuf<uint32_t> candOffset; DevBuf<uint64_t> mergeScratch;
+    // ... its probe-list cut: all shards' occupancy maps + their union; the probes this context enumerated, by destination shard; the probes it was sent
+    DevBuf<uint64_t> shardMaps, unionMap; uint32_t nShardMaps = 0; uint64_t probeMapsSerial = 0;
+    DevBuf<uint32_t> pbKey[kMaxProbeShards]; DevBuf<unsigned long long> pbVal[kMaxProbeShards]; DevBuf<uint32_t> probeCursor; size_t probeCap = 0; uint32_t probeCnt[kMaxProbeShards] = {};
+    DevBuf<uint32_t> pinKey, pinKeySorted, probeOff; DevBuf<unsigned long long> pinVal, pinValSorted; DevBuf<char> probeSortTmp; size_t probeIn = 0;
+    DevBuf<uint32_t> pxKey; DevBuf<unsigned long long> pxVal;      // (receive side of the exchange)
     uint32_t nCand = 0;
     SwState sw;
     SwDev swd;
@@ -607,9 +613,13 @@ bool Gpu::uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std:
 #define SP_DBG_SYNC(tag) do { HIP_OK(hipGetLastError()); if (dbg) { HIP_OK(hipStreamSynchronize(d.stream)); fprintf(stderr, "[sp] %s done\n", tag); } } while (0)
 
 // k_prep, k_match, k_score for every resident query; leaves the scored double-hit diagonals in HBM (events 0..3)
-bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
+// probeMode 1: the enumerating side of the probe-list cut (queries [qFrom, qTo) against the union of the shards' maps; the occupied probes leave by destination
+// shard, nothing is matched or scored); probeMode 2: its fetching side (the probes in pinKeySorted / pinValSorted / probeOff instead of an enumeration)
+bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMode, size_t qFrom, size_t qTo) {
     Impl &d = *d_;
     overflowList_.clear();
+    if (probeMode && d.maxQLen > 64) { err = "the probe-list cut serves queries of up to 64 residues (spacer peptides)"; return false; }
+    const size_t nqRun = probeMode == 1 ? qTo - qFrom : nq_;      // queries this pass's matching kernel takes
     if (!d.tab->ext3.p || !d.tgt->pbits.p) { err = "tables/targets not resident"; return false; }
     if (d.hitsInFlight) { (void) hipEventSynchronize(d.hitsOnHost); d.hitsInFlight = false; }     // the previous pass's hit list is still being copied
     // persistent match grid: as many blocks per CU as the LDS footprint admits.  512 hits per query live in LDS; more go to
@@ -619,8 +629,8 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     // (its ordinal arrays push the large footprint to two blocks per CU)
     const bool small = d.knob.matchSmall >= 0 ? d.knob.matchSmall != 0 : (withOrd || !d.tgt->denseIndex);
     // short queries against a sparse index, unsharded: the grouped kernel (sp_gpu_match_grp.inc) -- same records, four queries per pass of a wave
-    const bool grouped = small && d.knob.matchGroup != 0 && d.maxQLen <= 64 && d.tgt->nTargets < ((size_t) 1 << 30);      // (with ordinals too since round 5: the target-sharded search)
-    const void *fn = grouped ? (withOrd ? (const void *) k_match_grp<true> : (const void *) k_match_grp<false>) :
+    const bool grouped = probeMode ? probeMode == 1 : (small && d.knob.matchGroup != 0 && d.maxQLen <= 64 && d.tgt->nTargets < ((size_t) 1 << 30));      // (with ordinals too since round 5: the target-sharded search)
+    const void *fn = probeMode == 1 ? (const void *) k_match_grp<true, true> : probeMode == 2 ? (const void *) k_match<256, true, true, true> : grouped ? (withOrd ? (const void *) k_match_grp<true> : (const void *) k_match_grp<false>) :
                      small ? (withOrd ? (const void *) k_match<256, true, true> : (const void *) k_match<256, false, true>)
                            : (withOrd ? (const void *) k_match<512, true, false> : (const void *) k_match<512, false, false>);
     int perCU = 2;
@@ -633,7 +643,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     if (d.knob.matchPerCU > 0) perCU = d.knob.matchPerCU;
     const bool dbg = d.knob.debug;
     if (dbg) fprintf(stderr, "[sp] k_match footprint=%s ord=%d blocks/CU=%d\n", grouped ? "grouped" : (small ? "small" : "large"), (int) withOrd, perCU);
-    const uint32_t blocks = (uint32_t) std::min<size_t>((nq_ + kWavesPerBlock - 1) / kWavesPerBlock, (size_t) d.numCU * perCU);
+    const uint32_t blocks = (uint32_t) std::max<size_t>(1, std::min<size_t>((nqRun + kWavesPerBlock - 1) / kWavesPerBlock, (size_t) d.numCU * perCU));
     d.matchBlocks = blocks;
     if (!d.spill.ensure((size_t) blocks * kWavesPerBlock * kSpillWordsPerWave, err)) return false;
     if (!d.queue.ensure(8, err) || !d.counters.ensure(16, err) || !d.heavyList.ensure((size_t) kHeavyLists * nq_ + 1, err) || !d.heavyCnt.ensure(kHeavyLists * kHeavyStride, err) || !d.heavyFlag.ensure(nq_ + 1, err) || !d.wavePartial.ensure((size_t) blocks * kWavesPerBlock * 4, err)) return false;
@@ -651,7 +661,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
     // longer decide when the kernel ends)
     // (the grouped kernel's list schedule wants the weights of ANY batch: 6 x 10^5 peptides -- 146 per wave -- still end 5 % apart, 2.98 -> 2.82 ms for 0.07 ms of weighing
     // and sorting)
-    const uint32_t heavyThr = d.knob.matchHeavy >= 0 ? (uint32_t) d.knob.matchHeavy
+    const uint32_t heavyThr = probeMode ? 0u : d.knob.matchHeavy >= 0 ? (uint32_t) d.knob.matchHeavy
                             : ((nq_ <= (size_t) blocks * kWavesPerBlock * 32 || ((grouped || !small) && d.knob.matchOrder != 0 && d.maxQLen <= 64 && !d.knob.prepSplit)) ? 4000u : 0u);
     // exact weights order the heavy queries better (k_match alone 0.43 instead of 0.47 ms on the bench workload) and cost k_prep8 two table rows per window -- 20 us alone, a
     // multiple beside other contexts' matching kernels, where the estimate wins: exact while this context is the only one searching on its device
@@ -701,13 +711,33 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err) {
         d.tgt->bucketsValid = true;
       }
     }
-    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.tab->ext3.p, d.tab->ext3cnt.p, d.tab->cntMin, d.tgt->pbits.p, d.tgt->prank.p, d.tgt->prow.p, d.tgt->slots.p, d.tgt->ientries.p, small ? nullptr : d.tgt->buckets.p, d.spill.p, d.queue.p,
+    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nqRun, d.qthr.p, d.tab->ext3.p, d.tab->ext3cnt.p, d.tab->cntMin, d.tgt->pbits.p, d.tgt->prank.p, d.tgt->prow.p, d.tgt->slots.p, d.tgt->ientries.p, small ? nullptr : d.tgt->buckets.p, d.spill.p, d.queue.p,
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
                  (uint32_t) d.knob.matchStatic, (uint32_t) d.knob.matchDChunk,
                  d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p, d.wavePartial.p,
                  ordered ? d.qorder.p : nullptr, ordered ? reinterpret_cast<const OrderHeader *>(d.orderHeader.p) : nullptr, ordered ? d.orderQueues.p : nullptr};
-    if (grouped) { if (withOrd) hipLaunchKernelGGL(k_match_grp<true>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma); else hipLaunchKernelGGL(k_match_grp<false>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma); }
+    if (probeMode == 1) {
+        // capacity per destination: whole chunks per wave on top of a generous share of the slice's similar k-mers (a full buffer is counted as an overflow and reported)
+        const size_t cap = std::max<size_t>((size_t) 1 << 20, nqRun * (size_t) std::max(64, d.knob.probePerQuery)) + (size_t) blocks * kWavesPerBlock * kProbeChunk;
+        if (cap >= ((size_t) 1 << 31)) { err = "probe-list cut: the slice is too large for one pass (" + std::to_string(nqRun) + " queries)"; return false; }
+        if (!d.probeCursor.ensure(kMaxProbeShards, err)) return false;
+        for (uint32_t s = 0; s < d.nShardMaps; s++) if (!d.pbKey[s].ensure(cap, err) || !d.pbVal[s].ensure(cap, err)) return false;
+        d.probeCap = cap;
+        HIP_OK(hipMemsetAsync(d.probeCursor.p, 0, kMaxProbeShards * sizeof(uint32_t), d.stream));
+        ma.pbits = d.unionMap.p; ma.prank = nullptr; ma.prow = nullptr; ma.slots = nullptr; ma.ientries = nullptr;
+        ma.qFirst = (uint32_t) qFrom; ma.shardBits = d.shardMaps.p; ma.nShards = d.nShardMaps; ma.probeCursor = d.probeCursor.p; ma.probeCap = (uint32_t) cap;
+        for (uint32_t s = 0; s < d.nShardMaps; s++) { ma.probeKey[s] = d.pbKey[s].p; ma.probeVal[s] = d.pbVal[s].p; }
+        hipLaunchKernelGGL((k_match_grp<true, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+        SP_DBG_SYNC("k_match_grp (probes out)");
+        SP_EV(2, 1);
+        return true;
+    }
+    if (probeMode == 2) {
+        ma.probeOff = d.probeOff.p; ma.probeIn = d.pinValSorted.p;
+        hipLaunchKernelGGL((k_match<256, true, true, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+    }
+    else if (grouped) { if (withOrd) hipLaunchKernelGGL(k_match_grp<true>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma); else hipLaunchKernelGGL(k_match_grp<false>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma); }
     else if (small) {
         if (withOrd) hipLaunchKernelGGL((k_match<256, true, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
         else hipLaunchKernelGGL((k_match<256, false, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
@@ -932,6 +962,10 @@ bool Gpu::prefilterCandidates(int kmerThr, int minDiagScore, std::string &err) {
     if (nq_ == 0) return true;
     if (d.stepsBegun != d.stepsEnded && !d.drained) { err = "prefilterCandidates: a device-driven step is in flight (collect it with stepEnd first)"; return false; }
     if (!matchAndScore(kmerThr, true, err)) return false;
+    return candidatesTail(minDiagScore, err);
+}
+bool Gpu::candidatesTail(int minDiagScore, std::string &err) {
+    Impl &d = *d_;
     const bool dbg = d.knob.debug;
     if (!d.cand.ensure(d.diagCap, err)) return false;
     CandArgs ca{d.diagRec.p, d.diagQuery.p, d.diagScore.p, d.diagOrd.p, d.queue.p + 1, (uint32_t) d.diagCap, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qoff.p, minDiagScore,
@@ -942,6 +976,130 @@ bool Gpu::prefilterCandidates(int kmerThr, int minDiagScore, std::string &err) {
     if (!finishPrefilter(true, err)) return false;
     counters_.hits = 0;
     return true;
+}
+
+static bool agreeOk(Comm &comm, bool localOk, std::string &err);
+// ---- the probe-list cut (opt-in: SP_SHARD=probes in bench.py, sp_ctx_probe_* in the ABI) ------------------------------------------------------------------------
+// Target-sharded search as above, but the similar-k-mer enumeration -- the same on every shard, and most of the matching kernel's time -- is done ONCE per query: rank r
+// enumerates its slice of the queries against the union of the shards' occupancy maps and sends every occupied probe (query, ordinal, slot, window position: 12 bytes) to
+// the shards whose own map has the slot; a shard fetches the lists of the probes it received and detects the double hits.  Candidates, their exchange and the merge are
+// unchanged, and so are the results: a shard sees exactly the probes its own enumeration would have found occupied, in the same order, with the same ordinals.
+bool Gpu::shardOccupancy(void *out, bool onDevice, std::string &err) {
+    Impl &d = *d_;
+    if (!d.tgt->pbits.p) { err = "shardOccupancy: no target set resident"; return false; }
+    HIP_OK(hipStreamSynchronize(d.stream));
+    HIP_OK(hipMemcpy(out, d.tgt->pbits.p, kShardMapBytes, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    return true;
+}
+
+bool Gpu::probeSetShardMaps(const void *maps, int nShards, bool onDevice, std::string &err) {
+    Impl &d = *d_;
+    if (nShards < 1 || nShards > kMaxProbeShards) { err = "probeSetShardMaps: 1 .. " + std::to_string(kMaxProbeShards) + " shards"; return false; }
+    const size_t words = kTableSize / 64;
+    if (!d.shardMaps.ensure(words * (size_t) nShards, err) || !d.unionMap.ensure(words, err)) return false;
+    if (maps != d.shardMaps.p) HIP_OK(hipMemcpyAsync(d.shardMaps.p, maps, kShardMapBytes * (size_t) nShards, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, d.stream));
+    hipLaunchKernelGGL(k_probe_union, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, d.shardMaps.p, (uint32_t) nShards, (uint32_t) words, d.unionMap.p);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(d.stream));
+    d.nShardMaps = (uint32_t) nShards;
+    return true;
+}
+
+bool Gpu::probeEnumerate(int kmerThr, size_t qFrom, size_t qTo, uint64_t *counts, std::string &err) {
+    Impl &d = *d_;
+    if (!d.nShardMaps) { err = "probeEnumerate: the shards' occupancy maps are not set (probeSetShardMaps)"; return false; }
+    if (qFrom > qTo || qTo > nq_) { err = "probeEnumerate: the slice ends behind the last query"; return false; }
+    if (d.stepsBegun != d.stepsEnded && !d.drained) { err = "probeEnumerate: a device-driven step is in flight (collect it with stepEnd first)"; return false; }
+    for (int s = 0; s < kMaxProbeShards; s++) d.probeCnt[s] = 0;
+    if (qTo > qFrom) {
+        if (!matchAndScore(kmerThr, true, err, 1, qFrom, qTo)) return false;
+        unsigned long long over = 0;
+        HIP_OK(hipMemcpyAsync(d.probeCnt, d.probeCursor.p, kMaxProbeShards * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+        HIP_OK(hipMemcpyAsync(&over, d.counters.p + 2, sizeof(over), hipMemcpyDeviceToHost, d.stream));
+        HIP_OK(hipStreamSynchronize(d.stream));
+        if (over) { err = "probeEnumerate: more occupied probes than the buffers hold (" + std::to_string(d.probeCap) + " per shard; SP_PROBE_PER_QUERY raises the room)"; return false; }
+    }
+    if (counts) for (uint32_t s = 0; s < d.nShardMaps; s++) counts[s] = d.probeCnt[s];
+    return true;
+}
+size_t Gpu::probeCount(int dest) const { return dest >= 0 && dest < kMaxProbeShards ? d_->probeCnt[dest] : 0; }
+const uint32_t *Gpu::probeKeysDevice(int dest) const { return d_->pbKey[dest].p; }
+const unsigned long long *Gpu::probeValsDevice(int dest) const { return d_->pbVal[dest].p; }
+
+// the probes addressed to this shard -- the enumerating ranks' lists back to back, in any order of the ranks -- -> this shard's candidates (as prefilterCandidates leaves them)
+bool Gpu::probeFetch(const uint32_t *keys, const unsigned long long *vals, size_t n, bool onDevice, int kmerThr, int minDiagScore, std::string &err) {
+    Impl &d = *d_;
+    d.nCand = 0;
+    if (nq_ == 0) return true;
+    if (n >= ((size_t) 1 << 31)) { err = "probeFetch: more than 2^31 probes in one pass"; return false; }
+    if (d.stepsBegun != d.stepsEnded && !d.drained) { err = "probeFetch: a device-driven step is in flight (collect it with stepEnd first)"; return false; }
+    if (!d.pinKey.ensure(n + 1, err) || !d.pinVal.ensure(n + 1, err) || !d.pinKeySorted.ensure(n + 1, err) || !d.pinValSorted.ensure(n + 1, err) || !d.probeOff.ensure(nq_ + 2, err)) return false;
+    const uint32_t *kIn = keys; const unsigned long long *vIn = vals;
+    if (!onDevice && n) {
+        HIP_OK(hipMemcpyAsync(d.pinKey.p, keys, n * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+        HIP_OK(hipMemcpyAsync(d.pinVal.p, vals, n * sizeof(unsigned long long), hipMemcpyHostToDevice, d.stream));
+        kIn = d.pinKey.p; vIn = d.pinVal.p;
+    }
+    if (n) {      // stable by query: a query's probes came from ONE rank, in its stream order
+        size_t bytes = 0;
+        int endBit = 1; while (endBit < 32 && ((size_t) 1 << endBit) <= nq_) endBit++;      // (query numbers < nq; padding records carry 0xFFFFFFFF: every bit up to endBit set, behind every query)
+        HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kIn, d.pinKeySorted.p, vIn, d.pinValSorted.p, (int) n, 0, endBit, d.stream));
+        if (!d.probeSortTmp.ensure(bytes + 256, err)) return false;
+        bytes = d.probeSortTmp.n;
+        HIP_OK(hipcub::DeviceRadixSort::SortPairs(d.probeSortTmp.p, bytes, kIn, d.pinKeySorted.p, vIn, d.pinValSorted.p, (int) n, 0, endBit, d.stream));
+    }
+    hipLaunchKernelGGL(k_probe_offsets, dim3((unsigned) ((n + 256) / 256)), dim3(256), 0, d.stream, d.pinKeySorted.p, (uint32_t) n, (uint32_t) nq_, d.probeOff.p);
+    HIP_OK(hipGetLastError());
+    d.probeIn = n;
+    if (!matchAndScore(kmerThr, true, err, 2)) return false;
+    return candidatesTail(minDiagScore, err);
+}
+
+// collective: rank r of `comm` holds shard r and enumerates queries [qFrom, qTo) (the ranks' slices tile the batch); leaves this shard's candidates
+bool Gpu::probeSearch(Comm &comm, int kmerThr, int minDiagScore, size_t qFrom, size_t qTo, double *exchangeMs, std::string &err) {
+    Impl &d = *d_;
+    const int world = comm.world(), me = comm.rank();
+    if (world > kMaxProbeShards) { err = "probeSearch: at most " + std::to_string(kMaxProbeShards) + " ranks"; return false; }
+    const auto t0 = std::chrono::steady_clock::now();
+    double xMs = 0;
+    if (d.nShardMaps != (uint32_t) world || d.probeMapsSerial != d.tgt->buildSerial || !d.tgt->buildSerial) {      // once per target set: everybody's occupancy map
+        const size_t words = kTableSize / 64;
+        bool ok = d.tgt->pbits.p && d.shardMaps.ensure(words * (size_t) world, err) && d.unionMap.ensure(words, err);
+        if (ok && hipStreamSynchronize(d.stream) != hipSuccess) { ok = false; err = "probeSearch: the search stream failed"; }
+        if (!agreeOk(comm, ok, err)) return false;
+        if (!comm.allgather(d.tgt->pbits.p, kShardMapBytes, d.shardMaps.p, true, err)) return false;
+        if (!agreeOk(comm, probeSetShardMaps(d.shardMaps.p, world, true, err), err)) return false;
+        d.probeMapsSerial = d.tgt->buildSerial;
+    }
+    xMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    uint64_t mine[kMaxProbeShards] = {};
+    const bool sliceOk = qFrom <= qTo && qTo <= nq_;
+    std::string lerr;
+    bool ok = sliceOk && probeEnumerate(kmerThr, qFrom, qTo, mine, lerr);
+    if (!sliceOk) lerr = "probeSearch: the slice ends behind the last query";
+    if (!ok) err = lerr;
+    if (!agreeOk(comm, ok, err)) return false;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::vector<uint64_t> all((size_t) world * kMaxProbeShards, 0);
+    if (!comm.allgather(mine, sizeof(mine), all.data(), false, err)) return false;
+    size_t recvTotal = 0; std::vector<size_t> recvCnt((size_t) world), sendCnt((size_t) world);
+    for (int r = 0; r < world; r++) { recvCnt[(size_t) r] = (size_t) all[(size_t) r * kMaxProbeShards + (size_t) me]; recvTotal += recvCnt[(size_t) r]; sendCnt[(size_t) r] = (size_t) mine[r]; }
+    ok = recvTotal < ((size_t) 1 << 31) && d.pxKey.ensure(recvTotal + 1, err) && d.pxVal.ensure(recvTotal + 1, err);
+    if (ok && recvTotal >= ((size_t) 1 << 31)) { ok = false; err = "probeSearch: more than 2^31 probes for one shard"; }
+    if (!agreeOk(comm, ok, err)) return false;
+    {   std::vector<const void *> sp((size_t) world); std::vector<void *> rp((size_t) world); std::vector<size_t> sb((size_t) world), rb((size_t) world);
+        size_t at = 0;
+        for (int r = 0; r < world; r++) { sp[(size_t) r] = d.pbKey[r].p; sb[(size_t) r] = sendCnt[(size_t) r] * sizeof(uint32_t); rp[(size_t) r] = d.pxKey.p + at; rb[(size_t) r] = recvCnt[(size_t) r] * sizeof(uint32_t); at += recvCnt[(size_t) r]; }
+        if (!comm.alltoallv(sp.data(), sb.data(), rp.data(), rb.data(), true, err)) return false;
+        at = 0;
+        for (int r = 0; r < world; r++) { sp[(size_t) r] = d.pbVal[r].p; sb[(size_t) r] = sendCnt[(size_t) r] * sizeof(unsigned long long); rp[(size_t) r] = d.pxVal.p + at; rb[(size_t) r] = recvCnt[(size_t) r] * sizeof(unsigned long long); at += recvCnt[(size_t) r]; }
+        if (!comm.alltoallv(sp.data(), sb.data(), rp.data(), rb.data(), true, err)) return false;
+    }
+    xMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    if (exchangeMs) *exchangeMs = xMs;
+    ok = probeFetch(d.pxKey.p, d.pxVal.p, recvTotal, true, kmerThr, minDiagScore, lerr);
+    if (!ok) err = lerr;
+    return agreeOk(comm, ok, err);
 }
 
 const Candidate *Gpu::candidatesDevice() const { return d_->cand.p; }
@@ -1176,7 +1334,7 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
     to = std::min(to, n); from = std::min(from, to);
     const uint64_t R = ts.offsets[n];
     if (d.tgt.use_count() > 1) d.tgt = std::make_shared<Impl::Targets>();      // a shared target set belongs to the others from here on: this context stages its own
-    d.tgt->nTargets = n; d.tgt->indexEntries = 0; d.tgt->indexSlots = 0; d.tgt->bucketsValid = false;
+    d.tgt->nTargets = n; d.tgt->indexEntries = 0; d.tgt->indexSlots = 0; d.tgt->bucketsValid = false; { static std::atomic<uint64_t> serial{0}; d.tgt->buildSerial = ++serial; }
     out = TargetBuild();
     if (!upload(d.tgt->tascii, ascii, (size_t) R, d.stream, err) || !upload(d.tgt->toff, ts.offsets.data(), n + 1, d.stream, err) ||
         !upload(d.tgt->tkeys, ts.keys.data(), n, d.stream, err)) return false;

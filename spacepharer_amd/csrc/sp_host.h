@@ -16,6 +16,7 @@ constexpr int kAlph = 21;          // ACDEFGHIKLMNPQRSTVWYX
 constexpr int kKmer = 6;
 constexpr int kSpan = 8;           // spaced pattern 11011101
 constexpr uint32_t kTableSize = 64000000u;   // 20^6
+constexpr size_t kShardMapBytes = kTableSize / 8;      // a target shard's occupancy map: one bit per k-mer slot (the probe-list cut, sp_gpu.hip)
 constexpr int kX = 20;
 extern const int kPatternPos[kKmer];
 
