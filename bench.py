@@ -325,8 +325,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=None,
                     help="search contexts per GPU, each on its own HIP streams and host thread with its own query batch, taking the steps in turn "
                          "(1 = strictly one pass at a time)")
-    ap.add_argument("--shard", default=None, choices=["queries", "targets"],
-                    help="decomposition: target shards + RCCL all-gather (default at N > 1) or query partition with replicated index (default at N = 1)")
+    ap.add_argument("--shard", default=None, choices=["queries", "targets", "probes"],
+                    help="decomposition: target shards + RCCL all-gather (default at N > 1) or query partition with replicated index (default at N = 1); \"probes\" (or SP_SHARD=probes "
+                         "in the environment): target shards with the probe-list cut -- every rank enumerates its query slice once and sends the occupied probes to the shards (opt-in)")
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2], help="device-driven steps queued per context before the oldest is collected")
     ap.add_argument("--host-driven", action="store_true", help="the round-2 step: the host learns the hit count between prefilter and align and the record count after align "
                     "(sp_ctx_prefilter + sp_ctx_align_hits_begin / _end) instead of one device-driven step (sp_ctx_search_begin / _end)")
@@ -354,8 +355,9 @@ def main():
     local_rank = 0 if args.same_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus is not None and args.gpus != world:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (start it without a launcher, or make the two agree)" % (args.gpus, world))
-    mode = args.shard or ("targets" if world > 1 else "queries")
-    sharded = mode == "targets"
+    mode = args.shard or (os.environ.get("SP_SHARD") if os.environ.get("SP_SHARD") in ("queries", "targets", "probes") else None) or ("targets" if world > 1 else "queries")
+    probe_cut = mode == "probes"
+    sharded = mode in ("targets", "probes")
     n_spacers = args.spacers or (100000 if (sharded and world > 1) else 10000)
     full = args.stage == "full"
 
@@ -448,11 +450,13 @@ def main():
             c.set_queries_raw(batches[b][2].tobytes(), u64p(batches[b][3]), nq)
             ctxs.append(c)
         ctx = ctxs[0]
-        xch = {"s": 0.0, "bytes": 0, "n": 0}
+        xch = {"s": 0.0, "bytes": 0, "n": 0, "probe_s": 0.0}
+        cut_on = [False]      # (the probe-list cut: switched on AFTER the reference digests, which come from every shard enumerating every query itself)
 
         def search(c):
             if shard_targets:
-                info = sharded_prefilter(c, sub or comm, q_from, q_to)     # own shard -> all-gather (within the query group) -> selection on the union
+                info = sharded_prefilter(c, sub or comm, q_from, q_to, probes=probe_cut and cut_on[0])     # own shard -> all-gather (within the query group) -> selection on the union
+                xch["probe_s"] += info["probe_exchange_s"]
                 xch["s"] += info["exchange_s"]
                 xch["bytes"] += info["bytes"]
                 xch["n"] += 1
@@ -514,6 +518,7 @@ def main():
             barrier()
             assert ref_slot[i].hits_ptr_ok
             ref.append(ref_slot[i].digest(full))
+        cut_on[0] = True
         if n_pipe > 1:
             for c in ctxs:
                 c.set_tuning("match_blocks_per_cu", args.match_blocks)     # leaves LDS / registers for the other context's aligner on every CU
@@ -781,6 +786,10 @@ def main():
                            "allgather_bytes_per_step": x["bytes"] / max(1, x["n"]),
                            "exchange_ms_per_step": 1e3 * x["s"] / max(1, x["n"]),
                            "query_slice_of_rank0": list(m["q_slice"])}
+        if probe_cut:
+            out["exchange"]["probe_cut"] = {"what": "every rank enumerates its query slice once (k_match_grp<true, 1>) and sends the occupied probes (12 bytes each) to the shards that hold the slot "
+                                                    "(sp_ctx_probe_search: all-to-all); the shards fetch (k_match_grp<true, 2>); every timed step compared with the pass in which every shard enumerates every query",
+                                            "probe_exchange_ms_per_step": 1e3 * x["probe_s"] / max(1, x["n"])}
     if hyb is not None:
         hdt, hregions = region_summary(hyb, n_spacers * max(4, args.steps // 2))
         out["hybrid"] = {"value": n_spacers * max(4, args.steps // 2) / hdt, "unit": "spacer-queries/s", "scaling": "strong", "ms_per_step": hdt / max(4, args.steps // 2) * 1e3,
@@ -805,12 +814,12 @@ def main():
     if world > 1 and sharded:
         # the headline at N > 1 is BASELINE configs[3]'s decomposition, fixed: target shards + all-gather of the candidates (RCCL over xGMI).  The other cuts of the
         # SAME job (100 000 spacers against the whole target set, strong scaling) stay in the line as side figures; `weak_replica` is the N = 1 job on every rank.
-        cands = {"target_shards": out["value"]}
+        cands = {"target_shards_probe_cut" if probe_cut else "target_shards": out["value"]}
         if hyb is not None:
             cands["hybrid"] = out["hybrid"]["value"]
         if qpart is not None:
             cands["query_partition"] = out["query_partition"]["value"]
-        out["decompositions"] = {"spacer_queries_per_s": cands, "value_from": "target_shards (fixed: BASELINE configs[3])", "best_measured": max(cands, key=cands.get),
+        out["decompositions"] = {"spacer_queries_per_s": cands, "value_from": ("target_shards_probe_cut (asked for: --shard probes / SP_SHARD=probes; the default is target_shards)" if probe_cut else "target_shards (fixed: BASELINE configs[3])"), "best_measured": max(cands, key=cands.get),
                                  "target_shards_ms_per_step": out["ms_per_step"]}
         out["scaling_note"] = ("N = 1 measures configs[2] (10 000 spacers per step on one GPU, `weak_replica` continues that job to N ranks); N > 1 measures configs[3] (100 000 spacers, "
                                "target shards, strong scaling) -- two different jobs, do not join them into one efficiency curve; use `weak_replica` for the weak series.  No 1 -> 8 curve "

@@ -269,26 +269,30 @@ int sp_ctx_merge_candidates(sp_ctx *c, const sp_candidate *candidates, uint64_t 
  * sp_ctx_prefilter_candidates() makes every shard enumerate the similar k-mers of EVERY query -- the same work on every GPU, and most of the matching kernel's time
  * (the reference's MPI target split does the same: prefiltering/Prefiltering.cpp:258-362, each rank runs QueryMatcher::match over all queries against its index split).
  * With the cut a query is enumerated once: every rank takes a slice of the batch, tests its similar k-mers against the union of the shards' occupancy maps
- * (SP_SHARD_MAP_BYTES each: one bit per k-mer slot) and sends every occupied probe -- 4 + 8 bytes: query | ordinal of the k-mer in the query's enumeration,
- * slot, window position -- to the shards whose own map holds the slot; a shard fetches the index lists of the probes it received and detects the double hits.
- * It ends where sp_ctx_prefilter_candidates() ends (same candidates, bit for bit); the candidates' exchange and sp_ctx_merge_candidates() follow unchanged.
+ * (SP_SHARD_MAP_BYTES each: one bit per k-mer slot) and sends every occupied probe -- a 16-byte sp_probe: query, position of the probe in the query's list on that
+ * shard, ordinal of the k-mer in the query's enumeration, rank of the slot in the shard's slot array | window position << 26 -- to the shards whose own map holds the
+ * slot, together with the number of probes per query; a shard places the probes it received by (query, position) -- no sort --, fetches their index lists and detects
+ * the double hits.  It ends where sp_ctx_prefilter_candidates() ends (same candidates, bit for bit); the candidates' exchange and sp_ctx_merge_candidates() follow.
  *   sp_ctx_shard_occupancy     this shard's map -> out (host or device memory)
  *   sp_ctx_probe_set_shards    all shards' maps, in shard order, n_shards x SP_SHARD_MAP_BYTES
  *   sp_ctx_probe_enumerate     queries [q_from, q_to) of the resident batch -> probe lists by destination shard; counts[n_shards] = records per list
- *                              (incl. padding records, key 0xFFFFFFFF, that the fetch side skips)
- *   sp_ctx_probe_get           list `dest` -> keys[count], vals[count] (host or device memory); sp_ctx_probe_keys_device / _vals_device: where it lies in HBM
- *   sp_ctx_probe_fetch         the lists addressed to this shard, back to back in any order of their senders -> this shard's candidates
+ *                              (incl. padding records, query 0xFFFFFFFF, that the fetch side skips)
+ *   sp_ctx_probe_get           list `dest` -> records[count] and query_counts[q_to - q_from] (host or device memory); sp_ctx_probe_records_device /
+ *                              sp_ctx_probe_query_counts_device: where they lie in HBM
+ *   sp_ctx_probe_fetch         the lists addressed to this shard, back to back in any order of their senders, and query_counts[n_queries]: the senders' counts
+ *                              in the order of their slices (the slices tile the batch) -> this shard's candidates
  *   sp_ctx_probe_search        collective, the steps above for rank r = shard r of `comm` (maps all-gathered once per target set, lists by all-to-all:
  *                              RCCL send/recv pairs over xGMI, or through host memory); exchange_s: wall time of the exchanges */
 #define SP_SHARD_MAP_BYTES 8000000u
 #define SP_MAX_PROBE_SHARDS 8
+typedef struct { uint32_t query; uint32_t position; uint32_t kmer_ordinal; uint32_t slot_rank_window; } sp_probe;      /* 16 bytes */
 int sp_ctx_shard_occupancy(sp_ctx *c, void *out, int on_device);
 int sp_ctx_probe_set_shards(sp_ctx *c, const void *maps, int n_shards, int on_device);
 int sp_ctx_probe_enumerate(sp_ctx *c, uint64_t q_from, uint64_t q_to, uint64_t *counts);
-int sp_ctx_probe_get(sp_ctx *c, int dest, uint32_t *keys, uint64_t *vals, int on_device);
-const void *sp_ctx_probe_keys_device(const sp_ctx *c, int dest);
-const void *sp_ctx_probe_vals_device(const sp_ctx *c, int dest);
-int sp_ctx_probe_fetch(sp_ctx *c, const uint32_t *keys, const uint64_t *vals, uint64_t n, int on_device);
+int sp_ctx_probe_get(sp_ctx *c, int dest, sp_probe *records, uint32_t *query_counts, int on_device);
+const void *sp_ctx_probe_records_device(const sp_ctx *c, int dest);
+const void *sp_ctx_probe_query_counts_device(const sp_ctx *c, int dest);
+int sp_ctx_probe_fetch(sp_ctx *c, const sp_probe *records, uint64_t n, const uint32_t *query_counts, int on_device);
 int sp_ctx_probe_search(sp_ctx *c, sp_comm *comm, uint64_t q_from, uint64_t q_to, double *exchange_s);
 /* After sp_ctx_prefilter() / sp_ctx_prefilter_candidates() returned SP_ERR_OVERFLOW: the positions (in the batch) of the queries whose
  * hit stream does not fit one pass (more than 65 535 index hits; QueryMatcher's own buffer, prefiltering/QueryMatcher.cpp:39-50, holds

@@ -115,9 +115,9 @@ def load_library():
     L.sp_ctx_probe_set_shards.argtypes = [vp, vp, C.c_int, C.c_int]
     L.sp_ctx_probe_enumerate.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     L.sp_ctx_probe_get.argtypes = [vp, C.c_int, vp, vp, C.c_int]
-    L.sp_ctx_probe_keys_device.argtypes = [vp, C.c_int]; L.sp_ctx_probe_keys_device.restype = vp
-    L.sp_ctx_probe_vals_device.argtypes = [vp, C.c_int]; L.sp_ctx_probe_vals_device.restype = vp
-    L.sp_ctx_probe_fetch.argtypes = [vp, vp, vp, C.c_uint64, C.c_int]
+    L.sp_ctx_probe_records_device.argtypes = [vp, C.c_int]; L.sp_ctx_probe_records_device.restype = vp
+    L.sp_ctx_probe_query_counts_device.argtypes = [vp, C.c_int]; L.sp_ctx_probe_query_counts_device.restype = vp
+    L.sp_ctx_probe_fetch.argtypes = [vp, vp, C.c_uint64, vp, C.c_int]
     L.sp_ctx_probe_search.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]
     L.sp_ctx_num_candidates.restype = C.c_uint64
     L.sp_ctx_overflow_queries.restype = C.c_uint64
@@ -313,23 +313,23 @@ class SearchContext:
         self.n_shards = len(maps)
 
     def probe_enumerate(self, q_from, q_to):
-        """queries [q_from, q_to) -> per destination shard (keys uint32[n], vals uint64[n]) host copies"""
+        """queries [q_from, q_to) -> per destination shard (records uint32[n, 4], probes per query of the slice uint32[q_to - q_from]) host copies"""
         import numpy as np
         counts = (C.c_uint64 * 8)()
         _check(self.L.sp_ctx_probe_enumerate(self.ctx, q_from, q_to, counts))
         out = []
         for s in range(self.n_shards):
-            k = np.zeros(max(1, counts[s]), dtype=np.uint32); v = np.zeros(max(1, counts[s]), dtype=np.uint64)
-            _check(self.L.sp_ctx_probe_get(self.ctx, s, k.ctypes.data, v.ctypes.data, 0))
-            out.append((k[:counts[s]], v[:counts[s]]))
+            r = np.zeros((max(1, counts[s]), 4), dtype=np.uint32); qc = np.zeros(max(1, q_to - q_from), dtype=np.uint32)
+            _check(self.L.sp_ctx_probe_get(self.ctx, s, r.ctypes.data, qc.ctypes.data, 0))
+            out.append((r[:counts[s]], qc[:q_to - q_from]))
         return out
 
-    def probe_fetch(self, keys, vals):
-        """the probes addressed to this shard -> its candidates (returns their number)"""
+    def probe_fetch(self, records, query_counts):
+        """the probes addressed to this shard + the number of probes per query of the batch -> its candidates (returns their number)"""
         import numpy as np
-        keys = np.ascontiguousarray(keys, dtype=np.uint32); vals = np.ascontiguousarray(vals, dtype=np.uint64)
-        assert len(keys) == len(vals)
-        _check(self.L.sp_ctx_probe_fetch(self.ctx, keys.ctypes.data, vals.ctypes.data, len(keys), 0))
+        records = np.ascontiguousarray(records, dtype=np.uint32).reshape(-1, 4); query_counts = np.ascontiguousarray(query_counts, dtype=np.uint32)
+        assert len(query_counts) == self.n_queries
+        _check(self.L.sp_ctx_probe_fetch(self.ctx, records.ctypes.data, len(records), query_counts.ctypes.data, 0))
         return int(self.L.sp_ctx_num_candidates(self.ctx))
 
     def probe_search(self, comm, q_from, q_to):

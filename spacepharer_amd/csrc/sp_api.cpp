@@ -302,22 +302,23 @@ int sp_ctx_probe_enumerate(sp_ctx *c, uint64_t q_from, uint64_t q_to, uint64_t *
     if (!c->gpu.probeEnumerate(c->kmerThr, (size_t) q_from, (size_t) q_to, counts, err)) { g_err = err; return SP_ERR_OVERFLOW; }
     return SP_OK;
 }
-int sp_ctx_probe_get(sp_ctx *c, int dest, uint32_t *keys, uint64_t *vals, int on_device) {
-    if (!c || !keys || !vals || dest < 0 || dest >= SP_MAX_PROBE_SHARDS) { g_err = "sp_ctx_probe_get: bad argument"; return SP_ERR_ARG; }
+int sp_ctx_probe_get(sp_ctx *c, int dest, sp_probe *records, uint32_t *query_counts, int on_device) {
+    if (!c || !records || !query_counts || dest < 0 || dest >= SP_MAX_PROBE_SHARDS) { g_err = "sp_ctx_probe_get: bad argument"; return SP_ERR_ARG; }
     c->gpu.makeCurrent();
-    const size_t n = c->gpu.probeCount(dest);
-    if (n && (hipMemcpy(keys, c->gpu.probeKeysDevice(dest), n * sizeof(uint32_t), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost) != hipSuccess ||
-              hipMemcpy(vals, c->gpu.probeValsDevice(dest), n * sizeof(uint64_t), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost) != hipSuccess)) { g_err = "sp_ctx_probe_get: copy failed"; return SP_ERR_DEVICE; }
+    const size_t n = c->gpu.probeCount(dest), nq = c->gpu.probeSliceQueries();
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if ((n && hipMemcpy(records, c->gpu.probeRecordsDevice(dest), n * sizeof(sp_probe), kind) != hipSuccess) ||
+        (nq && hipMemcpy(query_counts, c->gpu.probeQueryCountsDevice(dest), nq * sizeof(uint32_t), kind) != hipSuccess)) { g_err = "sp_ctx_probe_get: copy failed"; return SP_ERR_DEVICE; }
     return SP_OK;
 }
-const void *sp_ctx_probe_keys_device(const sp_ctx *c, int dest) { return c && dest >= 0 && dest < SP_MAX_PROBE_SHARDS ? c->gpu.probeKeysDevice(dest) : nullptr; }
-const void *sp_ctx_probe_vals_device(const sp_ctx *c, int dest) { return c && dest >= 0 && dest < SP_MAX_PROBE_SHARDS ? c->gpu.probeValsDevice(dest) : nullptr; }
-int sp_ctx_probe_fetch(sp_ctx *c, const uint32_t *keys, const uint64_t *vals, uint64_t n, int on_device) {
-    if (!c || (n && (!keys || !vals))) { g_err = "sp_ctx_probe_fetch: null argument"; return SP_ERR_ARG; }
+const void *sp_ctx_probe_records_device(const sp_ctx *c, int dest) { return c && dest >= 0 && dest < SP_MAX_PROBE_SHARDS ? c->gpu.probeRecordsDevice(dest) : nullptr; }
+const void *sp_ctx_probe_query_counts_device(const sp_ctx *c, int dest) { return c && dest >= 0 && dest < SP_MAX_PROBE_SHARDS ? c->gpu.probeQueryCountsDevice(dest) : nullptr; }
+int sp_ctx_probe_fetch(sp_ctx *c, const sp_probe *records, uint64_t n, const uint32_t *query_counts, int on_device) {
+    if (!c || !query_counts || (n && !records)) { g_err = "sp_ctx_probe_fetch: null argument"; return SP_ERR_ARG; }
     c->gpu.makeCurrent();
     if (c->targets.n == 0) { g_err = "sp_ctx_probe_fetch: no target set"; return SP_ERR_STATE; }
     std::string err;
-    if (!c->gpu.probeFetch(keys, reinterpret_cast<const unsigned long long *>(vals), (size_t) n, on_device != 0, c->kmerThr, c->par.min_ungapped_score, err)) { g_err = err; return SP_ERR_OVERFLOW; }
+    if (!c->gpu.probeFetch(records, (size_t) n, query_counts, on_device != 0, c->kmerThr, c->par.min_ungapped_score, err)) { g_err = err; return SP_ERR_OVERFLOW; }
     prefilterStats(c);
     c->stats["candidates"] = (double) c->gpu.numCandidates();
     return SP_OK;

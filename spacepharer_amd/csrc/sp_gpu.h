@@ -113,9 +113,10 @@ public:
     bool probeSetShardMaps(const void *maps, int nShards, bool onDevice, std::string &err);
     bool probeEnumerate(int kmerThr, size_t qFrom, size_t qTo, uint64_t *counts, std::string &err);
     size_t probeCount(int dest) const;
-    const uint32_t *probeKeysDevice(int dest) const;
-    const unsigned long long *probeValsDevice(int dest) const;
-    bool probeFetch(const uint32_t *keys, const unsigned long long *vals, size_t n, bool onDevice, int kmerThr, int minDiagScore, std::string &err);
+    size_t probeSliceQueries() const;
+    const void *probeRecordsDevice(int dest) const;               // 16-byte records {query, position in the query's list, ordinal, slot rank | window position << 26}
+    const uint32_t *probeQueryCountsDevice(int dest) const;       // probes per query of the enumerated slice
+    bool probeFetch(const void *records, size_t n, const uint32_t *counts, bool onDevice, int kmerThr, int minDiagScore, std::string &err);
     bool probeSearch(class Comm &comm, int kmerThr, int minDiagScore, size_t qFrom, size_t qTo, double *exchangeMs, std::string &err);
     size_t numCandidates() const;
     const std::vector<uint32_t> &overflowQueries() const { return overflowList_; }      // positions (in the batch) of the queries the last pass refused

@@ -308,10 +308,9 @@ struct Gpu::Impl {
     DevBuf<uint32_t> xOff, xOffAll; DevBuf<GpuHit> xHit, xHitAll;      // send / receive buffers of the hit-list all-gather (query partition)
     DevBuf<uint32_t> candCnt; DevBuf<uint32_t> candFill; DevBuf<uint32_t> candOffset; DevBuf<uint64_t> mergeScratch;
     // ... its probe-list cut: all shards' occupancy maps + their union; the probes this context enumerated, by destination shard; the probes it was sent
-    DevBuf<uint64_t> shardMaps, unionMap; uint32_t nShardMaps = 0; uint64_t probeMapsSerial = 0;
-    DevBuf<uint32_t> pbKey[kMaxProbeShards]; DevBuf<unsigned long long> pbVal[kMaxProbeShards]; DevBuf<uint32_t> probeCursor; size_t probeCap = 0; uint32_t probeCnt[kMaxProbeShards] = {};
-    DevBuf<uint32_t> pinKey, pinKeySorted, probeOff; DevBuf<unsigned long long> pinVal, pinValSorted; DevBuf<char> probeSortTmp; size_t probeIn = 0;
-    DevBuf<uint32_t> pxKey; DevBuf<unsigned long long> pxVal;      // (receive side of the exchange)
+    DevBuf<uint64_t> shardMaps, unionMap, shardBitsIl; DevBuf<uint16_t> shardRankIl; DevBuf<uint32_t> shardRowTot, shardRowIl; uint32_t nShardMaps = 0; uint64_t probeMapsSerial = 0;
+    DevBuf<uint4> pbRec[kMaxProbeShards]; DevBuf<uint32_t> pbQCnt[kMaxProbeShards]; DevBuf<uint32_t> probeCursor; size_t probeCap = 0, probeSlice = 0; uint32_t probeCnt[kMaxProbeShards] = {};
+    DevBuf<uint4> pinRec, pxRec; DevBuf<uint32_t> pinCnt, probeOff; DevBuf<unsigned long long> probeList;      // received records, probes per query, their prefix sums, the lists by query
     uint32_t nCand = 0;
     SwState sw;
     SwDev swd;
@@ -629,8 +628,8 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMo
     // (its ordinal arrays push the large footprint to two blocks per CU)
     const bool small = d.knob.matchSmall >= 0 ? d.knob.matchSmall != 0 : (withOrd || !d.tgt->denseIndex);
     // short queries against a sparse index, unsharded: the grouped kernel (sp_gpu_match_grp.inc) -- same records, four queries per pass of a wave
-    const bool grouped = probeMode ? probeMode == 1 : (small && d.knob.matchGroup != 0 && d.maxQLen <= 64 && d.tgt->nTargets < ((size_t) 1 << 30));      // (with ordinals too since round 5: the target-sharded search)
-    const void *fn = probeMode == 1 ? (const void *) k_match_grp<true, true> : probeMode == 2 ? (const void *) k_match<256, true, true, true> : grouped ? (withOrd ? (const void *) k_match_grp<true> : (const void *) k_match_grp<false>) :
+    const bool grouped = probeMode ? true : (small && d.knob.matchGroup != 0 && d.maxQLen <= 64 && d.tgt->nTargets < ((size_t) 1 << 30));      // (with ordinals too since round 5: the target-sharded search)
+    const void *fn = probeMode == 1 ? (const void *) k_match_grp<true, 1> : probeMode == 2 ? (const void *) k_match_grp<true, 2> : grouped ? (withOrd ? (const void *) k_match_grp<true> : (const void *) k_match_grp<false>) :
                      small ? (withOrd ? (const void *) k_match<256, true, true> : (const void *) k_match<256, false, true>)
                            : (withOrd ? (const void *) k_match<512, true, false> : (const void *) k_match<512, false, false>);
     int perCU = 2;
@@ -661,7 +660,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMo
     // longer decide when the kernel ends)
     // (the grouped kernel's list schedule wants the weights of ANY batch: 6 x 10^5 peptides -- 146 per wave -- still end 5 % apart, 2.98 -> 2.82 ms for 0.07 ms of weighing
     // and sorting)
-    const uint32_t heavyThr = probeMode ? 0u : d.knob.matchHeavy >= 0 ? (uint32_t) d.knob.matchHeavy
+    const uint32_t heavyThr = d.knob.matchHeavy >= 0 ? (uint32_t) d.knob.matchHeavy
                             : ((nq_ <= (size_t) blocks * kWavesPerBlock * 32 || ((grouped || !small) && d.knob.matchOrder != 0 && d.maxQLen <= 64 && !d.knob.prepSplit)) ? 4000u : 0u);
     // exact weights order the heavy queries better (k_match alone 0.43 instead of 0.47 ms on the bench workload) and cost k_prep8 two table rows per window -- 20 us alone, a
     // multiple beside other contexts' matching kernels, where the estimate wins: exact while this context is the only one searching on its device
@@ -671,7 +670,8 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMo
     const bool weighExact = d.knob.weighExact > 0 || (d.knob.weighExact < 0 && !orderedPossible && g_searchers[d.device & 63].load(std::memory_order_relaxed) <= 1);
     // the grouped kernel takes its queries in the order of decreasing weight (k_order_*) instead of "heavy ones first, then shares": needs the weights (k_prep8)
     const bool ordered = orderedPossible;
-    const uint32_t orderTiles = (uint32_t) ((nq_ + kOrderTile - 1) / kOrderTile);
+    const uint32_t orderTiles = (uint32_t) ((nqRun + kOrderTile - 1) / kOrderTile);      // (the enumerating side of the probe-list cut orders ITS slice: positions relative to qFrom)
+    const size_t qOff = probeMode == 1 ? qFrom : 0;
     if (ordered && (!d.qweight.ensure(nq_ + 1, err) || !d.qorder.ensure(nq_ + 1, err) || !d.orderHist.ensure((size_t) orderTiles * kOrderClasses, err) || !d.orderHeader.ensure(16, err) ||
                     !d.orderQueues.ensure(kOrderQueues * kOrderQueueStride, err))) return false;
     WeighArgs wa{d.qres.p, d.qoff.p, (uint32_t) nq_, d.qthr.p, d.tab->ext3.p, d.tab->ext3cnt.p, d.tab->cntMin, ordered ? 0xFFFFFFFEu : (heavyThr ? heavyThr : 0xFFFFFFFFu), d.heavyList.p, d.heavyFlag.p, d.heavyCnt.p,
@@ -688,9 +688,9 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMo
         else hipLaunchKernelGGL(k_prep8<true>, dim3(weighBlocks), dim3(256), (size_t) 32 * stride * 12, d.stream, p8);
         SP_DBG_SYNC("k_prep8");
         if (ordered) {
-            hipLaunchKernelGGL(k_order_count, dim3(orderTiles), dim3(256), 0, d.stream, d.qweight.p, (uint32_t) nq_, d.orderHist.p);
-            hipLaunchKernelGGL(k_order_scatter, dim3(orderTiles), dim3(256), 0, d.stream, d.qweight.p, (uint32_t) nq_, d.orderHist.p, orderTiles, d.qorder.p, reinterpret_cast<OrderHeader *>(d.orderHeader.p),
-                               d.orderQueues.p, blocks * (uint32_t) kWavesPerBlock / (uint32_t) kOrderQueues, small ? 0u : 1u, (small && nq_ <= (size_t) blocks * kWavesPerBlock * 32) ? 36u : 44u);      // (finer tickets on the sparse index: 0.353 -> 0.360 ms -- its groups of four queries want whole tickets)
+            hipLaunchKernelGGL(k_order_count, dim3(orderTiles), dim3(256), 0, d.stream, d.qweight.p + qOff, (uint32_t) nqRun, d.orderHist.p);
+            hipLaunchKernelGGL(k_order_scatter, dim3(orderTiles), dim3(256), 0, d.stream, d.qweight.p + qOff, (uint32_t) nqRun, d.orderHist.p, orderTiles, d.qorder.p, reinterpret_cast<OrderHeader *>(d.orderHeader.p),
+                               d.orderQueues.p, blocks * (uint32_t) kWavesPerBlock / (uint32_t) kOrderQueues, small ? 0u : 1u, (small && nqRun <= (size_t) blocks * kWavesPerBlock * 32) ? 36u : 44u);      // (finer tickets on the sparse index: 0.353 -> 0.360 ms -- its groups of four queries want whole tickets)
             SP_DBG_SYNC("k_order");
         }
     } else {
@@ -722,20 +722,23 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMo
         const size_t cap = std::max<size_t>((size_t) 1 << 20, nqRun * (size_t) std::max(64, d.knob.probePerQuery)) + (size_t) blocks * kWavesPerBlock * kProbeChunk;
         if (cap >= ((size_t) 1 << 31)) { err = "probe-list cut: the slice is too large for one pass (" + std::to_string(nqRun) + " queries)"; return false; }
         if (!d.probeCursor.ensure(kMaxProbeShards, err)) return false;
-        for (uint32_t s = 0; s < d.nShardMaps; s++) if (!d.pbKey[s].ensure(cap, err) || !d.pbVal[s].ensure(cap, err)) return false;
-        d.probeCap = cap;
+        for (uint32_t s = 0; s < d.nShardMaps; s++) {
+            if (!d.pbRec[s].ensure(cap, err) || !d.pbQCnt[s].ensure(nqRun + 1, err)) return false;
+            HIP_OK(hipMemsetAsync(d.pbQCnt[s].p, 0, (nqRun + 1) * sizeof(uint32_t), d.stream));      // (a query without a scanned window never reports)
+        }
+        d.probeCap = cap; d.probeSlice = nqRun;
         HIP_OK(hipMemsetAsync(d.probeCursor.p, 0, kMaxProbeShards * sizeof(uint32_t), d.stream));
         ma.pbits = d.unionMap.p; ma.prank = nullptr; ma.prow = nullptr; ma.slots = nullptr; ma.ientries = nullptr;
-        ma.qFirst = (uint32_t) qFrom; ma.shardBits = d.shardMaps.p; ma.nShards = d.nShardMaps; ma.probeCursor = d.probeCursor.p; ma.probeCap = (uint32_t) cap;
-        for (uint32_t s = 0; s < d.nShardMaps; s++) { ma.probeKey[s] = d.pbKey[s].p; ma.probeVal[s] = d.pbVal[s].p; }
-        hipLaunchKernelGGL((k_match_grp<true, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+        ma.qFirst = (uint32_t) qFrom; ma.shardBitsIl = d.shardBitsIl.p; ma.shardRankIl = d.shardRankIl.p; ma.shardRowIl = d.shardRowIl.p; ma.nShards = d.nShardMaps; ma.probeCursor = d.probeCursor.p; ma.probeCap = (uint32_t) cap;
+        for (uint32_t s = 0; s < d.nShardMaps; s++) { ma.probeRec[s] = d.pbRec[s].p; ma.probeQCnt[s] = d.pbQCnt[s].p; }
+        hipLaunchKernelGGL((k_match_grp<true, 1>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
         SP_DBG_SYNC("k_match_grp (probes out)");
         SP_EV(2, 1);
         return true;
     }
     if (probeMode == 2) {
-        ma.probeOff = d.probeOff.p; ma.probeIn = d.pinValSorted.p;
-        hipLaunchKernelGGL((k_match<256, true, true, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+        ma.probeOff = d.probeOff.p; ma.probeIn = d.probeList.p;
+        hipLaunchKernelGGL((k_match_grp<true, 2>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     }
     else if (grouped) { if (withOrd) hipLaunchKernelGGL(k_match_grp<true>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma); else hipLaunchKernelGGL(k_match_grp<false>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma); }
     else if (small) {
@@ -996,9 +999,13 @@ bool Gpu::probeSetShardMaps(const void *maps, int nShards, bool onDevice, std::s
     Impl &d = *d_;
     if (nShards < 1 || nShards > kMaxProbeShards) { err = "probeSetShardMaps: 1 .. " + std::to_string(kMaxProbeShards) + " shards"; return false; }
     const size_t words = kTableSize / 64;
-    if (!d.shardMaps.ensure(words * (size_t) nShards, err) || !d.unionMap.ensure(words, err)) return false;
+    constexpr uint32_t kRows = kTableSize / 8000u;
+    if (!d.shardMaps.ensure(words * (size_t) nShards, err) || !d.unionMap.ensure(words, err) || !d.shardBitsIl.ensure(words * kMaxProbeShards, err) || !d.shardRankIl.ensure(words * kMaxProbeShards, err) ||
+        !d.shardRowTot.ensure((size_t) kRows * kMaxProbeShards, err) || !d.shardRowIl.ensure((size_t) kRows * kMaxProbeShards, err)) return false;
     if (maps != d.shardMaps.p) HIP_OK(hipMemcpyAsync(d.shardMaps.p, maps, kShardMapBytes * (size_t) nShards, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, d.stream));
     hipLaunchKernelGGL(k_probe_union, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, d.shardMaps.p, (uint32_t) nShards, (uint32_t) words, d.unionMap.p);
+    hipLaunchKernelGGL(k_probe_lines, dim3((kRows * kMaxProbeShards + 255u) / 256u), dim3(256), 0, d.stream, d.shardMaps.p, (uint32_t) nShards, d.shardBitsIl.p, d.shardRankIl.p, d.shardRowTot.p);
+    hipLaunchKernelGGL(k_probe_rows, dim3(kMaxProbeShards), dim3(256), 0, d.stream, d.shardRowTot.p, d.shardRowIl.p);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(d.stream));
     d.nShardMaps = (uint32_t) nShards;
@@ -1023,34 +1030,34 @@ bool Gpu::probeEnumerate(int kmerThr, size_t qFrom, size_t qTo, uint64_t *counts
     return true;
 }
 size_t Gpu::probeCount(int dest) const { return dest >= 0 && dest < kMaxProbeShards ? d_->probeCnt[dest] : 0; }
-const uint32_t *Gpu::probeKeysDevice(int dest) const { return d_->pbKey[dest].p; }
-const unsigned long long *Gpu::probeValsDevice(int dest) const { return d_->pbVal[dest].p; }
+size_t Gpu::probeSliceQueries() const { return d_->probeSlice; }
+const void *Gpu::probeRecordsDevice(int dest) const { return d_->pbRec[dest].p; }
+const uint32_t *Gpu::probeQueryCountsDevice(int dest) const { return d_->pbQCnt[dest].p; }
 
-// the probes addressed to this shard -- the enumerating ranks' lists back to back, in any order of the ranks -- -> this shard's candidates (as prefilterCandidates leaves them)
-bool Gpu::probeFetch(const uint32_t *keys, const unsigned long long *vals, size_t n, bool onDevice, int kmerThr, int minDiagScore, std::string &err) {
+// the probes addressed to this shard -- the enumerating ranks' lists back to back, in any order of the ranks, and the number of probes each query of the batch has among
+// them (the ranks' per-query counts in the order of their slices) -- -> this shard's candidates (as prefilterCandidates leaves them)
+bool Gpu::probeFetch(const void *records, size_t n, const uint32_t *counts, bool onDevice, int kmerThr, int minDiagScore, std::string &err) {
     Impl &d = *d_;
     d.nCand = 0;
     if (nq_ == 0) return true;
     if (n >= ((size_t) 1 << 31)) { err = "probeFetch: more than 2^31 probes in one pass"; return false; }
     if (d.stepsBegun != d.stepsEnded && !d.drained) { err = "probeFetch: a device-driven step is in flight (collect it with stepEnd first)"; return false; }
-    if (!d.pinKey.ensure(n + 1, err) || !d.pinVal.ensure(n + 1, err) || !d.pinKeySorted.ensure(n + 1, err) || !d.pinValSorted.ensure(n + 1, err) || !d.probeOff.ensure(nq_ + 2, err)) return false;
-    const uint32_t *kIn = keys; const unsigned long long *vIn = vals;
-    if (!onDevice && n) {
-        HIP_OK(hipMemcpyAsync(d.pinKey.p, keys, n * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
-        HIP_OK(hipMemcpyAsync(d.pinVal.p, vals, n * sizeof(unsigned long long), hipMemcpyHostToDevice, d.stream));
-        kIn = d.pinKey.p; vIn = d.pinVal.p;
+    if (!d.pinRec.ensure(n + 1, err) || !d.pinCnt.ensure(nq_ + 2, err) || !d.probeList.ensure(n + 1, err) || !d.probeOff.ensure(nq_ + 2, err) || !d.counters.ensure(16, err)) return false;
+    const uint4 *rIn = static_cast<const uint4 *>(records); const uint32_t *cIn = counts;
+    if (!onDevice) {
+        if (n) HIP_OK(hipMemcpyAsync(d.pinRec.p, records, n * sizeof(uint4), hipMemcpyHostToDevice, d.stream));
+        HIP_OK(hipMemcpyAsync(d.pinCnt.p, counts, nq_ * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+        rIn = d.pinRec.p; cIn = d.pinCnt.p;
     }
-    if (n) {      // stable by query: a query's probes came from ONE rank, in its stream order
-        size_t bytes = 0;
-        int endBit = 1; while (endBit < 32 && ((size_t) 1 << endBit) <= nq_) endBit++;      // (query numbers < nq; padding records carry 0xFFFFFFFF: every bit up to endBit set, behind every query)
-        HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kIn, d.pinKeySorted.p, vIn, d.pinValSorted.p, (int) n, 0, endBit, d.stream));
-        if (!d.probeSortTmp.ensure(bytes + 256, err)) return false;
-        bytes = d.probeSortTmp.n;
-        HIP_OK(hipcub::DeviceRadixSort::SortPairs(d.probeSortTmp.p, bytes, kIn, d.pinKeySorted.p, vIn, d.pinValSorted.p, (int) n, 0, endBit, d.stream));
-    }
-    hipLaunchKernelGGL(k_probe_offsets, dim3((unsigned) ((n + 256) / 256)), dim3(256), 0, d.stream, d.pinKeySorted.p, (uint32_t) n, (uint32_t) nq_, d.probeOff.p);
+    if (!d.scanCounts(cIn, (uint32_t) nq_, d.probeOff.p, err)) return false;
+    HIP_OK(hipMemsetAsync(d.counters.p + 15, 0, sizeof(unsigned long long), d.stream));
+    if (n) hipLaunchKernelGGL(k_probe_place, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, rIn, (uint32_t) n, (uint32_t) nq_, d.probeOff.p, d.probeList.p, d.counters.p + 15);
     HIP_OK(hipGetLastError());
-    d.probeIn = n;
+    unsigned long long bad = 0; uint32_t total = 0;
+    HIP_OK(hipMemcpyAsync(&bad, d.counters.p + 15, sizeof(bad), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipMemcpyAsync(&total, d.probeOff.p + nq_, sizeof(total), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipStreamSynchronize(d.stream));
+    if (bad || total > n) { err = "probeFetch: the probe records do not fit the per-query counts (" + std::to_string(bad) + " records out of place; lists and counts of different passes?)"; return false; }
     if (!matchAndScore(kmerThr, true, err, 2)) return false;
     return candidatesTail(minDiagScore, err);
 }
@@ -1072,32 +1079,44 @@ bool Gpu::probeSearch(Comm &comm, int kmerThr, int minDiagScore, size_t qFrom, s
         d.probeMapsSerial = d.tgt->buildSerial;
     }
     xMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    uint64_t mine[kMaxProbeShards] = {};
+    uint64_t mine[kMaxProbeShards + 2] = {};      // records per destination, then this rank's slice
     const bool sliceOk = qFrom <= qTo && qTo <= nq_;
     std::string lerr;
     bool ok = sliceOk && probeEnumerate(kmerThr, qFrom, qTo, mine, lerr);
     if (!sliceOk) lerr = "probeSearch: the slice ends behind the last query";
     if (!ok) err = lerr;
+    mine[kMaxProbeShards] = qFrom; mine[kMaxProbeShards + 1] = qTo;
     if (!agreeOk(comm, ok, err)) return false;
     const auto t1 = std::chrono::steady_clock::now();
-    std::vector<uint64_t> all((size_t) world * kMaxProbeShards, 0);
+    constexpr size_t kRow = kMaxProbeShards + 2;
+    std::vector<uint64_t> all((size_t) world * kRow, 0);
     if (!comm.allgather(mine, sizeof(mine), all.data(), false, err)) return false;
-    size_t recvTotal = 0; std::vector<size_t> recvCnt((size_t) world), sendCnt((size_t) world);
-    for (int r = 0; r < world; r++) { recvCnt[(size_t) r] = (size_t) all[(size_t) r * kMaxProbeShards + (size_t) me]; recvTotal += recvCnt[(size_t) r]; sendCnt[(size_t) r] = (size_t) mine[r]; }
-    ok = recvTotal < ((size_t) 1 << 31) && d.pxKey.ensure(recvTotal + 1, err) && d.pxVal.ensure(recvTotal + 1, err);
+    size_t recvTotal = 0, covered = 0; std::vector<size_t> recvCnt((size_t) world), sendCnt((size_t) world);
+    bool tiles = true;
+    for (int r = 0; r < world; r++) {
+        recvCnt[(size_t) r] = (size_t) all[(size_t) r * kRow + (size_t) me]; recvTotal += recvCnt[(size_t) r]; sendCnt[(size_t) r] = (size_t) mine[r];
+        const uint64_t f = all[(size_t) r * kRow + kMaxProbeShards], t = all[(size_t) r * kRow + kMaxProbeShards + 1];
+        covered += (size_t) (t - f);
+        for (int o = 0; o < r; o++) { const uint64_t f2 = all[(size_t) o * kRow + kMaxProbeShards], t2 = all[(size_t) o * kRow + kMaxProbeShards + 1]; if (f < t && f2 < t2 && f < t2 && f2 < t) tiles = false; }
+    }
+    if (!tiles || covered != nq_) { err = "probeSearch: the ranks' query slices do not tile the batch"; return false; }      // (every rank sees the same table)
+    ok = recvTotal < ((size_t) 1 << 31) && d.pxRec.ensure(recvTotal + 1, err) && d.pinCnt.ensure(nq_ + 2, err);
     if (ok && recvTotal >= ((size_t) 1 << 31)) { ok = false; err = "probeSearch: more than 2^31 probes for one shard"; }
     if (!agreeOk(comm, ok, err)) return false;
     {   std::vector<const void *> sp((size_t) world); std::vector<void *> rp((size_t) world); std::vector<size_t> sb((size_t) world), rb((size_t) world);
         size_t at = 0;
-        for (int r = 0; r < world; r++) { sp[(size_t) r] = d.pbKey[r].p; sb[(size_t) r] = sendCnt[(size_t) r] * sizeof(uint32_t); rp[(size_t) r] = d.pxKey.p + at; rb[(size_t) r] = recvCnt[(size_t) r] * sizeof(uint32_t); at += recvCnt[(size_t) r]; }
+        for (int r = 0; r < world; r++) { sp[(size_t) r] = d.pbRec[r].p; sb[(size_t) r] = sendCnt[(size_t) r] * sizeof(uint4); rp[(size_t) r] = d.pxRec.p + at; rb[(size_t) r] = recvCnt[(size_t) r] * sizeof(uint4); at += recvCnt[(size_t) r]; }
         if (!comm.alltoallv(sp.data(), sb.data(), rp.data(), rb.data(), true, err)) return false;
-        at = 0;
-        for (int r = 0; r < world; r++) { sp[(size_t) r] = d.pbVal[r].p; sb[(size_t) r] = sendCnt[(size_t) r] * sizeof(unsigned long long); rp[(size_t) r] = d.pxVal.p + at; rb[(size_t) r] = recvCnt[(size_t) r] * sizeof(unsigned long long); at += recvCnt[(size_t) r]; }
+        // the per-query counts: rank r's cover its slice, they land at the slice's place in the batch
+        for (int r = 0; r < world; r++) {
+            const uint64_t f = all[(size_t) r * kRow + kMaxProbeShards], t = all[(size_t) r * kRow + kMaxProbeShards + 1];
+            sp[(size_t) r] = d.pbQCnt[r].p; sb[(size_t) r] = (size_t) (qTo - qFrom) * sizeof(uint32_t); rp[(size_t) r] = d.pinCnt.p + f; rb[(size_t) r] = (size_t) (t - f) * sizeof(uint32_t);
+        }
         if (!comm.alltoallv(sp.data(), sb.data(), rp.data(), rb.data(), true, err)) return false;
     }
     xMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     if (exchangeMs) *exchangeMs = xMs;
-    ok = probeFetch(d.pxKey.p, d.pxVal.p, recvTotal, true, kmerThr, minDiagScore, lerr);
+    ok = probeFetch(d.pxRec.p, recvTotal, d.pinCnt.p, true, kmerThr, minDiagScore, lerr);
     if (!ok) err = lerr;
     return agreeOk(comm, ok, err);
 }

@@ -187,12 +187,17 @@ def allgather_hits(ctx, comm, query_offset, nq_total, hit_cap=None, my_hits=None
     return offs, hits[:int(n.value)]
 
 
-def sharded_prefilter(ctx, comm, q_from=0, q_to=None):
+def sharded_prefilter(ctx, comm, q_from=0, q_to=None, probes=False):
     """One target-sharded prefilter pass on this rank's context (targets staged with set_targets_shard*): candidates of the own shard -> all-gather (RCCL: HBM -> xGMI ->
     HBM) -> selection on the union for queries [q_from, q_to).  Afterwards ctx.hits_compact() / ctx.align_hits_raw() see the merged hits.
     Returns {"union": rows of the gathered list, "bytes": bytes this rank received, "exchange_s": wall time of the exchange (counts + payload)}."""
-    ctx.prefilter_candidates()
-    rows, secs = C.c_uint64(), C.c_double()
+    rows, secs, psecs = C.c_uint64(), C.c_double(), C.c_double()
     before = comm.bytes_moved()
+    if probes:
+        # the probe-list cut: this rank enumerates queries [q_from, q_to) only, the occupied probes travel to the shards that hold their slot (sp_ctx_probe_search; rank r
+        # of `comm` is shard r) -- the candidates it leaves are those of prefilter_candidates(), record for record
+        _lib._check(_L().sp_ctx_probe_search(ctx.ctx, comm.h, int(q_from), int(q_to if q_to is not None else ctx.n_queries), C.byref(psecs)))
+    else:
+        ctx.prefilter_candidates()
     _lib._check(_L().sp_ctx_allgather_candidates(ctx.ctx, comm.h, int(q_from), int(q_to if q_to is not None else (1 << 62)), C.byref(rows), C.byref(secs)))
-    return {"union": int(rows.value), "bytes": comm.bytes_moved() - before, "exchange_s": float(secs.value)}
+    return {"union": int(rows.value), "bytes": comm.bytes_moved() - before, "exchange_s": float(secs.value) + float(psecs.value), "probe_exchange_s": float(psecs.value)}

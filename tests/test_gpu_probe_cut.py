@@ -34,13 +34,17 @@ def _probe_cut(sa, T, Q, world, slices=None, **kw):
     if slices is None:                                        # the ranks' slices tile the batch
         cut = [len(Q) * r // world for r in range(world + 1)]
         slices = [(cut[r], cut[r + 1]) for r in range(world)]
-    sent = [c.probe_enumerate(a, b) for c, (a, b) in zip(ctxs, slices)]      # sent[src][dst] = (keys, vals)
+    sent = [c.probe_enumerate(a, b) for c, (a, b) in zip(ctxs, slices)]      # sent[src][dst] = (records, probes per query of the slice)
     cands = []
     for dst, c in enumerate(ctxs):
         order = list(range(world))[::-1] if dst % 2 else list(range(world))  # the order of the senders must not matter
-        keys = np.concatenate([sent[src][dst][0] for src in order])
-        vals = np.concatenate([sent[src][dst][1] for src in order])
-        n = c.probe_fetch(keys, vals)
+        recs = np.concatenate([sent[src][dst][0] for src in order])
+        per_query = np.zeros(len(Q), dtype=np.uint32)
+        for src, (a, b) in enumerate(slices):
+            per_query[a:b] = sent[src][dst][1]
+        real = recs[recs[:, 0] != 0xFFFFFFFF]
+        assert len(real) == per_query.sum()
+        n = c.probe_fetch(recs, per_query)
         cd = c.candidates().copy()
         assert cd.shape == (n, 16)
         cands.append(cd)
@@ -86,7 +90,7 @@ def test_probe_cut_with_ties_uneven_slices_and_an_empty_slice():
     # what travels: a probe names a query of the sender's slice, and a shard receives fewer probes than the queries have similar k-mers
     for src, (a, b) in enumerate([(0, 7), (7, 7), (7, 150), (150, 299), (299, 300)]):
         for dst in range(5):
-            k = sent[src][dst][0]
+            k = sent[src][dst][0][:, 0]
             real = k[k != 0xFFFFFFFF]
             assert len(real) == 0 or (real.min() >= a and real.max() < b)
     ref.close()
@@ -107,3 +111,29 @@ def test_probe_cut_rejects_long_queries_and_missing_maps():
     with pytest.raises(sa.SpError, match="64 residues"):
         c.probe_enumerate(0, len(g["queries"]))
     c.close()
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 4])
+def test_bench_probe_cut_on_several_ranks_of_one_gpu(ranks):
+    """SP_SHARD=probes: bench.py's N > 1 path with the probe-list cut -- ranks share the GPU, the probe lists and the candidates travel through the library's host
+    transport (sp_dist alltoallv / allgather).  Every timed step is compared inside bench.py with the pass in which every shard enumerates every query itself;
+    here the aligned pairs over all ranks must add up to the one-rank search's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "3", "--warmup", "1", "--regions", "2", "--spacers", "1500", "--targets", "6000", "--cpu-sample", "0", "--no-module-e2e"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--shard", "targets", "--exchange", "host"] + common, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    one = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--same-gpu", "--exchange", "host", "--no-replica", "--no-hybrid"] + common,
+                       capture_output=True, text=True, timeout=1800, env=dict(env, SP_SHARD="probes"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == ranks
+    assert out["decompositions"]["value_from"].startswith("target_shards_probe_cut")
+    assert out["exchange"]["probe_cut"]["probe_exchange_ms_per_step"] > 0
+    assert out["config"]["pairs_aligned_per_step"] == one["config"]["pairs_aligned_per_step"]
+    assert out["results_checked"]["steps"] == 6 and out["results_checked"]["equal_to_single_context_result"] is True
