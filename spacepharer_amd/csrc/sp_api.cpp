@@ -300,6 +300,7 @@ int sp_ctx_probe_enumerate(sp_ctx *c, uint64_t q_from, uint64_t q_to, uint64_t *
     c->gpu.makeCurrent();
     std::string err;
     if (!c->gpu.probeEnumerate(c->kmerThr, (size_t) q_from, (size_t) q_to, counts, err)) { g_err = err; return SP_ERR_OVERFLOW; }
+    { sp::KernelTimes kt = c->gpu.times(); c->stats["ms_prep"] = kt.prep; c->stats["ms_match"] = kt.match; }
     return SP_OK;
 }
 int sp_ctx_probe_get(sp_ctx *c, int dest, sp_probe *records, uint32_t *query_counts, int on_device) {

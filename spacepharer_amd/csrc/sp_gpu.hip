@@ -308,7 +308,7 @@ struct Gpu::Impl {
     DevBuf<uint32_t> xOff, xOffAll; DevBuf<GpuHit> xHit, xHitAll;      // send / receive buffers of the hit-list all-gather (query partition)
     DevBuf<uint32_t> candCnt; DevBuf<uint32_t> candFill; DevBuf<uint32_t> candOffset; DevBuf<uint64_t> mergeScratch;
     // ... its probe-list cut: all shards' occupancy maps + their union; the probes this context enumerated, by destination shard; the probes it was sent
-    DevBuf<uint64_t> shardMaps, unionMap, shardBitsIl; DevBuf<uint16_t> shardRankIl; DevBuf<uint32_t> shardRowTot, shardRowIl; uint32_t nShardMaps = 0; uint64_t probeMapsSerial = 0;
+    DevBuf<uint64_t> shardMaps, unionMap, shardLines; DevBuf<uint32_t> shardRowTot, shardRowIl; uint32_t nShardMaps = 0; uint64_t probeMapsSerial = 0;
     DevBuf<uint4> pbRec[kMaxProbeShards]; DevBuf<uint32_t> pbQCnt[kMaxProbeShards]; DevBuf<uint32_t> probeCursor; size_t probeCap = 0, probeSlice = 0; uint32_t probeCnt[kMaxProbeShards] = {};
     DevBuf<uint4> pinRec, pxRec; DevBuf<uint32_t> pinCnt, probeOff; DevBuf<unsigned long long> probeList;      // received records, probes per query, their prefix sums, the lists by query
     uint32_t nCand = 0;
@@ -721,15 +721,15 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMo
         // capacity per destination: whole chunks per wave on top of a generous share of the slice's similar k-mers (a full buffer is counted as an overflow and reported)
         const size_t cap = std::max<size_t>((size_t) 1 << 20, nqRun * (size_t) std::max(64, d.knob.probePerQuery)) + (size_t) blocks * kWavesPerBlock * kProbeChunk;
         if (cap >= ((size_t) 1 << 31)) { err = "probe-list cut: the slice is too large for one pass (" + std::to_string(nqRun) + " queries)"; return false; }
-        if (!d.probeCursor.ensure(kMaxProbeShards, err)) return false;
+        if (!d.probeCursor.ensure(kMaxProbeShards * kProbeCursorStride, err)) return false;
         for (uint32_t s = 0; s < d.nShardMaps; s++) {
             if (!d.pbRec[s].ensure(cap, err) || !d.pbQCnt[s].ensure(nqRun + 1, err)) return false;
             HIP_OK(hipMemsetAsync(d.pbQCnt[s].p, 0, (nqRun + 1) * sizeof(uint32_t), d.stream));      // (a query without a scanned window never reports)
         }
         d.probeCap = cap; d.probeSlice = nqRun;
-        HIP_OK(hipMemsetAsync(d.probeCursor.p, 0, kMaxProbeShards * sizeof(uint32_t), d.stream));
+        HIP_OK(hipMemsetAsync(d.probeCursor.p, 0, kMaxProbeShards * kProbeCursorStride * sizeof(uint32_t), d.stream));
         ma.pbits = d.unionMap.p; ma.prank = nullptr; ma.prow = nullptr; ma.slots = nullptr; ma.ientries = nullptr;
-        ma.qFirst = (uint32_t) qFrom; ma.shardBitsIl = d.shardBitsIl.p; ma.shardRankIl = d.shardRankIl.p; ma.shardRowIl = d.shardRowIl.p; ma.nShards = d.nShardMaps; ma.probeCursor = d.probeCursor.p; ma.probeCap = (uint32_t) cap;
+        ma.qFirst = (uint32_t) qFrom; ma.shardLines = d.shardLines.p; ma.nShards = d.nShardMaps; ma.probeCursor = d.probeCursor.p; ma.probeCap = (uint32_t) cap;
         for (uint32_t s = 0; s < d.nShardMaps; s++) { ma.probeRec[s] = d.pbRec[s].p; ma.probeQCnt[s] = d.pbQCnt[s].p; }
         hipLaunchKernelGGL((k_match_grp<true, 1>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
         SP_DBG_SYNC("k_match_grp (probes out)");
@@ -1000,12 +1000,14 @@ bool Gpu::probeSetShardMaps(const void *maps, int nShards, bool onDevice, std::s
     if (nShards < 1 || nShards > kMaxProbeShards) { err = "probeSetShardMaps: 1 .. " + std::to_string(kMaxProbeShards) + " shards"; return false; }
     const size_t words = kTableSize / 64;
     constexpr uint32_t kRows = kTableSize / 8000u;
-    if (!d.shardMaps.ensure(words * (size_t) nShards, err) || !d.unionMap.ensure(words, err) || !d.shardBitsIl.ensure(words * kMaxProbeShards, err) || !d.shardRankIl.ensure(words * kMaxProbeShards, err) ||
+    if (!d.shardMaps.ensure(words * (size_t) nShards, err) || !d.unionMap.ensure(words, err) || !d.shardLines.ensure(words * kProbeLineWords, err) ||
         !d.shardRowTot.ensure((size_t) kRows * kMaxProbeShards, err) || !d.shardRowIl.ensure((size_t) kRows * kMaxProbeShards, err)) return false;
     if (maps != d.shardMaps.p) HIP_OK(hipMemcpyAsync(d.shardMaps.p, maps, kShardMapBytes * (size_t) nShards, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, d.stream));
     hipLaunchKernelGGL(k_probe_union, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, d.shardMaps.p, (uint32_t) nShards, (uint32_t) words, d.unionMap.p);
-    hipLaunchKernelGGL(k_probe_lines, dim3((kRows * kMaxProbeShards + 255u) / 256u), dim3(256), 0, d.stream, d.shardMaps.p, (uint32_t) nShards, d.shardBitsIl.p, d.shardRankIl.p, d.shardRowTot.p);
+    HIP_OK(hipMemsetAsync(d.shardLines.p, 0, words * kProbeLineWords * sizeof(uint64_t), d.stream));
+    hipLaunchKernelGGL(k_probe_rowtot, dim3((kRows * kMaxProbeShards + 255u) / 256u), dim3(256), 0, d.stream, d.shardMaps.p, (uint32_t) nShards, d.shardRowTot.p);
     hipLaunchKernelGGL(k_probe_rows, dim3(kMaxProbeShards), dim3(256), 0, d.stream, d.shardRowTot.p, d.shardRowIl.p);
+    hipLaunchKernelGGL(k_probe_lines, dim3((kRows * kMaxProbeShards + 255u) / 256u), dim3(256), 0, d.stream, d.shardMaps.p, (uint32_t) nShards, d.shardRowIl.p, d.shardLines.p);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(d.stream));
     d.nShardMaps = (uint32_t) nShards;
@@ -1021,9 +1023,20 @@ bool Gpu::probeEnumerate(int kmerThr, size_t qFrom, size_t qTo, uint64_t *counts
     if (qTo > qFrom) {
         if (!matchAndScore(kmerThr, true, err, 1, qFrom, qTo)) return false;
         unsigned long long over = 0;
-        HIP_OK(hipMemcpyAsync(d.probeCnt, d.probeCursor.p, kMaxProbeShards * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+        HIP_OK(hipMemcpy2DAsync(d.probeCnt, sizeof(uint32_t), d.probeCursor.p, kProbeCursorStride * sizeof(uint32_t), sizeof(uint32_t), kMaxProbeShards, hipMemcpyDeviceToHost, d.stream));
         HIP_OK(hipMemcpyAsync(&over, d.counters.p + 2, sizeof(over), hipMemcpyDeviceToHost, d.stream));
         HIP_OK(hipStreamSynchronize(d.stream));
+        times_.prep = evMs(d.timing, 2, d.ev[d.evSet][0], d.ev[d.evSet][1]);
+        times_.match = evMs(d.timing, 1, d.ev[d.evSet][1], d.ev[d.evSet][2]);
+        if (d.knob.debug) {      // how evenly the enumerating kernel's waves were busy
+            std::vector<unsigned long long> wp((size_t) d.matchBlocks * kWavesPerBlock * 4);
+            if (hipMemcpy(wp.data(), d.wavePartial.p, wp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                std::vector<double> v; double sum = 0;
+                for (size_t w = 0; w < wp.size() / 4; w++) { const double t = (double) wp[w * 4 + 3] / (double) d.wallKHz * 1e3; sum += t; v.push_back(t); }
+                std::sort(v.begin(), v.end());
+                fprintf(stderr, "[sp] probe enumeration, waves %zu: busy mean %.1f us, median %.1f, p90 %.1f, p99 %.1f, max %.1f us\n", v.size(), sum / (double) v.size(), v[v.size() / 2], v[v.size() * 9 / 10], v[v.size() * 99 / 100], v.back());
+            }
+        }
         if (over) { err = "probeEnumerate: more occupied probes than the buffers hold (" + std::to_string(d.probeCap) + " per shard; SP_PROBE_PER_QUERY raises the room)"; return false; }
     }
     if (counts) for (uint32_t s = 0; s < d.nShardMaps; s++) counts[s] = d.probeCnt[s];
