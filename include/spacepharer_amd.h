@@ -193,6 +193,10 @@ int sp_dist_barrier(sp_comm *comm);
 /* equal-size all-gather: recv holds world x bytes, rank r's block at r x bytes; on_device: both buffers are memory of this rank's GPU */
 int sp_dist_allgather(sp_comm *comm, const void *send, uint64_t bytes, void *recv, int on_device);
 int sp_dist_allreduce_f64(sp_comm *comm, double *values, uint64_t n, int op /* 0 sum, 1 max, 2 min */);
+/* every rank sends block r (send[r], send_bytes[r]) to rank r and receives rank r's block for it into recv[r] (recv_bytes[r], agreed on beforehand: e.g. by an
+   all-gather of the sizes); device buffers over RCCL: one group of ncclSend / ncclRecv pairs; otherwise through rank 0 over the bootstrap sockets.  The probe lists of
+   sp_ctx_probe_search travel this way. */
+int sp_dist_alltoallv(sp_comm *comm, const void *const *send, const uint64_t *send_bytes, void *const *recv, const uint64_t *recv_bytes, int on_device);
 uint64_t sp_dist_bytes_moved(const sp_comm *comm);      /* bytes this rank has received through the communicator so far */
 /* DBReader::decomposeDomainByAminoAcid: contiguous slices balanced by data size; entry_lengths = the index `length` fields (sequence length + 2) */
 int sp_dist_decompose(const uint64_t *entry_lengths, uint64_t n, int rank, int world, uint64_t *start, uint64_t *count);

@@ -397,6 +397,15 @@ int sp_dist_allreduce_f64(sp_comm *comm, double *values, uint64_t n, int op) {
     if (!comm || !comm->c->allreduce(values, (size_t) n, op, err)) { g_err = comm ? err : "sp_dist_allreduce_f64: null communicator"; return SP_ERR_DEVICE; }
     return SP_OK;
 }
+int sp_dist_alltoallv(sp_comm *comm, const void *const *send, const uint64_t *send_bytes, void *const *recv, const uint64_t *recv_bytes, int on_device) {
+    if (!comm || !send || !send_bytes || !recv || !recv_bytes) { g_err = "sp_dist_alltoallv: null argument"; return SP_ERR_ARG; }
+    std::string err;
+    const size_t W = (size_t) comm->c->world();
+    std::vector<size_t> sb(W), rb(W);
+    for (size_t k = 0; k < W; k++) { sb[k] = (size_t) send_bytes[k]; rb[k] = (size_t) recv_bytes[k]; }
+    if (!comm->c->alltoallv(send, sb.data(), recv, rb.data(), on_device != 0, err)) { g_err = err; return SP_ERR_DEVICE; }
+    return SP_OK;
+}
 uint64_t sp_dist_bytes_moved(const sp_comm *comm) { return comm ? comm->c->bytesMoved() : 0; }
 int sp_dist_decompose(const uint64_t *entry_lengths, uint64_t n, int rank, int world, uint64_t *start, uint64_t *count) {
     size_t s = 0, k = 0;

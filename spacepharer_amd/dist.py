@@ -89,6 +89,19 @@ class Comm:
         allp = self.allgather_host(pad)
         return [allp[r][:int(n[r])] for r in range(self.world)]
 
+    def alltoallv_host(self, blocks):
+        """blocks[r]: the numpy array (1-D, one dtype for all) this rank sends to rank r; returns the list of the arrays the ranks sent to this one (sizes exchanged first)"""
+        blocks = [np.ascontiguousarray(b) for b in blocks]
+        assert len(blocks) == self.world
+        dt = blocks[0].dtype
+        sizes = self.allgather_host(np.array([b.nbytes for b in blocks], dtype=np.uint64))      # [src, dst]
+        recv = [np.empty(int(sizes[r][self.rank]) // dt.itemsize, dtype=dt) for r in range(self.world)]
+        vp = C.c_void_p * self.world
+        u64 = C.c_uint64 * self.world
+        self.L.sp_dist_alltoallv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib._check(self.L.sp_dist_alltoallv(self.h, vp(*[b.ctypes.data for b in blocks]), u64(*[b.nbytes for b in blocks]), vp(*[b.ctypes.data for b in recv]), u64(*[b.nbytes for b in recv]), 0))
+        return recv
+
     def allreduce(self, values, op="sum"):
         v = (C.c_double * len(values))(*[float(x) for x in values])
         _lib._check(self.L.sp_dist_allreduce_f64(self.h, v, len(values), {"sum": 0, "max": 1, "min": 2}[op]))

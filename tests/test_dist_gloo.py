@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -114,3 +115,33 @@ def test_candidate_allgather_gloo(tmp_path):
     out = str(tmp_path / "cand")
     mp.spawn(_cand_worker, args=(3, binascii.hexlify(spd.unique_id()).decode(), out), nprocs=3, join=True)
     assert [open("%s.%d" % (out, r)).read() for r in range(3)] == ["ok"] * 3
+
+
+def _a2a_block(src, dst):
+    """what rank src sends to rank dst: (src + 2 * dst) % 5 * 1000 + 3 words (rank 1 sends rank 2 nothing)"""
+    n = 0 if (src, dst) == (1, 2) else ((src + 2 * dst) % 5) * 1000 + 3
+    return (np.arange(n, dtype=np.uint32) * 2654435761 + src * 97 + dst).astype(np.uint32)
+
+
+def _a2a_worker(rank, world, uid_hex, out):
+    os.environ["SP_DIST_ID"] = uid_hex
+    from spacepharer_amd import dist as spd
+    comm = spd.init_from_env(spd.TRANSPORT_HOST, rank=rank, world=world)
+    before = comm.bytes_moved()
+    got = comm.alltoallv_host([_a2a_block(rank, r) for r in range(world)])
+    ok = all(got[r].tolist() == _a2a_block(r, rank).tolist() for r in range(world)) and comm.bytes_moved() > before
+    got = comm.alltoallv_host([_a2a_block(rank, r)[:1] for r in range(world)])      # a second round on the same sockets, tiny blocks
+    ok = ok and all(got[r].tolist() == _a2a_block(r, rank)[:1].tolist() for r in range(world))
+    open("%s.%d" % (out, rank), "w").write("ok" if ok else "mismatch")
+    comm.barrier()
+    comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_alltoallv_host_transport(tmp_path, world):
+    """sp_dist_alltoallv (the probe lists of the probe-list cut travel this way): ragged blocks, one of them empty, through rank 0 over the bootstrap sockets"""
+    import binascii
+    from spacepharer_amd import dist as spd
+    out = str(tmp_path / "a2a")
+    mp.spawn(_a2a_worker, args=(world, binascii.hexlify(spd.unique_id()).decode(), out), nprocs=world, join=True)
+    assert [open("%s.%d" % (out, r)).read() for r in range(world)] == ["ok"] * world

@@ -100,11 +100,14 @@ def test_bench_sharded_path_over_rccl_single_rank():
             "--cpu-sample", "0"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     outs = []
-    for extra in ([], ["--shard", "targets"]):
+    for extra in ([], ["--shard", "targets"], ["--shard", "probes"]):
         p = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, env=env)
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]))
-    a, b = outs
+    a, b, c = outs
+    # the probe-list cut through the same one-rank RCCL group (its all-to-all degenerates to the rank's own block): every timed step equals the plain sharded pass
+    assert c["config"]["pairs_aligned_per_step"] == a["config"]["pairs_aligned_per_step"] and c["counters_per_step"]["hits"] == a["counters_per_step"]["hits"]
+    assert "probe_cut" in c["exchange"] and c["exchange"]["rccl_ranks"] == 1
     assert b["scaling"] == "strong" and "target shards" in b["config"]["parallelism"]
     assert a["config"]["pairs_aligned_per_step"] == b["config"]["pairs_aligned_per_step"] > 0
     assert a["counters_per_step"]["hits"] == b["counters_per_step"]["hits"]
