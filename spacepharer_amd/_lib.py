@@ -252,6 +252,11 @@ class SearchContext:
             self._cig_cap = 64 * self._aln_cap
             self._new_pinned_results()
 
+    def reserve_results(self, n_hits):
+        """page-locked result buffers for align_hits_raw() / align_hits_begin() with room for n_hits alignments, ahead of the first call (pinning a few hundred MB takes
+        0.1-0.3 s: a caller that knows its scale does it beside something else)"""
+        self._result_buffers(int(n_hits))
+
     def _new_pinned_results(self):
         if not hasattr(self, "_pinned"):
             self._pinned = []

@@ -757,7 +757,10 @@ int sp_ctx_set_scores(sp_ctx *c, const sp_set_layout *l, const sp_alignment *aln
     c->gpu.makeCurrent();
     memset(out, 0, sizeof(*out));
     const sp::GpuHit *h = nullptr; const uint32_t *off = nullptr; size_t n = 0; std::string err;
+    const bool laps = getenv("SP_MODULE_TIMES") != nullptr; double tLap = nowMs();
+    auto lap = [&](const char *what) { if (laps) { const double t = nowMs(); fprintf(stderr, "[sp] set_scores: %-24s %8.3f ms\n", what, t - tLap); tLap = t; } };
     if (!c->gpu.hostHits(h, off, n, err)) { g_err = err; return SP_ERR_DEVICE; }
+    lap("hit list on the host");
     if (n && (!aln || !cigars)) { g_err = "sp_ctx_set_scores: no alignment records"; return SP_ERR_ARG; }
     if (stage != 1 && (!l->q_nucl || !l->q_nucl_off || !l->t_nucl || !l->t_nucl_off)) { g_err = "sp_ctx_set_scores: the nucleotide ORFs are missing"; return SP_ERR_ARG; }
     sp::sets::SetInputs in;
@@ -774,7 +777,9 @@ int sp_ctx_set_scores(sp_ctx *c, const sp_set_layout *l, const sp_alignment *aln
     if (l->nucl_gap_extend > 0) in.gapExtend = l->nucl_gap_extend;
     in.simpleBestHit = l->simple_best_hit != 0; in.threads = c->threads;
     std::vector<uint32_t> keys; std::vector<std::string> entries;
+    lap("inputs");
     if (!sp::sets::setScores(in, stage, keys, entries, err)) { g_err = err; return SP_ERR_ARG; }
+    lap("setScores");
     uint64_t total = 0; for (const std::string &e : entries) total += e.size() + 1;
     out->n = keys.size();
     out->keys = (uint32_t *) malloc(sizeof(uint32_t) * std::max<size_t>(1, keys.size()));
