@@ -1082,7 +1082,12 @@ bool Gpu::probeSearch(Comm &comm, int kmerThr, int minDiagScore, size_t qFrom, s
     if (world > kMaxProbeShards) { err = "probeSearch: at most " + std::to_string(kMaxProbeShards) + " ranks"; return false; }
     const auto t0 = std::chrono::steady_clock::now();
     double xMs = 0;
-    if (d.nShardMaps != (uint32_t) world || d.probeMapsSerial != d.tgt->buildSerial || !d.tgt->buildSerial) {      // once per target set: everybody's occupancy map
+    // once per target set: everybody's occupancy map.  The ranks decide TOGETHER (a rank that alone thought its maps were stale would wait in an all-gather nobody else enters)
+    bool needMaps = d.nShardMaps != (uint32_t) world || d.probeMapsSerial != d.tgt->buildSerial || !d.tgt->buildSerial;
+    {   unsigned char mineFlag = needMaps ? 1 : 0; std::vector<unsigned char> flags((size_t) world, 0);
+        if (!comm.allgather(&mineFlag, 1, flags.data(), false, err)) return false;
+        for (unsigned char f : flags) needMaps = needMaps || f != 0; }
+    if (needMaps) {
         const size_t words = kTableSize / 64;
         bool ok = d.tgt->pbits.p && d.shardMaps.ensure(words * (size_t) world, err) && d.unionMap.ensure(words, err);
         if (ok && hipStreamSynchronize(d.stream) != hipSuccess) { ok = false; err = "probeSearch: the search stream failed"; }

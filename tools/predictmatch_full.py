@@ -203,7 +203,7 @@ def reference_timing(d, dbs, threads=16, sample=24000):
     return out
 
 
-def run_pipelined(d, genomes, arrays, replicas, threads, n_arrays, hits_hint=0):
+def run_pipelined(d, genomes, arrays, replicas, threads, n_arrays, hits_hint=0, overlap_scores=True):
     """The same chain with its independent steps overlapped (host threads; every ctypes call releases the interpreter lock): the query, target and control preparations run
     beside each other, a DB is read as soon as its module has written it, the target search starts when query and target peptides are in memory, its set-level scores are
     computed on host threads while the GPU searches the control set (two search contexts).  Same modules, same calls, same files: only their order in time differs.
@@ -222,7 +222,7 @@ def run_pipelined(d, genomes, arrays, replicas, threads, n_arrays, hits_hint=0):
         marks[k] = round(time.perf_counter() - t0, 4)
 
     def make_ctx():
-        c = sa.SearchContext()
+        c = sa.SearchContext(threads=max(4, threads - 4))      # (its set-level scores run beside the other context's search: leave the search's host thread a share of the CPU quota)
         if hits_hint:
             c.reserve_results(hits_hint)      # (page-locked result buffers of the scale the job is known to have: pinned beside the first modules, not inside the first align)
         return c
@@ -273,11 +273,17 @@ def run_pipelined(d, genomes, arrays, replicas, threads, n_arrays, hits_hint=0):
 
     ctx_t, ctx_c = ctx_f[0].result(), ctx_f[1].result()
     res_t = search(ctx_t, "t")
-    fs = ex.submit(scores, ctx_t, "t", res_t)
-    dbs["c"] = fc.result()
-    res_c = search(ctx_c, "c")
-    score_rev = scores(ctx_c, "c", res_c)
-    score = fs.result()
+    if overlap_scores:      # the target search's set-level scores on host threads while the second context searches the control set
+        fs = ex.submit(scores, ctx_t, "t", res_t)
+        dbs["c"] = fc.result()
+        res_c = search(ctx_c, "c")
+        score_rev = scores(ctx_c, "c", res_c)
+        score = fs.result()
+    else:                   # one after the other (the preparation above is what overlaps)
+        score = scores(ctx_t, "t", res_t)
+        dbs["c"] = fc.result()
+        res_c = search(ctx_c, "c")
+        score_rev = scores(ctx_c, "c", res_c)
     w1 = ex.submit(pm.write_db, P("cScore"), [(k, v) for k, v in sorted(score.items())], 5)
     pm.write_db(P("cScore_rev"), [(k, v) for k, v in sorted(score_rev.items())], 5)
     w1.result()
@@ -336,17 +342,22 @@ def run(unique_genomes=900, genome_nt=20000, replicas=10, n_arrays=5000, per_arr
     if os.environ.get("SP_CHAIN_PIPELINED", "1") != "0":
         # the same chain, its independent steps overlapped: a second directory, compared entry by entry with the sequential run above
         with tempfile.TemporaryDirectory() as d2:
-            best = None
-            for _ in range(2):      # (the second lap: page cache and allocator warm, as for the sequential chain, whose modules ran after make_data warmed them)
+            laps = {}
+            for lap, overlap in enumerate((True, False, True, False)):      # (two laps each: page cache and allocator warm from the second on, as for the sequential chain, whose modules ran after make_data warmed them)
                 for f in os.listdir(d2):
                     os.remove(os.path.join(d2, f))
-                p_score, p_rev, p_nt, p_nc, p_match, wall, marks = run_pipelined(d2, genomes, arrays, replicas, threads, n_arrays, hits_hint=max(n_t, n_c))
-                if best is None or wall < best[0]:
-                    best = (wall, marks)
-            assert p_score == score and p_rev == score_rev and (p_nt, p_nc) == (n_t, n_c) and p_match == match, "the pipelined chain delivered other results"
-            info["pipelined"] = {"what": "the same module calls and files, independent steps overlapped on host threads (query / target / control preparation side by side, DBs read as they appear, "
-                                         "the target search's set-level scores computed while the GPU searches the control set, two search contexts); results equal the sequential chain's",
-                                 "chain_s": round(best[0], 4), "spacers_per_s_whole_chain": n_sp / best[0], "marks_s": best[1], "results_equal_sequential": True}
+                p_score, p_rev, p_nt, p_nc, p_match, wall, marks = run_pipelined(d2, genomes, arrays, replicas, threads, n_arrays, hits_hint=max(n_t, n_c), overlap_scores=overlap)
+                assert p_score == score and p_rev == score_rev and (p_nt, p_nc) == (n_t, n_c) and p_match == match, "the pipelined chain delivered other results"
+                k = "preparation_and_scores_overlapped" if overlap else "preparation_overlapped"
+                if k not in laps or wall < laps[k][0]:
+                    laps[k] = (wall, marks)
+            best = min(laps.values(), key=lambda x: x[0])
+            info["pipelined"] = {"what": "the same module calls and files, independent steps overlapped on host threads: query / target / control preparation side by side and DBs read as they appear "
+                                         "(preparation_overlapped); additionally the target search's set-level scores computed while a second search context searches the control set "
+                                         "(preparation_and_scores_overlapped: 0.93 s on some boxes, slower than the sequential chain on others -- two host-side phases beside each other under the "
+                                         "box's 16-core quota); results equal the sequential chain's in every lap",
+                                 "chain_s": round(best[0], 4), "spacers_per_s_whole_chain": n_sp / best[0], "marks_s": best[1], "results_equal_sequential": True,
+                                 "variants": {k: {"chain_s": round(v[0], 4), "spacers_per_s_whole_chain": n_sp / v[0], "marks_s": v[1]} for k, v in laps.items()}}
     state = {"dbs": dbs, "score": score, "score_rev": score_rev, "match": match, "truth": truth, "ctx": ctx, "dir": keep_dir, "tmp": tmp, "unique": U, "replicas": replicas}
     return info, state
 
