@@ -79,6 +79,46 @@ def test_prefilter_matches_oracle_on_fresh_inputs():
     o.close()
 
 
+def test_selection_paths_by_number_of_diagonals_against_oracle():
+    """k_select takes a query by its number of double-hit diagonals: <= 4 inside a lane, <= 64 one record per lane, <= 256 four per lane + one LDS sort
+    (selectMedium, round 5), the general path beyond or at --max-seqs.  Families of near-identical targets (and exact copies: several diagonals and equal scores
+    per target) put queries into every class; each one must equal the oracle's list -- same hits, same scores, same order."""
+    import random
+    from golden.make_golden import make_case, mutate, rand_seq
+    from oracle_lib import Oracle
+    import spacepharer_amd as sa
+    T, Q = make_case(seed=777001, n_targets=1200, n_queries=60, tmin=40, tmax=200, qmin=9, qmax=30, families=0)
+    rng = random.Random(5150)
+    planted = []
+    for size in (3, 30, 70, 130, 200, 222, 232, 250, 290, 340):              # family sizes -> diagonals per query of that family
+        base = rand_seq(rng, 90)
+        members = [mutate(rng, base, rng.randint(0, 2)) + rand_seq(rng, rng.randint(0, 15)) for _ in range(size)]
+        members += [members[i % len(members)] for i in range(size // 10)]          # exact copies
+        members += [m[:50] + m[20:] for m in members[:size // 8]]                  # a repeated stretch: two diagonals on one target
+        T += members
+        for _ in range(4):
+            p = rng.randrange(0, 60)
+            planted.append(mutate(rng, base[p:p + rng.randint(10, 24)], rng.choice([0, 0, 1])))
+    Q = planted + Q
+    for max_seqs in (300, 100):
+        o = Oracle(sens=5.7, max_seqs=max_seqs)
+        o.set_targets(T)
+        ctx = sa.SearchContext(max_seqs=max_seqs)
+        ctx.set_targets(T)
+        ctx.set_queries(Q)
+        ctx.prefilter()
+        got = ctx.hits()
+        sizes = []
+        for i, q in enumerate(Q):
+            exp = o.prefilter_list(q)
+            assert [list(h) for h in got[i]] == exp, (max_seqs, i, len(exp))
+            sizes.append(len(exp))
+        if max_seqs == 300:
+            assert any(s <= 4 for s in sizes) and any(4 < s <= 64 for s in sizes) and any(64 < s <= 256 for s in sizes) and any(256 < s < 300 for s in sizes) and any(s == 300 for s in sizes), sorted(sizes)
+        ctx.close()
+        o.close()
+
+
 def test_degenerate_targets_and_queries_against_oracle():
     """the device-side target preparation and the search on empty / shorter-than-a-window / all-X / repeat-rich targets"""
     from golden.make_golden import make_case
