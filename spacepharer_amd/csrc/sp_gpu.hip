@@ -613,7 +613,7 @@ bool Gpu::uploadQueries(const uint8_t *res, const uint32_t *off, size_t nq, std:
 
 // k_prep, k_match, k_score for every resident query; leaves the scored double-hit diagonals in HBM (events 0..3)
 // probeMode 1: the enumerating side of the probe-list cut (queries [qFrom, qTo) against the union of the shards' maps; the occupied probes leave by destination
-// shard, nothing is matched or scored); probeMode 2: its fetching side (the probes in pinKeySorted / pinValSorted / probeOff instead of an enumeration)
+// shard, nothing is matched or scored); probeMode 2: its fetching side (the probes in probeList / probeOff, placed by k_probe_place, instead of an enumeration)
 bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMode, size_t qFrom, size_t qTo) {
     Impl &d = *d_;
     overflowList_.clear();
