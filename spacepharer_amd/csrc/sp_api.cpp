@@ -228,12 +228,15 @@ int sp_ctx_set_queries(sp_ctx *c, const char *residues, const uint64_t *offsets,
     if (c) c->gpu.makeCurrent();
     if (!c || !residues || !offsets) { g_err = "sp_ctx_set_queries: null argument"; return SP_ERR_ARG; }
     if (offsets[n] >= (1ull << 32)) { g_err = "query batch larger than 4 GiB of residues"; return SP_ERR_ARG; }
+    const bool laps = n > 100000 && getenv("SP_MODULE_TIMES") != nullptr; double tLap = laps ? nowMs() : 0;
+    auto lap = [&](const char *what) { if (laps) { const double t = nowMs(); fprintf(stderr, "[sp]   set_queries: %-22s %8.3f ms\n", what, t - tLap); tLap = t; } };
     c->qres.resize(offsets[n]);
     c->qoff.resize(n + 1);
     c->gateValid = false;
     c->qascii.assign(residues, residues + offsets[n]);
     c->qasciiOff.assign(offsets, offsets + n + 1);
     for (uint64_t i = 0; i <= n; i++) c->qoff[i] = (uint32_t) offsets[i];
+    lap("copies");
     {   // letters -> residue classes, a few threads for batches of millions of residues
         const uint64_t R = offsets[n];
         const size_t T = (size_t) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::min(16, std::max(1, c->threads)), R / (1u << 19) + 1));
@@ -241,8 +244,10 @@ int sp_ctx_set_queries(sp_ctx *c, const char *residues, const uint64_t *offsets,
         if (T == 1) map(0);
         else sp::runTasks(T, map);
     }
+    lap("letters -> classes");
     std::string err;
     if (!c->gpu.uploadQueries(c->qres.data(), c->qoff.data(), (size_t) n, err)) { g_err = err; return SP_ERR_DEVICE; }
+    lap("to the device");
     return SP_OK;
 }
 
