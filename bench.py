@@ -307,6 +307,61 @@ def launch_ranks(n, argv):
     return rc
 
 
+def probe_cut_proxy(sa, args, shards=8, spacers=100000):
+    """one GPU as shard 0 of `shards` (configs[3]: 100 000 spacers against 1e7 residues cut into target shards): HIP-event time of the matching kernel when the shard
+    enumerates every query itself (sp_ctx_prefilter_candidates) against the probe-list cut -- enumerate 1 / shards of the queries against the union of all shards'
+    occupancy maps (sp_ctx_probe_enumerate), place the probes the `shards` enumerating ranks address to shard 0 and fetch (sp_ctx_probe_fetch); the candidates of both
+    ways are compared record for record.  All shard contexts live on this GPU (their maps make the union; their enumerations produce what shard 0 receives)."""
+    import ctypes as C
+    from spacepharer_amd.dist import decompose_by_residues
+    tres, toff, qres, qoff = make_workload(spacers, args.targets, args.target_len, 12345)
+    lens = np.diff(toff).astype(np.int64) + 2
+    nq = len(qoff) - 1
+    ctxs = []
+    for r in range(shards):
+        start, count = decompose_by_residues(lens, r, shards)
+        c = sa.SearchContext()
+        c.set_targets_shard_raw(tres.tobytes(), u64p(toff), len(toff) - 1, start, start + count)
+        c.set_queries_raw(qres.tobytes(), u64p(qoff), nq)
+        c.set_timing(2)
+        ctxs.append(c)
+    c0 = ctxs[0]
+    plain_ms = []
+    for _ in range(6):
+        c0.prefilter_candidates()
+        plain_ms.append(c0.stat("ms_match"))
+    plain = np.ascontiguousarray(c0.candidates())
+    maps = [c.shard_occupancy() for c in ctxs]
+    for c in ctxs:
+        c.probe_set_shards(maps)
+    qlens = np.diff(qoff).astype(np.int64) + 2
+    recs, per_query, enum_ms = [], np.zeros(nq, dtype=np.uint32), []
+    for r, c in enumerate(ctxs):
+        a, n = decompose_by_residues(qlens, r, shards)
+        for _ in range(4 if r == 0 else 1):
+            out = c.probe_enumerate(a, a + n)
+            if r == 0:
+                enum_ms.append(c.stat("ms_match"))
+        recs.append(out[0][0])
+        per_query[a:a + n] = out[0][1]
+    R = np.concatenate(recs)
+    fetch_ms = []
+    for _ in range(6):
+        c0.probe_fetch(R, per_query)
+        fetch_ms.append(c0.stat("ms_match"))
+    cut = np.ascontiguousarray(c0.candidates())
+    equal = sorted(bytes(x) for x in cut) == sorted(bytes(x) for x in plain)
+    for c in ctxs:
+        c.close()
+    real = int((R[:, 0] != 0xFFFFFFFF).sum())
+    return {"what": "one GPU as shard 0 of %d, %d spacers (%d peptides) against 1 / %d of %.1e residues: the matching kernel when the shard enumerates every query itself against "
+                    "enumerate 1 / %d of the queries (against the union of the shards' maps) + fetch of the probes the %d enumerating ranks address to this shard; HIP events, the "
+                    "other shard contexts idle on the same GPU; the exchange the cut adds has not run on xGMI" % (shards, spacers, nq, shards, float(toff[-1]), shards, shards),
+            "plain_k_match_grp_ms": round(min(plain_ms[2:]), 4), "cut_enumerate_ms": round(min(enum_ms[1:]), 4), "cut_fetch_ms": round(min(fetch_ms[2:]), 4),
+            "cut_matching_ms": round(min(enum_ms[1:]) + min(fetch_ms[2:]), 4), "x_plain": round(min(plain_ms[2:]) / (min(enum_ms[1:]) + min(fetch_ms[2:])), 3),
+            "probes_received_by_the_shard": real, "probe_bytes_received": real * 16, "candidates": int(len(plain)), "candidates_equal_plain_pass": bool(equal)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None)
@@ -335,6 +390,7 @@ def main():
     ap.add_argument("--unshared", action="store_true", help="every search context of a GPU stages its own copy of the target set and tables (the round-3 configuration; default: one staged set, shared)")
     ap.add_argument("--no-module-e2e", action="store_true", help="N = 1: skip the files-to-files timing of the module drop-ins (tools/module_e2e.py)")
     ap.add_argument("--shards", type=int, default=0, help="N > 1, target-sharded: S target shards x N / S query groups (all-gather within a group); 0 = N shards, every rank matches all queries (BASELINE configs[3])")
+    ap.add_argument("--no-probe-proxy", action="store_true", help="N = 1, default workload: skip the one-GPU measurement of the probe-list cut (shard 0 of 8 at 100 000 spacers: plain pass against enumerate + place + fetch)")
     ap.add_argument("--no-hybrid", action="store_true", help="N >= 4: skip the additional 2-shard x N/2-group measurement")
     ap.add_argument("--no-replica", action="store_true", help="N > 1: skip the additional query-partition (replica) measurement")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "host", "gloo"], help="transport of the all-gathers: RCCL (HBM -> xGMI -> HBM), or through host memory and the library's bootstrap sockets (\"host\"; \"gloo\" is the old name) for ranks that share a GPU (tests)")
@@ -688,6 +744,14 @@ def main():
         # host-driven steps in two contexts, fewer steps -- a step is ten times longer.  (The dense matching kernel fills every CU's LDS: more contexts LOSE there
         # -- three 1.4 M, four 1.7 M spacer-queries/s -- and the device-driven step in two contexts 2.1 M against 2.5 M: profiles/r04_dense_step_modes.txt)
         dense = measure(False, 10000, max(4, args.steps // 10), max(1, min(3, args.regions)), 2, True, pipeline=2, host_driven=True, targets=1000000)
+    probe_proxy = None
+    if dual and not args.no_probe_proxy and (n_spacers, args.targets, args.target_len) == (10000, 50000, 200):
+        # the probe-list cut of the target-sharded search on ONE GPU playing shard 0 of 8 at configs[3]'s size: what the matching work of a step costs
+        # when every shard enumerates every query (the N > 1 `value`'s decomposition) against enumerate-an-eighth + place + fetch; no N > 1 run has measured its exchange
+        try:
+            probe_proxy = probe_cut_proxy(sa, args)
+        except Exception as e:      # (a side figure must not cost the line)
+            probe_proxy = {"error": repr(e)[:300]}
     pairs_total = all_sum(float(m["pairs"][0]))      # batch 0 of every rank (sharded: the ranks' query slices add up to the batch)
     if comm is not None:
         comm.barrier()
@@ -790,6 +854,8 @@ def main():
             out["exchange"]["probe_cut"] = {"what": "every rank enumerates its query slice once (k_match_grp<true, 1>) and sends the occupied probes (12 bytes each) to the shards that hold the slot "
                                                     "(sp_ctx_probe_search: all-to-all); the shards fetch (k_match_grp<true, 2>); every timed step compared with the pass in which every shard enumerates every query",
                                             "probe_exchange_ms_per_step": 1e3 * x["probe_s"] / max(1, x["n"])}
+    if probe_proxy is not None:
+        out["probe_cut_one_gpu"] = probe_proxy
     if hyb is not None:
         hdt, hregions = region_summary(hyb, n_spacers * max(4, args.steps // 2))
         out["hybrid"] = {"value": n_spacers * max(4, args.steps // 2) / hdt, "unit": "spacer-queries/s", "scaling": "strong", "ms_per_step": hdt / max(4, args.steps // 2) * 1e3,

@@ -235,11 +235,11 @@ struct Gpu::Impl {
     int numCU = 256;
     // environment knobs (diagnostics / experiments), read once per context instead of once per pass
     struct Knobs {
-        int matchSmall = -1, matchPerCU = 0, matchHeavy = -1, matchStatic = 4, matchDChunk = 4, weighExact = -1, matchGroup = 1, matchOrder = 1, selChunkDense = 8, selDynamic = 0, probePerQuery = 1024;
+        int matchSmall = -1, matchPerCU = 0, matchHeavy = -1, matchStatic = 4, matchDChunk = 4, weighExact = -1, matchGroup = 1, matchOrder = 1, selChunkDense = 8, selDynamic = 0, probePerQuery = 192;
         bool debug = false, prepSplit = false, swRows32 = false, swRows16 = false, swOldForward = false;
         void read() {
             auto num = [](const char *k, int d) { const char *e = getenv(k); return e ? atoi(e) : d; };
-            matchSmall = num("SP_MATCH_SMALL", -1); matchGroup = num("SP_MATCH_GROUP", 1); matchOrder = num("SP_MATCH_ORDER", 1); { const int we = num("SP_MATCH_WEIGH_EXACT", -1); weighExact = we < 0 ? -1 : (we ? 1 : 0); } matchPerCU = num("SP_MATCH_PERCU", 0); selChunkDense = num("SP_SEL_CHUNK", 8); selDynamic = num("SP_SEL_DYNAMIC", 0); matchHeavy = num("SP_MATCH_HEAVY", -1); probePerQuery = num("SP_PROBE_PER_QUERY", 1024);
+            matchSmall = num("SP_MATCH_SMALL", -1); matchGroup = num("SP_MATCH_GROUP", 1); matchOrder = num("SP_MATCH_ORDER", 1); { const int we = num("SP_MATCH_WEIGH_EXACT", -1); weighExact = we < 0 ? -1 : (we ? 1 : 0); } matchPerCU = num("SP_MATCH_PERCU", 0); selChunkDense = num("SP_SEL_CHUNK", 8); selDynamic = num("SP_SEL_DYNAMIC", 0); matchHeavy = num("SP_MATCH_HEAVY", -1); probePerQuery = num("SP_PROBE_PER_QUERY", 192);
             matchStatic = std::min(8, std::max(0, num("SP_MATCH_STATIC", 4))); matchDChunk = std::min(32, std::max(1, num("SP_MATCH_DCHUNK", 4)));      // (a chunk's offsets live in the lanes of a wave)
             debug = getenv("SP_DEBUG") != nullptr; prepSplit = getenv("SP_PREP_SPLIT") != nullptr; swRows32 = getenv("SP_SW_ROWS32") != nullptr;
             swRows16 = getenv("SP_SW_ROWS16") != nullptr; swOldForward = getenv("SP_SW_OLD_FORWARD") != nullptr;
