@@ -324,6 +324,7 @@ def probe_cut_proxy(sa, args, shards=8, spacers=100000):
         c.set_targets_shard_raw(tres.tobytes(), u64p(toff), len(toff) - 1, start, start + count)
         c.set_queries_raw(qres.tobytes(), u64p(qoff), nq)
         c.set_timing(2)
+        c.set_tuning("match_blocks_per_cu", -1)      # (all that fit, as for the ONE context a rank of the sharded job has: the library leaves room for other contexts' aligners when it sees several searching on a device)
         ctxs.append(c)
     c0 = ctxs[0]
     plain_ms = []

@@ -25,6 +25,7 @@ for r in range(S):
     c.set_targets_shard_raw(tres.tobytes(), bench.u64p(toff), 50000, start, start + count)
     c.set_queries_raw(qres.tobytes(), bench.u64p(qoff), len(qoff) - 1)
     c.set_timing(2)
+    c.set_tuning("match_blocks_per_cu", int(os.environ.get("BLOCKS_PER_CU", "-1")))      # -1: all that fit, as for the one context a rank of the sharded job has (0: the library's choice -- two while it sees several contexts searching on the device)
     ctxs.append(c)
 c0 = ctxs[0]
 ms = []
@@ -49,11 +50,13 @@ for r, c in enumerate(ctxs):
         t0 = time.perf_counter()
         out = c.probe_enumerate(a, a + n)
         best = min(best, time.perf_counter() - t0)
+        if r == 0:
+            en_kernel = c.stat("ms_match")
     en.append(best * 1e3)
     recs.append(out[0][0]); per_query[a:a + n] = out[0][1]
     if r == 0:
-        print("cut, enumerate: slice of %d queries -> %s records per destination (16 bytes each: %.1f MB sent in total), wall %.3f ms incl. k_prep8 of all queries + copy of the lists to the host"
-              % (n, [len(o[0]) for o in out], sum(len(o[0]) for o in out) * 16 / 1e6, best * 1e3))
+        print("cut, enumerate: slice of %d queries -> %s records per destination (16 bytes each: %.1f MB sent in total), k_match_grp<true, 1> %.3f ms (wall %.3f ms incl. k_prep8 of all queries + copy of the lists to the host)"
+              % (n, [len(o[0]) for o in out], sum(len(o[0]) for o in out) * 16 / 1e6, en_kernel, best * 1e3))
 R = np.concatenate(recs)
 ms, wall = [], []
 for _ in range(8):
