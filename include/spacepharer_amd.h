@@ -274,7 +274,7 @@ int sp_ctx_merge_candidates(sp_ctx *c, const sp_candidate *candidates, uint64_t 
  * (the reference's MPI target split does the same: prefiltering/Prefiltering.cpp:258-362, each rank runs QueryMatcher::match over all queries against its index split).
  * With the cut a query is enumerated once: every rank takes a slice of the batch, tests its similar k-mers against the union of the shards' occupancy maps
  * (SP_SHARD_MAP_BYTES each: one bit per k-mer slot) and sends every occupied probe -- a 16-byte sp_probe: query, position of the probe in the query's list on that
- * shard, ordinal of the k-mer in the query's enumeration, rank of the slot in the shard's slot array | window position << 26 -- to the shards whose own map holds the
+ * shard, ordinal of the k-mer in the query's enumeration, k-mer slot | window position << 26 -- to the shards whose own map holds the
  * slot, together with the number of probes per query; a shard places the probes it received by (query, position) -- no sort --, fetches their index lists and detects
  * the double hits.  It ends where sp_ctx_prefilter_candidates() ends (same candidates, bit for bit); the candidates' exchange and sp_ctx_merge_candidates() follow.
  *   sp_ctx_shard_occupancy     this shard's map -> out (host or device memory)
@@ -289,7 +289,7 @@ int sp_ctx_merge_candidates(sp_ctx *c, const sp_candidate *candidates, uint64_t 
  *                              RCCL send/recv pairs over xGMI, or through host memory); exchange_s: wall time of the exchanges */
 #define SP_SHARD_MAP_BYTES 8000000u
 #define SP_MAX_PROBE_SHARDS 8
-typedef struct { uint32_t query; uint32_t position; uint32_t kmer_ordinal; uint32_t slot_rank_window; } sp_probe;      /* 16 bytes */
+typedef struct { uint32_t query; uint32_t position; uint32_t kmer_ordinal; uint32_t slot_window; } sp_probe;      /* 16 bytes; slot_window = k-mer slot | window position << 26 */
 int sp_ctx_shard_occupancy(sp_ctx *c, void *out, int on_device);
 int sp_ctx_probe_set_shards(sp_ctx *c, const void *maps, int n_shards, int on_device);
 int sp_ctx_probe_enumerate(sp_ctx *c, uint64_t q_from, uint64_t q_to, uint64_t *counts);

@@ -308,7 +308,7 @@ struct Gpu::Impl {
     DevBuf<uint32_t> xOff, xOffAll; DevBuf<GpuHit> xHit, xHitAll;      // send / receive buffers of the hit-list all-gather (query partition)
     DevBuf<uint32_t> candCnt; DevBuf<uint32_t> candFill; DevBuf<uint32_t> candOffset; DevBuf<uint64_t> mergeScratch;
     // ... its probe-list cut: all shards' occupancy maps + their union; the probes this context enumerated, by destination shard; the probes it was sent
-    DevBuf<uint64_t> shardMaps, unionMap, shardLines; DevBuf<uint32_t> shardRowTot, shardRowIl; uint32_t nShardMaps = 0; uint64_t probeMapsSerial = 0;
+    DevBuf<uint64_t> shardMaps, unionMap; DevBuf<uint8_t> shardOwners; uint32_t nShardMaps = 0; uint64_t probeMapsSerial = 0;
     DevBuf<uint4> pbRec[kMaxProbeShards]; DevBuf<uint32_t> pbQCnt[kMaxProbeShards]; DevBuf<uint32_t> probeCursor; size_t probeCap = 0, probeSlice = 0; uint32_t probeCnt[kMaxProbeShards] = {};
     DevBuf<uint4> pinRec, pxRec; DevBuf<uint32_t> pinCnt, probeOff; DevBuf<unsigned long long> probeList;      // received records, probes per query, their prefix sums, the lists by query
     uint32_t nCand = 0;
@@ -729,7 +729,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMo
         d.probeCap = cap; d.probeSlice = nqRun;
         HIP_OK(hipMemsetAsync(d.probeCursor.p, 0, kMaxProbeShards * kProbeCursorStride * sizeof(uint32_t), d.stream));
         ma.pbits = d.unionMap.p; ma.prank = nullptr; ma.prow = nullptr; ma.slots = nullptr; ma.ientries = nullptr;
-        ma.qFirst = (uint32_t) qFrom; ma.shardLines = d.shardLines.p; ma.nShards = d.nShardMaps; ma.probeCursor = d.probeCursor.p; ma.probeCap = (uint32_t) cap;
+        ma.qFirst = (uint32_t) qFrom; ma.shardOwners = d.shardOwners.p; ma.nShards = d.nShardMaps; ma.probeCursor = d.probeCursor.p; ma.probeCap = (uint32_t) cap;
         for (uint32_t s = 0; s < d.nShardMaps; s++) { ma.probeRec[s] = d.pbRec[s].p; ma.probeQCnt[s] = d.pbQCnt[s].p; }
         hipLaunchKernelGGL((k_match_grp<true, 1>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
         SP_DBG_SYNC("k_match_grp (probes out)");
@@ -999,15 +999,10 @@ bool Gpu::probeSetShardMaps(const void *maps, int nShards, bool onDevice, std::s
     Impl &d = *d_;
     if (nShards < 1 || nShards > kMaxProbeShards) { err = "probeSetShardMaps: 1 .. " + std::to_string(kMaxProbeShards) + " shards"; return false; }
     const size_t words = kTableSize / 64;
-    constexpr uint32_t kRows = kTableSize / 8000u;
-    if (!d.shardMaps.ensure(words * (size_t) nShards, err) || !d.unionMap.ensure(words, err) || !d.shardLines.ensure(words * kProbeLineWords, err) ||
-        !d.shardRowTot.ensure((size_t) kRows * kMaxProbeShards, err) || !d.shardRowIl.ensure((size_t) kRows * kMaxProbeShards, err)) return false;
+    if (!d.shardMaps.ensure(words * (size_t) nShards, err) || !d.unionMap.ensure(words, err) || !d.shardOwners.ensure((size_t) kTableSize, err)) return false;
     if (maps != d.shardMaps.p) HIP_OK(hipMemcpyAsync(d.shardMaps.p, maps, kShardMapBytes * (size_t) nShards, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, d.stream));
     hipLaunchKernelGGL(k_probe_union, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, d.shardMaps.p, (uint32_t) nShards, (uint32_t) words, d.unionMap.p);
-    HIP_OK(hipMemsetAsync(d.shardLines.p, 0, words * kProbeLineWords * sizeof(uint64_t), d.stream));
-    hipLaunchKernelGGL(k_probe_rowtot, dim3((kRows * kMaxProbeShards + 255u) / 256u), dim3(256), 0, d.stream, d.shardMaps.p, (uint32_t) nShards, d.shardRowTot.p);
-    hipLaunchKernelGGL(k_probe_rows, dim3(kMaxProbeShards), dim3(256), 0, d.stream, d.shardRowTot.p, d.shardRowIl.p);
-    hipLaunchKernelGGL(k_probe_lines, dim3((kRows * kMaxProbeShards + 255u) / 256u), dim3(256), 0, d.stream, d.shardMaps.p, (uint32_t) nShards, d.shardRowIl.p, d.shardLines.p);
+    hipLaunchKernelGGL(k_probe_owners, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, d.stream, d.shardMaps.p, (uint32_t) nShards, (uint32_t) words, d.shardOwners.p);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(d.stream));
     d.nShardMaps = (uint32_t) nShards;
