@@ -255,7 +255,7 @@ struct Gpu::Impl {
         std::mutex mu;      // a sharing context may add the similar-k-mer tables to a set that was staged without them
     };
     struct Targets {
-        DevBuf<uint64_t> buckets; bool bucketsValid = false; size_t indexSlots = 0; uint64_t buildSerial = 0;      // large-footprint layout of the slot table, derived from slots / ientries on first use
+        DevBuf<uint64_t> buckets; bool bucketsValid = false; DevBuf<uint64_t> slotDirect; bool slotDirectValid = false; size_t indexSlots = 0; uint64_t buildSerial = 0;      // large-footprint layout of the slot table, derived from slots / ientries on first use
         DevBuf<uint64_t> pbits; DevBuf<uint16_t> prank; DevBuf<uint32_t> prow; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff; DevBuf<uint32_t> tkeys;
         size_t nTargets = 0; size_t indexEntries = 0;
         bool denseIndex = false;      // 1.5+ entries per occupied k-mer on average: k_match runs with its large footprint
@@ -702,6 +702,16 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMo
         SP_DBG_SYNC("k_weigh");
     }
     SP_EV(1, 1);
+    if (grouped && probeMode != 1) {      // (the slot words by k-mer slot: once per target set, on the first pass of the grouped kernel -- of whichever context sharing the set gets here first)
+      std::lock_guard<std::mutex> shared(d.tgt->mu);
+      if (!d.tgt->slotDirectValid) {
+        if (!d.tgt->slotDirect.ensure((size_t) kSlots, err)) return false;
+        hipLaunchKernelGGL(k_idx_slot_direct, dim3((unsigned) ((kSlots + 255) / 256)), dim3(256), 0, d.stream, d.tgt->pbits.p, d.tgt->prank.p, d.tgt->prow.p, d.tgt->slots.p, d.tgt->slotDirect.p);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(d.stream));      // (complete before another context's stream reads it)
+        d.tgt->slotDirectValid = true;
+      }
+    }
     if (!small) {      // (the bucket table: once per target set, on the first pass with the large footprint -- of whichever context sharing the set gets here first)
       std::lock_guard<std::mutex> shared(d.tgt->mu);
       if (!d.tgt->bucketsValid) {
@@ -711,7 +721,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMo
         d.tgt->bucketsValid = true;
       }
     }
-    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nqRun, d.qthr.p, d.tab->ext3.p, d.tab->ext3cnt.p, d.tab->cntMin, d.tgt->pbits.p, d.tgt->prank.p, d.tgt->prow.p, d.tgt->slots.p, d.tgt->ientries.p, small ? nullptr : d.tgt->buckets.p, d.spill.p, d.queue.p,
+    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nqRun, d.qthr.p, d.tab->ext3.p, d.tab->ext3cnt.p, d.tab->cntMin, d.tgt->pbits.p, d.tgt->prank.p, d.tgt->prow.p, d.tgt->slots.p, d.tgt->ientries.p, (grouped && probeMode != 1) ? d.tgt->slotDirect.p : nullptr, small ? nullptr : d.tgt->buckets.p, d.spill.p, d.queue.p,
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
                  (uint32_t) d.knob.matchStatic, (uint32_t) d.knob.matchDChunk,
@@ -1366,7 +1376,7 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
     to = std::min(to, n); from = std::min(from, to);
     const uint64_t R = ts.offsets[n];
     if (d.tgt.use_count() > 1) d.tgt = std::make_shared<Impl::Targets>();      // a shared target set belongs to the others from here on: this context stages its own
-    d.tgt->nTargets = n; d.tgt->indexEntries = 0; d.tgt->indexSlots = 0; d.tgt->bucketsValid = false; { static std::atomic<uint64_t> serial{0}; d.tgt->buildSerial = ++serial; }
+    d.tgt->nTargets = n; d.tgt->indexEntries = 0; d.tgt->indexSlots = 0; d.tgt->bucketsValid = false; d.tgt->slotDirectValid = false; { static std::atomic<uint64_t> serial{0}; d.tgt->buildSerial = ++serial; }
     out = TargetBuild();
     if (!upload(d.tgt->tascii, ascii, (size_t) R, d.stream, err) || !upload(d.tgt->toff, ts.offsets.data(), n + 1, d.stream, err) ||
         !upload(d.tgt->tkeys, ts.keys.data(), n, d.stream, err)) return false;
