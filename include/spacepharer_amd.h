@@ -329,7 +329,8 @@ int sp_ctx_sync(sp_ctx *c);
 int sp_ctx_set_timing(sp_ctx *c, int level);
 /* tuning knobs (never change a result).  "match_blocks_per_cu": resident blocks of the matching kernel per CU, 0 = as many as
    fit.  Fewer leave LDS for the aligner of another context on the same GPU -- better when several passes are in flight.
-   "match_small": footprint of the matching kernel, -1 by index density (default), 0 large, 1 small.  "match_heavy_threshold": similar
+   "match_small": footprint of the matching kernel, -1 by index density (default), 0 large, 1 small.  "match_dense2": 1 = a dense index (target ids
+   below 2^24) is searched by k_match_dense (64-byte double buckets, 5-byte hit stream; round 6, same records, slower) instead of k_match.  "match_heavy_threshold": similar
    k-mers from which a query is started first, -1 by batch size (default), 0 no list.  "match_weigh_exact": 1 = those k-mers counted exactly
    (two table rows read per window) instead of estimated from the window's slack over its threshold (default).  "match_chunk" (1..32) /
    "match_static" (0..8): queries per pop of the dynamically dealt part / eighths of the batch dealt round-robin.  "step_capacity": pairs the

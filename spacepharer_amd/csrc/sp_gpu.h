@@ -176,7 +176,7 @@ public:
     bool alignHitsText(int gapOpen, int gapExtend, const GateTable &gate, AlignHost &host, double minSeqId, uint32_t minAlnLen, char *text, uint64_t cap, uint64_t &used, uint32_t *entryLen, bool &fellBack, std::string &err);
     void setTiming(int level);
     void setMatchBlocksPerCU(int n);   // 0 = as many as fit
-    bool setKnob(const std::string &name, int value);      // "match_small", "match_heavy_threshold"; false: unknown
+    bool setKnob(const std::string &name, int value);      // "match_small", "match_dense2", "match_heavy_threshold"; false: unknown
     void makeCurrent();            // HIP's current device is per host thread: every entry point that may run on another thread calls this     // 0 none, 1 k_match only (default), 2 every stage
     void *stream() const { return stream_; }
 

@@ -185,6 +185,7 @@ __device__ __forceinline__ uint32_t extIndex(uint32_t packed) { return packed & 
 
 #include "sp_gpu_prep.inc"
 #include "sp_gpu_match.inc"
+#include "sp_gpu_match_dense.inc"
 #include "sp_gpu_match_grp.inc"
 #include "sp_gpu_select.inc"
 #include "sp_gpu_probe.inc"
@@ -235,11 +236,11 @@ struct Gpu::Impl {
     int numCU = 256;
     // environment knobs (diagnostics / experiments), read once per context instead of once per pass
     struct Knobs {
-        int matchSmall = -1, matchPerCU = 0, matchHeavy = -1, matchStatic = 4, matchDChunk = 4, weighExact = -1, matchGroup = 1, matchOrder = 1, selChunkDense = 8, selDynamic = 0, probePerQuery = 192;
+        int matchSmall = -1, matchPerCU = 0, matchHeavy = -1, matchStatic = 4, matchDChunk = 4, weighExact = -1, matchGroup = 1, matchOrder = 1, selChunkDense = 8, selDynamic = 0, probePerQuery = 192, matchDense2 = 0;
         bool debug = false, prepSplit = false, swRows32 = false, swRows16 = false, swOldForward = false;
         void read() {
             auto num = [](const char *k, int d) { const char *e = getenv(k); return e ? atoi(e) : d; };
-            matchSmall = num("SP_MATCH_SMALL", -1); matchGroup = num("SP_MATCH_GROUP", 1); matchOrder = num("SP_MATCH_ORDER", 1); { const int we = num("SP_MATCH_WEIGH_EXACT", -1); weighExact = we < 0 ? -1 : (we ? 1 : 0); } matchPerCU = num("SP_MATCH_PERCU", 0); selChunkDense = num("SP_SEL_CHUNK", 8); selDynamic = num("SP_SEL_DYNAMIC", 0); matchHeavy = num("SP_MATCH_HEAVY", -1); probePerQuery = num("SP_PROBE_PER_QUERY", 192);
+            matchSmall = num("SP_MATCH_SMALL", -1); matchGroup = num("SP_MATCH_GROUP", 1); matchOrder = num("SP_MATCH_ORDER", 1); { const int we = num("SP_MATCH_WEIGH_EXACT", -1); weighExact = we < 0 ? -1 : (we ? 1 : 0); } matchPerCU = num("SP_MATCH_PERCU", 0); selChunkDense = num("SP_SEL_CHUNK", 8); selDynamic = num("SP_SEL_DYNAMIC", 0); matchHeavy = num("SP_MATCH_HEAVY", -1); probePerQuery = num("SP_PROBE_PER_QUERY", 192); matchDense2 = num("SP_MATCH_DENSE2", 0);
             matchStatic = std::min(8, std::max(0, num("SP_MATCH_STATIC", 4))); matchDChunk = std::min(32, std::max(1, num("SP_MATCH_DCHUNK", 4)));      // (a chunk's offsets live in the lanes of a wave)
             debug = getenv("SP_DEBUG") != nullptr; prepSplit = getenv("SP_PREP_SPLIT") != nullptr; swRows32 = getenv("SP_SW_ROWS32") != nullptr;
             swRows16 = getenv("SP_SW_ROWS16") != nullptr; swOldForward = getenv("SP_SW_OLD_FORWARD") != nullptr;
@@ -255,7 +256,8 @@ struct Gpu::Impl {
         std::mutex mu;      // a sharing context may add the similar-k-mer tables to a set that was staged without them
     };
     struct Targets {
-        DevBuf<uint64_t> buckets; bool bucketsValid = false; DevBuf<uint64_t> slotDirect; bool slotDirectValid = false; size_t indexSlots = 0; uint64_t buildSerial = 0;      // large-footprint layout of the slot table, derived from slots / ientries on first use
+        DevBuf<uint64_t> buckets; bool bucketsValid = false; DevBuf<uint64_t> buckets2; bool buckets2Valid = false;      // (buckets2: the 64-byte double buckets of k_match_dense)
+        DevBuf<uint64_t> slotDirect; bool slotDirectValid = false; size_t indexSlots = 0; uint64_t buildSerial = 0;      // large-footprint layout of the slot table, derived from slots / ientries on first use
         DevBuf<uint64_t> pbits; DevBuf<uint16_t> prank; DevBuf<uint32_t> prow; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff; DevBuf<uint32_t> tkeys;
         size_t nTargets = 0; size_t indexEntries = 0;
         bool denseIndex = false;      // 1.5+ entries per occupied k-mer on average: k_match runs with its large footprint
@@ -398,6 +400,7 @@ bool Gpu::setKnob(const std::string &name, int value) {
     if (name == "match_chunk") { d_->knob.matchDChunk = std::min(32, std::max(1, value)); return true; }      // queries per pop of the dynamically dealt part
     if (name == "match_static") { d_->knob.matchStatic = std::min(8, std::max(0, value)); return true; }      // eighths of the queries dealt round-robin without atomics
     if (name == "match_small") { d_->knob.matchSmall = value < 0 ? -1 : (value ? 1 : 0); return true; }
+    if (name == "match_dense2") { d_->knob.matchDense2 = value ? 1 : 0; return true; }
     if (name == "match_order") { d_->knob.matchOrder = value ? 1 : 0; return true; }      // k_match_grp takes the batch in the order of decreasing weight (list schedule); 0: heavy queries first, then shares
     if (name == "match_group") { d_->knob.matchGroup = value ? 1 : 0; return true; }      // k_match_grp (queries matched four at a time) where its preconditions hold; 0: always k_match
     if (name == "match_heavy_threshold") { d_->knob.matchHeavy = value < 0 ? -1 : value; return true; }
@@ -629,9 +632,12 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMo
     const bool small = d.knob.matchSmall >= 0 ? d.knob.matchSmall != 0 : (withOrd || !d.tgt->denseIndex);
     // short queries against a sparse index, unsharded: the grouped kernel (sp_gpu_match_grp.inc) -- same records, four queries per pass of a wave
     const bool grouped = probeMode ? true : (small && d.knob.matchGroup != 0 && d.maxQLen <= 64 && d.tgt->nTargets < ((size_t) 1 << 30));      // (with ordinals too since round 5: the target-sharded search)
+    // dense index, unsharded, target ids below 2^24, on request (SP_MATCH_DENSE2=1 / set_tuning("match_dense2", 1)): k_match_dense (sp_gpu_match_dense.inc: 64-byte double buckets, a
+    // 5-byte hit stream read back by LDS-DMA) -- round 6's decomposition: the same records, 41 % fewer bytes written, and 8 % SLOWER than k_match<512, false, false>
+    const bool dense2 = !probeMode && !small && !withOrd && d.knob.matchDense2 != 0 && d.tgt->nTargets <= ((size_t) 1 << 24);
     const void *fn = probeMode == 1 ? (const void *) k_match_grp<true, 1> : probeMode == 2 ? (const void *) k_match_grp<true, 2> : grouped ? (withOrd ? (const void *) k_match_grp<true> : (const void *) k_match_grp<false>) :
                      small ? (withOrd ? (const void *) k_match<256, true, true> : (const void *) k_match<256, false, true>)
-                           : (withOrd ? (const void *) k_match<512, true, false> : (const void *) k_match<512, false, false>);
+                           : (withOrd ? (const void *) k_match<512, true, false> : dense2 ? (const void *) k_match_dense : (const void *) k_match<512, false, false>);
     int perCU = 2;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, fn, 64 * kWavesPerBlock, 0) != hipSuccess || perCU < 1) perCU = 2;
     if (d.matchPerCU > 0) perCU = std::min(perCU, d.matchPerCU);
@@ -641,10 +647,10 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMo
     else if (d.matchPerCU == 0 && grouped && g_searchers[d.device & 63].load(std::memory_order_relaxed) >= 2) perCU = std::min(perCU, 2);
     if (d.knob.matchPerCU > 0) perCU = d.knob.matchPerCU;
     const bool dbg = d.knob.debug;
-    if (dbg) fprintf(stderr, "[sp] k_match footprint=%s ord=%d blocks/CU=%d\n", grouped ? "grouped" : (small ? "small" : "large"), (int) withOrd, perCU);
+    if (dbg) fprintf(stderr, "[sp] k_match footprint=%s ord=%d blocks/CU=%d\n", grouped ? "grouped" : (small ? "small" : (dense2 ? "dense" : "large")), (int) withOrd, perCU);
     const uint32_t blocks = (uint32_t) std::max<size_t>(1, std::min<size_t>((nqRun + kWavesPerBlock - 1) / kWavesPerBlock, (size_t) d.numCU * perCU));
     d.matchBlocks = blocks;
-    if (!d.spill.ensure((size_t) blocks * kWavesPerBlock * kSpillWordsPerWave, err)) return false;
+    if (!d.spill.ensure((size_t) blocks * kWavesPerBlock * (dense2 ? std::max<size_t>(kSpillWordsPerWave, kDScrBytesPerWave / 8) : kSpillWordsPerWave), err)) return false;
     if (!d.queue.ensure(8, err) || !d.counters.ensure(16, err) || !d.heavyList.ensure((size_t) kHeavyLists * nq_ + 1, err) || !d.heavyCnt.ensure(kHeavyLists * kHeavyStride, err) || !d.heavyFlag.ensure(nq_ + 1, err) || !d.wavePartial.ensure((size_t) blocks * kWavesPerBlock * 4, err)) return false;
     // diagonal buffer: generous, HBM is plentiful (64 M records = 512 MB + side arrays)
     const size_t diagCap = std::max<size_t>((size_t) 1 << 22, std::min<size_t>((size_t) 1 << 26, nq_ * 64));
@@ -712,7 +718,15 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMo
         d.tgt->slotDirectValid = true;
       }
     }
-    if (!small) {      // (the bucket table: once per target set, on the first pass with the large footprint -- of whichever context sharing the set gets here first)
+    if (dense2) {      // (the double-bucket table: once per target set, on the first pass of k_match_dense -- of whichever context sharing the set gets here first)
+      std::lock_guard<std::mutex> shared(d.tgt->mu);
+      if (!d.tgt->buckets2Valid) {
+        if (!d.tgt->buckets2.ensure(8 * (size_t) kSlots, err)) return false;
+        hipLaunchKernelGGL(k_idx_buckets2, dim3((unsigned) ((kSlots + 255) / 256)), dim3(256), 0, d.stream, d.tgt->pbits.p, d.tgt->prank.p, d.tgt->prow.p, d.tgt->slots.p, d.tgt->ientries.p, d.tgt->buckets2.p);
+        HIP_OK(hipStreamSynchronize(d.stream));      // (complete before another context's stream reads it)
+        d.tgt->buckets2Valid = true;
+      }
+    } else if (!small) {      // (the bucket table: once per target set, on the first pass with the large footprint -- of whichever context sharing the set gets here first)
       std::lock_guard<std::mutex> shared(d.tgt->mu);
       if (!d.tgt->bucketsValid) {
         if (!d.tgt->buckets.ensure(4 * (size_t) kSlots, err)) return false;
@@ -721,7 +735,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMo
         d.tgt->bucketsValid = true;
       }
     }
-    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nqRun, d.qthr.p, d.tab->ext3.p, d.tab->ext3cnt.p, d.tab->cntMin, d.tgt->pbits.p, d.tgt->prank.p, d.tgt->prow.p, d.tgt->slots.p, d.tgt->ientries.p, (grouped && probeMode != 1) ? d.tgt->slotDirect.p : nullptr, small ? nullptr : d.tgt->buckets.p, d.spill.p, d.queue.p,
+    MatchArgs ma{d.qres.p, d.qoff.p, (uint32_t) nqRun, d.qthr.p, d.tab->ext3.p, d.tab->ext3cnt.p, d.tab->cntMin, d.tgt->pbits.p, d.tgt->prank.p, d.tgt->prow.p, d.tgt->slots.p, d.tgt->ientries.p, (grouped && probeMode != 1) ? d.tgt->slotDirect.p : nullptr, small ? nullptr : (dense2 ? d.tgt->buckets2.p : d.tgt->buckets.p), d.spill.p, d.queue.p,
                  d.diagRec.p, d.diagQuery.p, (uint32_t) diagCap, d.queue.p + 1, d.qDiagBase.p, d.qDiagCnt.p, d.counters.p,
                  withOrd ? d.diagOrd.p : nullptr, withOrd ? d.spillOrd.p : nullptr,
                  (uint32_t) d.knob.matchStatic, (uint32_t) d.knob.matchDChunk,
@@ -755,6 +769,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMo
         if (withOrd) hipLaunchKernelGGL((k_match<256, true, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
         else hipLaunchKernelGGL((k_match<256, false, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     } else if (withOrd) hipLaunchKernelGGL((k_match<512, true, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
+    else if (dense2) hipLaunchKernelGGL(k_match_dense, dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     else hipLaunchKernelGGL((k_match<512, false, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0, d.stream, ma);
     SP_DBG_SYNC("k_match");
     SP_EV(2, 1);
@@ -1376,7 +1391,7 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
     to = std::min(to, n); from = std::min(from, to);
     const uint64_t R = ts.offsets[n];
     if (d.tgt.use_count() > 1) d.tgt = std::make_shared<Impl::Targets>();      // a shared target set belongs to the others from here on: this context stages its own
-    d.tgt->nTargets = n; d.tgt->indexEntries = 0; d.tgt->indexSlots = 0; d.tgt->bucketsValid = false; d.tgt->slotDirectValid = false; { static std::atomic<uint64_t> serial{0}; d.tgt->buildSerial = ++serial; }
+    d.tgt->nTargets = n; d.tgt->indexEntries = 0; d.tgt->indexSlots = 0; d.tgt->bucketsValid = false; d.tgt->buckets2Valid = false; d.tgt->slotDirectValid = false; { static std::atomic<uint64_t> serial{0}; d.tgt->buildSerial = ++serial; }
     out = TargetBuild();
     if (!upload(d.tgt->tascii, ascii, (size_t) R, d.stream, err) || !upload(d.tgt->toff, ts.offsets.data(), n + 1, d.stream, err) ||
         !upload(d.tgt->tkeys, ts.keys.data(), n, d.stream, err)) return false;

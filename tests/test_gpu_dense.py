@@ -50,6 +50,14 @@ def test_dense_unsplit_equals_union_of_eight_sparse_shards():
         ctx.set_tuning("match_small", -1)
     h2, off2, n2 = _hits_np(ctx)
     assert n2 == n and np.array_equal(h2, h) and np.array_equal(off2, off)
+    ctx.set_tuning("match_dense2", 1)                                                   # round 6's kernel for this regime (64-byte double buckets, a 5-byte
+    try:                                                                                # hit stream read back by LDS-DMA; opt-in: it is slower): same hits
+        ctx.prefilter()
+        assert ctx.stat("db_matches") > 1.2e8
+    finally:
+        ctx.set_tuning("match_dense2", 0)
+    h2, off2, n2 = _hits_np(ctx)
+    assert n2 == n and np.array_equal(h2, h) and np.array_equal(off2, off)
     aln, cig, na = ctx.align_hits_raw()
     rec = bench.record_fields(C.addressof(aln), n)
     ctx.close()
