@@ -316,7 +316,8 @@ double sp_ctx_stat(const sp_ctx *c, const char *name);
      sp_ctx_hits_text        after sp_ctx_prefilter(): "<target key>\t<score>\t<diagonal>\n" per hit (QueryMatcher::prefilterHitToBuffer, prefiltering/QueryMatcher.h:114-126)
      sp_ctx_align_hits_text  aligns the resident hits like sp_ctx_align_hits() and writes, per query, the accepted alignments (Alignment::checkCriteria with
                              min_seq_id / min_aln_len, alignment/Alignment.cpp:555-574) sorted by Matcher::compareHits as Matcher::resultToBuffer lines with
-                             backtrace (alignment/Matcher.cpp:211-230,323-370).  SP_ERR_UNSUPPORTED: this batch needs the host path (sp_ctx_align_hits + own formatting). */
+                             backtrace (alignment/Matcher.cpp:211-230,323-370).  SP_ERR_UNSUPPORTED: this batch needs the host path (sp_ctx_align_hits + own formatting).
+   Either call returns SP_ERR_UNSUPPORTED, before writing anything, when the batch's entries would add up to 4 GiB of text or more (the device keeps 32-bit offsets). */
 /* ... and the INDEX text of those entries (commons/DBWriter.cpp:409-419: "<key>\t<offset>\t<length>\n" per entry, keys[e] = key of the batch's e-th query, offsets counted
    from `base`), formatted on the device from the lengths the last sp_ctx_hits_text / sp_ctx_align_hits_text call left there.  Same buffer rules. */
 int sp_ctx_text_index(sp_ctx *c, const uint32_t *keys, uint64_t n, uint64_t base, char *text, uint64_t text_cap, uint64_t *text_used);

@@ -640,8 +640,9 @@ int sp_ctx_align_hits(sp_ctx *c, sp_alignment *res, char *cigars, uint64_t cigar
 int sp_ctx_hits_text(sp_ctx *c, char *text, uint64_t textCap, uint64_t *textUsed, uint32_t *entryLen) {
     if (c) c->gpu.makeCurrent();
     if (!c || c->targets.n == 0 || !textUsed || !entryLen) { g_err = "sp_ctx_hits_text: no target set / missing output"; return SP_ERR_STATE; }
-    std::string err; uint64_t used = 0;
-    if (!c->gpu.hitsText(text, text ? textCap : 0, used, entryLen, err)) { g_err = "sp_ctx_hits_text: " + err; return SP_ERR_DEVICE; }
+    std::string err; uint64_t used = 0; bool declined = false;
+    if (!c->gpu.hitsText(text, text ? textCap : 0, used, entryLen, declined, err)) { g_err = "sp_ctx_hits_text: " + err; return SP_ERR_DEVICE; }
+    if (declined) { g_err = "sp_ctx_hits_text: the entries of this batch add up to 4 GiB of text or more (32-bit offsets on the device): format them on the host (sp_ctx_get_hits) or search smaller batches"; return SP_ERR_UNSUPPORTED; }
     *textUsed = used;
     return used > (text ? textCap : 0) ? SP_ERR_OVERFLOW : SP_OK;
 }
@@ -661,7 +662,7 @@ int sp_ctx_align_hits_text(sp_ctx *c, double minSeqId, uint32_t minAlnLen, char 
     buildGate(c);
     uint64_t used = 0; bool fellBack = false;
     if (!c->gpu.alignHitsText(c->par.gap_open, c->par.gap_extend, c->gate, c->alnHost, minSeqId, minAlnLen, text, text ? textCap : 0, used, entryLen, fellBack, err)) { g_err = "sp_ctx_align_hits_text: " + err; return SP_ERR_DEVICE; }
-    if (fellBack) { g_err = "sp_ctx_align_hits_text: this batch needs the host's formatting (a pair took the host-driven traceback, or an E-value has no table text): use sp_ctx_align_hits"; return SP_ERR_UNSUPPORTED; }
+    if (fellBack) { g_err = "sp_ctx_align_hits_text: this batch needs the host's formatting (a pair took the host-driven traceback, an E-value has no table text, or the entries add up to 4 GiB of text): use sp_ctx_align_hits"; return SP_ERR_UNSUPPORTED; }
     *textUsed = used;
     return used > (text ? textCap : 0) ? SP_ERR_OVERFLOW : SP_OK;
 }

@@ -278,6 +278,18 @@ bool Comm::alltoallv(const void *const *send, const size_t *sendBytes, void *con
         memmove(recv[me], send[me], sendBytes[me]); return true;
     };
     if (world_ == 1) { if (!selfCopy()) { err = "sp_dist alltoallv: copy failed"; return false; } return true; }
+    // The sizes first, over the bootstrap sockets, on EVERY transport: each rank publishes what it sends and what it expects, every rank checks the whole matrix and so reaches the
+    // same verdict -- a mismatch fails all ranks together here instead of leaving the others in a receive without a time-out (or inside ncclGroupEnd).
+    std::vector<uint64_t> mineSz(2 * W), both(2 * W * W), mat(W * W);
+    for (size_t k = 0; k < W; k++) { mineSz[k] = sendBytes[k]; mineSz[W + k] = recvBytes[k]; }
+    if (!hostAllgather(mineSz.data(), 2 * W * sizeof(uint64_t), both.data(), err)) return false;
+    for (size_t src = 0; src < W; src++) for (size_t dst = 0; dst < W; dst++) {
+        mat[src * W + dst] = both[src * 2 * W + dst];
+        if (both[src * 2 * W + dst] != both[dst * 2 * W + W + src]) {
+            err = "sp_dist alltoallv: rank " + std::to_string(src) + " sends " + std::to_string(both[src * 2 * W + dst]) + " bytes to rank " + std::to_string(dst) + ", which expects " + std::to_string(both[dst * 2 * W + W + src]);
+            return false;
+        }
+    }
     if (onDevice && transport_ == kTransportRccl && g_rccl.send && g_rccl.recv && g_rccl.groupStart && g_rccl.groupEnd) {
         ncclComm_t nc = static_cast<ncclComm_t>(nccl_); hipStream_t st = static_cast<hipStream_t>(stream_);
         ncclResult_t r = g_rccl.groupStart();
@@ -294,10 +306,6 @@ bool Comm::alltoallv(const void *const *send, const size_t *sendBytes, void *con
         return true;
     }
     // through rank 0: everybody hands it all its blocks (sizes first), it hands everybody the blocks addressed to them, in the order of the senders
-    std::vector<uint64_t> mineSz(W), mat(W * W);
-    for (size_t k = 0; k < W; k++) mineSz[k] = sendBytes[k];
-    if (!hostAllgather(mineSz.data(), W * sizeof(uint64_t), mat.data(), err)) return false;
-    for (size_t k = 0; k < W; k++) if (mat[k * W + me] != recvBytes[k]) { err = "sp_dist alltoallv: rank " + std::to_string(k) + " sends another size than this rank expects"; return false; }
     size_t sendTotal = 0, recvTotal = 0;
     for (size_t k = 0; k < W; k++) { sendTotal += sendBytes[k]; recvTotal += recvBytes[k]; }
     std::vector<unsigned char> out(sendTotal + 1), in(recvTotal + 1);

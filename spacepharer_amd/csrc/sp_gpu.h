@@ -170,7 +170,7 @@ public:
     // hitsText: the prefilter entries of the last pass's hit list.  alignHitsText: aligns the resident hits and writes the alignment entries (accepted records, sorted);
     // fellBack = true (and nothing written): a pair needed the host-driven traceback or an E-value has no table text -- the caller formats on the host.
     // used > cap: nothing copied, `used` says how much room the text needs.
-    bool hitsText(char *text, uint64_t cap, uint64_t &used, uint32_t *entryLen, std::string &err);
+    bool hitsText(char *text, uint64_t cap, uint64_t &used, uint32_t *entryLen, bool &declined, std::string &err);      // declined: the text would not fit 32-bit offsets (nothing written)
     // the index text of the entries the last hitsText / alignHitsText call produced ("<key>\t<offset>\t<length>\n", offsets from `base`): keys[e] names entry e
     bool textIndex(const uint32_t *keys, size_t n, uint64_t base, char *text, uint64_t cap, uint64_t &used, std::string &err);
     bool alignHitsText(int gapOpen, int gapExtend, const GateTable &gate, AlignHost &host, double minSeqId, uint32_t minAlnLen, char *text, uint64_t cap, uint64_t &used, uint32_t *entryLen, bool &fellBack, std::string &err);

@@ -271,7 +271,7 @@ struct Gpu::Impl {
     // index construction scratch (kept for the next target set)
     DevBuf<uint32_t> ixKeys, ixKeys2, ixKeep, ixPos, ixKmer, ixHead, ixSlotOf, ixHeadPos, ixCnt, ixBefore; DevBuf<uint64_t> ixVals, ixVals2;
     DevBuf<unsigned char> ixTemp; DevBuf<float> ttProbs; DevBuf<double> ttScale, ttLr; DevBuf<uint64_t> ttPlane; DevBuf<unsigned long long> ixCounters;
-    DevBuf<uint32_t> txLen, txOff, txLineOff, txLineLen, txFlags; DevBuf<char> txText, txIdxText; DevBuf<uint32_t> txKeys, txIdxLen, txIdxOff; DevBuf<unsigned char> txEval; uint64_t txEvalVersion = 0;      // device-side result text (sp_gpu_text.inc)
+    DevBuf<uint32_t> txLen, txOff, txLineOff, txLineLen, txFlags; DevBuf<char> txText, txIdxText; DevBuf<uint32_t> txKeys, txIdxLen, txIdxOff; DevBuf<unsigned long long> txTotal; DevBuf<unsigned char> txEval; uint64_t txEvalVersion = 0;      // device-side result text (sp_gpu_text.inc)
     // queries
     DevBuf<uint8_t> qres; DevBuf<uint32_t> qoff; DevBuf<float> biasf; DevBuf<short> qthr; DevBuf<signed char> qcorr; DevBuf<int> qbias; DevBuf<int> qself;
     size_t qTotal = 0; uint32_t maxQLen = 0;
@@ -417,6 +417,14 @@ __global__ void k_fill(FillArgs a) {
         uint32_t *w = static_cast<uint32_t *>(a.p[r]); const unsigned long long n = a.bytes[r] / 4;
         for (unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long) gridDim.x * blockDim.x) w[i] = a.value[r];
     }
+}
+
+// sum of n 32-bit lengths in 64 bits (the result text's offsets are 32-bit: a batch whose text would not fit them is declined -- Gpu::hitsText)
+__global__ void k_sum_u64(const uint32_t *v, uint32_t n, unsigned long long *out) {
+    unsigned long long s = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += v[i];
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
 }
 
 // small results for the host: one kernel stores them straight into the page-locked mailbox (each hipMemcpyAsync of a few
@@ -631,7 +639,9 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMo
     // (its ordinal arrays push the large footprint to two blocks per CU)
     const bool small = d.knob.matchSmall >= 0 ? d.knob.matchSmall != 0 : (withOrd || !d.tgt->denseIndex);
     // short queries against a sparse index, unsharded: the grouped kernel (sp_gpu_match_grp.inc) -- same records, four queries per pass of a wave
-    const bool grouped = probeMode ? true : (small && d.knob.matchGroup != 0 && d.maxQLen <= 64 && d.tgt->nTargets < ((size_t) 1 << 30));      // (with ordinals too since round 5: the target-sharded search)
+    // (with ordinals too since round 5: the target-sharded search -- of SPARSE shards: the kernel, its list schedule and its 512 MB direct slot table are built and measured for a sparse
+    // index; a dense shard with ordinals -- 2e8 residues over two ranks -- keeps k_match<256, true, true>)
+    const bool grouped = probeMode ? true : (small && d.knob.matchGroup != 0 && d.maxQLen <= 64 && d.tgt->nTargets < ((size_t) 1 << 30) && !(withOrd && d.tgt->denseIndex));
     // dense index, unsharded, target ids below 2^24, on request (SP_MATCH_DENSE2=1 / set_tuning("match_dense2", 1)): k_match_dense (sp_gpu_match_dense.inc: 64-byte double buckets, a
     // 5-byte hit stream read back by LDS-DMA) -- round 6's decomposition: the same records, 41 % fewer bytes written, and 8 % SLOWER than k_match<512, false, false>
     const bool dense2 = !probeMode && !small && !withOrd && d.knob.matchDense2 != 0 && d.tgt->nTargets <= ((size_t) 1 << 24);
@@ -676,6 +686,7 @@ bool Gpu::matchAndScore(int kmerThr, bool withOrd, std::string &err, int probeMo
     const bool weighExact = d.knob.weighExact > 0 || (d.knob.weighExact < 0 && !orderedPossible && g_searchers[d.device & 63].load(std::memory_order_relaxed) <= 1);
     // the grouped kernel takes its queries in the order of decreasing weight (k_order_*) instead of "heavy ones first, then shares": needs the weights (k_prep8)
     const bool ordered = orderedPossible;
+    if (probeMode == 1 && !ordered) { err = "the probe-list cut enumerates its slice under the list schedule only (SP_MATCH_ORDER=0, SP_MATCH_HEAVY=0 and SP_PREP_SPLIT switch it off: the heavy-query lists are laid out for the whole batch)"; return false; }
     const uint32_t orderTiles = (uint32_t) ((nqRun + kOrderTile - 1) / kOrderTile);      // (the enumerating side of the probe-list cut orders ITS slice: positions relative to qFrom)
     const size_t qOff = probeMode == 1 ? qFrom : 0;
     if (ordered && (!d.qweight.ensure(nq_ + 1, err) || !d.qorder.ensure(nq_ + 1, err) || !d.orderHist.ensure((size_t) orderTiles * kOrderClasses, err) || !d.orderHeader.ensure(16, err) ||
@@ -1083,13 +1094,14 @@ bool Gpu::probeFetch(const void *records, size_t n, const uint32_t *counts, bool
         rIn = d.pinRec.p; cIn = d.pinCnt.p;
     }
     if (!d.scanCounts(cIn, (uint32_t) nq_, d.probeOff.p, err)) return false;
-    HIP_OK(hipMemsetAsync(d.counters.p + 15, 0, sizeof(unsigned long long), d.stream));
+    HIP_OK(hipMemsetAsync(d.counters.p + 14, 0, 2 * sizeof(unsigned long long), d.stream));      // ([14] records placed, [15] records out of place)
     if (n) hipLaunchKernelGGL(k_probe_place, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, rIn, (uint32_t) n, (uint32_t) nq_, d.probeOff.p, d.probeList.p, d.counters.p + 15);
     HIP_OK(hipGetLastError());
-    unsigned long long bad = 0; uint32_t total = 0;
-    HIP_OK(hipMemcpyAsync(&bad, d.counters.p + 15, sizeof(bad), hipMemcpyDeviceToHost, d.stream));
+    unsigned long long pb[2] = {0, 0}; uint32_t total = 0;
+    HIP_OK(hipMemcpyAsync(pb, d.counters.p + 14, sizeof(pb), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipMemcpyAsync(&total, d.probeOff.p + nq_, sizeof(total), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipStreamSynchronize(d.stream));
+    const unsigned long long bad = pb[1] + (pb[0] != total ? 1ull : 0ull);      // (every position of every list must have received its record: a hole would be fetched as whatever the buffer held)
     if (bad || total > n) { err = "probeFetch: the probe records do not fit the per-query counts (" + std::to_string(bad) + " records out of place; lists and counts of different passes?)"; return false; }
     if (!matchAndScore(kmerThr, true, err, 2)) return false;
     return candidatesTail(minDiagScore, err);
@@ -1245,19 +1257,31 @@ bool Gpu::allgatherHits(Comm &comm, size_t queryOffset, size_t nqTotal, const Gp
 }
 
 // ---- result-DB text on the device (sp_gpu_text.inc) ---------------------------------------------------------------------------------------------------------
-bool Gpu::hitsText(char *text, uint64_t cap, uint64_t &used, uint32_t *entryLen, std::string &err) {
+// Entry lengths, offsets and the text total of the device-side formatters are 32-bit.  A batch whose text would reach 4 GiB (2^20 queries x 300 hits of a saturated
+// dense DB: 4.7 GB of prefilter lines, several times that in alignment lines) is DECLINED before anything is written -- the caller's host formatter takes it -- instead of
+// wrapping the scan.  SP_TEXT_LIMIT (bytes) lowers the bound for tests.
+static uint64_t deviceTextLimit() {
+    static const uint64_t lim = [] { const char *e = getenv("SP_TEXT_LIMIT"); const uint64_t v = e ? strtoull(e, nullptr, 10) : 0; return v ? v : (1ull << 32) - (1ull << 20); }();
+    return lim;
+}
+bool Gpu::hitsText(char *text, uint64_t cap, uint64_t &used, uint32_t *entryLen, bool &declined, std::string &err) {
     Impl &d = *d_;
-    used = 0;
+    used = 0; declined = false;
     if (nq_ == 0) return true;
     if (d.stepsBegun != d.stepsEnded && !d.drained) { err = "hitsText: a device-driven step is in flight"; return false; }
     const size_t nHits = (size_t) counters_.hits;
     if (!d.txLen.ensure(nq_ + 1, err) || !d.txOff.ensure(nq_ + 2, err) || !d.txLineOff.ensure(nHits + 1, err)) return false;
     HitTextArgs a{d.outHits.p, d.outOffset.p, d.outQuery.p, (uint32_t) nq_, d.outOffset.p + nq_, d.tgt->tkeys.p, d.txLen.p, d.txOff.p, d.txLineOff.p, nullptr};
     hipLaunchKernelGGL(k_hits_text_len, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, a);
+    if (!d.txTotal.ensure(2, err)) return false;
+    HIP_OK(hipMemsetAsync(d.txTotal.p, 0, sizeof(unsigned long long), d.stream));
+    hipLaunchKernelGGL(k_sum_u64, dim3((unsigned) std::min<size_t>((nq_ + 255) / 256, 1024)), dim3(256), 0, d.stream, d.txLen.p, (uint32_t) nq_, d.txTotal.p);
     if (!d.scanCounts(d.txLen.p, (uint32_t) nq_, d.txOff.p, err)) return false;
-    uint32_t total = 0;
+    uint32_t total = 0; unsigned long long total64 = 0;
     HIP_OK(hipMemcpyAsync(&total, d.txOff.p + nq_, sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipMemcpyAsync(&total64, d.txTotal.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipStreamSynchronize(d.stream));
+    if (total64 >= deviceTextLimit()) { declined = true; return true; }
     used = total;
     if (used > cap) return true;
     if (!d.txText.ensure((size_t) total + 16, err)) return false;
@@ -1275,6 +1299,7 @@ bool Gpu::textIndex(const uint32_t *keys, size_t n, uint64_t base, char *text, u
     used = 0;
     if (n == 0) return true;
     if (n != nq_ || !d.txLen.p || !d.txOff.p) { err = "textIndex: no entries of this batch on the device (call hitsText / alignHitsText first)"; return false; }
+    if ((uint64_t) n * 48ull >= deviceTextLimit()) { err = "textIndex: the index text of " + std::to_string(n) + " entries would not fit 32-bit offsets"; return false; }      // (key + offset + length + separators: at most 44 bytes a line)
     if (!upload(d.txKeys, keys, n, d.stream, err) || !d.txIdxLen.ensure(n + 1, err) || !d.txIdxOff.ensure(n + 2, err)) return false;
     IndexTextArgs a{d.txKeys.p, d.txLen.p, d.txOff.p, (uint32_t) n, base, d.txIdxLen.p, d.txIdxOff.p, nullptr};
     hipLaunchKernelGGL(k_index_text_len, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, a);
@@ -1316,12 +1341,16 @@ bool Gpu::alignHitsText(int gapOpen, int gapExtend, const GateTable &gate, Align
     if (const char *e = getenv("SP_TEXT_WAVE")) a.waveServes = *e != '0' ? 1u : 0u;      // (tests: either kernel on any batch)      // (two or more alignments per query on average -- the dense index: a wave per query for those with 2 .. 64 records)
     hipLaunchKernelGGL(k_aln_text_measure, dim3((unsigned) ((nq_ + 63) / 64)), dim3(64), 0, d.stream, a);
     if (a.waveServes) hipLaunchKernelGGL(k_aln_text_measure_wave, dim3((unsigned) std::min<size_t>((nq_ + 3) / 4, (size_t) d.numCU * 8)), dim3(256), 0, d.stream, a);
+    if (!d.txTotal.ensure(2, err)) return false;
+    HIP_OK(hipMemsetAsync(d.txTotal.p, 0, sizeof(unsigned long long), d.stream));
+    hipLaunchKernelGGL(k_sum_u64, dim3((unsigned) std::min<size_t>((nq_ + 255) / 256, 1024)), dim3(256), 0, d.stream, d.txLen.p, (uint32_t) nq_, d.txTotal.p);
     if (!d.scanCounts(d.txLen.p, (uint32_t) nq_, d.txOff.p, err)) return false;
-    uint32_t back[2] = {0, 0};
+    uint32_t back[2] = {0, 0}; unsigned long long total64 = 0;
     HIP_OK(hipMemcpyAsync(&back[0], d.txOff.p + nq_, sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipMemcpyAsync(&back[1], d.txFlags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipMemcpyAsync(&total64, d.txTotal.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, d.stream));
     HIP_OK(hipStreamSynchronize(d.stream));
-    if (back[1] != 0) { fellBack = true; return true; }
+    if (back[1] != 0 || total64 >= deviceTextLimit()) { fellBack = true; return true; }      // (a text of 4 GiB or more does not fit the 32-bit offsets: the host formats)
     used = back[0];
     if (used > cap) return true;
     if (!d.txText.ensure((size_t) back[0] + 16, err)) return false;

@@ -2,8 +2,8 @@
 """Generate tests/golden/examples.json.gz: BASELINE.json configs[0] -- the reference's bundled examples
 (/root/reference/examples: two spacer files vs three phage genomes, the workload of util/run_regression.sh) taken through
 the set-level steps around the search hot path by the REAL reference code: oracle/_ref/ref_sets runs the reference's own
-module translation units (extractorfs.cpp ... SummarizeResults.cpp, compiled in place and unmodified, only the parameter
-singleton is a plain record filled from the flags below -- oracle/ref_par.h), oracle/_ref/ref_harness the search classes.
+module translation units (extractorfs.cpp ... SummarizeResults.cpp, compiled in place and unmodified, with the reference's own
+Parameters.cpp / LocalParameters.cpp parsing the flags below -- round 6), oracle/_ref/ref_harness the search classes.
 
 Runs only in the build container.  The committed output is pure data: the example sequences (data files of the reference's
 own regression test) and the content of every DB a step produced, keyed by DB key.
@@ -142,7 +142,8 @@ XCHECK = {"n": 0}
 def module(name, dbs, flags=(), outputs=1, binary_flags=None, binary_extra=(), **kw):
     """one module call through oracle/_ref/ref_sets (the reference's translation unit); when the reference binary exists the same call
     goes through it as well, into <out>.bin, and the DB contents must be equal.  The last `outputs` DBs are outputs."""
-    p = run(SETS, name, *dbs, *flags, **kw)
+    # (round 6: ref_sets parses its command line with the reference's own Parameters / LocalParameters -- the flag spellings are the binary's)
+    p = run(SETS, name, *dbs, *(flags if binary_flags is None else binary_flags), "--threads", "1", "-v", "1", **kw)
     if os.path.exists(REF_BINARY) and outputs:
         alt = list(dbs[:-outputs]) + [x + ".bin" for x in dbs[-outputs:]]
         run(REF_BINARY, name, *alt, *binary_extra, *(flags if binary_flags is None else binary_flags), "--threads", "1", "-v", "1", stdout=subprocess.DEVNULL)

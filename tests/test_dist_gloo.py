@@ -132,6 +132,17 @@ def _a2a_worker(rank, world, uid_hex, out):
     ok = all(got[r].tolist() == _a2a_block(r, rank).tolist() for r in range(world)) and comm.bytes_moved() > before
     got = comm.alltoallv_host([_a2a_block(rank, r)[:1] for r in range(world)])      # a second round on the same sockets, tiny blocks
     ok = ok and all(got[r].tolist() == _a2a_block(r, rank)[:1].tolist() for r in range(world))
+    # a size mismatch (rank 0 expects one byte more from rank 1 than rank 1 sends): EVERY rank must fail, together, before any payload moves -- nobody is left in a receive
+    import ctypes as C
+    from spacepharer_amd import _lib
+    blocks = [np.zeros(8, np.uint8) for _ in range(world)]
+    recv = [np.zeros(9 if (rank == 0 and r == 1) else 8, np.uint8) for r in range(world)]
+    vp, u64 = C.c_void_p * world, C.c_uint64 * world
+    comm.L.sp_dist_alltoallv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    rc = comm.L.sp_dist_alltoallv(comm.h, vp(*[b.ctypes.data for b in blocks]), u64(*[b.nbytes for b in blocks]), vp(*[b.ctypes.data for b in recv]), u64(*[b.nbytes for b in recv]), 0)
+    ok = ok and rc != 0 and b"rank 1 sends 8 bytes to rank 0, which expects 9" in _lib.load_library().sp_last_error()
+    got = comm.alltoallv_host([_a2a_block(rank, r)[:2] for r in range(world)])      # ... and the sockets are still in step
+    ok = ok and all(got[r].tolist() == _a2a_block(r, rank)[:2].tolist() for r in range(world))
     open("%s.%d" % (out, rank), "w").write("ok" if ok else "mismatch")
     comm.barrier()
     comm.close()

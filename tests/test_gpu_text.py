@@ -57,3 +57,33 @@ def test_prefilter_and_alignment_entries_equal_the_reference_text(name):
 def _aln_len(line):
     import re
     return sum(int(n) for n in re.findall(r"(\d+)[MID]", line.split("\t")[10]))
+
+
+def test_text_that_would_not_fit_32_bit_offsets_is_declined_before_anything_is_written():
+    """Entry lengths / offsets on the device are 32-bit: a batch whose text reaches the limit (4 GiB; SP_TEXT_LIMIT lowers it for this test, read once per process) must be refused with
+    SP_ERR_UNSUPPORTED -- the module drivers then format on the host -- and never wrap."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import spacepharer_amd as sa
+from conftest import load_golden
+g = load_golden("small"); r = g["ref"]
+ctx = sa.SearchContext(sensitivity=r["sens"], max_seqs=r["maxSeqs"], bin_size=r["binSize"], evalue=200.0)
+ctx.set_targets(g["targets"]); ctx.set_queries(g["queries"]); ctx.prefilter()
+assert sum(map(len, ctx.hits())) > 10
+for call in (ctx.hits_text, ctx.align_hits_text):
+    try:
+        call()
+    except sa.SpError as e:
+        assert "4 GiB" in str(e) and "code -6" in str(e), str(e)
+    else:
+        raise SystemExit("the device text was not declined")
+print("declined twice")
+''' % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, SP_TEXT_LIMIT="64")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "declined twice" in out.stdout, out.stdout[-500:] + out.stderr[-1500:]

@@ -47,11 +47,16 @@ def test_match_and_sw_kernels_keep_their_occupancy(tmp_path):
     assert small["Occupancy [waves/SIMD]"] >= 4 and small["VGPRs"] <= 128 and small.get("VGPRs Spill", 0) <= 4, small
     assert small["LDS Size [bytes/block]"] * 4 <= 160 * 1024, small
     assert small["LDS Size [bytes/block]"] * 3 + 2 * 25 * 1024 <= 160 * 1024, small      # three blocks per CU leave two blocks of the forward aligner their LDS
-    grp = kernel("k_match_grpILb0E")                                # short queries, sparse index, unsharded: four queries per pass of a wave -- four blocks per CU,
+    grp = kernel("k_match_grpILb0ELi0E")                            # short queries, sparse index, unsharded: four queries per pass of a wave -- four blocks per CU,
     assert grp["Occupancy [waves/SIMD]"] >= 4 and grp["VGPRs"] <= 128 and grp.get("VGPRs Spill", 0) == 0, grp      # or three and room for an aligner
     assert grp["LDS Size [bytes/block]"] * 4 <= 160 * 1024, grp
-    grpo = kernel("k_match_grpILb1E")                         # ... and with k-mer ordinals (the target-sharded search, round 5): three blocks per CU, no spills
+    grpo = kernel("k_match_grpILb1ELi0E")                     # ... and with k-mer ordinals (the target-sharded search, round 5): three blocks per CU, no spills
     assert grpo["Occupancy [waves/SIMD]"] >= 3 and grpo.get("VGPRs Spill", 0) == 0 and grpo["LDS Size [bytes/block]"] * 3 <= 160 * 1024, grpo
+    for side in ("k_match_grpILb1ELi1E", "k_match_grpILb1ELi2E"):      # the two sides of the probe-list cut (enumerate / fetch): laid out for four blocks per CU
+        pc = kernel(side)
+        assert pc["Occupancy [waves/SIMD]"] >= 4 and pc.get("VGPRs Spill", 0) == 0 and pc["LDS Size [bytes/block]"] * 4 <= 160 * 1024, (side, pc)
+    dense2 = kernel("k_match_dense")                          # round 6's opt-in kernel for the dense index: three blocks per CU, nothing spilled
+    assert dense2["Occupancy [waves/SIMD]"] >= 3 and dense2.get("VGPRs Spill", 0) == 0 and dense2["LDS Size [bytes/block]"] * 3 <= 160 * 1024, dense2
     shard = kernel("k_matchILi256ELb1ELb1")                   # k_match<256, true, true>: the target-sharded search (ordinals recorded): three blocks per CU
     assert shard["Occupancy [waves/SIMD]"] >= 3 and shard["LDS Size [bytes/block]"] * 3 <= 160 * 1024, shard
     for gl in (10, 12, 16, 32):                               # the packed Smith-Waterman kernels: eight waves per SIMD

@@ -94,3 +94,18 @@ def test_fdr_and_summary(g):
     for fmt in (0, 1, 2):
         assert {k: so.summarize(v, aln[k], fmt) for k, v in match.items()} == db(g, "summary%d" % fmt)
     assert {k: so.summarize(v, aln[k], 1, report_fdr=True) for k, v in db(g, "match_fdr").items()} == db(g, "summary_fdr")
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_the_reference_harnesses_are_built_from_the_real_parameter_classes():
+    """Round 6: oracle/Makefile compiles the reference's Parameters.cpp / LocalParameters.cpp (headers generated by the reference's own cmake/xxdi.pl from its data files) and
+    links both drivers with every symbol resolved -- no `#define Parameters ...` stand-in, no --unresolved-symbols=ignore-all."""
+    mk = open(os.path.join(ROOT, "oracle", "Makefile")).read()
+    rules = "\n".join(ln for ln in mk.splitlines() if not ln.lstrip().startswith("#"))
+    assert "unresolved-symbols" not in rules and "ref_par" not in rules
+    assert "Parameters.cpp" in rules and "LocalParameters.cpp" in rules and "xxdi.pl" in rules
+    assert not os.path.exists(os.path.join(ROOT, "oracle", "ref_par.h"))
+    src = open(os.path.join(ROOT, "oracle", "ref_sets.cpp")).read()
+    assert "#define Parameters" not in src and "LocalParameters::getLocalInstance()" in src
