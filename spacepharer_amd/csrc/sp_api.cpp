@@ -63,7 +63,12 @@ struct sp_ctx {
     sp::AlignHost alnHost;                                 // pinned staging, reused; declared last = released before the device context
 };
 
-static uint64_t fnv1a(const void *p, size_t n, uint64_t h);
+static uint64_t fnv1a(const void *p, size_t n, uint64_t h) {
+    const unsigned char *c = (const unsigned char *) p;
+    if (h == 0) h = 1469598103934665603ULL;
+    for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 1099511628211ULL; }
+    return h;
+}
 // digest of a packed similar-3-mer table over the byte streams the reference holds (short score[8000], uint index[8000] per row)
 static uint64_t ext3Digest(const std::vector<uint32_t> &packed, int16_t *scoreHead64, uint32_t *indexHead64, uint32_t row) {
     uint64_t h = 0; std::vector<int16_t> sc(8000); std::vector<uint32_t> ix(8000);
@@ -860,12 +865,6 @@ int sp_ctx_diag_stream_read(sp_ctx *c, uint64_t bytes, int laneBytes, double *ms
 }
 
 /* ---- host-side diagnostics (no device needed): used by the CPU test-suite to check the set-up code ---- */
-static uint64_t fnv1a(const void *p, size_t n, uint64_t h) {
-    const unsigned char *c = (const unsigned char *) p;
-    if (h == 0) h = 1469598103934665603ULL;
-    for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 1099511628211ULL; }
-    return h;
-}
 
 int sp_host_matrix(const char *spec, double bitFactor, double scoreBias, int16_t *sub441, double *pBack21) {
     sp::SubMat m; std::string err;

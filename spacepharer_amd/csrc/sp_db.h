@@ -108,7 +108,7 @@ struct Db {
         }
         std::ifstream t(path + ".dbtype", std::ios::binary);
         if (t.good()) { int32_t v = 0; t.read((char *) &v, 4); dbtype = v; }
-        for (const DbEntry &e : entries) if (e.offset + e.length > size_ || e.length == 0) { err = "index of " + path + " points past the data file"; return false; }
+        for (const DbEntry &e : entries) if (e.length == 0 || e.length > size_ || e.offset > size_ - e.length) { err = "index of " + path + " points past the data file"; return false; }      // (no offset + length: a length of 2^64 - 1 wraps it -- found by tests/test_host_fuzz.py under ASan)
         bool sorted = true;
         for (size_t i = 1; i < entries.size() && sorted; i++) sorted = entries[i - 1].offset <= entries[i].offset;
         if (!sorted) std::sort(entries.begin(), entries.end(), [](const DbEntry &a, const DbEntry &b) { return a.offset < b.offset; });
