@@ -234,12 +234,20 @@ def pmc_traffic(kernel):
         doc = json.load(open(files[-1]))
         k = doc["kernels"][kernel]
         pmc_traffic.measured_stream = doc.get("streaming_read_of_1GiB")
+        # the counter pass names the device sources it was collected on (tools/pmc_summary.py: binary_identity); another tree's kernels -> stale
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from pmc_summary import binary_identity
+        here, there = binary_identity(), doc.get("binary") or {}
+        pmc_traffic.stale = there.get("device_sources_sha256") != here["device_sources_sha256"]
+        pmc_traffic.collected_on = there.get("device_sources_sha256")
         return k["fetch_bytes_corrected"] + k.get("write_bytes_raw", 0.0), "profiles/" + os.path.basename(files[-1])
     except (KeyError, ValueError):
         return None, None
 
 
 pmc_traffic.measured_stream = None
+pmc_traffic.stale = None
+pmc_traffic.collected_on = None
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -307,7 +315,7 @@ def launch_ranks(n, argv):
     return rc
 
 
-def probe_cut_proxy(sa, args, shards=8, spacers=100000):
+def probe_cut_proxy(sa, args, shards=8, spacers=100000, probes_per_query=0):
     """one GPU as shard 0 of `shards` (configs[3]: 100 000 spacers against 1e7 residues cut into target shards): HIP-event time of the matching kernel when the shard
     enumerates every query itself (sp_ctx_prefilter_candidates) against the probe-list cut -- enumerate 1 / shards of the queries against the union of all shards'
     occupancy maps (sp_ctx_probe_enumerate), place the probes the `shards` enumerating ranks address to shard 0 and fetch (sp_ctx_probe_fetch); the candidates of both
@@ -325,6 +333,8 @@ def probe_cut_proxy(sa, args, shards=8, spacers=100000):
         c.set_queries_raw(qres.tobytes(), u64p(qoff), nq)
         c.set_timing(2)
         c.set_tuning("match_blocks_per_cu", -1)      # (all that fit, as for the ONE context a rank of the sharded job has: the library leaves room for other contexts' aligners when it sees several searching on a device)
+        if probes_per_query:
+            c.set_tuning("probe_per_query", probes_per_query)      # (room per destination: a dense shard holds a third of all k-mer slots)
         ctxs.append(c)
     c0 = ctxs[0]
     plain_ms = []
@@ -414,6 +424,10 @@ def main():
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (start it without a launcher, or make the two agree)" % (args.gpus, world))
     mode = args.shard or (os.environ.get("SP_SHARD") if os.environ.get("SP_SHARD") in ("queries", "targets", "probes") else None) or ("targets" if world > 1 else "queries")
     probe_cut = mode == "probes"
+    # N > 1 without an explicit --shard / SP_SHARD: the target-sharded pass is chosen by the library's rule from the shards' measured occupancy and the number of ranks
+    # (spacepharer_amd.dist.choose_sharded_pass: the probe-list cut on sparse shards from four ranks on, the plain pass otherwise)
+    auto_pass = args.shard is None and os.environ.get("SP_SHARD") not in ("queries", "targets", "probes")
+    rule = {"on": probe_cut, "verdict": None, "occupancy": None}
     sharded = mode in ("targets", "probes")
     n_spacers = args.spacers or (100000 if (sharded and world > 1) else 10000)
     full = args.stage == "full"
@@ -507,12 +521,23 @@ def main():
             c.set_queries_raw(batches[b][2].tobytes(), u64p(batches[b][3]), nq)
             ctxs.append(c)
         ctx = ctxs[0]
+        if shard_targets and auto_pass and world > 1:
+            rule["verdict"], rule["occupancy"] = spd.agree_sharded_pass(ctxs[0], sub or comm, int(np.diff(batches[0][3]).max()))
+            rule["on"] = rule["verdict"] == "probes"
         xch = {"s": 0.0, "bytes": 0, "n": 0, "probe_s": 0.0}
         cut_on = [False]      # (the probe-list cut: switched on AFTER the reference digests, which come from every shard enumerating every query itself)
 
         def search(c):
             if shard_targets:
-                info = sharded_prefilter(c, sub or comm, q_from, q_to, probes=probe_cut and cut_on[0])     # own shard -> all-gather (within the query group) -> selection on the union
+                try:
+                    info = sharded_prefilter(c, sub or comm, q_from, q_to, probes=rule["on"] and cut_on[0])     # own shard -> all-gather (within the query group) -> selection on the union
+                except sa.SpError as e:
+                    # the probe-list cut chosen by the RULE (nobody asked for it) and its exchange failed -- on all ranks together, the library agrees on failures before its
+                    # collectives: the job goes on with the plain pass and says so
+                    if not (rule["on"] and cut_on[0] and auto_pass):
+                        raise
+                    rule["on"], rule["fallback"] = False, str(e)[:300]
+                    info = sharded_prefilter(c, sub or comm, q_from, q_to, probes=False)
                 xch["probe_s"] += info["probe_exchange_s"]
                 xch["s"] += info["exchange_s"]
                 xch["bytes"] += info["bytes"]
@@ -753,6 +778,21 @@ def main():
             probe_proxy = probe_cut_proxy(sa, args)
         except Exception as e:      # (a side figure must not cost the line)
             probe_proxy = {"error": repr(e)[:300]}
+    c3_one = c3_four = dense_shard = None
+    if dual and not args.no_dense and (n_spacers, args.targets, args.target_len) == (10000, 50000, 200):
+        # BASELINE configs[3]'s job -- 100 000 spacers of a step against the whole target set -- UNSPLIT on this one GPU: the N = 1 anchor of the N > 1 line (the same job, strong
+        # scaling).  One context = what a rank of the N > 1 run has; four host-driven contexts = this GPU's best.
+        k3 = max(3, args.steps // 20)
+        c3_one = measure(False, 100000, k3, max(1, min(3, args.regions)), 2, False, pipeline=1, host_driven=True)
+        c3_four = measure(False, 100000, 4 * k3, max(1, min(3, args.regions)), 2, False, pipeline=4, host_driven=True)
+    if dual and not args.no_probe_proxy and (n_spacers, args.targets, args.target_len) == (10000, 50000, 200):
+        # ... and the target-sharded passes at the density north_star's DB has: this GPU as shard 0 of 8 of 2e8 residues (2.5e7 per shard, 31 % of the slots occupied), 20 000
+        # spacers: the plain pass against the probe-list cut -- the measurement behind spacepharer_amd.dist.choose_sharded_pass
+        try:
+            import argparse as _ap
+            dense_shard = probe_cut_proxy(sa, _ap.Namespace(targets=1000000, target_len=200), shards=8, spacers=20000, probes_per_query=640)
+        except Exception as e:
+            dense_shard = {"error": repr(e)[:300]}
     pairs_total = all_sum(float(m["pairs"][0]))      # batch 0 of every rank (sharded: the ranks' query slices add up to the batch)
     if comm is not None:
         comm.barrier()
@@ -808,7 +848,7 @@ def main():
         "counters_per_step": {"similar_kmers": K, "index_entries_fetched": M, "diagonals_scored": D, "diag_residues": R, "hits": H},
         "roofline": {"bound": "hbm", "kernel": "k_match_grp (the matching kernel for short queries on a sparse index; k_match otherwise)" if (args.target_len * args.targets <= 50000000 and not sharded) else "k_match", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": traffic,
-                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
+                     "traffic_source": traffic_src, "traffic_stale": pmc_traffic.stale, "traffic_device_sources_sha256": pmc_traffic.collected_on, "algorithmic_bytes_per_launch": algo_bytes,
                      "measured_streaming_read_GBps": pmc_traffic.measured_stream,
                      # the same kernel with the GPU to itself (one context, the breakdown pass after the timed regions): its launches in the
                      # timed regions share the machine with the other context's aligner and take longer each, while more work gets done
@@ -851,12 +891,21 @@ def main():
                            "allgather_bytes_per_step": x["bytes"] / max(1, x["n"]),
                            "exchange_ms_per_step": 1e3 * x["s"] / max(1, x["n"]),
                            "query_slice_of_rank0": list(m["q_slice"])}
-        if probe_cut:
+        if rule["on"]:
             out["exchange"]["probe_cut"] = {"what": "every rank enumerates its query slice once (k_match_grp<true, 1>) and sends the occupied probes (12 bytes each) to the shards that hold the slot "
                                                     "(sp_ctx_probe_search: all-to-all); the shards fetch (k_match_grp<true, 2>); every timed step compared with the pass in which every shard enumerates every query",
                                             "probe_exchange_ms_per_step": 1e3 * x["probe_s"] / max(1, x["n"])}
     if probe_proxy is not None:
         out["probe_cut_one_gpu"] = probe_proxy
+    if c3_one is not None:
+        blk = {"what": "BASELINE configs[3]'s job unsplit on ONE GPU: 100 000 synthetic spacers (600 000 peptides) per step against the whole target set (1e7 residues), prefilter + align, "
+                       "host-driven steps; the N = 1 anchor of the N > 1 line (same job, strong scaling)"}
+        for tag, mm, k in (("one_context", c3_one, max(3, args.steps // 20)), ("four_contexts", c3_four, 4 * max(3, args.steps // 20))):
+            cdt, cregions = region_summary(mm, 100000 * k)
+            blk[tag] = {"value": 100000 * k / cdt, "unit": "spacer-queries/s", "ms_per_step": cdt / k * 1e3, "steps": k, "regions": cregions, "results_checked": mm["checked"]}
+        out["configs3_one_gpu"] = blk
+    if dense_shard is not None:
+        out["dense_shard_proxy"] = dense_shard
     if hyb is not None:
         hdt, hregions = region_summary(hyb, n_spacers * max(4, args.steps // 2))
         out["hybrid"] = {"value": n_spacers * max(4, args.steps // 2) / hdt, "unit": "spacer-queries/s", "scaling": "strong", "ms_per_step": hdt / max(4, args.steps // 2) * 1e3,
@@ -881,12 +930,15 @@ def main():
     if world > 1 and sharded:
         # the headline at N > 1 is BASELINE configs[3]'s decomposition, fixed: target shards + all-gather of the candidates (RCCL over xGMI).  The other cuts of the
         # SAME job (100 000 spacers against the whole target set, strong scaling) stay in the line as side figures; `weak_replica` is the N = 1 job on every rank.
+        probe_cut = rule["on"]
         cands = {"target_shards_probe_cut" if probe_cut else "target_shards": out["value"]}
         if hyb is not None:
             cands["hybrid"] = out["hybrid"]["value"]
         if qpart is not None:
             cands["query_partition"] = out["query_partition"]["value"]
-        out["decompositions"] = {"spacer_queries_per_s": cands, "value_from": ("target_shards_probe_cut (asked for: --shard probes / SP_SHARD=probes; the default is target_shards)" if probe_cut else "target_shards (fixed: BASELINE configs[3])"), "best_measured": max(cands, key=cands.get),
+        out["decompositions"] = {"spacer_queries_per_s": cands, "value_from": (("target_shards_probe_cut" if probe_cut else "target_shards") + (" (BASELINE configs[3]; the pass on the shards chosen by spacepharer_amd.dist.choose_sharded_pass from the fullest shard's occupancy %.3f and %d ranks: %s)" % (rule["occupancy"], world, rule["verdict"]) if rule["verdict"] else " (asked for: --shard / SP_SHARD)")),
+                                 "rule": {"occupancy_of_the_fullest_shard": rule["occupancy"], "ranks": world, "verdict": rule["verdict"], "probe_cut_max_occupancy": spd.PROBE_CUT_MAX_OCCUPANCY, "probe_cut_min_shards": spd.PROBE_CUT_MIN_SHARDS,
+                                          "measured_on": "profiles/r05_probe_cut.txt, profiles/r06_probe_cut_dense.txt", "fell_back_to_plain": rule.get("fallback")}, "best_measured": max(cands, key=cands.get),
                                  "target_shards_ms_per_step": out["ms_per_step"]}
         out["scaling_note"] = ("N = 1 measures configs[2] (10 000 spacers per step on one GPU, `weak_replica` continues that job to N ranks); N > 1 measures configs[3] (100 000 spacers, "
                                "target shards, strong scaling) -- two different jobs, do not join them into one efficiency curve; use `weak_replica` for the weak series.  No 1 -> 8 curve "
@@ -999,6 +1051,30 @@ def main():
                 out["files_to_files"]["dense"] = fd
             except Exception as e:      # noqa: BLE001
                 out["files_to_files"]["dense"] = {"error": repr(e)[:300]}
+    # the figures a reader of the LAST 2 000 characters of this line needs (the side blocks above are long): one flat object, last key of the line; the dense kernel's
+    # fraction also rides in `roofline` itself
+    if "dense" in out and isinstance(out["dense"].get("roofline"), dict):
+        out["roofline"]["dense_index"] = {"kernel": out["dense"]["roofline"]["kernel"], "exclusive_ms_per_launch": out["dense"]["roofline"]["exclusive_ms_per_launch"],
+                                          "exclusive_frac": out["dense"]["roofline"]["exclusive_frac"], "ms_per_step": out["dense"]["ms_per_step"], "value": out["dense"]["value"]}
+    summ = {"value": out["value"], "ms_per_step": out["ms_per_step"], "roofline_frac": out["roofline"]["frac"], "roofline_exclusive_frac": out["roofline"]["exclusive"]["frac"],
+            "traffic_stale": out["roofline"].get("traffic_stale")}
+    if "dense" in out:
+        summ["dense"] = {"value": out["dense"]["value"], "ms_per_step": out["dense"]["ms_per_step"], "k_match_exclusive_ms": out["dense"]["roofline"]["exclusive_ms_per_launch"],
+                         "exclusive_frac": out["dense"]["roofline"]["exclusive_frac"], "x_cpu_reference": (round(out["dense"]["value"] / out["dense"]["cpu_baseline"]["value"], 1) if (out["dense"].get("cpu_baseline") or {}).get("value") else None)}
+    if "configs3_one_gpu" in out:
+        summ["configs3_one_gpu"] = {k: {"value": v["value"], "ms_per_step": v["ms_per_step"]} for k, v in out["configs3_one_gpu"].items() if isinstance(v, dict)}
+    if isinstance(out.get("dense_shard_proxy"), dict) and "x_plain" in out["dense_shard_proxy"]:
+        summ["dense_shard_proxy"] = {k: out["dense_shard_proxy"][k] for k in ("plain_k_match_grp_ms", "cut_matching_ms", "x_plain", "probe_bytes_received")}
+    if isinstance(out.get("probe_cut_one_gpu"), dict) and "x_plain" in out["probe_cut_one_gpu"]:
+        summ["sparse_shard_proxy"] = {k: out["probe_cut_one_gpu"][k] for k in ("plain_k_match_grp_ms", "cut_matching_ms", "x_plain", "probe_bytes_received")}
+    f2f = out.get("files_to_files") or {}
+    for tag, blk in (("files_to_files_1e7", f2f), ("files_to_files_2e8", f2f.get("dense") or {})):
+        xs = {m: (blk.get(m) or {}).get("x_reference") for m in ("fused_search", "prefilter_then_align") if isinstance(blk.get(m), dict)}
+        if any(xs.values()):
+            summ[tag] = {m: {k: round(v, 1) for k, v in x.items()} for m, x in xs.items() if x}
+    if "cpu_baseline" in out:
+        summ["x_cpu_reference"] = round(out["value"] / out["cpu_baseline"]["value"], 1) if out["cpu_baseline"].get("value") else None
+    out["summary"] = summ
     C.CDLL(None).fflush(None)      # library chatter buffered in C stdio (RCCL prints its path) goes out BEFORE the result line
     print(json.dumps(out), flush=True)
 

@@ -314,6 +314,7 @@ struct Gpu::Impl {
     DevBuf<uint4> pbRec[kMaxProbeShards]; DevBuf<uint32_t> pbQCnt[kMaxProbeShards]; DevBuf<uint32_t> probeCursor; size_t probeCap = 0, probeSlice = 0; uint32_t probeCnt[kMaxProbeShards] = {};
     DevBuf<uint4> pinRec, pxRec; DevBuf<uint32_t> pinCnt, probeOff; DevBuf<unsigned long long> probeList;      // received records, probes per query, their prefix sums, the lists by query
     uint32_t nCand = 0;
+    bool candFailed = false; std::string candError;      // the last candidate pass of this context failed (a query beyond the hit-stream limit ...): allgatherCandidates tells every rank
     SwState sw;
     SwDev swd;
     // device-driven steps (stepBegin / stepEnd): the whole pass -- prefilter, selection, align, record assembly, delivery -- is queued without a
@@ -401,6 +402,7 @@ bool Gpu::setKnob(const std::string &name, int value) {
     if (name == "match_static") { d_->knob.matchStatic = std::min(8, std::max(0, value)); return true; }      // eighths of the queries dealt round-robin without atomics
     if (name == "match_small") { d_->knob.matchSmall = value < 0 ? -1 : (value ? 1 : 0); return true; }
     if (name == "match_dense2") { d_->knob.matchDense2 = value ? 1 : 0; return true; }
+    if (name == "probe_per_query") { d_->knob.probePerQuery = std::max(64, value); return true; }      // probe records per query and destination the enumerating side of the probe-list cut has room for (SP_PROBE_PER_QUERY)
     if (name == "match_order") { d_->knob.matchOrder = value ? 1 : 0; return true; }      // k_match_grp takes the batch in the order of decreasing weight (list schedule); 0: heavy queries first, then shares
     if (name == "match_group") { d_->knob.matchGroup = value ? 1 : 0; return true; }      // k_match_grp (queries matched four at a time) where its preconditions hold; 0: always k_match
     if (name == "match_heavy_threshold") { d_->knob.matchHeavy = value < 0 ? -1 : value; return true; }
@@ -997,11 +999,13 @@ bool Gpu::stepEnd(StepResult &r, std::string &err) {
 // sharded search, step 1: this shard's candidates (per query and target the best double-hit diagonal with score >= min)
 bool Gpu::prefilterCandidates(int kmerThr, int minDiagScore, std::string &err) {
     Impl &d = *d_;
-    d.nCand = 0;
+    d.nCand = 0; d.candFailed = false; d.candError.clear();
     if (nq_ == 0) return true;
     if (d.stepsBegun != d.stepsEnded && !d.drained) { err = "prefilterCandidates: a device-driven step is in flight (collect it with stepEnd first)"; return false; }
-    if (!matchAndScore(kmerThr, true, err)) return false;
-    return candidatesTail(minDiagScore, err);
+    // (a failure here is rank-local -- one shard's queries beyond the hit-stream limit, say: it is remembered so that the collective behind this call, allgatherCandidates,
+    // fails on EVERY rank instead of leaving the others in a receive)
+    if (!matchAndScore(kmerThr, true, err) || !candidatesTail(minDiagScore, err)) { d.candFailed = true; d.candError = err; d.nCand = 0; return false; }
+    return true;
 }
 bool Gpu::candidatesTail(int minDiagScore, std::string &err) {
     Impl &d = *d_;
@@ -1103,8 +1107,9 @@ bool Gpu::probeFetch(const void *records, size_t n, const uint32_t *counts, bool
     HIP_OK(hipStreamSynchronize(d.stream));
     const unsigned long long bad = pb[1] + (pb[0] != total ? 1ull : 0ull);      // (every position of every list must have received its record: a hole would be fetched as whatever the buffer held)
     if (bad || total > n) { err = "probeFetch: the probe records do not fit the per-query counts (" + std::to_string(bad) + " records out of place; lists and counts of different passes?)"; return false; }
-    if (!matchAndScore(kmerThr, true, err, 2)) return false;
-    return candidatesTail(minDiagScore, err);
+    d.candFailed = false; d.candError.clear();
+    if (!matchAndScore(kmerThr, true, err, 2) || !candidatesTail(minDiagScore, err)) { d.candFailed = true; d.candError = err; d.nCand = 0; return false; }
+    return true;
 }
 
 // collective: rank r of `comm` holds shard r and enumerates queries [qFrom, qTo) (the ranks' slices tile the batch); leaves this shard's candidates
@@ -1190,8 +1195,12 @@ static bool agreeOk(Comm &comm, bool localOk, std::string &err) {
 bool Gpu::allgatherCandidates(Comm &comm, size_t &unionRows, std::string &err) {
     Impl &d = *d_;
     const int world = comm.world();
-    uint64_t mine = d.nCand; std::vector<uint64_t> all((size_t) world, 0);
+    uint64_t mine = d.candFailed ? ~0ull : (uint64_t) d.nCand; std::vector<uint64_t> all((size_t) world, 0);
     if (!comm.allgather(&mine, sizeof(mine), all.data(), false, err)) return false;
+    for (int r = 0; r < world; r++) if (all[(size_t) r] == ~0ull) {      // (every rank sees the same numbers: all of them stop here, together)
+        err = "allgatherCandidates: the candidate pass of rank " + std::to_string(r) + " failed" + (d.candFailed ? ": " + d.candError : std::string(" (see its own error); no rank holds a complete candidate list"));
+        return false;
+    }
     uint64_t longest = 1; for (uint64_t x : all) longest = std::max(longest, x);
     if (longest * (uint64_t) world >= (1ull << 32)) { err = "allgatherCandidates: more than 2^32 candidate rows"; return false; }      // (every rank sees the same numbers)
     bool ok = d.candPad.ensure((size_t) longest, err) && d.candUnion.ensure((size_t) longest * world + 1, err);

@@ -200,6 +200,36 @@ def allgather_hits(ctx, comm, query_offset, nq_total, hit_cap=None, my_hits=None
     return offs, hits[:int(n.value)]
 
 
+K_SLOTS = 64000000      # 20^6 k-mer slots
+
+# Which pass a target-sharded search runs on every rank -- decided from what was MEASURED on one MI355X playing shard 0 of S (profiles/r05_probe_cut.txt: 1e7 residues,
+# profiles/r06_probe_cut_dense.txt: 2e8 residues; 100 000 / 20 000 spacers):
+#     occupancy of the shard's slot table   S    plain k_match_grp<true>   enumerate 1/S + fetch   cut / plain   probes received per rank and 100 000 spacers
+#     0.02  (1e7 residues / 8)              8    2.60 ms                   0.46 + 0.55 ms          2.5x          10 M  (161 MB)
+#     0.04  (1e7 / 4)                       4    2.81                      0.74 + 0.72             1.9x          17 M
+#     0.07  (1e7 / 2)                       2    3.10                      1.69 + 1.00             1.16x         31 M
+#     0.31  (2e8 / 8)                       8    1.31 (20 000 spacers)     0.75 + 0.89             0.80x         119 M (1.9 GB)
+# The cut removes the enumeration every shard repeats; what it adds grows with the number of occupied probes, i.e. with the occupancy.  On a sparse shard (phage-scale proxy) the
+# enumeration is the matching kernel's time and the cut wins from four shards on; at the density of the real DB the index hits dominate, a k-mer is held by 2.5 of 8 shards and
+# the probes drown the exchange: the plain pass, which there scales by itself (an eighth of 2e8 residues costs 0.36 of the unsplit matcher's time).
+PROBE_CUT_MAX_OCCUPANCY = 0.08
+PROBE_CUT_MIN_SHARDS = 4
+
+
+def choose_sharded_pass(occupancy, shards, max_query_len=64):
+    """'probes' or 'plain' for a target-sharded search over `shards` ranks whose fullest shard has `occupancy` of its k-mer slots occupied (see the table above)"""
+    if shards >= PROBE_CUT_MIN_SHARDS and shards <= 8 and occupancy <= PROBE_CUT_MAX_OCCUPANCY and max_query_len <= 64:
+        return "probes"
+    return "plain"
+
+
+def agree_sharded_pass(ctx, comm, max_query_len=64):
+    """the ranks' verdict (one all-reduce of the occupancies: every rank decides from the fullest shard, hence alike)"""
+    occ = ctx.stat("index_slots") / float(K_SLOTS)
+    occ = comm.allreduce([occ], "max")[0] if comm.world > 1 else occ
+    return choose_sharded_pass(occ, comm.world, max_query_len), occ
+
+
 def sharded_prefilter(ctx, comm, q_from=0, q_to=None, probes=False):
     """One target-sharded prefilter pass on this rank's context (targets staged with set_targets_shard*): candidates of the own shard -> all-gather (RCCL: HBM -> xGMI ->
     HBM) -> selection on the union for queries [q_from, q_to).  Afterwards ctx.hits_compact() / ctx.align_hits_raw() see the merged hits.
@@ -211,6 +241,11 @@ def sharded_prefilter(ctx, comm, q_from=0, q_to=None, probes=False):
         # of `comm` is shard r) -- the candidates it leaves are those of prefilter_candidates(), record for record
         _lib._check(_L().sp_ctx_probe_search(ctx.ctx, comm.h, int(q_from), int(q_to if q_to is not None else ctx.n_queries), C.byref(psecs)))
     else:
-        ctx.prefilter_candidates()
+        try:
+            ctx.prefilter_candidates()
+        except _lib.SpError:
+            # rank-local (a query of THIS shard beyond the hit-stream limit, say): the context remembers it and the collective below fails on every rank, together --
+            # nobody is left waiting in a receive for the rank that stopped here
+            pass
     _lib._check(_L().sp_ctx_allgather_candidates(ctx.ctx, comm.h, int(q_from), int(q_to if q_to is not None else (1 << 62)), C.byref(rows), C.byref(secs)))
     return {"union": int(rows.value), "bytes": comm.bytes_moved() - before, "exchange_s": float(secs.value) + float(psecs.value), "probe_exchange_s": float(psecs.value)}

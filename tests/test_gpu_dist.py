@@ -120,3 +120,63 @@ def test_ranks_that_cannot_have_rccl_agree_on_the_host_transport(tmp_path, monke
     for p in procs: p.start()
     for p in procs: p.join(600)
     assert all(p.exitcode not in (0, None) for p in procs)      # (SpError in both ranks: nobody hangs)
+
+
+def _overflow_rank(rank, world, uid_hex, out):
+    """shard 0 holds 2 400 near-copies of one sequence (a query of that family has more than 65 535 index hits there), the other shards random sequences"""
+    sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
+    import random
+    import spacepharer_amd as sa
+    from spacepharer_amd import dist as spd
+    rnd = random.Random(11)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    core = "".join(rnd.choice(aa) for _ in range(60))
+    fam = []
+    for i in range(2400):
+        s = list(core)
+        for _ in range(3):
+            s[rnd.randrange(60)] = rnd.choice(aa)
+        fam.append("".join(rnd.choice(aa) for _ in range(rnd.randrange(0, 20))) + "".join(s) + "".join(rnd.choice(aa) for _ in range(20)))
+    per = sum(len(s) + 2 for s in fam)
+    T = list(fam)
+    while sum(len(s) + 2 for s in T) < world * per:
+        T.append("".join(rnd.choice(aa) for _ in range(90)))
+    Q = ["".join(rnd.choice(aa) for _ in range(12)), core, "".join(rnd.choice(aa) for _ in range(10))]
+    comm = spd.Comm(binascii.unhexlify(uid_hex), rank, world, spd.TRANSPORT_HOST)
+    t_from, t_cnt = spd.decompose_by_residues([len(s) + 2 for s in T], rank, world)
+    c = sa.SearchContext()
+    c.set_targets_shard(T, t_from, t_from + t_cnt)
+    c.set_queries(Q)
+    ok = True
+    try:
+        spd.sharded_prefilter(c, comm, 0, len(Q))
+        ok = False                                   # every rank must fail ...
+    except sa.SpError as e:
+        ok = "candidate pass of rank 0 failed" in str(e) and (rank != 0 or "65535" in str(e))      # ... with rank 0 named, and rank 0 says why
+    # the job goes on: the same ranks, the batch without the heavy query
+    c.set_queries([Q[0], Q[2]])
+    spd.sharded_prefilter(c, comm, 0, 2)
+    ref = sa.SearchContext()
+    ref.set_targets(T)
+    ref.set_queries([Q[0], Q[2]])
+    ref.prefilter()
+    ok = ok and c.hits() == ref.hits()
+    c.close(); ref.close()
+    comm.barrier()
+    comm.close()
+    open("%s.%d" % (out, rank), "w").write("ok" if ok else "mismatch")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_rank_beyond_the_hit_stream_limit_fails_all_ranks_together(world, tmp_path):
+    """target shards, one rank's shard refuses a query (more than 65 535 index hits): the candidate all-gather behind it fails on EVERY rank with the offender named --
+    no rank is left in a receive -- and the same communicator carries the next batch"""
+    from spacepharer_amd import dist as spd
+    uid = binascii.hexlify(spd.unique_id()).decode()
+    out = str(tmp_path / "ovf")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_overflow_rank, args=(r, world, uid, out)) for r in range(world)]
+    for p in procs: p.start()
+    for p in procs: p.join(600)
+    assert [p.exitcode for p in procs] == [0] * world
+    assert [open("%s.%d" % (out, r)).read() for r in range(world)] == ["ok"] * world

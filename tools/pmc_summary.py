@@ -24,6 +24,23 @@ def short(name):
     return name[:48]
 
 
+def binary_identity():
+    """what the counters were collected on: sha256 of the library the workload loaded and of the device sources it was built from (bench.py compares the latter with the
+    tree it runs from and marks `roofline.traffic` stale when they differ -- a host-only change rebuilds the library but not its kernels)"""
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "spacepharer_amd", os.environ.get("SP_LIB_NAME", "libspacepharer_amd.so"))
+    out = {"library": os.path.basename(lib), "library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None}
+    h = hashlib.sha256()
+    src = os.path.join(root, "spacepharer_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if f.endswith(".hip") or f.endswith(".inc"):
+            h.update(f.encode()); h.update(open(os.path.join(src, f), "rb").read())
+    out["device_sources_sha256"] = h.hexdigest()
+    return out
+
+
 def main():
     out_path, paths = sys.argv[1], sys.argv[2:]
     acc = defaultdict(lambda: defaultdict(list))
@@ -53,7 +70,7 @@ def main():
         if name in res and res[name].get("mean_us_under_pmc"):
             stream["%dB_per_lane_GBps" % width] = GIB / (res[name]["mean_us_under_pmc"] * 1e-6) / 1e9
     f4 = calib.get("4B_per_lane", 1.0)
-    summary = {"source": paths, "unit_note": "FETCH_SIZE/WRITE_SIZE in KiB as printed by rocprofv3; *_bytes fields are bytes per launch",
+    summary = {"source": paths, "binary": binary_identity(), "unit_note": "FETCH_SIZE/WRITE_SIZE in KiB as printed by rocprofv3; *_bytes fields are bytes per launch",
                "calibration_factor_known_over_counted": calib, "streaming_read_of_1GiB": stream, "kernels": res}
     for k in res:
         if "FETCH_SIZE" in res[k] and not k.startswith("k_diag"):
