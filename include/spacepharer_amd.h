@@ -46,6 +46,9 @@ extern "C" {
 
 /* ---- process level ---- */
 int sp_init(int device_mask);              /* bit i = use HIP device i; 0 = device of LOCAL_RANK (or 0) */
+/* the same on a thread of its own, plus the one-time device set-up of the process (HIP runtime, device context, this library's code object): returns at once; sp_init() /
+   sp_ctx_create() wait for it.  A module front end calls it first and reads its DBs meanwhile (0.1-0.2 s of a fresh process); the reference has no counterpart. */
+int sp_init_async(int device_mask);
 void sp_shutdown(void);
 const char *sp_last_error(void);
 int sp_device_count(void);

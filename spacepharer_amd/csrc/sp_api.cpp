@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -92,7 +93,24 @@ int sp_device_memory(uint64_t *free_bytes, uint64_t *total_bytes) {
 }
 const char *sp_version(void) { return "spacepharer_amd 0.1 (gfx950)"; }
 
-int sp_init(int device_mask) {
+static int sp_init_sync(int device_mask);
+// sp_init_async: the same on a thread of its own, plus the process's one-time device set-up (runtime, context, code object); whoever needs the device next -- sp_init,
+// sp_ctx_create -- waits for it.  A front end calls it first thing and reads its DBs meanwhile: 0.1-0.2 s of a fresh module process.
+static std::mutex g_asyncMu; static std::condition_variable g_asyncCv; static bool g_asyncRunning = false;
+static void waitForAsyncInit() { std::unique_lock<std::mutex> lk(g_asyncMu); g_asyncCv.wait(lk, [] { return !g_asyncRunning; }); }
+int sp_init_async(int device_mask) {
+    {   std::lock_guard<std::mutex> lk(g_asyncMu);
+        if (g_asyncRunning) return SP_OK;
+        g_asyncRunning = true; }
+    std::thread([device_mask] {
+        if (sp_init_sync(device_mask) == SP_OK) { std::string err; (void) sp::Gpu::warmUp(sp::currentDevice(), err); }      // (a failure shows when the context is created)
+        { std::lock_guard<std::mutex> lk(g_asyncMu); g_asyncRunning = false; }
+        g_asyncCv.notify_all();
+    }).detach();
+    return SP_OK;
+}
+int sp_init(int device_mask) { waitForAsyncInit(); return sp_init_sync(device_mask); }
+static int sp_init_sync(int device_mask) {
     std::lock_guard<std::mutex> lk(g_mu);
     sp::Gpu probe;
     int n = probe.deviceCount();
@@ -125,6 +143,7 @@ void sp_default_params(sp_search_params *p) {
 }
 
 sp_ctx *sp_ctx_create(const sp_search_params *p) {
+    waitForAsyncInit();
     std::unique_ptr<sp_ctx> c(new sp_ctx);
     c->par = *p;
     c->seedName = p->seed_sub_mat ? p->seed_sub_mat : "VTML80.out";

@@ -82,6 +82,7 @@ public:
     Gpu();
     ~Gpu();
     bool init(int device, std::string &err);
+    static bool warmUp(int device, std::string &err);      // runtime + device context + code object, nothing of a search context (sp_init_async)
     int deviceCount() const;
     const std::string &deviceName() const { return name_; }
 

@@ -448,6 +448,23 @@ __global__ void k_step_counts(StepCountArgs a) {
 
 int Gpu::deviceCount() const { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
+// What a process pays ONCE before its first kernel can run -- the HIP runtime, the device's context, this library's code object -- without anything that belongs to a search
+// context: a front end starts it on a second thread while it reads its DBs (sp_init_async)
+bool Gpu::warmUp(int device, std::string &err) {
+    int n = 0;
+    HIP_OK(hipGetDeviceCount(&n));
+    if (n <= 0) { err = "no HIP device visible"; return false; }
+    HIP_OK(hipSetDevice(device % n));
+    HIP_OK(hipFree(nullptr));
+    void *p = nullptr;      // (a first allocation and a first kernel: the memory pools and the code object are there when the search context asks)
+    HIP_OK(hipMalloc(&p, 1 << 20));
+    FillArgs fa{{p, nullptr, nullptr, nullptr}, {1 << 20, 0, 0, 0}, {0u, 0u, 0u, 0u}};
+    hipLaunchKernelGGL(k_fill, dim3(4), dim3(256), 0, nullptr, fa);
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipFree(p));
+    return true;
+}
+
 bool Gpu::init(int device, std::string &err) {
     int n = 0;
     HIP_OK(hipGetDeviceCount(&n));

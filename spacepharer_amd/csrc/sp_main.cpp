@@ -29,6 +29,7 @@
 #include <sys/time.h>
 #include <sys/un.h>
 #include <sys/wait.h>
+#include <time.h>
 #include <unistd.h>
 #include <vector>
 
@@ -55,6 +56,7 @@ static void *libSym(const char *name) {
     return f;
 }
 static int sp_init(int mask) { return ((int (*)(int)) libSym("sp_init"))(mask); }
+static int sp_init_async(int mask) { return ((int (*)(int)) libSym("sp_init_async"))(mask); }
 static void sp_shutdown() { ((void (*)()) libSym("sp_shutdown"))(); }
 static const char *sp_last_error() { return ((const char *(*)()) libSym("sp_last_error"))(); }
 constexpr int SP_OK = 0;
@@ -141,7 +143,9 @@ static int serve(const char *path, int idleSeconds) {
     const bool bound = ls >= 0 && bind(ls, (sockaddr *) &a, sizeof(a)) == 0 && listen(ls, 64) == 0;
     umask(old);
     if (!bound) { fprintf(stderr, "spacepharer-amd serve: cannot listen on %s: %s\n", path, strerror(errno)); return 1; }
-    if (sp_init(0) != SP_OK) { fprintf(stderr, "%s\n", sp_last_error()); close(ls); unlink(path); return 1; }
+    // (the runtime comes up on a second thread while the first client's call -- already waiting in the backlog of an auto-started server -- reads its DBs; a machine without a
+    // device shows in that call's error)
+    if (sp_init_async(0) != SP_OK) { fprintf(stderr, "%s\n", sp_last_error()); close(ls); unlink(path); return 1; }
     if (!getenv("SP_CONTEXT_CACHE")) setenv("SP_CONTEXT_CACHE", "4", 1);
     fprintf(stderr, "spacepharer-amd: serving on %s\n", path);
     for (;;) {      // one call at a time: a module call owns the GPU while it runs
@@ -239,16 +243,67 @@ int main(int argc, const char **argv) {
     }
     const Module *m = findModule(argv[1]);
     if (!m) { fprintf(stderr, "unknown module %s\n", argv[1]); return 1; }
+    // SP_MODULE_TIMES=1: where a fresh process spends its time AROUND the module's own laps -- since exec (the kernel's start time of this process), loading the library,
+    // bringing the runtime up, the module, and (by the caller's clock) whatever the exit costs
+    const bool times = getenv("SP_MODULE_TIMES") != nullptr;
+    auto nowMs = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    auto sinceExecMs = [&]() -> double {      // /proc/self/stat field 22: start time in clock ticks since boot (CLOCK_BOOTTIME's origin)
+        FILE *f = fopen("/proc/self/stat", "r"); if (!f) return -1;
+        char buf[2048]; const size_t n = fread(buf, 1, sizeof(buf) - 1, f); fclose(f); buf[n] = 0;
+        const char *p = strrchr(buf, ')'); if (!p) return -1;
+        unsigned long long start = 0; int field = 2;
+        for (p++; *p && field < 22; p++) if (*p == ' ') field++;
+        start = strtoull(p, nullptr, 10);
+        timespec ts; clock_gettime(CLOCK_BOOTTIME, &ts);
+        return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6 - (double) start * 1e3 / (double) sysconf(_SC_CLK_TCK);
+    };
+    const double tMain = nowMs(), preMain = times ? sinceExecMs() : 0;
     // SP_GPUS=N: the module starts one worker process per GPU (this binary again, with SP_PART set); the parent only merges
     // the parts and has no use for a device
     const char *gpus = getenv("SP_GPUS");
     const bool fanOut = gpus && atoi(gpus) > 1;
-    if (m->device && !fanOut && sp_init(0) != SP_OK) { fprintf(stderr, "%s\n", sp_last_error()); return 1; }
+    // A device module in a fresh process: the WORK runs in a child (forked here, before this process has loaded the library or touched the GPU); the parent returns the child's
+    // status as soon as the child has closed its output DBs, and the child's exit -- the driver unmapping some gigabytes of device buffers, 80-100 ms -- goes on behind the
+    // caller's back.  SP_DETACH_EXIT=0 (or SP_ORDERLY_EXIT=1) keeps everything in one process.
+    int reportFd = -1;
+    if (m->device && !fanOut && !getenv("SP_ORDERLY_EXIT") && !(getenv("SP_DETACH_EXIT") && atoi(getenv("SP_DETACH_EXIT")) == 0)) {
+        int pfd[2];
+        if (pipe(pfd) == 0) {
+            fflush(NULL);
+            const pid_t pid = fork();
+            if (pid > 0) {
+                close(pfd[1]);
+                int32_t rc = 1; ssize_t got = 0;
+                while ((got = read(pfd[0], &rc, sizeof(rc))) < 0 && errno == EINTR) { }
+                if (got == (ssize_t) sizeof(rc)) return rc;                      // the outputs are on disk; the worker finishes dying on its own
+                int st = 0; while (waitpid(pid, &st, 0) < 0 && errno == EINTR) { }      // the worker ended without reporting: its exit status says how
+                return WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+            }
+            if (pid == 0) { close(pfd[0]); reportFd = pfd[1]; }
+            else { close(pfd[0]); close(pfd[1]); }      // (fork failed: run the module here)
+        }
+    }
+    if (m->device && !fanOut) setenv("SP_ONESHOT", "1", 0);      // (before the library loads: it reads the variable once)
+    (void) libSym("sp_last_error");
+    const double tLib = nowMs();
+    // this process runs the module itself and ends with it: the runtime comes up on a second thread while the module reads its DBs (the module's context waits for it), result
+    // buffers are ordinary memory and nothing is torn down in order at the end (SP_ONESHOT: sp_modules.cpp)
+    if (m->device && !fanOut) { if (sp_init_async(0) != SP_OK) { fprintf(stderr, "%s\n", sp_last_error()); return 1; } }
+    const double tInit = nowMs();
     const int rc = m->run(argc - 2, argv + 2);
     if (rc != 0) fprintf(stderr, "%s\n", sp_last_error());
+    if (times) fprintf(stderr, "[sp] process: exec -> main %.1f ms (10 ms resolution), library loaded %.1f ms, runtime started on a second thread %.1f ms, module %.1f ms; since exec %.1f ms at exit\n",
+                       preMain, tLib - tMain, tInit - tLib, nowMs() - tInit, sinceExecMs());
     // The outputs are on disk (write + close, nothing buffered).  Tearing the HIP runtime down in order -- contexts, 0.5 GB of tables,
     // code objects -- takes ~50 ms of a module call whose GPU work takes less; the kernel driver reclaims everything at exit anyway.
     // SP_ORDERLY_EXIT=1 keeps the orderly path (leak checkers).
+    if (reportFd >= 0) {      // tell the parent, let go of the caller's pipes (whoever reads them to the end must not wait for this process's exit), then leave
+        fflush(NULL);
+        const int32_t r = rc; (void) !write(reportFd, &r, sizeof(r)); close(reportFd);
+        const int nul = open("/dev/null", O_RDWR);
+        if (nul >= 0) { dup2(nul, 0); dup2(nul, 1); dup2(nul, 2); }
+        _exit(rc);
+    }
     if (m->device && !getenv("SP_ORDERLY_EXIT")) { fflush(NULL); _exit(rc); }
     if (m->device) sp_shutdown();
     return rc;

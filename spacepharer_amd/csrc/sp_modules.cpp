@@ -15,6 +15,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <functional>
 #include <memory>
 #include <set>
 #include <sstream>
@@ -54,9 +55,12 @@ static const std::set<std::string> kRescoreFlags = {
 // it lives for the call.  In a serving process (`spacepharer-amd serve`, SP_CONTEXT_CACHE=<n>) the last n of them stay resident,
 // keyed by the search parameters and the identity of the target DB files, so that the next call against the same target set -- the
 // control search of predictmatch, the next batch of spacers -- finds its index in HBM: 288 GB hold hundreds of phage-scale sets.
+// SP_ONESHOT (set by the front end when it runs a module in its own, fresh process -- never by a server): the process ends with this call
+static bool oneShotProcess() { static const bool v = getenv("SP_ONESHOT") != nullptr && getenv("SP_CONTEXT_CACHE") == nullptr; return v; }
+
 struct Ctx {
     sp_ctx *c = nullptr; bool cached = false; bool targetsStaged = false;
-    ~Ctx() { if (c && !cached) sp_ctx_destroy(c); }
+    ~Ctx() { if (c && !cached && !oneShotProcess()) sp_ctx_destroy(c); }      // (a process that ends with this call: the driver reclaims 10 GB of device buffers faster than hipFree gives them back one by one)
 };
 struct CachedCtx { std::string key; sp_ctx *c; uint64_t stamp; std::string target; bool indexed; };
 static std::vector<CachedCtx> g_ctxCache; static uint64_t g_ctxStamp = 0; static std::mutex g_ctxMutex;
@@ -307,19 +311,24 @@ struct ResultBufsRef {               // the served pair, or a pair of this call'
 // and must outlive the writer's close() -- it belongs to the module call, or to the server between calls.  SP_DEVICE_TEXT=0: the host formats (the round-4 path, also
 // taken for whatever the device path declines: --max-accept / --max-rejected, runs of several batches, target shards, queries retried through shards, batches with a pair
 // that needs the host-driven traceback).
+// (a one-shot process takes ordinary memory here as for the records above: page-locking the 150-550 MB these buffers are sized for costs 40-130 ms, the staged copy of the
+// text that is really there 20)
 struct TextBufs {
     char *text = nullptr; uint32_t *lens = nullptr; uint64_t textCap = 0, lenCap = 0;
     char *index = nullptr; uint64_t indexCap = 0;
-    void release() { sp_host_free(text); sp_host_free(lens); sp_host_free(index); text = nullptr; lens = nullptr; index = nullptr; textCap = lenCap = indexCap = 0; }
+    const bool pinned = !oneShotProcess();
+    void *take(uint64_t n) { return pinned ? sp_host_alloc(n) : malloc(n); }
+    void give(void *p) { if (pinned) sp_host_free(p); else free(p); }
+    void release() { give(text); give(lens); give(index); text = nullptr; lens = nullptr; index = nullptr; textCap = lenCap = indexCap = 0; }
     bool ensureIndex(uint64_t n) {
         if (n <= indexCap) return true;
-        sp_host_free(index); indexCap = n + n / 4 + 4096; index = static_cast<char *>(sp_host_alloc(indexCap));
+        give(index); indexCap = n + n / 4 + 4096; index = static_cast<char *>(take(indexCap));
         if (!index) { indexCap = 0; sp::setLastError("out of page-locked memory for the index text"); return false; }
         return true;
     }
     bool ensure(uint64_t nText, uint64_t nLens) {
-        if (nText > textCap) { sp_host_free(text); textCap = nText + nText / 4 + 4096; text = static_cast<char *>(sp_host_alloc(textCap)); if (!text) { textCap = 0; sp::setLastError("out of page-locked memory for the result text"); return false; } }
-        if (nLens > lenCap) { sp_host_free(lens); lenCap = nLens + nLens / 4 + 1024; lens = static_cast<uint32_t *>(sp_host_alloc(lenCap * sizeof(uint32_t))); if (!lens) { lenCap = 0; sp::setLastError("out of page-locked memory for the result text"); return false; } }
+        if (nText > textCap) { give(text); textCap = nText + nText / 4 + 4096; text = static_cast<char *>(take(textCap)); if (!text) { textCap = 0; sp::setLastError("out of page-locked memory for the result text"); return false; } }
+        if (nLens > lenCap) { give(lens); lenCap = nLens + nLens / 4 + 1024; lens = static_cast<uint32_t *>(take(lenCap * sizeof(uint32_t))); if (!lens) { lenCap = 0; sp::setLastError("out of page-locked memory for the result text"); return false; } }
         return true;
     }
 };
@@ -333,7 +342,9 @@ static bool deviceTextEnabled() { const char *e = getenv("SP_DEVICE_TEXT"); retu
 // the entries of the context's resident batch as one external block of `w`: 1 = added, 0 = the device path declined (the caller formats on the host), -1 = error
 static int deviceTextBlock(sp_ctx *c, bool alignments, double minSeqId, long minAlnLen, const std::vector<uint32_t> &keys, TextBufs &tb, DbWriter &w) {
     const uint64_t nHits = sp_ctx_num_hits(c);
-    if (!tb.ensure(nHits * (alignments ? 72 : 24) + keys.size() + (1u << 16), keys.size() + 1)) return -1;
+    // (first guess: 40 / 20 bytes a line -- an alignment line of a spacer peptide has 27, a prefilter line 15; the formatter says what it needs when that is too little and the
+    // second attempt below has it.  Sized for the worst line, 72 / 24 bytes, a resident server's first call page-locked 550 MB for 170 MB of text.)
+    if (!tb.ensure(nHits * (alignments ? 40 : 20) + keys.size() + (1u << 16), keys.size() + 1)) return -1;
     for (int attempt = 0; attempt < 2; attempt++) {
         uint64_t used = 0;
         const int rc = alignments ? sp_ctx_align_hits_text(c, minSeqId, (uint32_t) std::max<long>(0, minAlnLen), tb.text, tb.textCap, &used, tb.lens)
@@ -630,11 +641,18 @@ static bool collectTriples(const Db &res, const KeyMap &qIndex, const KeyMap &tI
     return true;
 }
 
+// (everything the host can do without the device comes FIRST -- reading and flattening both DBs, and `beforeContext`, the caller's own host work (align: reading and
+// parsing the result DB): in a fresh process the runtime is still coming up on its own thread meanwhile, sp_init_async, and the context waits for it)
 static bool openSearch(const Flags &f, const char *module, bool gapped, Ctx &ctx, Db &qdb, Db &tdb, std::vector<uint32_t> &qkeys, std::vector<uint32_t> &tkeys,
-                       std::vector<char> &qres, std::vector<uint64_t> &qoff, std::string &err) {
+                       std::vector<char> &qres, std::vector<uint64_t> &qoff, std::string &err, const std::function<bool(std::string &)> &beforeContext = nullptr) {
     Laps laps(module);
     if (!loadSeqDb(f.positional[0], qdb, err) || !loadSeqDb(f.positional[1], tdb, err)) return false;
     laps.lap("  read sequence DBs");
+    std::vector<char> tres; std::vector<uint64_t> toff;
+    flatten(tdb, tres, toff, tkeys);
+    flatten(qdb, qres, qoff, qkeys);
+    laps.lap("  flatten targets, queries");
+    if (beforeContext && !beforeContext(err)) return false;
     sp_search_params p; sp_default_params(&p);
     static std::string sub; sub = aaPart(f.str("--sub-mat", "VTML40.out"));
     p.sub_mat = sub.c_str();
@@ -644,12 +662,8 @@ static bool openSearch(const Flags &f, const char *module, bool gapped, Ctx &ctx
     ctx.c = sp_ctx_create(&p);
     if (!ctx.c) { err = sp_last_error(); return false; }
     laps.lap("  context");
-    std::vector<char> tres; std::vector<uint64_t> toff;
-    flatten(tdb, tres, toff, tkeys);
-    laps.lap("  flatten targets");
     if (sp_ctx_set_targets_ex(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size(), 1 /* no k-mer index needed */) != SP_OK) { err = sp_last_error(); return false; }
     laps.lap("  targets -> device");
-    flatten(qdb, qres, qoff, qkeys);
     if (sp_ctx_set_queries(ctx.c, qres.data(), qoff.data(), qkeys.size()) != SP_OK) { err = sp_last_error(); return false; }
     laps.lap("  queries -> device");
     return true;
@@ -709,12 +723,15 @@ int runAlignModule(int argc, const char **argv) {
         tr.perQuery.assign(ho, ho + g_memo.qkeys.size() + 1);
         laps.lap("align on the device (resident hits)");
     } else {
-        if (!openSearch(f, "align", true, ctx, qdb, tdb, qkeys, tkeys, qres, qoff, err)) return fail("align: " + err);
-        laps.lap("read DBs, context, device");
-        if (!rdb.load(f.positional[2], err)) return fail("align: " + err);
-        KeyMap qIndex, tIndex; qIndex.build(qkeys); tIndex.build(tkeys);
-        if (!collectTriples(rdb, qIndex, tIndex, tr, err)) return fail("align: " + err);
-        laps.lap("read + parse result DB");
+        if (!openSearch(f, "align", true, ctx, qdb, tdb, qkeys, tkeys, qres, qoff, err, [&](std::string &e) {
+                Laps inner("align");
+                if (!rdb.load(f.positional[2], e)) return false;
+                KeyMap qIndex, tIndex; qIndex.build(qkeys); tIndex.build(tkeys);
+                const bool ok = collectTriples(rdb, qIndex, tIndex, tr, e);
+                inner.lap("  read + parse result DB");
+                return ok;
+            })) return fail("align: " + err);
+        laps.lap("read DBs + result DB, context, device");
         if (!bufs.b->ensure(tr.q.size() + 16, 24 * (tr.q.size() + 16))) return fail(std::string("align: ") + sp_last_error());
         int rc = sp_ctx_align(ctx.c, tr.q.data(), tr.t.data(), tr.q.size(), bufs.b->res, bufs.b->cig, bufs.b->cigCap, &used);
         if (rc == SP_ERR_OVERFLOW && used > bufs.b->cigCap) { if (!bufs.b->ensure(tr.q.size() + 16, used + 16)) return fail(std::string("align: ") + sp_last_error()); rc = sp_ctx_align(ctx.c, tr.q.data(), tr.t.data(), tr.q.size(), bufs.b->res, bufs.b->cig, bufs.b->cigCap, &used); }
@@ -824,11 +841,18 @@ int runSearchModule(int argc, const char **argv) {
         comm.c = sp_dist_init(id, myPart.rank, myPart.count, transport);
         if (!comm.c) return fail(std::string("search: ") + sp_last_error());
     }
+    std::vector<char> tres; std::vector<uint64_t> toff; std::vector<uint32_t> tkeys;
+    bool targetsRead = false;
+    if (oneShotProcess() && !shardTargets) {      // (a fresh process: the runtime is still coming up on its own thread -- sp_init_async -- and the context below waits for it: the target DB is read and flattened meanwhile)
+        if (!loadSeqDb(f.positional[1], tdb, err)) return fail("search: " + err);
+        flatten(tdb, tres, toff, tkeys);
+        targetsRead = true;
+        laps.lap("read + flatten target DB");
+    }
     Ctx ctx;
     if (shardTargets) { ctx.c = sp_ctx_create(&p); if (!ctx.c) return fail(std::string("search: ") + sp_last_error()); }      // (a shard is not a cacheable target set)
     else if (!acquireCtx(p, f.positional[1], "index", ctx, err)) return fail("search: " + err);
     laps.lap("context (matrices, tables)");
-    std::vector<char> tres; std::vector<uint64_t> toff; std::vector<uint32_t> tkeys;
     const std::vector<char> &qres = qf->res; const std::vector<uint64_t> &qoff = qf->off; const std::vector<uint32_t> &qkeys = qf->keys;
     if (shardTargets) {
         if (!loadSeqDb(f.positional[1], tdb, err)) return fail("search: " + err);
@@ -838,8 +862,10 @@ int runSearchModule(int argc, const char **argv) {
         if (sp_dist_decompose(lens.data(), lens.size(), myPart.rank, myPart.count, &tFrom, &tCnt) != SP_OK ||
             sp_ctx_set_targets_shard(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size(), tFrom, tFrom + tCnt) != SP_OK) return fail(std::string("search: ") + sp_last_error());
     } else if (!ctx.targetsStaged) {      // (a cached context -- the resident server -- holds the target set of this very DB: nothing to read)
-        if (!loadSeqDb(f.positional[1], tdb, err)) { dropCtx(ctx); return fail("search: " + err); }
-        flatten(tdb, tres, toff, tkeys);
+        if (!targetsRead) {
+            if (!loadSeqDb(f.positional[1], tdb, err)) { dropCtx(ctx); return fail("search: " + err); }
+            flatten(tdb, tres, toff, tkeys);
+        }
         if (sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) { const std::string e = sp_last_error(); dropCtx(ctx); return fail("search: " + e); }
     }
     laps.lap("targets -> device, index");
