@@ -1047,6 +1047,8 @@ def main():
                     if ref_s:
                         ent["x_reference"] = {"fresh_process": ref_s / min(run["process_total_s"]), "auto_server_first": ref_s / run["auto_server_total_s"][0],
                                               "auto_server_next": ref_s / min(run["auto_server_total_s"][1:]), "served": ref_s / min(run["served_total_s"][1:])}
+                    if run.get("fresh_process_laps"):
+                        ent["fresh_process_laps"] = run["fresh_process_laps"]
                     fd[tag] = ent
                 out["files_to_files"]["dense"] = fd
             except Exception as e:      # noqa: BLE001
@@ -1072,6 +1074,9 @@ def main():
         xs = {m: (blk.get(m) or {}).get("x_reference") for m in ("fused_search", "prefilter_then_align") if isinstance(blk.get(m), dict)}
         if any(xs.values()):
             summ[tag] = {m: {k: round(v, 1) for k, v in x.items()} for m, x in xs.items() if x}
+    lp = ((f2f.get("dense") or {}).get("fused_search") or {}).get("fresh_process_laps")
+    if lp:
+        summ["fresh_fused_process_2e8_laps_ms"] = {k: v for k, v in lp.items() if k != "note"}
     if "cpu_baseline" in out:
         summ["x_cpu_reference"] = round(out["value"] / out["cpu_baseline"]["value"], 1) if out["cpu_baseline"].get("value") else None
     out["summary"] = summ

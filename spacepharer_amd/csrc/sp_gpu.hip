@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -287,6 +288,8 @@ struct Gpu::Impl {
     int device = 0;
     bool searcher = false;                       // counted in g_searchers: this context holds a query batch
     int matchPerCU = 0;                          // resident k_match blocks per CU (0 = what the occupancy calculator says)
+    char *ring[2] = {nullptr, nullptr}; hipEvent_t ringEv[2] = {nullptr, nullptr};      // staging of device -> host copies into ordinary memory (copyOut)
+    bool copyOut(void *dst, const void *srcDev, size_t bytes, std::string &err);
     int timing = 1;                              // 0: no HIP events in the pipeline, 1: around k_match only (each record costs ~6 us of idle GPU), 2: every stage
     // the hit list starts travelling to the host on its own stream as soon as a prefilter pass is complete, so that the copy
     // overlaps whatever the caller queues next (typically the align kernels)
@@ -362,6 +365,7 @@ Gpu::~Gpu() {
         for (auto &set : d_->ev) for (hipEvent_t e : set) if (e) (void) hipEventDestroy(e);
         for (Impl::StepSlot &ss : d_->step) for (hipEvent_t e : {ss.selected, ss.assembled, ss.hitsOnHost, ss.alnOnHost}) if (e) (void) hipEventDestroy(e);
         if (d_->stepMail) pinnedFree(d_->stepMail);
+        for (int k = 0; k < 2; k++) { if (d_->ring[k]) pinnedFree(d_->ring[k]); if (d_->ringEv[k]) (void) hipEventDestroy(d_->ringEv[k]); }
         if (d_->mailbox) pinnedFree(d_->mailbox);
         if (d_->copyStream) (void) hipStreamSynchronize(d_->copyStream);
         if (d_->stream) giveStreams(d_->device, d_->stream);      // (idle now: the next context of this device takes the pair)
@@ -451,17 +455,25 @@ int Gpu::deviceCount() const { int n = 0; if (hipGetDeviceCount(&n) != hipSucces
 // What a process pays ONCE before its first kernel can run -- the HIP runtime, the device's context, this library's code object -- without anything that belongs to a search
 // context: a front end starts it on a second thread while it reads its DBs (sp_init_async)
 bool Gpu::warmUp(int device, std::string &err) {
+    const bool times = getenv("SP_MODULE_TIMES") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     int n = 0;
     HIP_OK(hipGetDeviceCount(&n));
     if (n <= 0) { err = "no HIP device visible"; return false; }
+    const double t1 = now();
     HIP_OK(hipSetDevice(device % n));
     HIP_OK(hipFree(nullptr));
+    const double t2 = now();
     void *p = nullptr;      // (a first allocation and a first kernel: the memory pools and the code object are there when the search context asks)
     HIP_OK(hipMalloc(&p, 1 << 20));
+    const double t3 = now();
     FillArgs fa{{p, nullptr, nullptr, nullptr}, {1 << 20, 0, 0, 0}, {0u, 0u, 0u, 0u}};
     hipLaunchKernelGGL(k_fill, dim3(4), dim3(256), 0, nullptr, fa);
     HIP_OK(hipDeviceSynchronize());
+    const double t4 = now();
     HIP_OK(hipFree(p));
+    if (times) fprintf(stderr, "[sp] runtime (second thread): device count %.1f ms, device + context %.1f ms, first allocation %.1f ms, code object + first kernel %.1f ms\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3);
     return true;
 }
 
@@ -1290,6 +1302,33 @@ static uint64_t deviceTextLimit() {
     static const uint64_t lim = [] { const char *e = getenv("SP_TEXT_LIMIT"); const uint64_t v = e ? strtoull(e, nullptr, 10) : 0; return v ? v : (1ull << 32) - (1ull << 20); }();
     return lim;
 }
+// Device -> host for a destination that may be ORDINARY memory (a one-shot process does not page-lock its result buffers: that costs 0.23 ms per MB).  The runtime's own
+// staging of such a copy took anything between 40 ms and 2.3 s for 170 MB on the pool's boxes; here the bytes go through two page-locked 8 MB buffers of the context,
+// the copy of chunk i + 1 running while the CPU moves chunk i to its place.  Page-locked destinations take the plain asynchronous copy.
+bool Gpu::Impl::copyOut(void *dst, const void *srcDev, size_t bytes, std::string &err) {
+    if (bytes == 0) return true;
+    hipPointerAttribute_t at;
+    const bool pinnedDst = hipPointerGetAttributes(&at, dst) == hipSuccess && at.type == hipMemoryTypeHost;
+    (void) hipGetLastError();      // (an unregistered pointer is an "error" of the query, not of the stream)
+    if (pinnedDst) { HIP_OK(hipMemcpyAsync(dst, srcDev, bytes, hipMemcpyDeviceToHost, stream)); return true; }
+    constexpr size_t kChunk = 8u << 20;
+    if (!ring[0]) { ring[0] = static_cast<char *>(pinnedAlloc(kChunk)); ring[1] = static_cast<char *>(pinnedAlloc(kChunk)); HIP_OK(hipEventCreateWithFlags(&ringEv[0], hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&ringEv[1], hipEventDisableTiming)); }
+    const size_t nChunks = (bytes + kChunk - 1) / kChunk;
+    auto issue = [&](size_t c) -> hipError_t {
+        const size_t off = c * kChunk, n = std::min(kChunk, bytes - off);
+        hipError_t e = hipMemcpyAsync(ring[c & 1], static_cast<const char *>(srcDev) + off, n, hipMemcpyDeviceToHost, stream);
+        return e != hipSuccess ? e : hipEventRecord(ringEv[c & 1], stream);
+    };
+    HIP_OK(issue(0));
+    for (size_t c = 0; c < nChunks; c++) {
+        if (c + 1 < nChunks) HIP_OK(issue(c + 1));
+        HIP_OK(hipEventSynchronize(ringEv[c & 1]));
+        const size_t off = c * kChunk, n = std::min(kChunk, bytes - off);
+        memcpy(static_cast<char *>(dst) + off, ring[c & 1], n);
+    }
+    return true;
+}
+
 bool Gpu::hitsText(char *text, uint64_t cap, uint64_t &used, uint32_t *entryLen, bool &declined, std::string &err) {
     Impl &d = *d_;
     used = 0; declined = false;
@@ -1314,8 +1353,7 @@ bool Gpu::hitsText(char *text, uint64_t cap, uint64_t &used, uint32_t *entryLen,
     a.text = d.txText.p;
     if (nHits) hipLaunchKernelGGL(k_hits_text_write, dim3((unsigned) ((nHits + 255) / 256)), dim3(256), 0, d.stream, a);
     hipLaunchKernelGGL(k_text_entry_ends, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.txLen.p, d.txOff.p, (uint32_t) nq_, d.txText.p);
-    HIP_OK(hipMemcpyAsync(text, d.txText.p, total, hipMemcpyDeviceToHost, d.stream));
-    HIP_OK(hipMemcpyAsync(entryLen, d.txLen.p, nq_ * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    if (!d.copyOut(text, d.txText.p, total, err) || !d.copyOut(entryLen, d.txLen.p, nq_ * sizeof(uint32_t), err)) return false;
     HIP_OK(hipStreamSynchronize(d.stream));
     return true;
 }
@@ -1338,7 +1376,7 @@ bool Gpu::textIndex(const uint32_t *keys, size_t n, uint64_t base, char *text, u
     if (!d.txIdxText.ensure((size_t) total + 16, err)) return false;
     a.text = d.txIdxText.p;
     hipLaunchKernelGGL(k_index_text_write, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, a);
-    HIP_OK(hipMemcpyAsync(text, d.txIdxText.p, total, hipMemcpyDeviceToHost, d.stream));
+    if (!d.copyOut(text, d.txIdxText.p, total, err)) return false;
     HIP_OK(hipStreamSynchronize(d.stream));
     return true;
 }
@@ -1383,8 +1421,7 @@ bool Gpu::alignHitsText(int gapOpen, int gapExtend, const GateTable &gate, Align
     a.text = d.txText.p;
     if (n) hipLaunchKernelGGL(k_aln_text_write, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, a);
     hipLaunchKernelGGL(k_text_entry_ends, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, d.txLen.p, d.txOff.p, (uint32_t) nq_, d.txText.p);
-    HIP_OK(hipMemcpyAsync(text, d.txText.p, back[0], hipMemcpyDeviceToHost, d.stream));
-    HIP_OK(hipMemcpyAsync(entryLen, d.txLen.p, nq_ * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    if (!d.copyOut(text, d.txText.p, back[0], err) || !d.copyOut(entryLen, d.txLen.p, nq_ * sizeof(uint32_t), err)) return false;
     HIP_OK(hipStreamSynchronize(d.stream));
     return true;
 }

@@ -55,7 +55,6 @@ static void *libSym(const char *name) {
     if (!f) { fprintf(stderr, "spacepharer-amd: libspacepharer_amd.so has no %s\n", name); exit(1); }
     return f;
 }
-static int sp_init(int mask) { return ((int (*)(int)) libSym("sp_init"))(mask); }
 static int sp_init_async(int mask) { return ((int (*)(int)) libSym("sp_init_async"))(mask); }
 static void sp_shutdown() { ((void (*)()) libSym("sp_shutdown"))(); }
 static const char *sp_last_error() { return ((const char *(*)()) libSym("sp_last_error"))(); }
@@ -262,27 +261,6 @@ int main(int argc, const char **argv) {
     // the parts and has no use for a device
     const char *gpus = getenv("SP_GPUS");
     const bool fanOut = gpus && atoi(gpus) > 1;
-    // A device module in a fresh process: the WORK runs in a child (forked here, before this process has loaded the library or touched the GPU); the parent returns the child's
-    // status as soon as the child has closed its output DBs, and the child's exit -- the driver unmapping some gigabytes of device buffers, 80-100 ms -- goes on behind the
-    // caller's back.  SP_DETACH_EXIT=0 (or SP_ORDERLY_EXIT=1) keeps everything in one process.
-    int reportFd = -1;
-    if (m->device && !fanOut && !getenv("SP_ORDERLY_EXIT") && !(getenv("SP_DETACH_EXIT") && atoi(getenv("SP_DETACH_EXIT")) == 0)) {
-        int pfd[2];
-        if (pipe(pfd) == 0) {
-            fflush(NULL);
-            const pid_t pid = fork();
-            if (pid > 0) {
-                close(pfd[1]);
-                int32_t rc = 1; ssize_t got = 0;
-                while ((got = read(pfd[0], &rc, sizeof(rc))) < 0 && errno == EINTR) { }
-                if (got == (ssize_t) sizeof(rc)) return rc;                      // the outputs are on disk; the worker finishes dying on its own
-                int st = 0; while (waitpid(pid, &st, 0) < 0 && errno == EINTR) { }      // the worker ended without reporting: its exit status says how
-                return WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
-            }
-            if (pid == 0) { close(pfd[0]); reportFd = pfd[1]; }
-            else { close(pfd[0]); close(pfd[1]); }      // (fork failed: run the module here)
-        }
-    }
     if (m->device && !fanOut) setenv("SP_ONESHOT", "1", 0);      // (before the library loads: it reads the variable once)
     (void) libSym("sp_last_error");
     const double tLib = nowMs();
@@ -297,13 +275,6 @@ int main(int argc, const char **argv) {
     // The outputs are on disk (write + close, nothing buffered).  Tearing the HIP runtime down in order -- contexts, 0.5 GB of tables,
     // code objects -- takes ~50 ms of a module call whose GPU work takes less; the kernel driver reclaims everything at exit anyway.
     // SP_ORDERLY_EXIT=1 keeps the orderly path (leak checkers).
-    if (reportFd >= 0) {      // tell the parent, let go of the caller's pipes (whoever reads them to the end must not wait for this process's exit), then leave
-        fflush(NULL);
-        const int32_t r = rc; (void) !write(reportFd, &r, sizeof(r)); close(reportFd);
-        const int nul = open("/dev/null", O_RDWR);
-        if (nul >= 0) { dup2(nul, 0); dup2(nul, 1); dup2(nul, 2); }
-        _exit(rc);
-    }
     if (m->device && !getenv("SP_ORDERLY_EXIT")) { fflush(NULL); _exit(rc); }
     if (m->device) sp_shutdown();
     return rc;

@@ -60,7 +60,9 @@ static bool oneShotProcess() { static const bool v = getenv("SP_ONESHOT") != nul
 
 struct Ctx {
     sp_ctx *c = nullptr; bool cached = false; bool targetsStaged = false;
-    ~Ctx() { if (c && !cached && !oneShotProcess()) sp_ctx_destroy(c); }      // (a process that ends with this call: the driver reclaims 10 GB of device buffers faster than hipFree gives them back one by one)
+    // (also in a process that ends with this call: left to the driver at exit, the 10 GB of device buffers are reclaimed BEHIND the exit -- and the next fresh process, the
+    // workflow's following module, then waits up to 2 s for its own first allocations; measured in round 6)
+    ~Ctx() { if (c && !cached) sp_ctx_destroy(c); }
 };
 struct CachedCtx { std::string key; sp_ctx *c; uint64_t stamp; std::string target; bool indexed; };
 static std::vector<CachedCtx> g_ctxCache; static uint64_t g_ctxStamp = 0; static std::mutex g_ctxMutex;

@@ -61,6 +61,29 @@ def worker(n_spacers, d, mode, n_targets=50000, light=False):
         procs.append(round(time.perf_counter() - t0, 4))
     out["process_total_s"] = procs
     out["process_spacer_queries_per_s"] = n_spacers / min(procs)
+    # where a fresh process of the fused call spends its time (SP_MODULE_TIMES=1: the front end's and the module's own laps), one more run
+    if mode != "two_step":
+        import re
+        for f in os.listdir(d):
+            if f.startswith("aln"):
+                os.remove(os.path.join(d, f))
+        t0 = time.perf_counter()
+        p = subprocess.run([exe, "search", q, t, aln, d] + sf, check=True, capture_output=True, text=True, env=dict(os.environ, SP_MODULE_TIMES="1"))
+        wall = time.perf_counter() - t0
+        laps = {"wall_s": round(wall, 4)}
+        for ln in p.stderr.splitlines():
+            m = re.match(r"\[sp\] search: (.+?)\s+([0-9.]+) ms$", ln)
+            if m:
+                laps[m.group(1).strip()] = float(m.group(2))
+            m = re.search(r"process: exec -> main ([0-9.]+) ms.*library loaded ([0-9.]+) ms.*module ([0-9.]+) ms; since exec ([0-9.]+) ms at exit", ln)
+            if m:
+                laps["exec_to_main_ms"], laps["library_loaded_ms"], laps["module_ms"], laps["since_exec_at_exit_ms"] = (float(x) for x in m.groups())
+                laps["exit_and_teardown_ms"] = round(wall * 1e3 - laps["since_exec_at_exit_ms"], 1)
+            m = re.search(r"runtime \(second thread\): .*code object \+ first kernel ([0-9.]+) ms", ln)
+            if m:
+                laps["code_object_and_first_kernel_ms"] = float(m.group(1))
+        laps["note"] = "`context (matrices, tables)` is mostly the wait for the HIP runtime, which comes up on a second thread from the process's first millisecond while the DBs are read"
+        out["fresh_process_laps"] = laps
     # the same client processes against a resident server (`spacepharer-amd serve`): runtime, tables and the target set stay up
     sock = os.path.join(d, "sp.sock")
     srv = subprocess.Popen([exe, "serve", sock], stderr=subprocess.DEVNULL)
