@@ -11,7 +11,10 @@ class SpError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(HERE, LIB_NAME)
+    # the product library lives in the package directory; instrumented / sanitized builds (make variant | phase | ablate | asan) in csrc/build/
+    here = os.path.join(HERE, LIB_NAME)
+    alt = os.path.join(HERE, "csrc", "build", LIB_NAME)
+    return alt if (LIB_NAME != "libspacepharer_amd.so" and not os.path.exists(here) and os.path.exists(alt)) else here
 
 
 def build_library():

@@ -206,6 +206,8 @@ struct DevBuf {
         if (p) (void) hipFree(p);
         p = nullptr; n = 0;
         size_t want = count + count / 8 + 64;
+        static const bool trace = getenv("SP_MEM_TRACE") != nullptr;      // (every device allocation of 32 MB or more, with the element size: which buffers a call asks the driver for)
+        if (trace && want * sizeof(T) >= (32u << 20)) fprintf(stderr, "[sp] hipMalloc %9.1f MB  (%zu elements of %zu bytes)\n", (double) (want * sizeof(T)) / 1e6, want, sizeof(T));
         hipError_t e = hipMalloc((void **) &p, want * sizeof(T));
         if (e != hipSuccess) { err = std::string("hipMalloc: ") + hipGetErrorString(e); return false; }
         n = want;
@@ -892,8 +894,10 @@ bool Gpu::queueSelect(unsigned binSize, int maxHits, int minDiagScore, void *hit
     Impl &d = *d_;
     const bool dbg = d.knob.debug;
     // a query's selected hits are staged where its diagonal records sit (they are at most as many): no separate layout pass
-    const size_t stageCap = std::max<size_t>(nq_ * (size_t) maxHits, d.diagCap);
-    if (!d.outHits.ensure(nq_ * (size_t) maxHits, err) || !d.outStage.ensure(stageCap, err) || !d.outQuery.ensure(stageCap, err)) return false;
+    // (... and a query has at most as many hits as diagonal records: the whole list never exceeds the record buffer -- nq x --max-seqs, 180 M entries = 3.6 GB in three buffers for
+    // 100 000 spacers, is a bound no batch reaches)
+    const size_t stageCap = d.diagCap;
+    if (!d.outHits.ensure(std::min<size_t>(nq_ * (size_t) maxHits, d.diagCap), err) || !d.outStage.ensure(stageCap, err) || !d.outQuery.ensure(stageCap, err)) return false;
     SelectArgs se{(uint32_t) nq_, d.diagRec.p, d.diagScore.p, d.qDiagBase.p, d.qDiagCnt.p, d.qbias.p, d.qself.p, d.qoff.p, d.diagFlag.p, d.spill.p, d.qDiagBase.p,
                   binSize - 1, maxHits, minDiagScore, d.outStage.p, d.outQuery.p, d.outCount.p, d.outBase.p, d.counters.p, d.tgt->denseIndex ? (uint32_t) std::max(1, d.knob.selChunkDense) : (uint32_t) kSelChunk,
                   (d.tgt->denseIndex && d.knob.selDynamic) ? d.queue.p + 2 : nullptr};      // (queue words 2, 3 are zeroed with the rest at the start of the pass: matchAndScore's k_fill)      // (dense index: every query takes the whole-wave path -- small chunks deal them evenly)
@@ -943,7 +947,8 @@ bool Gpu::stepBegin(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
     if (d.stepCap == 0) d.stepCap = counters_.hits ? (size_t) counters_.hits + (size_t) counters_.hits / 8 + 4096 : nq_ * 4 + 4096;
     // (... and by what the selection can deliver at all: nq x maxHits is what queueSelect() sizes the hit buffer for -- a small batch with a generous caller buffer
     // would otherwise copy past it)
-    const size_t cap = std::max<size_t>(1, std::min<size_t>({d.stepCap, (size_t) out.hitCap, (size_t) out.recordCap, (size_t) 0x7FFFFFF0u, nq_ * (size_t) std::max(1, maxHits)}));
+    const size_t cap = std::max<size_t>(1, std::min<size_t>({d.stepCap, (size_t) out.hitCap, (size_t) out.recordCap, (size_t) 0x7FFFFFF0u, nq_ * (size_t) std::max(1, maxHits),
+                                                              std::max<size_t>((size_t) 1 << 22, std::min<size_t>((size_t) 1 << 26, nq_ * 64))}));      // (... or the diagonal-record buffer, whichever is smaller: matchAndScore's diagCap)
     ss.cap = cap; ss.out = out;
     maxHits_ = maxHits;
     if (!d.stepWords.ensure(4, err)) return false;

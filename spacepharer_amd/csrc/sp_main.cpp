@@ -47,6 +47,7 @@ static void *libSym(const char *name) {
             std::string dir(exe); const size_t cut = dir.rfind('/'); dir = cut == std::string::npos ? "." : dir.substr(0, cut);
             const char *lib = getenv("SP_LIB_NAME");
             g_lib = dlopen((dir + "/" + (lib ? lib : "libspacepharer_amd.so")).c_str(), RTLD_NOW | RTLD_GLOBAL);
+            if (!g_lib && lib) g_lib = dlopen((dir + "/csrc/build/" + lib).c_str(), RTLD_NOW | RTLD_GLOBAL);      // (instrumented / sanitized builds: make variant | asan)
         }
         if (!g_lib) g_lib = dlopen("libspacepharer_amd.so", RTLD_NOW | RTLD_GLOBAL);
         if (!g_lib) { fprintf(stderr, "spacepharer-amd: cannot load libspacepharer_amd.so: %s\n", dlerror()); exit(1); }

@@ -5,6 +5,7 @@
 //   lib/mmseqs/src/alignment/rescorediagonal.cpp:381-431  (rescorediagonal)
 // Host orchestration only: every score comes from the HIP kernels behind the in-memory C ABI.
 #include "sp_modules.h"
+#include "sp_gpu.h"
 
 #include <algorithm>
 #include <climits>
@@ -406,6 +407,11 @@ struct Laps {
     bool on = getenv("SP_MODULE_TIMES") != nullptr; const char *module;
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     explicit Laps(const char *m) : module(m) {}
+    void memory(const char *what) {      // device memory in use (all processes): what a fresh process asks the driver for, and what the driver clears behind it
+        if (!on) return;
+        size_t fr = 0, tot = 0;
+        if (sp::deviceMemory(fr, tot)) fprintf(stderr, "[sp] %s: %-28s %8.2f GB of device memory in use\n", module, what, (double) (tot - fr) / 1e9);
+    }
     void lap(const char *what) {
         if (!on) return;
         const auto n = std::chrono::steady_clock::now();
@@ -871,6 +877,7 @@ int runSearchModule(int argc, const char **argv) {
         if (sp_ctx_set_targets(ctx.c, tres.data(), toff.data(), tkeys.data(), tkeys.size()) != SP_OK) { const std::string e = sp_last_error(); dropCtx(ctx); return fail("search: " + e); }
     }
     laps.lap("targets -> device, index");
+    laps.memory("after the target set");
     const double minSeqId = f.real("--min-seq-id", 0.0); const long minAlnLen = f.num("--min-aln-len", 0);
     const long maxAccept = f.num("--max-accept", INT_MAX), maxRejected = f.num("--max-rejected", INT_MAX);
     const int threads = (int) f.num("--threads", 0) > 0 ? (int) f.num("--threads", 0) : defaultThreads();
@@ -981,6 +988,7 @@ int runSearchModule(int argc, const char **argv) {
     freeBufs();
     if (!w.close(err)) return fail("search: " + err);
     laps.lap("write DB");
+    laps.memory("at the end of the call");
     return 0;
 }
 

@@ -31,6 +31,8 @@ def binary_identity():
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, "spacepharer_amd", os.environ.get("SP_LIB_NAME", "libspacepharer_amd.so"))
+    if not os.path.exists(lib):
+        lib = os.path.join(root, "spacepharer_amd", "csrc", "build", os.path.basename(lib))
     out = {"library": os.path.basename(lib), "library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None}
     h = hashlib.sha256()
     src = os.path.join(root, "spacepharer_amd", "csrc")
