@@ -605,31 +605,48 @@ def main():
                 acc[i][2] += 0.0 if v != v else v
 
         region_dt, region_match, region_active, checked = [], [], [], 0
+        done = {}
+
+        def exchanger():      # collectives from ONE host thread per rank, steps in the order (round, context)
+            for j in range(max(share)):
+                for i2 in range(n_pipe):
+                    if j < share[i2]:
+                        done[id(slots[i2][j])].wait()
+                        exchange_hits(slots[i2][j])
+        # the contexts' host threads exist BEFORE the clock starts and wait at a gate (round 6: starting four Python threads inside the timed region cost 0.2-0.4 ms of a 20-step
+        # region of 9 ms); a region = gate opens -> every thread runs its share of the K steps -> all are back
+        jobs = [lambda i=i: run(i) for i in range(n_pipe)] + ([exchanger] if partition and world > 1 else [])
+        gate_in, gate_out, stop, failed = threading.Barrier(len(jobs) + 1), threading.Barrier(len(jobs) + 1), [False], []
+
+        def worker(job):
+            while True:
+                gate_in.wait()
+                if stop[0]:
+                    return
+                try:
+                    job()
+                except BaseException as e:      # noqa: BLE001  (reported by the main thread after the region)
+                    failed.append(e)
+                gate_out.wait()
+        pool = [threading.Thread(target=worker, args=(job,), daemon=True) for job in jobs] if len(jobs) > 1 else []
+        for th in pool:
+            th.start()
         for _ in range(regions):
             for a in acc:
                 a[0] = 0.0
                 a[2] = 0.0
             xch.update(s=0.0, bytes=0, n=0)
+            done.clear()
+            done.update({id(sl): threading.Event() for grp in slots for sl in grp})
             barrier()
             t0 = time.perf_counter()
-            done = {id(sl): threading.Event() for grp in slots for sl in grp}
-
-            def exchanger():      # collectives from ONE host thread per rank, steps in the order (round, context)
-                for j in range(max(share)):
-                    for i2 in range(n_pipe):
-                        if j < share[i2]:
-                            done[id(slots[i2][j])].wait()
-                            exchange_hits(slots[i2][j])
-            threads = [threading.Thread(target=run, args=(i,)) for i in range(n_pipe)]
-            if partition and world > 1:
-                threads.append(threading.Thread(target=exchanger))
-            if len(threads) == 1:
+            if not pool:
                 run(0)
             else:
-                for th in threads:
-                    th.start()
-                for th in threads:
-                    th.join()
+                gate_in.wait()
+                gate_out.wait()
+                if failed:
+                    raise failed[0]
             barrier()
             dt = time.perf_counter() - t0
             region_dt.append(all_max(dt))
@@ -642,6 +659,11 @@ def main():
                     if not s.hits_ptr_ok or s.digest(full) != ref[i]:
                         raise RuntimeError("rank %d: result of step %d of context %d differs from the single-context result of the same batch" % (rank, j, i))
                     checked += 1
+        if pool:
+            stop[0] = True
+            gate_in.wait()
+            for th in pool:
+                th.join()
         xch_region = dict(xch)
         pairs = [acc[i][1] for i in range(n_pipe)]
         stats = None

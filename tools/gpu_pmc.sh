@@ -12,6 +12,6 @@ cd $R
 python3 tools/pmc_summary.py gpurun_out/pmc_traffic.json $(find gpurun_out/pmc_fetch gpurun_out/pmc_write -name '*counter_collection.csv')
 python3 tools/pmc_summary.py gpurun_out/pmc_sq.json $(find gpurun_out/pmc_sq gpurun_out/pmc_lds -name '*counter_collection.csv') | cut -c1-400
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_full -o full -- python3 $R/bench.py --steps 100 --warmup 3 --regions 2 --cpu-sample 0 --no-module-e2e --no-dense 2>&1 | grep "^{" | tail -1 > $R/gpurun_out/bench_under_rocprof.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_full -o full -- python3 $R/bench.py --steps 100 --warmup 3 --regions 2 --cpu-sample 0 --no-module-e2e --no-dense --no-probe-proxy 2>&1 | grep "^{" | tail -1 > $R/gpurun_out/bench_under_rocprof.json
 cat $R/gpurun_out/prof_full/full_kernel_stats.csv | cut -c1-200
 cd $R && timeout 900 python3 bench.py > gpurun_out/bench_default.json 2>gpurun_out/bench_default.err; cut -c1-600 gpurun_out/bench_default.json
