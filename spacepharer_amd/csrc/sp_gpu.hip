@@ -262,7 +262,7 @@ struct Gpu::Impl {
         DevBuf<uint64_t> buckets; bool bucketsValid = false; DevBuf<uint64_t> buckets2; bool buckets2Valid = false;      // (buckets2: the 64-byte double buckets of k_match_dense)
         DevBuf<uint64_t> slotDirect; bool slotDirectValid = false; size_t indexSlots = 0; uint64_t buildSerial = 0;      // large-footprint layout of the slot table, derived from slots / ientries on first use
         DevBuf<uint64_t> pbits; DevBuf<uint16_t> prank; DevBuf<uint32_t> prow; DevBuf<uint64_t> slots; DevBuf<uint64_t> ientries; DevBuf<uint8_t> tmasked; DevBuf<uint8_t> tplain; DevBuf<char> tascii; DevBuf<uint64_t> toff; DevBuf<uint32_t> tkeys;
-        size_t nTargets = 0; size_t indexEntries = 0;
+        size_t nTargets = 0; size_t indexEntries = 0; uint64_t maxTLen = 0;      // (maxTLen: longest target -- k_sw_fwd1p packs end columns in 16 bits)
         bool denseIndex = false;      // 1.5+ entries per occupied k-mer on average: k_match runs with its large footprint
         std::mutex mu;      // the bucket table is derived by whichever sharing context needs it first
     };
@@ -1489,6 +1489,8 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
     const uint64_t R = ts.offsets[n];
     if (d.tgt.use_count() > 1) d.tgt = std::make_shared<Impl::Targets>();      // a shared target set belongs to the others from here on: this context stages its own
     d.tgt->nTargets = n; d.tgt->indexEntries = 0; d.tgt->indexSlots = 0; d.tgt->bucketsValid = false; d.tgt->buckets2Valid = false; d.tgt->slotDirectValid = false; { static std::atomic<uint64_t> serial{0}; d.tgt->buildSerial = ++serial; }
+    d.tgt->maxTLen = 0;
+    for (size_t i = 0; i < n; i++) d.tgt->maxTLen = std::max<uint64_t>(d.tgt->maxTLen, ts.offsets[i + 1] - ts.offsets[i]);
     out = TargetBuild();
     if (!upload(d.tgt->tascii, ascii, (size_t) R, d.stream, err) || !upload(d.tgt->toff, ts.offsets.data(), n + 1, d.stream, err) ||
         !upload(d.tgt->tkeys, ts.keys.data(), n, d.stream, err)) return false;

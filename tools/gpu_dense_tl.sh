@@ -3,8 +3,8 @@
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/dtl
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/dtl -o tl -- python3 $R/bench.py --targets 1000000 --cpu-sample 0 --no-module-e2e --no-dense --no-probe-proxy --steps 10 --regions 2 --warmup 2 --pipeline 2 --host-driven > /dev/null 2>&1
-python3 - $R/gpurun_out/dtl <<'PY' > $R/gpurun_out/dense_tl.txt
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/dtl -o tl -- python3 $R/bench.py --targets 1000000 --cpu-sample 0 --no-module-e2e --no-dense --no-probe-proxy --steps 10 --regions 2 --warmup 2 --pipeline 2 --host-driven ${BENCH_FLAGS} > /dev/null 2>&1
+python3 - $R/gpurun_out/dtl <<'PY' > $R/gpurun_out/${1:-dense_tl}.txt
 import csv, glob, sys
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
