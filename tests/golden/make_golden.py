@@ -98,6 +98,10 @@ CASES = {
     # targets beyond 32 768 residues: 16-bit diagonals wrap and UngappedAlignment scores such diagonals in pieces
     # (UngappedAlignment.cpp:216-233 computeLongScore); see make_long_target_case
     "longt":   (31, 40, 60, 50, 300, 10, 40, 0, ["--dump-kmers", "0"]),
+    # other sensitivities than the workflow's 5.7 (PredictMatch.cpp:11): -s 7.5 = k-mer threshold 96, long similar-k-mer lists, and -s 1 = threshold 154, nearly
+    # exact k-mers only; --max-seqs 50 cuts inside the lists of the family members (round 6)
+    "sens75":  (4242, 1200, 300, 40, 300, 9, 14, 2, ["--dump-kmers", "2", "-s", "7.5", "--max-seqs", "50"]),
+    "sens1":   (4243, 1200, 300, 40, 300, 9, 30, 2, ["--dump-kmers", "2", "-s", "1", "--max-seqs", "300"]),
 }
 
 
@@ -162,10 +166,13 @@ def cross_check(d, T, Q, ref, flags):
     if not os.path.exists(REF_BINARY) or "--bin-size" in flags:
         return False
     max_seqs = flags[flags.index("--max-seqs") + 1] if "--max-seqs" in flags else "300"
+    pref_flags = list(PREF_FLAGS)
+    if "-s" in flags:
+        pref_flags[pref_flags.index("-s") + 1] = flags[flags.index("-s") + 1]
     q, t, pref, aln = (os.path.join(d, x) for x in ("qdb", "tdb", "pref", "aln"))
     write_db(q, Q)
     write_db(t, T)
-    subprocess.check_call([REF_BINARY, "prefilter", q, t, pref, "--max-seqs", max_seqs] + PREF_FLAGS, stdout=subprocess.DEVNULL)
+    subprocess.check_call([REF_BINARY, "prefilter", q, t, pref, "--max-seqs", max_seqs] + pref_flags, stdout=subprocess.DEVNULL)
     subprocess.check_call([REF_BINARY, "align", q, t, pref, aln] + ALN_FLAGS, stdout=subprocess.DEVNULL)
     got_pref, got_aln = read_db(pref), read_db(aln)
     exp_pref = {x["id"]: x["pref"] for x in ref["queries"]}

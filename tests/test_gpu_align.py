@@ -6,7 +6,7 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["small", "spacer", "family", "longq", "family16", "longt"]
+CASES = ["small", "spacer", "family", "longq", "family16", "longt", "sens75", "sens1"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -100,6 +100,41 @@ def test_align_matches_oracle_on_fresh_inputs():
         if e.passed:
             assert (res.q_start, res.db_start, res.aln_len, res.evalue, cig) == (e.qStartPos, e.dbStartPos, e.alnLength, e.eval, e.backtrace.decode())
             assert res.seq_id == e.seqId
+    ctx.close()
+    o.close()
+
+
+def test_align_against_a_target_longer_than_65535_residues():
+    """the forward kernel for short queries packs end columns in 16 bits; a target set with a longer target takes the general kernel: ends beyond column 65 535 vs the oracle"""
+    import random
+    from golden.make_golden import make_case, rand_seq
+    from oracle_lib import Alp, Oracle
+    import spacepharer_amd as sa
+    g = load_golden("spacer")["ref"]
+    T, _ = make_case(seed=5, n_targets=40, n_queries=1, tmin=30, tmax=300, qmin=9, qmax=12, families=0)
+    rng = random.Random(17)
+    T.append(rand_seq(rng, 70000))
+    Q, pairs = [], []
+    for pos in (0, 1000, 32760, 65530, 65536, 66000, 69990):      # windows of the long target (one substitution each), and the same queries against a short target
+        q = list(T[-1][pos:pos + 10])
+        q[4] = "W" if q[4] != "W" else "Y"
+        Q.append("".join(q))
+        pairs += [(len(Q) - 1, len(T) - 1), (len(Q) - 1, 3)]
+    o = Oracle()
+    o.set_targets(T)
+    o.set_alp(Alp.from_ref(g["alpGapped"]), Alp.from_ref(g["alpGapless"]))
+    ctx = sa.SearchContext()
+    ctx.set_targets(T)
+    ctx.set_queries(Q)
+    got = ctx.align(pairs)
+    far = 0
+    for (qi, ti), (res, cig) in zip(pairs, got):
+        e = o.align(Q[qi], ti)
+        assert (res.raw_score, res.bit_score, res.q_end, res.db_end, res.passed) == (e.rawScore, e.score, e.qEndPos, e.dbEndPos, e.passed), (qi, ti)
+        if e.passed:
+            assert (res.q_start, res.db_start, res.aln_len, res.evalue, cig) == (e.qStartPos, e.dbStartPos, e.alnLength, e.eval, e.backtrace.decode())
+        far += e.dbEndPos > 65535
+    assert far >= 3
     ctx.close()
     o.close()
 

@@ -6,7 +6,7 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["small", "spacer", "family", "longq", "family16", "longt"]
+CASES = ["small", "spacer", "family", "longq", "family16", "longt", "sens75", "sens1"]
 
 
 def _ctx(r):

@@ -8,7 +8,7 @@ import pytest
 from conftest import load_golden
 from oracle_lib import Alp, Oracle, lib
 
-CASES = ["small", "spacer", "family", "longq", "family16", "longt"]
+CASES = ["small", "spacer", "family", "longq", "family16", "longt", "sens75", "sens1"]
 _or = {}
 
 
