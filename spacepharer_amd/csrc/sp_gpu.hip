@@ -579,8 +579,12 @@ bool Gpu::uploadTables(const SubMat &seed, const SubMat &ung, const SubMat &aln,
         if (hi - lo + 2 > kCntW || hi - lo >= 1024) { err = "seed matrix 3-mer score range " + std::to_string(hi - lo) + " exceeds the count-table width"; return false; }
         d.tab->cntMin = lo;
         DevBuf<uint32_t> k1, k2, v1, v2; DevBuf<unsigned char> tmp;
+        const bool laps = getenv("SP_MODULE_TIMES") != nullptr;
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = now();
         if (!d.tab->ext3.ensure(N2, err) || !d.tab->ext3cnt.ensure((size_t) 8000 * kCntW, err) || !k1.ensure(N2, err) || !k2.ensure(N2, err) || !v1.ensure(N2, err) || !v2.ensure(N2, err)) return false;
         ea.hi = hi; ea.keys = k1.p; ea.vals = v1.p;
+        const double t1 = now();
         hipLaunchKernelGGL(k_ext3_fill, dim3((unsigned) (N2 / 256)), dim3(256), 0, d.stream, ea);
         size_t tempBytes = 0;
         HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, k1.p, k2.p, v1.p, v2.p, (int) N2, 0, 23, d.stream));
@@ -599,8 +603,10 @@ bool Gpu::uploadTables(const SubMat &seed, const SubMat &ung, const SubMat &aln,
         }
         HIP_OK(hipGetLastError());
         HIP_OK(hipStreamSynchronize(d.stream));
+        const double t2 = now();
         for (DevBuf<uint32_t> *b : {&k1, &k2, &v1, &v2}) { (void) hipFree(b->p); b->p = nullptr; }
         (void) hipFree(tmp.p); tmp.p = nullptr;
+        if (laps) fprintf(stderr, "[sp]   similar-3-mer table: buffers %.1f ms, fill + sort + pack + counts %.1f ms, buffers returned %.1f ms\n", t1 - t0, t2 - t1, now() - t2);
     }
     short s16[kAlph * kAlph]; signed char u8[kAlph * kAlph], a8[kAlph * kAlph]; short a16[kAlph * kAlph];
     int mn = 0, mnAln = 0;
