@@ -48,7 +48,7 @@ static size_t words(const char *p, const char **w, size_t maxW) {
 }
 static const char *skipLine(const char *p) { while (*p != '\n' && *p != '\0') p++; return *p == '\n' ? p + 1 : p; }
 static unsigned long atou(const char *p) { unsigned long v = 0; while (*p >= '0' && *p <= '9') v = v * 10 + (unsigned long) (*p++ - '0'); return v; }
-static long atoiS(const char *p) { bool neg = *p == '-'; if (neg || *p == '+') p++; long v = (long) atou(p); return neg ? -v : v; }
+static long atoiS(const char *p) { bool neg = *p == '-'; if (neg || *p == '+') p++; unsigned long u = atou(p); if (u > (unsigned long) LONG_MAX) u = (unsigned long) LONG_MAX; const long v = (long) u; return neg ? -v : v; }
 
 // ------------------------------------------------------------------------------------------------------------------
 // ORFs (commons/Orf.cpp)
@@ -245,13 +245,15 @@ bool proteinLineToNucl(const char *line, const NuclScorer &sc, const char *qNuc,
     r.db_key = (uint32_t) atou(w[0]);
     long qs = atoiS(w[4]), qe = atoiS(w[5]), ts = atoiS(w[7]), te = atoiS(w[8]);
     if ((qStartCodon && qs == 0) || (tStartCodon && ts == 0)) { err = "proteinaln2nucl: alignment contains an unalignable character"; return false; }
+    const long lim = 1L << 40;      // (positions of a damaged record: nothing below multiplies or adds past a long -- UBSan on the fuzzed DBs of tests/test_host_fuzz.py)
+    if (qs < -lim || qs > lim || qe < -lim || qe > lim || ts < -lim || ts > lim || te < -lim || te > lim) { err = "proteinaln2nucl: invalid alignment result record"; return false; }
     ts = ts * 3 + (tStartCodon ? -3 : 0); te = te * 3 + 2 + (tStartCodon ? -3 : 0);
     qs = qs * 3 + (qStartCodon ? -3 : 0); qe = qe * 3 + 2 + (qStartCodon ? -3 : 0);
     size_t ids = 0, alnLen = 0; long qPos = qs, tPos = ts; int score = 0;
     std::string bt; char nb[16];
     for (const char *p = w[10]; *p != '\n' && *p != '\0' && !isWs(*p); p++) {
         int cnt = 0;
-        if (*p >= '0' && *p <= '9') { cnt = (int) atou(p); while (*p >= '0' && *p <= '9') p++; }
+        if (*p >= '0' && *p <= '9') { const unsigned long c = atou(p); if (c > (1ul << 28)) { err = "proteinaln2nucl: invalid alignment result record"; return false; } cnt = (int) c; while (*p >= '0' && *p <= '9') p++; }
         const char op = *p;
         if (op == 'M') {
             if (qPos < 0 || tPos < 0 || qPos + (long) cnt * 3 > (long) qNucLen || tPos + (long) cnt * 3 > (long) tNucLen) { err = "proteinaln2nucl: an alignment runs past its nucleotide ORF (peptide and nucleotide DBs disagree)"; return false; }
@@ -939,7 +941,7 @@ int runFilterMatchByFdr(int argc, const char **argv) {
     for (size_t i = 0; i < pos.entries.size(); i++) {
         out.clear();
         for (const char *p = pos.ptr(i); *p != '\0';) {
-            words(p, c, 8);
+            if (words(p, c, 8) < 3) return fail("filtermatchbyfdr: invalid result record (a score line has three columns)");      // (found by tests/test_host_fuzz.py: c[3] of a shorter line is the previous line's)
             const double score = strtod(c[1], NULL);
             p = skipLine(p);
             if (score < r.threshold) continue;
@@ -1060,6 +1062,9 @@ struct SummaryOptions { int fmt = 1; bool reportFdr = false; const TaxTable *tax
 // one match entry joined with the alignment lines of its query set (SummarizeResults.cpp:66-180); fmt: 0 short, 1 long, 2 long + alignment
 static bool summarizeEntry(const char *match, const char *aln, const SummaryOptions &o, std::string &out, std::string &err) {
     const char *e[20]; std::string cScore, fdr, tmp; char nb[24];
+    // a column without the separator behind it; a line that ends in white space has an EMPTY last word (words() is Util::getWordsOfLine), whose "length" would be -1
+    // (tests/test_host_fuzz.py found it: basic_string::append threw)
+    auto col = [](std::string &to, const char *from, const char *next) { if (next > from + 1) to.append(from, (size_t) (next - from - 1)); };
     for (const char *m = match; *m != '\0';) {
         const size_t matchColumns = words(m, e, 20);
         if (matchColumns < 2) { err = "summarizeresults: invalid match record"; return false; }
@@ -1071,10 +1076,10 @@ static bool summarizeEntry(const char *match, const char *aln, const SummaryOpti
             if (atou(cur) != targetSet) { cur = skipLine(cur); continue; }
             if (lines == 0) { cScore.assign(e[1], (size_t) (e[2] - e[1])); if (o.reportFdr) fdr.assign(e[3], (size_t) (e[4] - e[3])); }
             const size_t columns = words(cur, e, 20);
-            if (columns < 10) { err = "summarizeresults: invalid alignment result record"; return false; }
+            if (columns < 10 || (o.fmt == 2 && columns < 12)) { err = "summarizeresults: invalid alignment result record"; return false; }
             cur = skipLine(cur);
             if (lines == 0) {
-                out.push_back('#'); out.append(e[2], (size_t) (e[3] - e[2] - 1)); out.push_back('\t'); out.append(e[3], (size_t) (e[4] - e[3] - 1)); out.push_back('\t'); out += cScore;
+                out.push_back('#'); col(out, e[2], e[3]); out.push_back('\t'); col(out, e[3], e[4]); out.push_back('\t'); out += cScore;
                 if (o.reportFdr) { out += fdr; out.push_back('\t'); }
                 if (o.tax) {
                     if (columns < 13) { err = "summarizeresults: the target set has a taxonomy but the alignment records carry no taxid column"; return false; }
@@ -1083,10 +1088,10 @@ static bool summarizeEntry(const char *match, const char *aln, const SummaryOpti
             }
             lines++;
             if (o.fmt != 1 && o.fmt != 2) continue;
-            tmp.push_back('>'); tmp.append(e[1], (size_t) (e[2] - e[1] - 1));
-            for (int c : {3, 4, 5, 6, 8, 9}) { tmp.push_back('\t'); tmp.append(e[c], (size_t) (e[c + 1] - e[c] - 1)); }
-            if (columns == 15) { tmp.push_back('\t'); tmp.append(e[13], (size_t) (e[14] - e[13] - 1)); tmp.push_back('\t'); tmp.append(e[14], (size_t) (e[15] - e[14])); }
-            if (o.fmt == 2) { tmp.push_back('\n'); tmp.append(e[10], (size_t) (e[11] - e[10] - 1)); tmp.push_back('\n'); tmp.append(e[11], (size_t) (e[12] - e[11] - 1)); }
+            tmp.push_back('>'); col(tmp, e[1], e[2]);
+            for (int c : {3, 4, 5, 6, 8, 9}) { tmp.push_back('\t'); col(tmp, e[c], e[c + 1]); }
+            if (columns == 15) { tmp.push_back('\t'); col(tmp, e[13], e[14]); tmp.push_back('\t'); tmp.append(e[14], (size_t) (e[15] - e[14])); }
+            if (o.fmt == 2) { tmp.push_back('\n'); col(tmp, e[10], e[11]); tmp.push_back('\n'); col(tmp, e[11], e[12]); }
             tmp.push_back('\n');
         }
         if (lines > 0) {
