@@ -104,6 +104,55 @@ def test_align_matches_oracle_on_fresh_inputs():
     o.close()
 
 
+@pytest.mark.parametrize("gap_open,gap_extend", [(11, 1), (5, 1), (8, 3), (16, 2)])
+def test_align_with_other_gap_penalties_against_oracle(gap_open, gap_extend, monkeypatch):
+    """cheap gaps make the lazy-F step of the forward pass (its one-row shortcut, its closed-form scan) and the banded traceback do real work; query lengths cover
+    every width of the packed kernels (10 / 12 / 16 / 32 rows) and the striped ones beyond.  The Gumbel parameters are the tabulated 16/2 set on both sides
+    (SP_ALP_PARAMS here, set_alp there): scores, ends, starts and backtraces are what is compared"""
+    import random
+    from golden.make_golden import make_case, mutate, rand_seq
+    from oracle_lib import Alp, Oracle
+    import spacepharer_amd as sa
+    g = load_golden("spacer")["ref"]
+    names = ["lambda", "K", "a_I", "b_I", "alpha_I", "beta_I", "a_J", "b_J", "alpha_J", "beta_J", "sigma", "tau"]
+    monkeypatch.setenv("SP_ALP_PARAMS", ",".join(repr(float.fromhex(g["alpGapped"][n])) for n in names))
+    rng = random.Random(1000 * gap_open + gap_extend)
+    T, _ = make_case(seed=rng.randrange(1 << 30), n_targets=300, n_queries=1, tmin=60, tmax=400, qmin=9, qmax=12, families=1)
+    o = Oracle()
+    o.set_targets(T)
+    o.set_alp(Alp.from_ref(g["alpGapped"]), Alp.from_ref(g["alpGapless"]))
+    for qmax in (10, 12, 16, 32, 60):
+        Q, pairs = [], []
+        for _ in range(160):
+            ti = rng.randrange(len(T))
+            L = rng.randint(max(6, qmax - 4), qmax)
+            p = rng.randrange(0, len(T[ti]) - L + 1)
+            q = mutate(rng, T[ti][p:p + L], rng.choice([0, 1, 2]))
+            if L > 8 and rng.random() < 0.6:      # one or two gaps against the target
+                for _g in range(rng.choice([1, 1, 2])):
+                    c = rng.randrange(2, len(q) - 2)
+                    q = q[:c] + rand_seq(rng, rng.randint(1, 3)) + q[c:] if rng.random() < 0.5 else q[:c] + q[c + rng.randint(1, 2):]
+            q = q[:qmax]
+            if len(q) < 6:
+                continue
+            Q.append(q)
+            pairs += [(len(Q) - 1, ti), (len(Q) - 1, rng.randrange(len(T)))]
+        ctx = sa.SearchContext(gap_open=gap_open, gap_extend=gap_extend)
+        ctx.set_targets(T)
+        ctx.set_queries(Q)
+        got = ctx.align(pairs)
+        gapped = 0
+        for (qi, ti), (res, cig) in zip(pairs, got):
+            e = o.align(Q[qi], ti, gap_open=gap_open, gap_extend=gap_extend)
+            assert (res.raw_score, res.q_end, res.db_end, res.passed) == (e.rawScore, e.qEndPos, e.dbEndPos, e.passed), (qmax, qi, ti, Q[qi])
+            if e.passed:
+                assert (res.q_start, res.db_start, res.aln_len, cig) == (e.qStartPos, e.dbStartPos, e.alnLength, e.backtrace.decode()), (qmax, qi, ti, Q[qi])
+                gapped += ("I" in cig) or ("D" in cig)
+        assert gapped >= (3 if gap_open <= 11 else 0), (qmax, gapped)
+        ctx.close()
+    o.close()
+
+
 def test_align_against_a_target_longer_than_65535_residues():
     """the forward kernel for short queries packs end columns in 16 bits; a target set with a longer target takes the general kernel: ends beyond column 65 535 vs the oracle"""
     import random
