@@ -274,7 +274,7 @@ struct Gpu::Impl {
     // index construction scratch (kept for the next target set)
     DevBuf<uint32_t> ixKeys, ixKeys2, ixKeep, ixPos, ixKmer, ixHead, ixSlotOf, ixHeadPos, ixCnt, ixBefore; DevBuf<uint64_t> ixVals, ixVals2;
     DevBuf<unsigned char> ixTemp; DevBuf<float> ttProbs; DevBuf<double> ttScale, ttLr; DevBuf<uint64_t> ttPlane; DevBuf<unsigned long long> ixCounters;
-    DevBuf<uint32_t> txLen, txOff, txLineOff, txLineLen, txFlags; DevBuf<char> txText, txIdxText; DevBuf<uint32_t> txKeys, txIdxLen, txIdxOff; DevBuf<unsigned long long> txTotal; DevBuf<unsigned char> txEval; uint64_t txEvalVersion = 0;      // device-side result text (sp_gpu_text.inc)
+    DevBuf<uint32_t> txLen, txOff, txLineOff, txLineLen, txFlags, txWaveList; DevBuf<char> txText, txIdxText; DevBuf<uint32_t> txKeys, txIdxLen, txIdxOff; DevBuf<unsigned long long> txTotal; DevBuf<unsigned char> txEval; uint64_t txEvalVersion = 0;      // device-side result text (sp_gpu_text.inc)
     // queries
     DevBuf<uint8_t> qres; DevBuf<uint32_t> qoff; DevBuf<float> biasf; DevBuf<short> qthr; DevBuf<signed char> qcorr; DevBuf<int> qbias; DevBuf<int> qself;
     size_t qTotal = 0; uint32_t maxQLen = 0;
@@ -1348,6 +1348,7 @@ bool Gpu::hitsText(char *text, uint64_t cap, uint64_t &used, uint32_t *entryLen,
     const size_t nHits = (size_t) counters_.hits;
     if (!d.txLen.ensure(nq_ + 1, err) || !d.txOff.ensure(nq_ + 2, err) || !d.txLineOff.ensure(nHits + 1, err)) return false;
     HitTextArgs a{d.outHits.p, d.outOffset.p, d.outQuery.p, (uint32_t) nq_, d.outOffset.p + nq_, d.tgt->tkeys.p, d.txLen.p, d.txOff.p, d.txLineOff.p, nullptr};
+    if (nHits) hipLaunchKernelGGL(k_hits_text_linelen, dim3((unsigned) ((nHits + 255) / 256)), dim3(256), 0, d.stream, a);
     hipLaunchKernelGGL(k_hits_text_len, dim3((unsigned) ((nq_ + 255) / 256)), dim3(256), 0, d.stream, a);
     if (!d.txTotal.ensure(2, err)) return false;
     HIP_OK(hipMemsetAsync(d.txTotal.p, 0, sizeof(unsigned long long), d.stream));
@@ -1411,11 +1412,14 @@ bool Gpu::alignHitsText(int gapOpen, int gapExtend, const GateTable &gate, Align
     }
     HIP_OK(hipMemsetAsync(d.txFlags.p, 0, 4 * sizeof(uint32_t), d.stream));
     AlnTextArgs a{s.rec.p, s.cig.p, d.outOffset.p, d.outQuery.p, (uint32_t) nq_, d.outOffset.p + nq_, minSeqId, minAlnLen, d.txEval.p, s.gateSlot.p, gate.stride,
-                  d.txLineLen.p, d.txLineOff.p, d.txLen.p, d.txOff.p, nullptr, d.txFlags.p, 0u};
+                  d.txLineLen.p, d.txLineOff.p, d.txLen.p, d.txOff.p, nullptr, d.txFlags.p, 0u, nullptr};
+    if (!d.txWaveList.ensure(nq_ + 1, err)) return false;
+    a.waveList = d.txWaveList.p;
     a.waveServes = n >= 2 * nq_ ? 1u : 0u;
     if (const char *e = getenv("SP_TEXT_WAVE")) a.waveServes = *e != '0' ? 1u : 0u;      // (tests: either kernel on any batch)      // (two or more alignments per query on average -- the dense index: a wave per query for those with 2 .. 64 records)
+    if (n) hipLaunchKernelGGL(k_aln_text_linelen, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d.stream, a);
     hipLaunchKernelGGL(k_aln_text_measure, dim3((unsigned) ((nq_ + 63) / 64)), dim3(64), 0, d.stream, a);
-    if (a.waveServes) hipLaunchKernelGGL(k_aln_text_measure_wave, dim3((unsigned) std::min<size_t>((nq_ + 3) / 4, (size_t) d.numCU * 8)), dim3(256), 0, d.stream, a);
+    hipLaunchKernelGGL(k_aln_text_measure_wave, dim3((unsigned) std::min<size_t>((nq_ + 3) / 4, (size_t) d.numCU * (a.waveServes ? 8 : 2))), dim3(256), 0, d.stream, a);
     if (!d.txTotal.ensure(2, err)) return false;
     HIP_OK(hipMemsetAsync(d.txTotal.p, 0, sizeof(unsigned long long), d.stream));
     hipLaunchKernelGGL(k_sum_u64, dim3((unsigned) std::min<size_t>((nq_ + 255) / 256, 1024)), dim3(256), 0, d.stream, d.txLen.p, (uint32_t) nq_, d.txTotal.p);
