@@ -198,22 +198,54 @@ __device__ __forceinline__ uint32_t extIndex(uint32_t packed) { return packed & 
 // ---------------------------------------------------------------------------------------------------------------
 // device context
 // ---------------------------------------------------------------------------------------------------------------
+// Device blocks a one-shot process (a fresh module process: SP_ONESHOT, set by the front end) hands from buffers that are done to buffers that come later -- the index build's
+// scratch (12 GB at 2x10^8 residues) is dead when the search starts, and what the search needs (diagonal records, per-wave scratch, Smith-Waterman pools, records) fits into it.
+// A fresh process then asks the driver for ~20 GB instead of 32: on the pool's slow boxes the allocations of the first prefilter alone took 0.5 s (profiles/r06_fresh_process_pool.txt).
+// A block taken from the pool is cleared like a new one (code that relies on what hipMalloc hands out must not see another buffer's content).  Served / in-process contexts keep
+// their buffers as before: the pool is off.
+struct DevPool {
+    std::mutex mu; std::vector<std::pair<void *, size_t>> blocks;
+    static bool on() { static const bool v = getenv("SP_ONESHOT") != nullptr && getenv("SP_NO_DEVICE_POOL") == nullptr; return v; }
+    static DevPool &get() { static DevPool *p = new DevPool; return *p; }      // (never destroyed: the driver reclaims the blocks with the process)
+    static constexpr size_t kMin = (size_t) 32 << 20;
+    void *take(size_t bytes, size_t &got) {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t best = blocks.size();
+        for (size_t i = 0; i < blocks.size(); i++) if (blocks[i].second >= bytes && blocks[i].second <= bytes * 4 && (best == blocks.size() || blocks[i].second < blocks[best].second)) best = i;
+        if (best == blocks.size()) return nullptr;
+        void *p = blocks[best].first; got = blocks[best].second;
+        blocks.erase(blocks.begin() + (long) best);
+        return p;
+    }
+    void give(void *p, size_t bytes) { std::lock_guard<std::mutex> lk(mu); blocks.emplace_back(p, bytes); }
+};
+
 template <typename T>
 struct DevBuf {
-    T *p = nullptr; size_t n = 0;
+    T *p = nullptr; size_t n = 0; size_t bytes = 0;
     bool ensure(size_t count, std::string &err) {
         if (count <= n && p) return true;
-        if (p) (void) hipFree(p);
-        p = nullptr; n = 0;
+        release();
         size_t want = count + count / 8 + 64;
         static const bool trace = getenv("SP_MEM_TRACE") != nullptr;      // (every device allocation of 32 MB or more, with the element size: which buffers a call asks the driver for)
+        if (DevPool::on() && want * sizeof(T) >= DevPool::kMin) {
+            size_t got = 0;
+            if (void *q = DevPool::get().take(want * sizeof(T), got)) {
+                if (trace) fprintf(stderr, "[sp] recycled  %9.1f MB  for %.1f MB (%zu elements of %zu bytes)\n", (double) got / 1e6, (double) (want * sizeof(T)) / 1e6, want, sizeof(T));
+                if (hipMemset(q, 0, want * sizeof(T)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void) hipGetLastError(); (void) hipFree(q); }      // (cleared before any stream of the process can touch it)
+                else { p = (T *) q; bytes = got; n = got / sizeof(T); return true; }
+            }
+        }
         if (trace && want * sizeof(T) >= (32u << 20)) fprintf(stderr, "[sp] hipMalloc %9.1f MB  (%zu elements of %zu bytes)\n", (double) (want * sizeof(T)) / 1e6, want, sizeof(T));
         hipError_t e = hipMalloc((void **) &p, want * sizeof(T));
-        if (e != hipSuccess) { err = std::string("hipMalloc: ") + hipGetErrorString(e); return false; }
-        n = want;
+        if (e != hipSuccess) { p = nullptr; err = std::string("hipMalloc: ") + hipGetErrorString(e); return false; }
+        n = want; bytes = want * sizeof(T);
         return true;
     }
-    void release() { if (p) (void) hipFree(p); p = nullptr; n = 0; }
+    void release() {
+        if (p) { if (DevPool::on() && bytes >= DevPool::kMin) { (void) hipDeviceSynchronize(); DevPool::get().give(p, bytes); } else (void) hipFree(p); }      // (hipFree waits for the device; so does the hand-over)
+        p = nullptr; n = 0; bytes = 0;
+    }
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -604,8 +636,8 @@ bool Gpu::uploadTables(const SubMat &seed, const SubMat &ung, const SubMat &aln,
         HIP_OK(hipGetLastError());
         HIP_OK(hipStreamSynchronize(d.stream));
         const double t2 = now();
-        for (DevBuf<uint32_t> *b : {&k1, &k2, &v1, &v2}) { (void) hipFree(b->p); b->p = nullptr; }
-        (void) hipFree(tmp.p); tmp.p = nullptr;
+        for (DevBuf<uint32_t> *b : {&k1, &k2, &v1, &v2}) b->release();
+        tmp.release();
         if (laps) fprintf(stderr, "[sp]   similar-3-mer table: buffers %.1f ms, fill + sort + pack + counts %.1f ms, buffers returned %.1f ms\n", t1 - t0, t2 - t1, now() - t2);
     }
     short s16[kAlph * kAlph]; signed char u8[kAlph * kAlph], a8[kAlph * kAlph]; short a16[kAlph * kAlph];
@@ -1600,6 +1632,10 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
     out.maskedResidues = ctr[0];
     (void) hipEventElapsedTime(&out.msMask, d.ev[0][0], d.ev[0][1]);
     (void) hipEventElapsedTime(&out.msIndex, d.ev[0][1], d.ev[0][2]);
+    if (DevPool::on()) {      // a one-shot process builds one target set: the build's scratch goes to the buffers of the search (DevPool)
+        for (DevBuf<uint32_t> *b : {&d.ixKeys, &d.ixKeys2, &d.ixKeep, &d.ixPos, &d.ixKmer, &d.ixHead, &d.ixSlotOf, &d.ixHeadPos, &d.ixCnt, &d.ixBefore}) b->release();
+        d.ixVals.release(); d.ixVals2.release(); d.ixTemp.release(); d.ttProbs.release(); d.ttScale.release(); d.ttLr.release(); d.ttPlane.release();
+    }
     return true;
 }
 
