@@ -1590,6 +1590,9 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
         HIP_OK(hipMemcpyAsync(ctr, d.ixCounters.p, sizeof(ctr), hipMemcpyDeviceToHost, d.stream));
         HIP_OK(hipStreamSynchronize(d.stream));
         const uint32_t nValid = (uint32_t) ctr[1];
+        if (DevPool::on()) {      // (one-shot process: the sort's inputs and the masking planes are done -- the next buffers of the build take their blocks)
+            d.ixKeys.release(); d.ixVals.release(); d.ttProbs.release(); d.ttScale.release(); d.ttLr.release(); d.ttPlane.release();
+        }
         if (nValid) {
             const unsigned gv = (nValid + 255) / 256;
             if (!d.ixKeep.ensure(nValid + 1, err) || !d.ixPos.ensure(nValid + 1, err)) return false;
@@ -1601,8 +1604,10 @@ bool Gpu::buildTargets(const char *ascii, const TargetSet &ts, const SubMat &see
             HIP_OK(hipMemcpyAsync(&lastKeep, d.ixKeep.p + (nValid - 1), 4, hipMemcpyDeviceToHost, d.stream));
             HIP_OK(hipStreamSynchronize(d.stream));
             const uint32_t E = lastPos + lastKeep;
-            if (!d.tgt->ientries.ensure(E + 1, err) || !d.ixKmer.ensure(E + 1, err) || !d.ixHead.ensure(E + 1, err) || !d.ixSlotOf.ensure(E + 1, err)) return false;
+            if (!d.tgt->ientries.ensure(E + 1, err) || !d.ixKmer.ensure(E + 1, err)) return false;
             hipLaunchKernelGGL(k_idx_compact, dim3(gv), dim3(256), 0, d.stream, d.ixKeys2.p, d.ixVals2.p, d.ixKeep.p, d.ixPos.p, nValid, d.ixKmer.p, d.tgt->ientries.p);
+            if (DevPool::on()) { d.ixKeys2.release(); d.ixVals2.release(); d.ixKeep.release(); d.ixPos.release(); }      // (release() waits for the kernel above)
+            if (!d.ixHead.ensure(E + 1, err) || !d.ixSlotOf.ensure(E + 1, err)) return false;
             const unsigned ge = (E + 255) / 256;
             hipLaunchKernelGGL(k_idx_heads, dim3(ge), dim3(256), 0, d.stream, d.ixKmer.p, E, d.ixHead.p);
             sb = d.ixTemp.n;
