@@ -508,3 +508,27 @@ def test_modules_take_a_query_beyond_the_hit_stream_limit_through_target_shards(
     two, _ = read_db(aln)
     one, dbtype = read_db(fused)
     assert dbtype == 5 and one == two and one[4].count("\n") > 100
+
+
+def test_a_fresh_process_recycles_device_blocks_and_writes_the_same_db(tmp_path):
+    """a one-shot front-end process hands device blocks it is done with (similar-3-mer table scratch, index-build scratch) to later buffers (DevPool, csrc/sp_gpu.hip)
+    instead of allocating again: the alignment DB must be byte-identical with the pool off, and the trace must show that blocks WERE recycled"""
+    import subprocess
+    import bench
+    tres, toff, qres, qoff = bench.make_workload(20000, 50000, 200, 4321)
+    T = [tres[int(toff[i]):int(toff[i + 1])].tobytes().decode() for i in range(len(toff) - 1)]
+    Q = [qres[int(qoff[i]):int(qoff[i + 1])].tobytes().decode() for i in range(len(qoff) - 1)]
+    q, t = str(tmp_path / "q"), str(tmp_path / "t")
+    write_seq_db(q, Q)
+    write_seq_db(t, T)
+    flags = (PREF_FLAGS % 300).split() + ["-a", "1", "--alignment-mode", "2", "-e", "200", "--gap-open", "nucl:10,aa:16", "--gap-extend", "2"]
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spacepharer_amd", "spacepharer-amd")
+    outs = {}
+    for name, extra in (("pool", {}), ("nopool", {"SP_NO_DEVICE_POOL": "1"})):
+        env = dict(os.environ, SP_MEM_TRACE="1", **extra)
+        env.pop("SP_SERVER", None)
+        p = subprocess.run([exe, "search", q, t, str(tmp_path / name), str(tmp_path)] + flags, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[name] = (open(str(tmp_path / name), "rb").read(), open(str(tmp_path / name) + ".index").read(), p.stderr)
+    assert outs["pool"][0] == outs["nopool"][0] and outs["pool"][1] == outs["nopool"][1] and len(outs["pool"][0]) > 100000
+    assert "recycled" in outs["pool"][2] and "recycled" not in outs["nopool"][2]

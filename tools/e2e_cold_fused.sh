@@ -22,5 +22,7 @@ for extra in os.environ.get("EXTRAS", "").split(";"):
     for rep in range(int(os.environ.get("REPS", "2"))):
         t0 = time.perf_counter()
         p = subprocess.run([exe, "search", d + "/q", d + "/t", d + "/alnf%d" % rep, d] + sf, env=env, capture_output=True, text=True)
-        print("== [%s] fused search process %.3f s rc=%d" % (extra, time.perf_counter() - t0, p.returncode)); print("\n".join(l for l in p.stderr.splitlines() if "search:" in l or "process:" in l or "ctx_create" in l or "runtime" in l or ("MEM_SUMMARY" in os.environ and ("hipMalloc" in l or "recycled" in l))))
+        import zlib
+        crc = "%08x" % zlib.crc32(open(d + "/alnf%d.index" % rep, "rb").read(), zlib.crc32(open(d + "/alnf%d" % rep, "rb").read())) if p.returncode == 0 else "-"
+        print("== [%s] fused search process %.3f s rc=%d aln_db_crc %s" % (extra, time.perf_counter() - t0, p.returncode, crc)); print("\n".join(l for l in p.stderr.splitlines() if "search:" in l or "process:" in l or "ctx_create" in l or "runtime" in l or ("MEM_SUMMARY" in os.environ and ("hipMalloc" in l or "recycled" in l))))
 PY
