@@ -515,8 +515,8 @@ int sp_ctx_get_hits(sp_ctx *c, sp_hit *hits, uint32_t *counts) {
 }
 
 static bool ensureEvaluers(sp_ctx *c, bool gapped, std::string &err) {
-    if (gapped && !c->haveGapped) { if (!c->evGapped.init(c->aln.name, c->par.gap_open, c->par.gap_extend, c->targets.residues(), err)) return false; c->haveGapped = true; }
-    if (!gapped && !c->haveGapless) { if (!c->evGapless.init(c->aln.name, -1, -1, c->targets.residues(), err)) return false; c->haveGapless = true; }
+    if (gapped && !c->haveGapped) { if (!c->evGapped.init(c->aln.name, c->par.gap_open, c->par.gap_extend, c->targets.residues(), err, sp::matrixDigest(c->aln))) return false; c->haveGapped = true; }
+    if (!gapped && !c->haveGapless) { if (!c->evGapless.init(c->aln.name, -1, -1, c->targets.residues(), err, sp::matrixDigest(c->aln))) return false; c->haveGapless = true; }
     return true;
 }
 
@@ -919,8 +919,9 @@ int sp_host_index_digest(const char *seedSpec, float sensitivity, int mask, cons
 }
 
 int sp_host_evalue(const char *matrixName, int gapOpen, int gapExtend, uint64_t dbResidues, double score, double qLen, double *evalue, double *bitScore) {
-    sp::Evaluer e; std::string err;
-    if (!e.init(matrixName, gapOpen, gapExtend, dbResidues, err)) { g_err = err; return SP_ERR_UNSUPPORTED; }
+    sp::Evaluer e; std::string err, merr;
+    sp::SubMat m; const bool aa = m.load(matrixName, 2.0, 0.0, merr);      // (the align matrix as sp_ctx_create loads it; "nucleotide.out" is not an amino-acid table: name only)
+    if (!e.init(aa ? m.name : std::string(matrixName), gapOpen, gapExtend, dbResidues, err, aa ? sp::matrixDigest(m) : 0)) { g_err = err; return SP_ERR_UNSUPPORTED; }
     *evalue = e.evalue(score, qLen); *bitScore = e.bitScore(score);
     return SP_OK;
 }

@@ -416,9 +416,26 @@ static const AlpEntry kAlpTable[] = {
                               "0x1.7d956af2b60d6p-1", "-0x1.6ba8cc62c7c7ep-1", "0x1.037654c94bd2ep+0", "-0x1.42e626a2af9a8p+1", "0x1.00d16215dfda5p+0", "-0x1.306383babbceap+1"}},
 };
 
-bool Evaluer::init(const std::string &matrixName, int gapOpen, int gapExtend, uint64_t dbRes, std::string &err) {
+// The reference's bundled amino-acid matrices over a grid of gap penalties (gap open 5..20, extend 1..2, and gap-less), fitted by the reference's own EvalueComputation / ALP:
+// tools/gen_alp_table.py.  An entry applies to a matrix of that NAME whose integer table (bit factor 2.0) has that digest.
+struct AlpGridEntry { const char *matrix; uint64_t id; int gapOpen, gapExtend; double v[12]; };
+static const AlpGridEntry kAlpGrid[] = {
+#include "sp_alp_table.inc"
+};
+
+uint64_t matrixDigest(const SubMat &m) {      // FNV-1a 64 over (letter i, letter j, score as int16 little endian); tools/gen_alp_table.py: matrix_id
+    uint64_t h = 1469598103934665603ULL;
+    for (int i = 0; i < m.alph; i++) for (int j = 0; j < m.alph; j++) {
+        const uint16_t s = (uint16_t) m.sub[i][j];
+        const unsigned char b[4] = {(unsigned char) m.num2aa[i], (unsigned char) m.num2aa[j], (unsigned char) (s & 0xFF), (unsigned char) (s >> 8)};
+        for (unsigned char x : b) { h ^= x; h *= 1099511628211ULL; }
+    }
+    return h;
+}
+
+bool Evaluer::init(const std::string &matrixName, int gapOpen, int gapExtend, uint64_t dbRes, std::string &err, uint64_t matrixId) {
     dbResidues = (double) dbRes;
-    double v[12]; bool found = false;
+    double v[12]; bool found = false; bool otherMatrix = false;
     if (const char *env = getenv("SP_ALP_PARAMS")) {        // 12 comma separated numbers: lambda,K,a_I,b_I,alpha_I,beta_I,a_J,b_J,alpha_J,beta_J,sigma,tau
         std::string s(env); size_t at = 0; int k = 0;
         while (k < 12 && at < s.size()) { size_t c = s.find(',', at); if (c == std::string::npos) c = s.size(); v[k++] = strtod(s.substr(at, c - at).c_str(), NULL); at = c + 1; }
@@ -430,9 +447,17 @@ bool Evaluer::init(const std::string &matrixName, int gapOpen, int gapExtend, ui
             found = true; break;
         }
     }
+    if (!found) for (const AlpGridEntry &e : kAlpGrid) {
+        if (matrixName != e.matrix || !((gapOpen < 0 && e.gapOpen < 0) || (gapOpen == e.gapOpen && gapExtend == e.gapExtend))) continue;
+        if (matrixId != 0 && matrixId != e.id) { otherMatrix = true; continue; }      // (a file that shares a bundled matrix's name is not that matrix)
+        for (int k = 0; k < 12; k++) v[k] = e.v[k];
+        found = true; break;
+    }
     if (!found) {
         err = "no tabulated ALP (Gumbel) parameters for matrix " + matrixName + " with gap open/extend " + std::to_string(gapOpen) + "/" + std::to_string(gapExtend) +
-              "; supply them through SP_ALP_PARAMS";
+              (otherMatrix ? " (the table has this name with other scores)" : "") +
+              ": the reference fits them at run time (lib/alp); tabulated are its bundled matrices with gap open 5..20, extend 1..2 where ALP can fit them (tools/gen_alp_table.py); "
+              "supply others through SP_ALP_PARAMS";
         return false;
     }
     p = AlpParams{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11]};

@@ -90,15 +90,17 @@ unsigned binSizeFor(size_t dbSize, uint64_t l2);
 
 // E-value statistics (alignment/EvalueComputation.h, lib/alp)
 struct AlpParams { double lambda, K, a_I, b_I, alpha_I, beta_I, a_J, b_J, alpha_J, beta_J, sigma, tau; };
+uint64_t matrixDigest(const SubMat &m);      // identifies the integer table of a matrix (the ALP table is keyed by name AND digest)
+
 struct Evaluer {
     AlpParams p{};
     double dbResidues = 0;
     double logK = 0;
     bool ok = false;
     // gapOpen/gapExtend < 0 => gap-less statistics.  Parameters are the values ALP fits for the matrix/gap
-    // combination; the fit itself (Monte-Carlo, lib/alp) is not rebuilt: known combinations are tabulated and
-    // anything else must be supplied through SP_ALP_PARAMS.
-    bool init(const std::string &matrixName, int gapOpen, int gapExtend, uint64_t dbResidues, std::string &err);
+    // combination; the fit itself (Monte-Carlo, lib/alp) is not rebuilt: the reference's bundled matrices over a grid of
+    // gap penalties are tabulated (sp_alp_table.inc, generated from the reference), anything else must be supplied through SP_ALP_PARAMS.
+    bool init(const std::string &matrixName, int gapOpen, int gapExtend, uint64_t dbResidues, std::string &err, uint64_t matrixId = 0);      // matrixId: matrixDigest() of the matrix in use (0: not checked)
     double area(double score, double qLen) const;
     double evalue(double score, double qLen) const;
     double bitScore(double score) const;

@@ -1,5 +1,7 @@
 """GPU parity of the Smith-Waterman (align) and diagonal-rescoring kernels against the reference-generated golden
 vectors: integer scores, end/start positions, E-values (bit-identical doubles), acceptance and backtrace strings."""
+import os
+
 import pytest
 
 from conftest import load_golden
@@ -150,6 +152,38 @@ def test_align_with_other_gap_penalties_against_oracle(gap_open, gap_extend, mon
                 gapped += ("I" in cig) or ("D" in cig)
         assert gapped >= (3 if gap_open <= 11 else 0), (qmax, gapped)
         ctx.close()
+    o.close()
+
+
+def test_align_with_tabulated_gumbel_parameters_of_another_gap_pair():
+    """gap open 11 / extend 1 without SP_ALP_PARAMS: the E-values come from csrc/sp_alp_table.inc (the reference's own fit, tools/gen_alp_table.py); the oracle gets the same
+    twelve numbers from the fixture the reference's EvalueComputation wrote (tests/golden/alp_probes.json) -- E-values, bit scores and the pass decision must agree"""
+    import json
+    from golden.make_golden import make_case
+    from oracle_lib import Alp, Oracle
+    import spacepharer_amd as sa
+    assert "SP_ALP_PARAMS" not in os.environ
+    g = load_golden("spacer")["ref"]
+    probes = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "alp_probes.json")))["cases"]
+    T, Q = make_case(seed=4711, n_targets=400, n_queries=160, tmin=40, tmax=300, qmin=9, qmax=30, families=1)
+    o = Oracle()
+    o.set_targets(T)
+    o.set_alp(Alp(*[float.fromhex(x) for x in probes["VTML40.out 11 1"]["alp"]]), Alp.from_ref(g["alpGapless"]))
+    ctx = sa.SearchContext(gap_open=11, gap_extend=1)
+    ctx.set_targets(T)
+    ctx.set_queries(Q)
+    ctx.prefilter()
+    pairs = [(qi, h[0]) for qi, hs in enumerate(ctx.hits()) for h in hs]
+    assert len(pairs) > 100
+    n_pass = 0
+    for (qi, ti), (res, cig) in zip(pairs, ctx.align(pairs)):
+        e = o.align(Q[qi], ti, gap_open=11, gap_extend=1)
+        assert (res.raw_score, res.bit_score, res.q_end, res.db_end, res.passed) == (e.rawScore, e.score, e.qEndPos, e.dbEndPos, e.passed), (qi, ti)
+        if e.passed:
+            assert (res.q_start, res.db_start, res.aln_len, res.evalue, cig) == (e.qStartPos, e.dbStartPos, e.alnLength, e.eval, e.backtrace.decode())
+            n_pass += 1
+    assert n_pass > 50
+    ctx.close()
     o.close()
 
 

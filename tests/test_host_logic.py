@@ -105,7 +105,24 @@ def test_host_evalues(lib):
         assert (e.value, b.value) == (ev, bits)
         assert lib.sp_host_evalue(b"VTML40.out", -1, -1, r["aaDbSize"], float(s), float(ql), C.byref(e), C.byref(b)) == 0
         assert (e.value, b.value) == (evg, bitsg)
-    assert lib.sp_host_evalue(b"VTML40.out", 11, 1, 1000, 10.0, 10.0, C.byref(e), C.byref(b)) != 0   # untabulated combination: loud failure
+    # other matrix / gap pairs come from the table generated from the reference's EvalueComputation (tools/gen_alp_table.py -> csrc/sp_alp_table.inc); probes from the
+    # same classes: tests/golden/alp_probes.json
+    import json
+    probes = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "alp_probes.json")))["cases"]
+    assert len(probes) >= 5
+    for key, case in probes.items():
+        name, go, ge = key.split()
+        for s, ql, ev, bits in case["probes"]:
+            assert lib.sp_host_evalue(name.encode(), int(go), int(ge), case["db_residues"], float(s), float(ql), C.byref(e), C.byref(b)) == 0, (key, lib.sp_last_error())
+            assert (e.value, int(b.value)) == (float.fromhex(ev), bits), (key, s, ql)
+    assert lib.sp_host_evalue(b"VTML40.out", 5, 1, 1000, 10.0, 10.0, C.byref(e), C.byref(b)) != 0   # a pair ALP cannot fit (the reference fails on it too): loud failure
+    assert lib.sp_host_evalue(b"VTML40.out", 30, 7, 1000, 10.0, 10.0, C.byref(e), C.byref(b)) != 0  # outside the table
+    # a file that carries a bundled matrix's NAME but other scores is not given that matrix's parameters
+    from oracle_lib import matrix_text
+    other = matrix_text("VTML40").replace("A\t6\t", "A\t9\t", 1)      # the A-A score
+    assert other != matrix_text("VTML40")
+    assert lib.sp_host_evalue(("VTML40.out:" + matrix_text("VTML40")).encode(), 11, 1, 1000, 10.0, 10.0, C.byref(e), C.byref(b)) == 0, lib.sp_last_error()      # (the same table spelled out: accepted)
+    assert lib.sp_host_evalue(("VTML40.out:" + other).encode(), 11, 1, 1000, 10.0, 10.0, C.byref(e), C.byref(b)) != 0 and b"other scores" in lib.sp_last_error()
 
 
 def test_bench_reads_the_committed_counter_summary():
