@@ -420,7 +420,7 @@ static const AlpEntry kAlpTable[] = {
 // tools/gen_alp_table.py.  An entry applies to a matrix of that NAME whose integer table (bit factor 2.0) has that digest.
 struct AlpGridEntry { const char *matrix; uint64_t id; int gapOpen, gapExtend; double v[12]; };
 static const AlpGridEntry kAlpGrid[] = {
-#include "sp_alp_table.inc"
+#include "sp_alp_table.h"
 };
 
 uint64_t matrixDigest(const SubMat &m) {      // FNV-1a 64 over (letter i, letter j, score as int16 little endian); tools/gen_alp_table.py: matrix_id

@@ -99,7 +99,7 @@ struct Evaluer {
     bool ok = false;
     // gapOpen/gapExtend < 0 => gap-less statistics.  Parameters are the values ALP fits for the matrix/gap
     // combination; the fit itself (Monte-Carlo, lib/alp) is not rebuilt: the reference's bundled matrices over a grid of
-    // gap penalties are tabulated (sp_alp_table.inc, generated from the reference), anything else must be supplied through SP_ALP_PARAMS.
+    // gap penalties are tabulated (sp_alp_table.h, generated from the reference), anything else must be supplied through SP_ALP_PARAMS.
     bool init(const std::string &matrixName, int gapOpen, int gapExtend, uint64_t dbResidues, std::string &err, uint64_t matrixId = 0);      // matrixId: matrixDigest() of the matrix in use (0: not checked)
     double area(double score, double qLen) const;
     double evalue(double score, double qLen) const;

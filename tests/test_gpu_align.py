@@ -156,7 +156,7 @@ def test_align_with_other_gap_penalties_against_oracle(gap_open, gap_extend, mon
 
 
 def test_align_with_tabulated_gumbel_parameters_of_another_gap_pair():
-    """gap open 11 / extend 1 without SP_ALP_PARAMS: the E-values come from csrc/sp_alp_table.inc (the reference's own fit, tools/gen_alp_table.py); the oracle gets the same
+    """gap open 11 / extend 1 without SP_ALP_PARAMS: the E-values come from csrc/sp_alp_table.h (the reference's own fit, tools/gen_alp_table.py); the oracle gets the same
     twelve numbers from the fixture the reference's EvalueComputation wrote (tests/golden/alp_probes.json) -- E-values, bit scores and the pass decision must agree"""
     import json
     from golden.make_golden import make_case

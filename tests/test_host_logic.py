@@ -105,7 +105,7 @@ def test_host_evalues(lib):
         assert (e.value, b.value) == (ev, bits)
         assert lib.sp_host_evalue(b"VTML40.out", -1, -1, r["aaDbSize"], float(s), float(ql), C.byref(e), C.byref(b)) == 0
         assert (e.value, b.value) == (evg, bitsg)
-    # other matrix / gap pairs come from the table generated from the reference's EvalueComputation (tools/gen_alp_table.py -> csrc/sp_alp_table.inc); probes from the
+    # other matrix / gap pairs come from the table generated from the reference's EvalueComputation (tools/gen_alp_table.py -> csrc/sp_alp_table.h); probes from the
     # same classes: tests/golden/alp_probes.json
     import json
     probes = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "alp_probes.json")))["cases"]
