@@ -946,11 +946,57 @@ int runSearchModule(int argc, const char **argv) {
             // every worker matched the whole batch against its shard; this worker finishes slice `rank` of the batch
             std::vector<uint64_t> lens(b1 - b0); for (size_t i = 0; i < lens.size(); i++) lens[i] = off[i + 1] - off[i] + 2;
             uint64_t sFrom = 0, sCnt = 0, rows = 0; double secs = 0;
-            if (sp_dist_decompose(lens.data(), lens.size(), myPart.rank, myPart.count, &sFrom, &sCnt) != SP_OK || sp_ctx_prefilter_candidates(ctx.c) != SP_OK ||
-                sp_ctx_allgather_candidates(ctx.c, comm.c, sFrom, sFrom + sCnt, &rows, &secs) != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
-            laps.lap("queries -> device, candidates, all-gather, selection");
-            std::vector<uint32_t> sliceKeys(qkeys.begin() + b0 + sFrom, qkeys.begin() + b0 + sFrom + sCnt);
-            if (!alignAndFormat(ctx.c, sliceKeys, (size_t) sFrom)) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+            const int rcC = sp_ctx_prefilter_candidates(ctx.c);
+            // A query whose hit stream does not fit one pass over THIS rank's shard (QueryMatcher.cpp:254-283 is the reference's overflow path): the ranks agree on the union of
+            // such queries, search the batch without them as usual, and each refused query goes -- on one rank, round robin -- through sub-shards of the WHOLE target set
+            // (searchByShards: every rank has read the target DB), whose result equals the unsplit search.  Round 6; before, one rank's overflow ended the job on all ranks.
+            std::vector<uint32_t> refusedHere(rcC == SP_ERR_OVERFLOW ? sp_ctx_overflow_queries(ctx.c, nullptr, 0) : 0);
+            if (!refusedHere.empty()) sp_ctx_overflow_queries(ctx.c, refusedHere.data(), refusedHere.size());
+            const std::string candErr = rcC == SP_OK ? std::string() : std::string(sp_last_error());
+            std::vector<uint64_t> counts((size_t) myPart.count, 0);
+            uint64_t mine = (rcC != SP_OK && refusedHere.empty()) ? ~0ull : (uint64_t) refusedHere.size();      // (~0: this rank failed for another reason)
+            if (sp_dist_allgather(comm.c, &mine, sizeof(mine), counts.data(), 0) != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+            uint64_t most = 0; bool someoneFailed = false;
+            for (uint64_t n : counts) { if (n == ~0ull) someoneFailed = true; else most = std::max(most, n); }
+            if (someoneFailed) { freeBufs(); return fail("search: " + (candErr.empty() ? std::string("the candidate pass failed on another rank") : candErr)); }
+            std::vector<uint32_t> refused;
+            if (most) {
+                std::vector<uint32_t> padded((size_t) most, 0xFFFFFFFFu), all((size_t) most * (size_t) myPart.count);
+                std::copy(refusedHere.begin(), refusedHere.end(), padded.begin());
+                if (sp_dist_allgather(comm.c, padded.data(), most * sizeof(uint32_t), all.data(), 0) != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+                for (uint32_t q : all) if (q != 0xFFFFFFFFu) refused.push_back(q);
+                std::sort(refused.begin(), refused.end()); refused.erase(std::unique(refused.begin(), refused.end()), refused.end());
+            }
+            if (refused.empty()) {
+                if (sp_dist_decompose(lens.data(), lens.size(), myPart.rank, myPart.count, &sFrom, &sCnt) != SP_OK ||
+                    sp_ctx_allgather_candidates(ctx.c, comm.c, sFrom, sFrom + sCnt, &rows, &secs) != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+                laps.lap("queries -> device, candidates, all-gather, selection");
+                std::vector<uint32_t> sliceKeys(qkeys.begin() + b0 + sFrom, qkeys.begin() + b0 + sFrom + sCnt);
+                if (!alignAndFormat(ctx.c, sliceKeys, (size_t) sFrom)) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+                continue;
+            }
+            std::vector<char> res2; std::vector<uint64_t> off2; std::vector<uint32_t> kept;
+            withoutQueries(qres.data() + qoff[b0], off.data(), b1 - b0, refused, res2, off2, kept);
+            std::vector<uint64_t> lens2(kept.size()); for (size_t i = 0; i < kept.size(); i++) lens2[i] = off2[i + 1] - off2[i] + 2;
+            if (!kept.empty()) {      // (the same decision on every rank: `kept` follows from the agreed union)
+                if (sp_ctx_set_queries(ctx.c, res2.data(), off2.data(), kept.size()) != SP_OK || sp_dist_decompose(lens2.data(), lens2.size(), myPart.rank, myPart.count, &sFrom, &sCnt) != SP_OK ||
+                    sp_ctx_prefilter_candidates(ctx.c) != SP_OK || sp_ctx_allgather_candidates(ctx.c, comm.c, sFrom, sFrom + sCnt, &rows, &secs) != SP_OK) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+                laps.lap("queries -> device, candidates, all-gather, selection (without the refused queries)");
+                std::vector<uint32_t> sliceKeys; for (uint64_t i = sFrom; i < sFrom + sCnt; i++) sliceKeys.push_back(qkeys[b0 + kept[i]]);
+                if (!alignAndFormat(ctx.c, sliceKeys, (size_t) sFrom)) { freeBufs(); return fail(std::string("search: ") + sp_last_error()); }
+            }
+            std::vector<uint32_t> mineRefused;
+            for (size_t i = 0; i < refused.size(); i++) if ((int) (i % (size_t) myPart.count) == myPart.rank) mineRefused.push_back(refused[i]);
+            if (!mineRefused.empty()) {
+                sp_ctx *r = searchByShards(p, tres, toff, tkeys, qres.data() + qoff[b0], off.data(), mineRefused, err);
+                if (!r) { freeBufs(); return fail("search: " + err); }
+                std::vector<uint32_t> rk; for (uint32_t q : mineRefused) rk.push_back(qkeys[b0 + q]);
+                const bool ok = alignAndFormat(r, rk);
+                const std::string e = ok ? std::string() : std::string(sp_last_error());
+                sp_ctx_destroy(r);
+                if (!ok) { freeBufs(); return fail("search: " + e); }
+                laps.lap("refused queries through sub-shards of the whole target set");
+            }
             continue;
         }
         const int rc = sp_ctx_prefilter(ctx.c);

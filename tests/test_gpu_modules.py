@@ -532,3 +532,42 @@ def test_a_fresh_process_recycles_device_blocks_and_writes_the_same_db(tmp_path)
         outs[name] = (open(str(tmp_path / name), "rb").read(), open(str(tmp_path / name) + ".index").read(), p.stderr)
     assert outs["pool"][0] == outs["nopool"][0] and outs["pool"][1] == outs["nopool"][1] and len(outs["pool"][0]) > 100000
     assert "recycled" in outs["pool"][2] and "recycled" not in outs["nopool"][2]
+
+
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_target_sharded_search_takes_an_overflowing_query_through_sub_shards(gpus, tmp_path):
+    """SP_GPUS=N SP_SHARD=targets with a query whose hit stream overflows ONE rank's shard (a family of near-identical targets sits in the first shard only): the ranks agree
+    on the refused queries, search the rest as usual and take the refused ones through sub-shards of the whole target set -- every entry equals the unsplit run's
+    (round 5 ended the job on all ranks; the reference's own overflow path is QueryMatcher.cpp:254-283)"""
+    import random
+    import subprocess
+    import spacepharer_amd as sa
+    rnd = random.Random(23)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    core = "".join(rnd.choice(aa) for _ in range(60))
+    T = []
+    for i in range(2600):      # the family: shard 0 of 2 (and of 3) holds all of it
+        s = list(core)
+        for _ in range(3):
+            s[rnd.randrange(60)] = rnd.choice(aa)
+        T.append("".join(rnd.choice(aa) for _ in range(rnd.randrange(0, 20))) + "".join(s) + "".join(rnd.choice(aa) for _ in range(20)))
+    background = ["".join(rnd.choice(aa) for _ in range(rnd.randrange(60, 140))) for _ in range(6000)]
+    T += background
+    Q = ["".join(rnd.choice(aa) for _ in range(12)), core, background[17][10:24], core[5:55], background[4000][30:42], background[5999][5:20]]
+    q, t, one, many = (str(tmp_path / x) for x in ("qdb", "tdb", "one", "many"))
+    write_seq_db(q, Q, key0=3)
+    write_seq_db(t, T)
+    flags = (PREF_FLAGS % 300).split() + ["-a", "1", "--alignment-mode", "2", "-e", "200", "--min-seq-id", "0", "--min-aln-len", "0", "--max-rejected", "2147483647",
+                                          "--max-accept", "2147483647", "--gap-open", "nucl:10,aa:16", "--gap-extend", "2"]
+    sa.module_search([q, t, one, str(tmp_path)] + flags)      # unsplit, in this process
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spacepharer_amd", "spacepharer-amd")
+    env = dict(os.environ, SP_GPUS=str(gpus), SP_SHARD="targets", SP_MODULE_TIMES="1")
+    env.pop("SP_SERVER", None)
+    p = subprocess.run([exe, "search", q, t, many, str(tmp_path)] + flags, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "refused queries through sub-shards" in p.stderr      # (the fallback did run)
+    a, dbtype = read_db(one)
+    b, dbtype2 = read_db(many)
+    assert dbtype == 5 and dbtype2 == 5 and sorted(a) == [3 + i for i in range(len(Q))]
+    assert a == b
+    assert a[4].count("\n") > 100 and a[5].count("\n") >= 1
