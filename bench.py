@@ -10,7 +10,8 @@ queued without the host learning anything in between, two steps per context may 
 outputs outgrow the capacities is repeated the ordinary way inside _end ("steps_repeated" in the line; 0 on this workload).
 --host-driven times the round-2 sequence instead (sp_ctx_prefilter, sp_ctx_align_hits_begin / _end: the host reads the hit
 count between the two halves).  With no mode asked for (N = 1) BOTH are measured -- host-driven with four contexts first, then
-device-driven with two -- and `value` is the better one ("step_modes" holds both, with the k_match launch time of each).
+device-driven with four -- and `value` is the host-driven one, a fixed configuration ("step_modes" holds both, with the k_match launch time of each; since
+round 6 -- a step's results leave the device when its kernels are done instead of being queued behind events -- the two are level).
 All K steps complete inside the timed region.
 Every step delivers into its OWN page-locked buffers; after the clock has stopped every delivered result (hit list,
 offsets, alignment records, backtraces) is digested and must equal the digest of the same batch searched by one context
@@ -697,14 +698,14 @@ def main():
         # N > 1: the query partition with host-driven steps in four contexts per rank, measured before anything else for the same reason as at N = 1
         qpart_h = measure(False, n_spacers, max(4, args.steps // 2), max(1, min(3, args.regions)), args.warmup, False, partition=True, pipeline=4, host_driven=True)
     if dual:
-        # N = 1, no mode asked for: the step is measured both ways -- device-driven (two contexts, two steps in flight each) and host-driven with four
-        # contexts, whose idle moments between prefilter and align the other contexts fill -- and `value` is the better of the two; both stay in the line.
+        # N = 1, no mode asked for: the step is measured both ways -- device-driven (four contexts, two steps in flight each) and host-driven with four
+        # contexts, whose idle moments between prefilter and align the other contexts fill -- `value` is the host-driven one (fixed); both stay in the line.
         # (The eight HIP streams of four contexts share the runtime's four hardware queues pairwise -- search stream with search stream, copy stream with copy
         # stream -- when they are created in order; the library keeps its stream pairs in a per-device pool for that, so the order of the two measurements
         # does not matter any more: SP_BENCH_DEVICE_DRIVEN_FIRST=1 swaps them, 19.1 M either way; before the pool the second place cost 10 %.)
         if not os.environ.get("SP_BENCH_DEVICE_DRIVEN_FIRST"):      # (experiment: the other order, to check that the library's stream pool makes it irrelevant)
             alt = measure(False, n_spacers, args.steps, args.regions, args.warmup, False, pipeline=4, host_driven=True)
-    m = measure(sharded, n_spacers, args.steps, args.regions, args.warmup, True, shards=args.shards)
+    m = measure(sharded, n_spacers, args.steps, args.regions, args.warmup, True, shards=args.shards, pipeline=4 if dual else None)      # (dual: device-driven steps in FOUR contexts, two in flight each -- level with the host-driven four since round 6's late copies)
     if dual and alt is None:
         alt = measure(False, n_spacers, args.steps, args.regions, args.warmup, False, pipeline=4, host_driven=True)
     rep = hyb = qpart = None
@@ -721,10 +722,10 @@ def main():
         def active_ms(mm):
             o = sorted(range(len(mm["region_dt"])), key=lambda i: mm["region_dt"][i])
             return mm["region_active"][o[len(o) // 2]]
-        step_modes = {"device-driven x2": {"spacer_queries_per_s": n_spacers * args.steps / med(m), "ms_per_step": med(m) / args.steps * 1e3, "k_match_ms_per_launch": round(launch_ms(m), 4), "k_match_active_ms_per_launch": round(active_ms(m), 4)},
+        step_modes = {"device-driven x4": {"spacer_queries_per_s": n_spacers * args.steps / med(m), "ms_per_step": med(m) / args.steps * 1e3, "k_match_ms_per_launch": round(launch_ms(m), 4), "k_match_active_ms_per_launch": round(active_ms(m), 4)},
                       "host-driven x4": {"spacer_queries_per_s": n_spacers * args.steps / med(alt), "ms_per_step": med(alt) / args.steps * 1e3, "k_match_ms_per_launch": round(launch_ms(alt), 4), "k_match_active_ms_per_launch": round(active_ms(alt), 4)}}
-        # ONE fixed configuration carries `value`: host-driven steps in four contexts (the faster one in every run of rounds 3-5: 21-24 M against 15-17 M); the
-        # device-driven step -- the interface that needs no host threads -- is measured beside it and stays in the line (step_modes)
+        # ONE fixed configuration carries `value`: host-driven steps in four contexts (the faster one in every run of rounds 3-5: 21-24 M against 15-17 M; level since round 6); the
+        # device-driven step -- the interface that needs no host round trip inside a step -- is measured beside it and stays in the line (step_modes)
         alt["stats"] = m["stats"]
         m = alt
         step_modes["value_from"] = "host-driven x4 (fixed configuration; the device-driven step is reported beside it)"
@@ -851,7 +852,7 @@ def main():
                                      "exclusive_ms_per_launch": round(dexcl, 4), "exclusive_frac": dalgo / (dexcl * 1e-3) / 1e9 / 8000.0 if dexcl > 0 else None}}
     if step_modes is not None:
         out["config"]["step"] += " -- four search contexts (host threads) on one shared target set; fixed configuration, the device-driven step is measured beside it (step_modes)"
-        for k in ("device-driven x2", "host-driven x4"):      # the roofline fraction of a k_match launch in either mode (more passes in flight: longer launches, more work done)
+        for k in ("device-driven x4", "host-driven x4"):      # the roofline fraction of a k_match launch in either mode (more passes in flight: longer launches, more work done)
             step_modes[k]["roofline_frac_per_launch"] = round(algo_bytes / (step_modes[k]["k_match_ms_per_launch"] * 1e-3) / 1e9 / 8000.0, 4) if step_modes[k]["k_match_ms_per_launch"] > 0 else None
         out["step_modes"] = step_modes
     if sharded:

@@ -169,7 +169,7 @@ int sp_ctx_align_hits_end(sp_ctx *c);
    list (hits[n], offsets[n_queries + 1]), the records (results[i] belongs to hit i) and the packed backtraces travel on a copy stream into the
    caller's page-locked buffers (sp_host_alloc; hits and results hold hit_cap entries, cigars cigar_cap bytes).  _begin returns as soon as the
    step is queued; up to two steps may be in flight per context (the second one's kernels run while the first one's results travel); _end
-   waits for the OLDEST step and reports its counts.  Leave the buffers alone between _begin and _end; do not call sp_ctx_set_queries /
+   waits for the OLDEST step's kernels, sends its results on their way (from device buffers the younger step does not write) and reports its counts.  Leave the buffers alone between _begin and _end; do not call sp_ctx_set_queries /
    sp_ctx_set_targets or the synchronous entry points while a step is in flight.  A step that meets a capacity (more hits than earlier passes
    delivered, a traceback that needs the host path) is repeated the synchronous way inside _end: the results are always complete. */
 int sp_ctx_search_begin(sp_ctx *c, sp_hit_packed *hits, uint32_t *offsets, uint64_t hit_cap, sp_alignment *results, char *cigars, uint64_t cigar_cap);

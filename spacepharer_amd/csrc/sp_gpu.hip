@@ -356,7 +356,11 @@ struct Gpu::Impl {
     SwDev swd;
     // device-driven steps (stepBegin / stepEnd): the whole pass -- prefilter, selection, align, record assembly, delivery -- is queued without a
     // host round trip; counts stay on the device, results and counters travel on the copy stream.  Up to two steps in flight.
-    struct StepSlot { hipEvent_t selected = nullptr, assembled = nullptr, hitsOnHost = nullptr, alnOnHost = nullptr; size_t cap = 0; StepOut out; };
+    struct StepSlot { hipEvent_t selected = nullptr, assembled = nullptr, hitsOnHost = nullptr, alnOnHost = nullptr; size_t cap = 0; StepOut out;
+                      bool late = false; size_t nq = 0; const GpuHit *dHits = nullptr; const uint32_t *dOffsets = nullptr; const AlnRec *dRec = nullptr; const char *dCig = nullptr; size_t dCigN = 0; };
+    // late copies (SP_STEP_LATE_COPY): a step's results leave the device when stepEnd() has seen its last kernel finish, from buffers the NEXT step does not write -- no copy is
+    // queued behind an event that has not happened yet, no kernel waits for a copy (see stepBegin)
+    DevBuf<GpuHit> outHitsAlt; DevBuf<uint32_t> outOffsetAlt; DevBuf<AlnRec> recAlt; DevBuf<char> cigAlt;
     StepSlot step[2];
     uint64_t stepsBegun = 0, stepsEnded = 0;
     bool drained = false;                        // every queued step has finished on the device and its results are in host memory (drain())
@@ -998,12 +1002,35 @@ bool Gpu::stepBegin(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
         if (d.hitsInFlight) { (void) hipEventSynchronize(d.hitsOnHost); d.hitsInFlight = false; }
         if (!waitAlignCopy(err)) return false;
     }
+    // (round 6, default; SP_STEP_LATE_COPY=0 = the round-4 scheme: copies queued ahead on the copy stream behind events, the next step's kernels waiting for them.  Those
+    // barrier packets sat in hardware queues that other contexts' streams share and held their kernels back: four device-driven contexts 15.3 M spacer-queries/s, with late
+    // copies 24.0 M -- level with four host-driven contexts; profiles/r06_step_late_copy.txt)
+    static const bool lateCopy = !(getenv("SP_STEP_LATE_COPY") != nullptr && *getenv("SP_STEP_LATE_COPY") == '0');
+    ss.late = lateCopy;
+    if (lateCopy) {      // this step writes the buffer set the step in front of it does not use: that one's results may still be on the device, waiting for its stepEnd()
+        std::swap(d.outHits.p, d.outHitsAlt.p); std::swap(d.outHits.n, d.outHitsAlt.n); std::swap(d.outHits.bytes, d.outHitsAlt.bytes);
+        std::swap(d.outOffset.p, d.outOffsetAlt.p); std::swap(d.outOffset.n, d.outOffsetAlt.n); std::swap(d.outOffset.bytes, d.outOffsetAlt.bytes);
+        std::swap(s.rec.p, d.recAlt.p); std::swap(s.rec.n, d.recAlt.n); std::swap(s.rec.bytes, d.recAlt.bytes);
+        std::swap(s.cig.p, d.cigAlt.p); std::swap(s.cig.n, d.cigAlt.n); std::swap(s.cig.bytes, d.cigAlt.bytes);
+        if (!d.outOffset.ensure(nq_ + 2, err)) return false;
+    }
     d.evSet = slot;
     if (!matchAndScore(kmerThr, false, err)) return false;
-    if (!queueSelect(binSize, maxHits, minDiagScore, behind ? prev.hitsOnHost : nullptr, err)) return false;
+    if (!queueSelect(binSize, maxHits, minDiagScore, (behind && !lateCopy) ? prev.hitsOnHost : nullptr, err)) return false;
     {   StepCountArgs ca{d.outOffset.p + nq_, (uint32_t) cap, d.stepWords.p};
         hipLaunchKernelGGL(k_step_counts, dim3(1), dim3(64), 0, d.stream, ca); }
     HIP_OK(hipEventRecord(ss.selected, d.stream));
+    if (lateCopy) {
+        if (!queueAlign(cap, d.stepWords.p + 1, nullptr, gapOpen, gapExtend, gate, true, false, nullptr, err)) return false;
+        {   PublishArgs pa{{d.counters.p, d.queue.p, d.stepWords.p, s.counters.p, s.cigOff.p + cap}, {32, 8, 4, 8, 1}, {0, 32, 40, 44, 52}, d.stepMail + 64 * slot};
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, d.stream, pa); }
+        SP_EV(9, 2);
+        HIP_OK(hipEventRecord(ss.assembled, d.stream));
+        ss.nq = nq_; ss.dHits = d.outHits.p; ss.dOffsets = d.outOffset.p; ss.dRec = s.rec.p; ss.dCig = s.cig.p; ss.dCigN = s.cig.n;
+        HIP_OK(hipGetLastError());
+        d.stepsBegun++;
+        return true;
+    }
     // the hit list travels underneath the align kernels: offsets exactly, hit records up to the capacity
     HIP_OK(hipStreamWaitEvent(d.copyStream, ss.selected, 0));
     HIP_OK(hipMemcpyAsync(out.offsets, d.outOffset.p, (nq_ + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, d.copyStream));
@@ -1031,9 +1058,21 @@ bool Gpu::stepEnd(StepResult &r, std::string &err) {
     if (d.stepsBegun == d.stepsEnded) { err = "stepEnd: no step in flight"; return false; }
     const int slot = (int) (d.stepsEnded & 1);
     Impl::StepSlot &ss = d.step[slot];
-    for (hipEvent_t e : {ss.hitsOnHost, ss.alnOnHost}) {      // short waits on the critical path: poll
+    auto poll = [&](hipEvent_t e) -> bool {      // short waits on the critical path: poll
         unsigned tries = 0;
-        for (;;) { const hipError_t q = hipEventQuery(e); if (q == hipSuccess) break; if (q != hipErrorNotReady) { err = std::string("stepEnd: ") + hipGetErrorString(q); d.stepsEnded++; return false; } pollPause(tries); }
+        for (;;) { const hipError_t q = hipEventQuery(e); if (q == hipSuccess) return true; if (q != hipErrorNotReady) { err = std::string("stepEnd: ") + hipGetErrorString(q); d.stepsEnded++; return false; } pollPause(tries); }
+    };
+    if (ss.late) {      // the step's kernels are done: NOW its results travel (nothing was queued behind an event that had not happened)
+        if (!poll(ss.assembled)) return false;
+        HIP_OK(hipMemcpyAsync(ss.out.offsets, ss.dOffsets, (ss.nq + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, d.copyStream));
+        HIP_OK(hipMemcpyAsync(ss.out.hits, ss.dHits, ss.cap * sizeof(GpuHit), hipMemcpyDeviceToHost, d.copyStream));
+        HIP_OK(hipMemcpyAsync(ss.out.records, ss.dRec, ss.cap * sizeof(AlnRec), hipMemcpyDeviceToHost, d.copyStream));
+        const size_t cigBytes = (size_t) std::min<uint64_t>(ss.out.cigarCap, (uint64_t) ss.dCigN);
+        if (cigBytes) HIP_OK(hipMemcpyAsync(ss.out.cigars, ss.dCig, cigBytes, hipMemcpyDeviceToHost, d.copyStream));
+        HIP_OK(hipEventRecord(ss.alnOnHost, d.copyStream));
+        if (!poll(ss.alnOnHost)) return false;
+    } else {
+        if (!poll(ss.hitsOnHost) || !poll(ss.alnOnHost)) return false;
     }
     d.stepsEnded++;
     const uint32_t *m = d.stepMail + 64 * slot;

@@ -279,8 +279,8 @@ def test_bench_checks_every_delivered_result(tmp_path):
     assert out["regions"]["min"] <= out["value"] <= out["regions"]["max"]
     # no mode asked for: both step modes are measured, ONE fixed configuration carries the value (host-driven steps in four contexts), the other stays beside it
     modes = out["step_modes"]
-    assert set(modes) == {"device-driven x2", "host-driven x4", "value_from"}
+    assert set(modes) == {"device-driven x4", "host-driven x4", "value_from"}
     assert modes["value_from"].startswith("host-driven x4")
     assert out["config"]["distinct_query_batches"] == 4
     assert abs(out["value"] - modes["host-driven x4"]["spacer_queries_per_s"]) < 1e-6 * out["value"]
-    assert modes["device-driven x2"]["spacer_queries_per_s"] > 0
+    assert modes["device-driven x4"]["spacer_queries_per_s"] > 0

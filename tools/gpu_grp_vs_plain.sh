@@ -8,6 +8,6 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); sm = d['step_modes']
-        print('value %.2f M  ms_per_step %.4f  regions %s  host x4 %.2f M  device x2 %.2f M' % (d['value'] / 1e6, d['ms_per_step'], [round(x / 1e6, 2) for x in d['regions']['spacer_queries_per_s']], sm['host-driven x4']['spacer_queries_per_s'] / 1e6, sm['device-driven x2']['spacer_queries_per_s'] / 1e6))
+        print('value %.2f M  ms_per_step %.4f  regions %s  host x4 %.2f M  device x4 %.2f M' % (d['value'] / 1e6, d['ms_per_step'], [round(x / 1e6, 2) for x in d['regions']['spacer_queries_per_s']], sm['host-driven x4']['spacer_queries_per_s'] / 1e6, sm['device-driven x4']['spacer_queries_per_s'] / 1e6))
 "
 done; done 2>&1 | tee gpurun_out/grp_vs_plain.txt

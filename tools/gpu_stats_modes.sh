@@ -1,4 +1,4 @@
-# GPU box: rocprofv3 kernel stats of the bench step in each mode on its own (device-driven x2, host-driven x4) -> gpurun_out/stats_<mode>.csv + the bench line
+# GPU box: rocprofv3 kernel stats of the bench step in each mode on its own (device-driven x4, host-driven x4) -> gpurun_out/stats_<mode>.csv + the bench line
 # of the same run gpurun_out/stats_<mode>.json (k_match per launch by HIP events inside the timed regions: must agree with the profiler's average)
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
