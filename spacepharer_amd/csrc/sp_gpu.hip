@@ -201,20 +201,22 @@ __device__ __forceinline__ uint32_t extIndex(uint32_t packed) { return packed & 
 // Device blocks a one-shot process (a fresh module process: SP_ONESHOT, set by the front end) hands from buffers that are done to buffers that come later -- the index build's
 // scratch (12 GB at 2x10^8 residues) is dead when the search starts, and what the search needs (diagonal records, per-wave scratch, Smith-Waterman pools, records) fits into it.
 // A fresh process then asks the driver for ~20 GB instead of 32: on the pool's slow boxes the allocations of the first prefilter alone took 0.5 s (profiles/r06_fresh_process_pool.txt).
-// A block taken from the pool is cleared like a new one (code that relies on what hipMalloc hands out must not see another buffer's content).  Served / in-process contexts keep
-// their buffers as before: the pool is off.
+// A block taken from the pool is cleared like a new one (code that relies on what hipMalloc hands out must not see another buffer's content); blocks are split, never
+// returned to the driver before the process ends.  Served / in-process contexts keep their buffers as before: the pool is off.
 struct DevPool {
     std::mutex mu; std::vector<std::pair<void *, size_t>> blocks;
     static bool on() { static const bool v = getenv("SP_ONESHOT") != nullptr && getenv("SP_NO_DEVICE_POOL") == nullptr; return v; }
     static DevPool &get() { static DevPool *p = new DevPool; return *p; }      // (never destroyed: the driver reclaims the blocks with the process)
     static constexpr size_t kMin = (size_t) 32 << 20;
-    void *take(size_t bytes, size_t &got) {
+    void *take(size_t bytes, size_t &got) {      // the smallest block that holds `bytes`; a block more than twice as large is split, its tail stays in the pool
         std::lock_guard<std::mutex> lk(mu);
         size_t best = blocks.size();
-        for (size_t i = 0; i < blocks.size(); i++) if (blocks[i].second >= bytes && blocks[i].second <= bytes * 4 && (best == blocks.size() || blocks[i].second < blocks[best].second)) best = i;
+        for (size_t i = 0; i < blocks.size(); i++) if (blocks[i].second >= bytes && (best == blocks.size() || blocks[i].second < blocks[best].second)) best = i;
         if (best == blocks.size()) return nullptr;
         void *p = blocks[best].first; got = blocks[best].second;
-        blocks.erase(blocks.begin() + (long) best);
+        const size_t piece = (bytes + ((size_t) 2 << 20) - 1) & ~(((size_t) 2 << 20) - 1);      // (pieces start on 2 MB boundaries of the block)
+        if (got > bytes * 2 && got - piece >= kMin) { blocks[best] = {static_cast<char *>(p) + piece, got - piece}; got = piece; }
+        else blocks.erase(blocks.begin() + (long) best);
         return p;
     }
     void give(void *p, size_t bytes) { std::lock_guard<std::mutex> lk(mu); blocks.emplace_back(p, bytes); }
@@ -226,13 +228,13 @@ struct DevBuf {
     bool ensure(size_t count, std::string &err) {
         if (count <= n && p) return true;
         release();
-        size_t want = count + count / 8 + 64;
+        size_t want = DevPool::on() ? count + 64 : count + count / 8 + 64;      // (room to grow into: a long-lived context's next batch; a one-shot process sizes exactly)
         static const bool trace = getenv("SP_MEM_TRACE") != nullptr;      // (every device allocation of 32 MB or more, with the element size: which buffers a call asks the driver for)
         if (DevPool::on() && want * sizeof(T) >= DevPool::kMin) {
             size_t got = 0;
             if (void *q = DevPool::get().take(want * sizeof(T), got)) {
                 if (trace) fprintf(stderr, "[sp] recycled  %9.1f MB  for %.1f MB (%zu elements of %zu bytes)\n", (double) got / 1e6, (double) (want * sizeof(T)) / 1e6, want, sizeof(T));
-                if (hipMemset(q, 0, want * sizeof(T)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void) hipGetLastError(); (void) hipFree(q); }      // (cleared before any stream of the process can touch it)
+                if (hipMemset(q, 0, want * sizeof(T)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) (void) hipGetLastError();      // (cleared before any stream of the process can touch it; a block that cannot be cleared is dropped -- it may be a piece of a larger allocation)
                 else { p = (T *) q; bytes = got; n = got / sizeof(T); return true; }
             }
         }
