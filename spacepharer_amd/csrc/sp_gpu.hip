@@ -330,6 +330,11 @@ struct Gpu::Impl {
     // the hit list starts travelling to the host on its own stream as soon as a prefilter pass is complete, so that the copy
     // overlaps whatever the caller queues next (typically the align kernels)
     hipStream_t copyStream = nullptr; hipEvent_t hitsOnHost = nullptr, alnOnHost = nullptr; bool alnInFlight = false;
+    // Host-driven passes wait for their RECORDS on the copy stream, not on an event recorded behind them (round 6): the marker an event record puts behind a copy sits in a
+    // hardware queue that other contexts' streams share and holds their kernels back until the copy is done (SP_COPY_EVENT_WAIT=1: the event, as before).  The copy stream
+    // carries this context's result copies only, the records are the last of a pass.
+    static bool copyEvents() { static const bool v = getenv("SP_COPY_EVENT_WAIT") != nullptr; return v; }
+    hipError_t waitCopies(hipEvent_t e) { return copyEvents() ? hipEventSynchronize(e) : hipStreamSynchronize(copyStream); }
     PinVec<GpuHit> hitStage; PinVec<uint32_t> hitOffStage; bool hitsInFlight = false;
     GpuHit *sinkHits = nullptr; uint32_t *sinkOff = nullptr; size_t sinkCap = 0, sinkN = 0; bool sinkUsed = false;      // caller-owned delivery buffers (setHitSink)
     // exclusive scan of n counts into n + 1 offsets (offset[n] = total); count must have n + 1 readable entries.
@@ -1071,8 +1076,11 @@ bool Gpu::stepEnd(StepResult &r, std::string &err) {
         HIP_OK(hipMemcpyAsync(ss.out.records, ss.dRec, ss.cap * sizeof(AlnRec), hipMemcpyDeviceToHost, d.copyStream));
         const size_t cigBytes = (size_t) std::min<uint64_t>(ss.out.cigarCap, (uint64_t) ss.dCigN);
         if (cigBytes) HIP_OK(hipMemcpyAsync(ss.out.cigars, ss.dCig, cigBytes, hipMemcpyDeviceToHost, d.copyStream));
-        HIP_OK(hipEventRecord(ss.alnOnHost, d.copyStream));
-        if (!poll(ss.alnOnHost)) return false;
+        if (Impl::copyEvents()) { HIP_OK(hipEventRecord(ss.alnOnHost, d.copyStream)); if (!poll(ss.alnOnHost)) return false; }
+        else {      // (no marker behind the copies: the copy stream itself is asked -- see Impl::waitCopies)
+            unsigned tries = 0;
+            for (;;) { const hipError_t q = hipStreamQuery(d.copyStream); if (q == hipSuccess) break; if (q != hipErrorNotReady) { err = std::string("stepEnd: ") + hipGetErrorString(q); d.stepsEnded++; return false; } pollPause(tries); }
+        }
     } else {
         if (!poll(ss.hitsOnHost) || !poll(ss.alnOnHost)) return false;
     }
@@ -1732,7 +1740,7 @@ void pinnedFree(void *p) { if (p) (void) hipHostFree(p); }
 
 bool Gpu::waitAlignCopy(std::string &err) {
     Impl &d = *d_;
-    if (d.alnInFlight) { HIP_OK(hipEventSynchronize(d.alnOnHost)); d.alnInFlight = false; }
+    if (d.alnInFlight) { HIP_OK(d.waitCopies(d.alnOnHost)); d.alnInFlight = false; }
     return true;
 }
 
@@ -1758,7 +1766,7 @@ bool Gpu::prefetchHits(std::string &err) {
     if (nq_ == 0) { d.hitsInFlight = false; return true; }
     HIP_OK(hipMemcpyAsync(dstOff, d.outOffset.p, (nq_ + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, d.copyStream));
     if (nHits) HIP_OK(hipMemcpyAsync(dstHits, d.outHits.p, nHits * sizeof(GpuHit), hipMemcpyDeviceToHost, d.copyStream));
-    HIP_OK(hipEventRecord(d.hitsOnHost, d.copyStream));
+    HIP_OK(hipEventRecord(d.hitsOnHost, d.copyStream));      // (the hit list keeps its event: who waits for it must not wait for the records queued behind it)
     d.hitsInFlight = true;
     return true;
 }
