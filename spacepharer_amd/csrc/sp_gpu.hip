@@ -364,10 +364,20 @@ struct Gpu::Impl {
     // device-driven steps (stepBegin / stepEnd): the whole pass -- prefilter, selection, align, record assembly, delivery -- is queued without a
     // host round trip; counts stay on the device, results and counters travel on the copy stream.  Up to two steps in flight.
     struct StepSlot { hipEvent_t selected = nullptr, assembled = nullptr, hitsOnHost = nullptr, alnOnHost = nullptr; size_t cap = 0; StepOut out;
-                      bool late = false; size_t nq = 0; const GpuHit *dHits = nullptr; const uint32_t *dOffsets = nullptr; const AlnRec *dRec = nullptr; const char *dCig = nullptr; size_t dCigN = 0; };
+                      bool late = false, copied = false; size_t nq = 0; const GpuHit *dHits = nullptr; const uint32_t *dOffsets = nullptr; const AlnRec *dRec = nullptr; const char *dCig = nullptr; size_t dCigN = 0; };
     // late copies (SP_STEP_LATE_COPY): a step's results leave the device when stepEnd() has seen its last kernel finish, from buffers the NEXT step does not write -- no copy is
     // queued behind an event that has not happened yet, no kernel waits for a copy (see stepBegin)
     DevBuf<GpuHit> outHitsAlt; DevBuf<uint32_t> outOffsetAlt; DevBuf<AlnRec> recAlt; DevBuf<char> cigAlt;
+    hipError_t issueLateCopies(StepSlot &ss) {      // the results of a finished step, on the copy stream (stepEnd, or drain() for steps nobody has collected yet)
+        if (!ss.late || ss.copied) return hipSuccess;
+        hipError_t e = hipMemcpyAsync(ss.out.offsets, ss.dOffsets, (ss.nq + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, copyStream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ss.out.hits, ss.dHits, ss.cap * sizeof(GpuHit), hipMemcpyDeviceToHost, copyStream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ss.out.records, ss.dRec, ss.cap * sizeof(AlnRec), hipMemcpyDeviceToHost, copyStream);
+        const size_t cigBytes = (size_t) std::min<uint64_t>(ss.out.cigarCap, (uint64_t) ss.dCigN);
+        if (e == hipSuccess && cigBytes) e = hipMemcpyAsync(ss.out.cigars, ss.dCig, cigBytes, hipMemcpyDeviceToHost, copyStream);
+        ss.copied = e == hipSuccess;
+        return e;
+    }
     StepSlot step[2];
     uint64_t stepsBegun = 0, stepsEnded = 0;
     bool drained = false;                        // every queued step has finished on the device and its results are in host memory (drain())
@@ -974,6 +984,7 @@ bool Gpu::prefilter(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
 bool Gpu::drain(std::string &err) {
     Impl &d = *d_;
     HIP_OK(hipStreamSynchronize(d.stream));
+    for (uint64_t j = d.stepsEnded; j < d.stepsBegun; j++) HIP_OK(d.issueLateCopies(d.step[j & 1]));      // (the steps nobody has collected: their results travel now -- the caller may restage queries next)
     HIP_OK(hipStreamSynchronize(d.copyStream));
     d.drained = true;
     d.evSet = (int) (d.stepsEnded & 1) ^ 1;      // the event set no uncollected step reads its times from
@@ -1033,7 +1044,7 @@ bool Gpu::stepBegin(int kmerThr, unsigned binSize, int maxHits, int minDiagScore
             hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, d.stream, pa); }
         SP_EV(9, 2);
         HIP_OK(hipEventRecord(ss.assembled, d.stream));
-        ss.nq = nq_; ss.dHits = d.outHits.p; ss.dOffsets = d.outOffset.p; ss.dRec = s.rec.p; ss.dCig = s.cig.p; ss.dCigN = s.cig.n;
+        ss.copied = false; ss.nq = nq_; ss.dHits = d.outHits.p; ss.dOffsets = d.outOffset.p; ss.dRec = s.rec.p; ss.dCig = s.cig.p; ss.dCigN = s.cig.n;
         HIP_OK(hipGetLastError());
         d.stepsBegun++;
         return true;
@@ -1071,11 +1082,7 @@ bool Gpu::stepEnd(StepResult &r, std::string &err) {
     };
     if (ss.late) {      // the step's kernels are done: NOW its results travel (nothing was queued behind an event that had not happened)
         if (!poll(ss.assembled)) return false;
-        HIP_OK(hipMemcpyAsync(ss.out.offsets, ss.dOffsets, (ss.nq + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, d.copyStream));
-        HIP_OK(hipMemcpyAsync(ss.out.hits, ss.dHits, ss.cap * sizeof(GpuHit), hipMemcpyDeviceToHost, d.copyStream));
-        HIP_OK(hipMemcpyAsync(ss.out.records, ss.dRec, ss.cap * sizeof(AlnRec), hipMemcpyDeviceToHost, d.copyStream));
-        const size_t cigBytes = (size_t) std::min<uint64_t>(ss.out.cigarCap, (uint64_t) ss.dCigN);
-        if (cigBytes) HIP_OK(hipMemcpyAsync(ss.out.cigars, ss.dCig, cigBytes, hipMemcpyDeviceToHost, d.copyStream));
+        HIP_OK(d.issueLateCopies(ss));
         if (Impl::copyEvents()) { HIP_OK(hipEventRecord(ss.alnOnHost, d.copyStream)); if (!poll(ss.alnOnHost)) return false; }
         else {      // (no marker behind the copies: the copy stream itself is asked -- see Impl::waitCopies)
             unsigned tries = 0;
